@@ -1,0 +1,158 @@
+/*
+ * tpp_xsmm_abi.h - the dispatch/invoke C-ABI of tpp-mlir's runtime/Xsmm,
+ * re-declared for the MI355X-native runtime (libtpp_xsmm_runner_utils.so).
+ *
+ * Every entry point below replaces the symbol of the same name exported by the
+ * reference's libtpp_xsmm_runner_utils.so. Reference declarations:
+ *   runtime/Xsmm/XsmmRunnerUtils.h:22-83   (13 xsmm_* symbols)
+ *   runtime/PerfRunnerUtils.h:22-24        (perf_start_timer / perf_stop_timer)
+ * The reference header types the enum arguments as libxsmm enums; the compiler
+ * always materialises them as i64 constants (lib/TPP/Conversion/ConvertXsmmToFunc/
+ * ConvertXsmmToFunc.cpp:63-65, 319-340), and libxsmm is not a dependency of this
+ * runtime, so they are int64_t here. On x86-64 SysV the two declarations are
+ * call-compatible for the value range the compiler emits (non-negative, < 2^31).
+ *
+ * All matrices are row-major. `off*` are element offsets (memref offsets), added
+ * as typed pointer arithmetic (XsmmRunnerUtils.cpp:63-75).
+ *
+ * Data pointers may be device pointers (used in place, zero copy) or host
+ * pointers (staged through a device mirror; results are copied back before the
+ * invoke returns, preserving the reference's synchronous completion contract).
+ */
+#ifndef TPP_XSMM_ABI_H
+#define TPP_XSMM_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TPP_XSMM_EXPORT __attribute__((visibility("default")))
+
+/* ---- wire values: include/TPP/Dialect/Xsmm/XsmmEnum.td:13-84 ---------------- */
+enum { XSMM_DTYPE_F32 = 1, XSMM_DTYPE_BF16 = 2 };                          /* :13-20 */
+enum {                                                                     /* :34-45 */
+  XSMM_UNARY_NONE = 0, XSMM_UNARY_IDENTITY = 1, XSMM_UNARY_ZERO = 2,
+  XSMM_UNARY_RELU = 5, XSMM_UNARY_VNNI2 = 28, XSMM_UNARY_TRANSPOSE = 29
+};
+enum {                                                                     /* :47-56 */
+  XSMM_UNARY_FLAG_NONE = 0, XSMM_UNARY_FLAG_BCAST_ROW = 2,
+  XSMM_UNARY_FLAG_BCAST_COL = 4, XSMM_UNARY_FLAG_BCAST_SCALAR = 8
+};
+enum {                                                                     /* :22-32 */
+  XSMM_BINARY_NONE = 0, XSMM_BINARY_ADD = 1, XSMM_BINARY_MUL = 2,
+  XSMM_BINARY_SUB = 3, XSMM_BINARY_DIV = 4
+};
+enum {                                                                     /* :58-70 */
+  XSMM_BINARY_FLAG_NONE = 0,
+  XSMM_BINARY_FLAG_BCAST_ROW_IN_0 = 1, XSMM_BINARY_FLAG_BCAST_ROW_IN_1 = 2,
+  XSMM_BINARY_FLAG_BCAST_COL_IN_0 = 4, XSMM_BINARY_FLAG_BCAST_COL_IN_1 = 8,
+  XSMM_BINARY_FLAG_BCAST_SCALAR_IN_0 = 16, XSMM_BINARY_FLAG_BCAST_SCALAR_IN_1 = 32
+};
+/* GEMM flags AS THEY ARRIVE ON THE WIRE. The dialect values are VNNI_A=2048,
+ * VNNI_B=4096 (XsmmEnum.td:72-84) but ConvertXsmmToFunc.cpp:251-265 exchanges the
+ * two because the runtime swaps A and B for libxsmm's column-major view: a
+ * dialect `vnni_b` operand arrives as 2048, `vnni_a` as 4096. */
+enum {
+  XSMM_GEMM_FLAG_NONE = 0, XSMM_GEMM_FLAG_BETA_0 = 4,
+  XSMM_GEMM_FLAG_NO_RESET_TILECONFIG = 64, XSMM_GEMM_FLAG_NO_SETUP_TILECONFIG = 128,
+  XSMM_GEMM_WIRE_VNNI_B = 2048, /* row-major B operand is [K/2][N][2] */
+  XSMM_GEMM_WIRE_VNNI_A = 4096, /* row-major A operand is VNNI (unsupported: exit(-1)) */
+  XSMM_GEMM_FLAG_VNNI_C = 8192  /* unsupported: exit(-1) */
+};
+
+/* ---- dispatch: build (or look up) a kernel descriptor, return opaque handle ----
+ * Handles are never freed (the reference has no destroy call); dispatching the
+ * same arguments again returns the same handle. Unsupported arguments: message
+ * on stderr + exit(-1), as XsmmRunnerUtils.cpp:132-137,170-176,202-208,352-358. */
+
+/* replaces XsmmRunnerUtils.cpp:95-140 */
+TPP_XSMM_EXPORT int64_t xsmm_gemm_dispatch(int64_t dtype, int64_t m, int64_t n, int64_t k,
+                                           int64_t lda, int64_t ldb, int64_t ldc,
+                                           int64_t flags);
+/* replaces XsmmRunnerUtils.cpp:308-361 */
+TPP_XSMM_EXPORT int64_t xsmm_brgemm_dispatch(int64_t dtype, int64_t m, int64_t n, int64_t k,
+                                             int64_t lda, int64_t ldb, int64_t ldc,
+                                             int64_t stride_a, int64_t stride_b,
+                                             int64_t flags);
+/* replaces XsmmRunnerUtils.cpp:385-457 */
+TPP_XSMM_EXPORT int64_t xsmm_fused_brgemm_dispatch(int64_t dtype, int64_t m, int64_t n,
+                                                   int64_t k, int64_t lda, int64_t ldb,
+                                                   int64_t ldc, int64_t stride_a,
+                                                   int64_t stride_b, int64_t gemm_flags,
+                                                   int64_t unary_flags, int64_t unary_kind,
+                                                   int64_t binary_flags, int64_t binary_kind);
+/* replaces XsmmRunnerUtils.cpp:142-179 */
+TPP_XSMM_EXPORT int64_t xsmm_unary_dispatch(int64_t unary_kind, int64_t dtype, int64_t m,
+                                            int64_t n, int64_t ldi, int64_t ldo,
+                                            int64_t flags);
+/* replaces XsmmRunnerUtils.cpp:181-211 */
+TPP_XSMM_EXPORT int64_t xsmm_binary_dispatch(int64_t binary_kind, int64_t dtype, int64_t m,
+                                             int64_t n, int64_t ldi_lhs, int64_t ldi_rhs,
+                                             int64_t ldo, int64_t flags);
+/* replaces XsmmRunnerUtils.cpp:213-246 (Intel AMX only: a no-op here) */
+TPP_XSMM_EXPORT int64_t xsmm_intel_amx_tile_config_dispatch(int64_t dtype, int64_t m,
+                                                            int64_t n, int64_t k,
+                                                            int64_t lda, int64_t ldb,
+                                                            int64_t ldc, int64_t stride_a,
+                                                            int64_t stride_b, int64_t flags);
+
+/* ---- invoke: run a dispatched kernel; synchronous unless async mode is on ---- */
+
+/* replaces XsmmRunnerUtils.cpp:79-93 */
+TPP_XSMM_EXPORT void xsmm_gemm_invoke(int64_t dtype, int64_t handle, void *a, int64_t off_a,
+                                      void *b, int64_t off_b, void *c, int64_t off_c);
+/* replaces XsmmRunnerUtils.cpp:288-306 */
+TPP_XSMM_EXPORT void xsmm_brgemm_invoke(int64_t dtype, int64_t handle, void *a,
+                                        int64_t off_a, void *b, int64_t off_b, void *c,
+                                        int64_t off_c, int64_t num_batches);
+/* replaces XsmmRunnerUtils.cpp:363-383 */
+TPP_XSMM_EXPORT void xsmm_fused_brgemm_invoke(int64_t dtype, int64_t handle, void *a,
+                                              int64_t off_a, void *b, int64_t off_b, void *c,
+                                              int64_t off_c, void *d, int64_t off_d,
+                                              int64_t num_batches);
+/* replaces XsmmRunnerUtils.cpp:248-259 */
+TPP_XSMM_EXPORT void xsmm_unary_invoke(int64_t dtype, int64_t handle, void *in,
+                                       int64_t off_in, void *out, int64_t off_out);
+/* replaces XsmmRunnerUtils.cpp:276-286 (the scalar is ALWAYS an f32) */
+TPP_XSMM_EXPORT void xsmm_unary_scalar_invoke(int64_t dtype, int64_t handle, float scalar,
+                                              void *out, int64_t off_out);
+/* replaces XsmmRunnerUtils.cpp:261-274 */
+TPP_XSMM_EXPORT void xsmm_binary_invoke(int64_t dtype, int64_t handle, void *lhs,
+                                        int64_t off_lhs, void *rhs, int64_t off_rhs,
+                                        void *out, int64_t off_out);
+/* replaces XsmmRunnerUtils.cpp:459-469 (no-op) */
+TPP_XSMM_EXPORT void xsmm_intel_amx_tile_config_invoke(int64_t dtype, int64_t handle,
+                                                       void *tile_state, int64_t off);
+
+/* ---- timers: runtime/PerfRunnerUtils.cpp:23-35. perf_stop_timer drains the
+ * device queue before reading the clock so that async-mode launches are counted. */
+TPP_XSMM_EXPORT int64_t perf_start_timer(void);
+TPP_XSMM_EXPORT double perf_stop_timer(int64_t start);
+
+/* ---- extensions (NOT in the reference; the reference ABI has no config call) --
+ * The JIT'd code never calls these; harnesses (bench.py, tests, tpp_replay) do. */
+
+/* 0 (default): every invoke returns after its kernel completed (reference
+ * semantics). 1: invokes only enqueue on the runtime's stream; call
+ * xsmm_hip_synchronize() or perf_stop_timer() to drain. Returns previous mode.
+ * Also settable with env TPP_HIP_ASYNC=1. */
+TPP_XSMM_EXPORT int xsmm_hip_set_async(int enable);
+/* Stream the kernels are launched on (a hipStream_t). NULL = default stream. */
+TPP_XSMM_EXPORT void xsmm_hip_set_stream(void *hip_stream);
+TPP_XSMM_EXPORT void *xsmm_hip_get_stream(void);
+TPP_XSMM_EXPORT void xsmm_hip_synchronize(void);
+/* Number of visible HIP devices (0 on a CPU-only host; never exits). */
+TPP_XSMM_EXPORT int xsmm_hip_device_count(void);
+/* Name of the HIP kernel variant a GEMM-like handle selected, for profiles. */
+TPP_XSMM_EXPORT const char *xsmm_hip_kernel_name(int64_t handle);
+/* Force a GEMM tile variant for A/B benchmarking (-1 = automatic). */
+TPP_XSMM_EXPORT void xsmm_hip_force_variant(int variant);
+/* Library version string. */
+TPP_XSMM_EXPORT const char *xsmm_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TPP_XSMM_ABI_H */

@@ -1,0 +1,155 @@
+"""ctypes front-end of the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg. The product package (tpp-mlir_amd) never imports it.
+Function-by-function reference citations live in oracle/xsmm_oracle.c and
+oracle/tensor_init.cpp.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+F32, BF16 = 1, 2
+I64 = ctypes.c_int64
+VP = ctypes.c_void_p
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("xsmm_oracle.c", "tensor_init.cpp", "Makefile")]
+    stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "liboracle.so"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(so):
+            build()
+        try:
+            L = ctypes.CDLL(so)
+        except OSError:
+            build(force=True)
+            L = ctypes.CDLL(so)
+        L.oracle_fused_brgemm.restype = ctypes.c_int
+        L.oracle_fused_brgemm.argtypes = [I64] * 14 + [VP, VP, VP, VP, I64]
+        L.oracle_brgemm.restype = ctypes.c_int
+        L.oracle_brgemm.argtypes = [I64] * 10 + [VP, VP, VP, I64]
+        L.oracle_gemm.restype = ctypes.c_int
+        L.oracle_gemm.argtypes = [I64] * 8 + [VP, VP, VP]
+        L.oracle_unary.restype = ctypes.c_int
+        L.oracle_unary.argtypes = [I64] * 7 + [VP, VP, VP]
+        L.oracle_binary.restype = ctypes.c_int
+        L.oracle_binary.argtypes = [I64] * 8 + [VP, VP, VP]
+        L.oracle_fused_brgemm_omp.restype = ctypes.c_int
+        L.oracle_fused_brgemm_omp.argtypes = [I64] * 12 + [VP, VP, VP, VP, I64, I64]
+        L.oracle_num_threads.restype = ctypes.c_int
+        L.oracle_f32_to_bf16.restype = ctypes.c_uint16
+        L.oracle_f32_to_bf16.argtypes = [ctypes.c_float]
+        L.oracle_bf16_to_f32.restype = ctypes.c_float
+        L.oracle_bf16_to_f32.argtypes = [ctypes.c_uint16]
+        L.tinit_create.restype = VP
+        L.tinit_create.argtypes = [ctypes.c_int, ctypes.c_int]
+        L.tinit_destroy.argtypes = [VP]
+        L.tinit_fill.argtypes = [VP, VP, I64]
+        _LIB = L
+    return _LIB
+
+
+# ---- bf16 helpers on numpy (uint16 storage) -------------------------------------
+def f32_to_bf16(x):
+    """Round-to-nearest-even f32 -> bf16 bits (uint16), vectorised; NaN -> qNaN."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    u = x.view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+    nan = (u & 0x7FFFFFFF) > 0x7F800000
+    r[nan] = ((u[nan] >> 16) | 0x40).astype(np.uint16)
+    return r
+
+
+def bf16_to_f32(h):
+    h = np.ascontiguousarray(h, dtype=np.uint16)
+    return (h.astype(np.uint32) << 16).view(np.float32)
+
+
+def np_dtype(dt):
+    return np.float32 if dt == F32 else np.uint16
+
+
+def _p(arr, off=0):
+    """pointer to element `off` of a 1-D contiguous numpy buffer"""
+    if arr is None:
+        return None
+    return ctypes.c_void_p(arr.ctypes.data + off * arr.itemsize)
+
+
+# ---- ops (buffers are flat numpy arrays; offsets in elements, as on the wire) ----
+def brgemm(dt, m, n, k, lda, ldb, ldc, sa, sb, flags, A, offA, B, offB, C, offC, br):
+    rc = lib().oracle_brgemm(dt, m, n, k, lda, ldb, ldc, sa, sb, flags, _p(A, offA), _p(B, offB), _p(C, offC), br)
+    assert rc == 0, "oracle_brgemm: unsupported arguments"
+
+
+def gemm(dt, m, n, k, lda, ldb, ldc, flags, A, offA, B, offB, C, offC):
+    rc = lib().oracle_gemm(dt, m, n, k, lda, ldb, ldc, flags, _p(A, offA), _p(B, offB), _p(C, offC))
+    assert rc == 0
+
+
+def fused_brgemm(dt, m, n, k, lda, ldb, ldc, sa, sb, gflags, uflags, ukind, bflags, bkind,
+                 A, offA, B, offB, C, offC, D, offD, br):
+    rc = lib().oracle_fused_brgemm(dt, m, n, k, lda, ldb, ldc, sa, sb, gflags, uflags, ukind, bflags, bkind,
+                                   _p(A, offA), _p(B, offB), _p(C, offC), _p(D, offD), br)
+    assert rc == 0, "oracle_fused_brgemm: unsupported arguments"
+
+
+def unary(kind, dt, m, n, ldi, ldo, flags, inp, offIn, out, offOut):
+    rc = lib().oracle_unary(kind, dt, m, n, ldi, ldo, flags, _p(inp, offIn), _p(out, offOut), None)
+    assert rc == 0, "oracle_unary: unsupported arguments"
+
+
+def unary_scalar(kind, dt, m, n, ldi, ldo, flags, scalar, out, offOut):
+    s = ctypes.c_float(scalar)
+    rc = lib().oracle_unary(kind, dt, m, n, ldi, ldo, flags, None, _p(out, offOut), ctypes.byref(s))
+    assert rc == 0
+
+
+def binary(kind, dt, m, n, ldl, ldr, ldo, flags, lhs, offL, rhs, offR, out, offO):
+    rc = lib().oracle_binary(kind, dt, m, n, ldl, ldr, ldo, flags, _p(lhs, offL), _p(rhs, offR), _p(out, offO))
+    assert rc == 0, "oracle_binary: unsupported arguments"
+
+
+def fused_brgemm_omp(dt, m, n, k, lda, ldb, ldc, sa, sb, gflags, ukind, bkind, A, B, C, D, br, row_block=32):
+    rc = lib().oracle_fused_brgemm_omp(dt, m, n, k, lda, ldb, ldc, sa, sb, gflags, ukind, bkind,
+                                       _p(A), _p(B), _p(C), _p(D), br, row_block)
+    assert rc == 0
+
+
+def num_threads():
+    return lib().oracle_num_threads()
+
+
+class TensorInit:
+    """One cached generator of tpp-run (per init type / dtype / seed); fill the
+    kernel arguments of one dtype in argument order from a single instance."""
+    KINDS = {"const": 0, "simple": 1, "cont": 2, "random": 3, "normal": 4}
+
+    def __init__(self, kind="normal", seed=123):
+        self._h = lib().tinit_create(self.KINDS[kind], seed)
+
+    def fill(self, n, dt=F32):
+        out = np.empty(n, dtype=np.float32)
+        lib().tinit_fill(self._h, out.ctypes.data, n)
+        return out if dt == F32 else f32_to_bf16(out)
+
+    def __del__(self):
+        try:
+            lib().tinit_destroy(self._h)
+        except Exception:
+            pass
