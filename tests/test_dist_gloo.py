@@ -1,0 +1,109 @@
+"""The N>1 path on CPU: world_size-2 gloo processes run the row-sharded MLP (each rank
+its row block, all layers) and the all-gather of the output; the result must equal the
+unsharded computation bit for bit. The GPU kernels are replaced by the oracle here (this
+is a tests/ file) - what is under test is the partition + gather logic of
+tpp-mlir_amd/mlp.py, which is identical on RCCL."""
+import importlib
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import pyoracle as orc
+
+pkg = importlib.import_module("tpp-mlir_amd")
+
+
+def np_view(t):
+    if t.dtype == torch.bfloat16:
+        return t.view(torch.int16).numpy().reshape(-1).view(np.uint16)
+    return t.numpy().reshape(-1)
+
+
+class OracleRuntime:
+    """same two methods as XsmmRuntime, backed by oracle/xsmm_oracle.c on CPU tensors"""
+
+    def __init__(self):
+        self.descs = []
+
+    def fused_brgemm_dispatch(self, **kw):
+        self.descs.append(kw)
+        return len(self.descs)
+
+    def fused_brgemm(self, dtype, h, a, oa, b, ob, c, oc, d, od, br):
+        k = self.descs[h - 1]
+        orc.fused_brgemm(dtype, k["m"], k["n"], k["k"], k["lda"], k["ldb"], k["ldc"], k["stride_a"], k["stride_b"],
+                         k["gemm_flags"], k["unary_flags"], k["unary_kind"], k["binary_flags"], k["binary_kind"],
+                         np_view(a), oa, np_view(b), ob, np_view(c), oc, np_view(d), od, br)
+
+
+def make_problem(spec):
+    g = torch.Generator().manual_seed(3)
+    tdt = torch.bfloat16 if spec.dtype == 2 else torch.float32
+    X = (torch.randn(spec.batch, spec.layers[0], generator=g) * 0.5).to(tdt)
+    Ws, Bs = [], []
+    for k, n in zip(spec.layers[:-1], spec.layers[1:]):
+        w = (torch.randn(k, n, generator=g) * 0.1).to(tdt)
+        if spec.dtype == 2:  # VNNI-2 pack [k/2][n][2] with the oracle's pack op
+            packed = torch.empty_like(w)
+            orc.unary(28, 2, k, n, n, n, 0, np_view(w), 0, np_view(packed), 0)
+            w = packed
+        Ws.append(w)
+        Bs.append((torch.randn(n, generator=g) * 0.1).to(tdt))
+    return X, Ws, Bs
+
+
+def run_rank(rank, world, port, batch, dtype, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        spec = pkg.MlpSpec(batch=batch, layers=[128, 192, 128], dtype=dtype)
+        X, Ws, Bs = make_problem(spec)
+        sh = pkg.ShardedMlp(spec, rank, world, OracleRuntime())
+        xl = X[sh.row0: sh.row0 + sh.rows].contiguous()
+        acts = [torch.zeros(sh.rows, n, dtype=X.dtype) for n in spec.layers[1:]]
+        out = sh.forward(xl, Ws, Bs, acts)
+        if out is None:
+            out = torch.zeros(0, spec.layers[-1], dtype=X.dtype)
+        full = torch.zeros(spec.batch, spec.layers[-1], dtype=X.dtype)
+        pkg.all_gather_rows(out, full, spec, world)
+        # unsharded reference on every rank
+        one = pkg.ShardedMlp(spec, 0, 1, OracleRuntime())
+        acts1 = [torch.zeros(spec.batch, n, dtype=X.dtype) for n in spec.layers[1:]]
+        ref = one.forward(X, Ws, Bs, acts1)
+        ok = torch.equal(full.view(torch.int16) if dtype == 2 else full, ref.view(torch.int16) if dtype == 2 else ref)
+        out_q.put((rank, bool(ok), sh.row0, sh.rows))
+    finally:
+        dist.destroy_process_group()
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("batch,dtype", [(512, 1), (512, 2), (384, 2)])
+def test_row_sharded_mlp_with_all_gather_world2(batch, dtype):
+    orc.lib()  # make sure the oracle is built before forking
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=run_rank, args=(r, world, port, batch, dtype, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for (_, ok, _, _) in res), res
+    rows = sorted((r0, n) for (_, _, r0, n) in res)
+    assert rows[0][0] == 0 and rows[0][0] + rows[0][1] == rows[1][0] and rows[1][0] + rows[1][1] == batch

@@ -1,0 +1,505 @@
+"""Parity of the HIP path (through the C-ABI of libtpp_xsmm_runner_utils.so) with the
+CPU oracle, on a real MI355X:
+  * every golden fixture harvested from the reference's lit tests, through host
+    pointers (mirror path) and device pointers (zero-copy path);
+  * seeded random cases over the shapes / strides / flags the compiler can emit,
+    including ragged sizes (3, 5, 13, 33 ...), empty batches and overlapping batches;
+  * the BASELINE.json configurations at full size (rows sampled where the oracle
+    would be slow: output rows are independent) and size-independent properties.
+Bars: f32 max|gpu - ref| <= 1e-5 * max(1, max|ref|) (north_star); bf16 results within
+one bf16 ulp of the oracle's (reference convention fpcmp -r 0.01 is far looser);
+identity / zero / transpose / VNNI-2 pack bit-exact.
+"""
+import importlib
+import os
+import threading
+
+import numpy as np
+import pytest
+
+import fixture_runner as fr
+from abi_backend import AbiBackend
+from oracle import pyoracle as orc
+
+pytestmark = pytest.mark.gpu
+pkg = importlib.import_module("tpp-mlir_amd")
+F32, BF16 = 1, 2
+VB = 2048  # wire flag of a VNNI-2 B operand
+
+
+@pytest.fixture(scope="module")
+def rt():
+    r = pkg.get_runtime()
+    assert r.device_count() >= 1, "no HIP device visible: the gpu tests need an MI355X"
+    return r
+
+
+def dev(arr):
+    import torch
+    src = arr.view(np.int16) if arr.dtype == np.uint16 else arr
+    return torch.from_numpy(src.copy()).cuda()
+
+
+def host(t, like):
+    a = t.cpu().numpy()
+    return a.view(np.uint16) if like.dtype == np.uint16 else a
+
+
+def rand(rng, n, dt, lo=-1.0, hi=1.0):
+    v = rng.uniform(lo, hi, size=n).astype(np.float32)
+    return v if dt == F32 else orc.f32_to_bf16(v)
+
+
+def as_f32(a):
+    return a if a.dtype == np.float32 else orc.bf16_to_f32(a)
+
+
+def check_close(got, ref, dt, what):
+    g, r = as_f32(got).astype(np.float64), as_f32(ref).astype(np.float64)
+    assert np.isfinite(g).all(), what + ": non-finite values"
+    diff = np.abs(g - r)
+    if dt == F32:
+        tol = 1e-5 * max(1.0, float(np.abs(r).max()) if r.size else 1.0)
+        bad = diff > tol
+    else:  # one bf16 ulp of the reference value (2^-8 relative spacing, so 2^-7 covers a flip) + tiny abs
+        tol = np.abs(r) * 2.0 ** -7 + 1e-30
+        bad = diff > tol
+    assert not bad.any(), "%s: %d/%d mismatches, max abs diff %g (max |ref| %g)" % (
+        what, int(bad.sum()), bad.size, float(diff.max()), float(np.abs(r).max()))
+
+
+# ---------------------------------------------------------------- golden fixtures
+@pytest.mark.parametrize("mode", ["host", "device"])
+@pytest.mark.parametrize("path", fr.fixtures(), ids=lambda p: os.path.basename(p)[:-5])
+def test_golden_fixture_through_abi(rt, path, mode):
+    fr.run_fixture(path, AbiBackend(mode))
+
+
+# ---------------------------------------------------------------- GEMM family
+def gemm_case(rt, dt, m, n, k, br, lda=None, ldb=None, ldc=None, sa=None, sb=None, beta0=False, bias=False,
+              relu=False, vnni=False, fused=None, offs=(0, 0, 0, 0), seed=0, mode="device", force=None,
+              row_blocks=None):
+    """row_blocks: [(first_row, rows)] to verify when the full oracle would be slow - output
+    rows are independent, so the oracle is run on those row blocks only."""
+    rng = np.random.default_rng(seed)
+    lda = lda or max(k, 1)
+    ldb = ldb or max(n, 1)
+    ldc = ldc or max(n, 1)
+    kp = (k + 1) // 2
+    bmat = (kp * 2 * ldb) if vnni else k * ldb
+    sa = m * lda if sa is None else sa
+    sb = bmat if sb is None else sb
+    fused = (bias or relu) if fused is None else fused
+    na = offs[0] + max(br - 1, 0) * sa + m * lda + 8
+    nb = offs[1] + max(br - 1, 0) * sb + bmat + 2 * ldb + 8
+    nc = offs[2] + m * ldc + 8
+    A, B, C, D = rand(rng, na, dt), rand(rng, nb, dt), rand(rng, nc, dt), rand(rng, offs[3] + n + 8, dt)
+    flags = (4 if beta0 else 0) | (VB if vnni else 0)
+    Cref = C.copy()
+    for (r0, rr) in (row_blocks or [(0, m)]):
+        if fused:
+            orc.fused_brgemm(dt, rr, n, k, lda, ldb, ldc, sa, sb, flags, 0, 5 if relu else 0, 4 if bias else 0,
+                             1 if bias else 0, A, offs[0] + r0 * lda, B, offs[1], Cref, offs[2] + r0 * ldc, D,
+                             offs[3], br)
+        else:
+            orc.brgemm(dt, rr, n, k, lda, ldb, ldc, sa, sb, flags, A, offs[0] + r0 * lda, B, offs[1], Cref,
+                       offs[2] + r0 * ldc, br)
+    if force is not None:
+        rt.force_variant(force)
+    try:
+        if fused:
+            h = rt.fused_brgemm_dispatch(dt, m, n, k, lda, ldb, ldc, sa, sb, flags, 0, 5 if relu else 0,
+                                         4 if bias else 0, 1 if bias else 0)
+        else:
+            h = rt.brgemm_dispatch(dt, m, n, k, lda, ldb, ldc, sa, sb, flags)
+    finally:
+        if force is not None:
+            rt.force_variant(-1)
+    name = rt.kernel_name(h)
+    if mode == "device":
+        dA, dB, dC, dD = dev(A), dev(B), dev(C), dev(D)
+        if fused:
+            rt.fused_brgemm(dt, h, dA, offs[0], dB, offs[1], dC, offs[2], dD, offs[3], br)
+        else:
+            rt.brgemm(dt, h, dA, offs[0], dB, offs[1], dC, offs[2], br)
+        got = host(dC, C)
+    else:
+        got = C.copy()
+        if fused:
+            rt.fused_brgemm(dt, h, A, offs[0], B, offs[1], got, offs[2], D, offs[3], br)
+        else:
+            rt.brgemm(dt, h, A, offs[0], B, offs[1], got, offs[2], br)
+    what = "brgemm[%s] dt%d m%d n%d k%d br%d lda%d ldb%d ldc%d sa%d sb%d beta0=%d bias=%d relu=%d" % (
+        name, dt, m, n, k, br, lda, ldb, ldc, sa, sb, beta0, bias, relu)
+    if row_blocks:
+        sel = np.concatenate([np.arange(offs[2] + r * ldc, offs[2] + r * ldc + n)
+                              for (r0, rr) in row_blocks for r in range(r0, r0 + rr)])
+        check_close(got[sel], Cref[sel], dt, what)
+    else:
+        check_close(got, Cref, dt, what)
+    # bytes outside the m x n window (ldc padding, guard elements) must be untouched
+    mask = np.ones(C.size, dtype=bool)
+    for i in range(m):
+        mask[offs[2] + i * ldc: offs[2] + i * ldc + n] = False
+    assert np.array_equal(got[mask], C[mask]), what + ": wrote outside the output window"
+    return name
+
+
+F32_FAST = [
+    # (m, n, k, br, kwargs) - every fast tile variant, both epilogue flavours
+    (1024, 1024, 64, 16, dict(lda=1024, ldb=1024, sa=64, sb=65536)),                # C2: 64x64 tiles
+    (1024, 1024, 64, 16, dict(lda=1024, ldb=1024, sa=64, sb=65536, beta0=True)),
+    (512, 1024, 64, 16, dict(lda=1024, ldb=1024, sa=64, sb=65536, beta0=True, bias=True, relu=True)),  # C3
+    (256, 1024, 64, 4, dict(lda=256, ldb=1024, sa=64, sb=65536, bias=True)),        # 32x32 k-split 4
+    (64, 64, 64, 1, dict()),
+    (64, 64, 128, 3, dict(relu=True)),
+    (128, 192, 64, 2, dict(ldc=200, offs=(4, 8, 3, 1))),
+    (4096, 1024, 64, 5, dict(lda=320, ldb=1024, sa=64, sb=65536, beta0=True)),      # 128x64 tiles
+    (64, 64, 64, 0, dict()),                                                       # empty batch: C unchanged
+    (64, 64, 64, 0, dict(beta0=True, bias=True)),                                   # empty batch: C = bias
+]
+
+
+@pytest.mark.parametrize("case", F32_FAST, ids=lambda c: "m%d_n%d_k%d_br%d_%s" % (
+    c[0], c[1], c[2], c[3], "_".join(k for k in sorted(c[4]) if c[4][k] is True)))
+def test_brgemm_f32_fast_variants(rt, case):
+    m, n, k, br, kw = case
+    name = gemm_case(rt, F32, m, n, k, br, seed=m + n + k + br, **kw)
+    assert "fast" in name, name
+
+
+@pytest.mark.parametrize("variant,m,n", [(0, 128, 128), (1, 128, 96), (2, 96, 96), (3, 256, 128)])
+def test_brgemm_f32_forced_tile_variants(rt, variant, m, n):
+    gemm_case(rt, F32, m, n, 64, 4, sa=64, lda=256, sb=64 * n, beta0=False, bias=True, relu=True,
+              seed=variant, force=variant)
+
+
+RAGGED = [(3, 3, 4, 2), (5, 13, 10, 3), (33, 65, 70, 2), (6, 6, 6, 2), (1, 1, 1, 1), (10, 10, 10, 1),
+          (32, 32, 32, 32), (100, 40, 17, 4), (64, 64, 60, 2), (31, 200, 64, 1)]
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("shape", RAGGED, ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("mode", ["device", "host"])
+def test_brgemm_generic_ragged(rt, dt, shape, mode):
+    m, n, k, br = shape
+    gemm_case(rt, dt, m, n, k, br, lda=k + 3, ldb=n + 1, ldc=n + 2, offs=(1, 2, 3, 1), seed=sum(shape),
+              bias=(m % 2 == 1), relu=(n % 2 == 1), beta0=(k % 2 == 0), mode=mode,
+              vnni=(dt == BF16 and k % 2 == 0))
+
+
+def test_brgemm_unaligned_pointers_fall_back(rt):
+    # fast shape, but A/B offsets break 16-byte alignment: the runtime must pick the generic kernel
+    gemm_case(rt, F32, 64, 64, 64, 2, offs=(1, 3, 0, 0), seed=5)
+
+
+def test_brgemm_overlapping_batches(rt):
+    # stride_a smaller than a matrix (xsmm-strided-brgemm.mlir:34-44; xsmm-ternary-bf16 uses stride 8 on 4x4)
+    gemm_case(rt, F32, 64, 64, 64, 6, lda=512, sa=64, sb=64, ldb=128, seed=9)
+    gemm_case(rt, BF16, 4, 4, 4, 64, sa=8, sb=8, vnni=True, seed=10)
+
+
+BF16_CASES = [
+    (4096, 1024, 64, 16, dict(lda=1024, ldb=1024, sa=64, sb=65536, beta0=True, bias=True, relu=True)),  # C4 layer
+    (256, 256, 64, 4, dict(beta0=True)),
+    (128, 128, 128, 2, dict()),                                  # beta = 1 reads bf16 C
+    (64, 192, 64, 3, dict(ldc=200, bias=True)),
+    (2048, 2048, 128, 16, dict(lda=2048, ldb=2048, sa=128, sb=128 * 2048, beta0=True)),  # C5 GEMM
+]
+
+
+@pytest.mark.parametrize("case", BF16_CASES, ids=lambda c: "m%d_n%d_k%d_br%d" % c[:4])
+def test_brgemm_bf16_vnni_fast(rt, case):
+    m, n, k, br, kw = case
+    blocks = None
+    if m * n * k * br > 2 ** 31:  # oracle time: check row samples instead (rows are independent)
+        blocks = [(0, 48), (m // 2 - 16, 40), (m - 40, 40)]
+    name = gemm_case(rt, BF16, m, n, k, br, vnni=True, seed=m + n, row_blocks=blocks, **kw)
+    assert "bf16" in name, name
+
+
+def test_brgemm_bf16_flat_b_generic(rt):
+    gemm_case(rt, BF16, 48, 40, 24, 3, vnni=False, seed=3, bias=True)
+
+
+# ---------------------------------------------------------------- unary / binary
+UNARY = [(1, 0), (1, 2), (1, 4), (1, 8), (5, 0), (5, 2), (5, 4), (5, 8), (2, 0), (2, 8)]
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("kind,flags", UNARY)
+@pytest.mark.parametrize("shape", [(3, 3, 0), (13, 40, 3), (256, 1024, 0), (64, 48, 16)])
+def test_unary_eltwise(rt, dt, kind, flags, shape):
+    m, n, pad = shape
+    rng = np.random.default_rng(kind * 100 + flags + m)
+    ldo = n + pad
+    ldi = {0: n + pad, 2: 1, 4: n, 8: 1}[flags]
+    X = rand(rng, m * max(ldi, 1) + n + 8, dt)
+    O = rand(rng, m * ldo + 8, dt)
+    ref = O.copy()
+    orc.unary(kind, dt, m, n, ldi, ldo, flags, X, 0, ref, 0)
+    h = rt.unary_dispatch(kind, dt, m, n, ldi, ldo, flags)
+    for mode in ("device", "host"):
+        if mode == "device":
+            dO = dev(O)
+            rt.unary(dt, h, dev(X), 0, dO, 0)
+            got = host(dO, O)
+        else:
+            got = O.copy()
+            rt.unary(dt, h, X, 0, got, 0)
+        assert np.array_equal(got, ref), "unary kind %d flags %d %s %s: not bit-identical to the oracle" % (
+            kind, flags, shape, mode)
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+def test_unary_scalar_invoke(rt, dt):
+    # the scalar operand is an f32 regardless of dtype (XsmmRunnerUtils.cpp:276-286)
+    for kind, val in ((1, 1.2345678), (5, -3.0), (2, 9.0)):
+        O = rand(np.random.default_rng(1), 16 * 40, dt)
+        ref = O.copy()
+        orc.unary_scalar(kind, dt, 16, 33, 1, 40, 8, val, ref, 0)
+        h = rt.unary_dispatch(kind, dt, 16, 33, 1, 40, 8)
+        dO = dev(O)
+        rt.unary_scalar(dt, h, val, dO, 0)
+        assert np.array_equal(host(dO, O), ref)
+
+
+def test_relu_in_place(rt):
+    X = rand(np.random.default_rng(2), 64 * 64, F32)
+    ref = np.maximum(X, 0).astype(np.float32)
+    h = rt.unary_dispatch(5, F32, 64, 64, 64, 64, 0)
+    dX = dev(X)
+    rt.unary(F32, h, dX, 0, dX, 0)
+    assert np.array_equal(host(dX, X), ref)
+    Xh = X.copy()
+    rt.unary(F32, h, Xh, 0, Xh, 0)  # host pointers aliasing exactly: one mirror
+    assert np.array_equal(Xh, ref)
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("shape", [(4, 8), (3, 5), (64, 64), (100, 37), (1024, 512)])
+def test_transpose_bit_exact(rt, dt, shape):
+    m, n = shape
+    X = rand(np.random.default_rng(m), m * (n + 1), dt)
+    O = np.zeros(n * (m + 2), dtype=X.dtype)
+    ref = O.copy()
+    orc.unary(29, dt, m, n, n + 1, m + 2, 0, X, 0, ref, 0)
+    h = rt.unary_dispatch(29, dt, m, n, n + 1, m + 2, 0)
+    dO = dev(O)
+    rt.unary(dt, h, dev(X), 0, dO, 0)
+    got = host(dO, O)
+    assert got.tobytes() == ref.tobytes()
+    # involution: transposing back restores the input window bit for bit
+    back = dev(np.zeros(m * (n + 1), dtype=X.dtype))
+    h2 = rt.unary_dispatch(29, dt, n, m, m + 2, n + 1, 0)
+    rt.unary(dt, h2, dO, 0, back, 0)
+    b = host(back, X).reshape(m, n + 1)[:, :n]
+    assert np.array_equal(b, X[: m * (n + 1)].reshape(m, n + 1)[:, :n])
+
+
+@pytest.mark.parametrize("shape", [(16, 16, 16, 16), (4, 4, 4, 4), (6, 10, 11, 12), (2048, 2048, 2048, 2048), (64, 40, 48, 40)])
+def test_vnni2_pack_bit_exact(rt, shape):
+    m, n, ldi, ldo = shape
+    X = rand(np.random.default_rng(n), m * ldi, BF16)
+    O = np.zeros((m // 2) * 2 * ldo + 8, dtype=np.uint16)
+    ref = O.copy()
+    orc.unary(28, BF16, m, n, ldi, ldo, 0, X, 0, ref, 0)
+    h = rt.unary_dispatch(28, BF16, m, n, ldi, ldo, 0)
+    dO = dev(O)
+    rt.unary(BF16, h, dev(X), 0, dO, 0)
+    assert host(dO, O).tobytes() == ref.tobytes()
+    # unpack property: out[(i/2)][j][i%2] read back in (i, j) order is the input
+    got = host(dO, O)[: (m // 2) * 2 * ldo].reshape(m // 2, ldo, 2)[:, :n, :]
+    assert np.array_equal(got.transpose(0, 2, 1).reshape(m, n), X.reshape(m, ldi)[:, :n])
+
+
+BIN_FLAGS = [0, 1, 2, 4, 8, 16, 32, 1 | 8, 4 | 2, 16 | 2, 4 | 32]
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("kind", [1, 2, 3, 4])
+@pytest.mark.parametrize("flags", BIN_FLAGS)
+def test_binary_eltwise(rt, dt, kind, flags):
+    for (m, n, pad) in ((4, 8, 0), (13, 37, 2), (128, 256, 0)):
+        rng = np.random.default_rng(kind * 1000 + flags * 10 + m)
+        ldo = n + pad
+
+        def ld_for(row, col, sc):
+            return 1 if flags & (row | sc) else (n if flags & col else n + pad)
+        ldl, ldr = ld_for(1, 4, 16), ld_for(2, 8, 32)
+        L = rand(rng, m * max(ldl, n) + 8, dt, 0.5, 2.0)
+        R = rand(rng, m * max(ldr, n) + 8, dt, 0.5, 2.0)
+        O = rand(rng, m * ldo + 8, dt)
+        ref = O.copy()
+        orc.binary(kind, dt, m, n, ldl, ldr, ldo, flags, L, 0, R, 0, ref, 0)
+        h = rt.binary_dispatch(kind, dt, m, n, ldl, ldr, ldo, flags)
+        dO = dev(O)
+        rt.binary(dt, h, dev(L), 0, dev(R), 0, dO, 0)
+        got = host(dO, O)
+        if kind == 4:  # division: device fp32 divide may differ from the host's in the last place
+            check_close(got, ref, dt, "binary div flags %d" % flags)
+            if dt == F32:
+                assert np.abs(got.astype(np.float64) - ref).max() <= 2.5e-7 * np.abs(ref).max()
+        else:
+            assert np.array_equal(got, ref), "binary kind %d flags %d (%d x %d)" % (kind, flags, m, n)
+
+
+def test_binary_out_aliases_input(rt):
+    X = rand(np.random.default_rng(4), 32 * 32, F32)
+    bias = rand(np.random.default_rng(5), 32, F32)
+    ref = (X.reshape(32, 32) + bias[None, :]).reshape(-1)
+    h = rt.binary_dispatch(1, F32, 32, 32, 32, 32, 32, 8)  # rhs = bcast_col_in1
+    dX = dev(X)
+    rt.binary(F32, h, dX, 0, dev(bias), 0, dX, 0)
+    assert np.array_equal(host(dX, X), ref)
+    h2 = rt.binary_dispatch(2, F32, 32, 32, 32, 32, 32, 0)  # lhs == rhs (DefaultPipeline/xsmm.mlir:19-21)
+    Xh = X.copy()
+    rt.binary(F32, h2, Xh, 0, Xh, 0, Xh, 0)
+    assert np.array_equal(Xh, X * X)
+
+
+# ---------------------------------------------------------------- BASELINE configs, properties
+def test_c2_full_size_and_properties(rt):
+    """BASELINE config 2: C[1024x1024] += sum_{b<16} A_b[1024x64] B_b[64x1024], f32, with
+    tpp-run's `normal` init stream (seed 123) and with a sign-cancelling uniform stream."""
+    import torch
+    m = n = 1024
+    k, br = 64, 16
+    gen = orc.TensorInit("normal", 123)
+    for trial, (A, B, C) in enumerate([
+            (gen.fill(m * 1024), gen.fill(1024 * n), gen.fill(m * n)),
+            tuple(rand(np.random.default_rng(s), 1024 * 1024, F32) for s in (1, 2, 3))]):
+        ref = C.copy()
+        orc.fused_brgemm_omp(F32, m, n, k, 1024, 1024, 1024, 64, 65536, 0, 0, 0, A, B, ref, None, br)
+        h = rt.brgemm_dispatch(F32, m, n, k, 1024, 1024, 1024, 64, 65536, 0)
+        dA, dB, dC = dev(A), dev(B), dev(C)
+        rt.brgemm(F32, h, dA, 0, dB, 0, dC, 0, br)
+        got = host(dC, C)
+        check_close(got, ref, F32, "C2 trial %d" % trial)
+        # determinism: same inputs -> bit-identical output (no atomics, fixed summation order)
+        dC2 = dev(C)
+        rt.brgemm(F32, h, dA, 0, dB, 0, dC2, 0, br)
+        assert torch.equal(dC, dC2)
+        # beta: (beta=1 from C) == (beta=0 result) + C up to one rounding of the final add
+        h0 = rt.brgemm_dispatch(F32, m, n, k, 1024, 1024, 1024, 64, 65536, 4)
+        dZ = dev(np.zeros_like(C))
+        rt.brgemm(F32, h0, dA, 0, dB, 0, dZ, 0, br)
+        alt = host(dZ, C).astype(np.float64) + C
+        assert np.abs(alt - got).max() <= 1e-5 * max(1.0, np.abs(got).max())
+        # linearity in A: scaling A by 2 (exact in binary fp) doubles the beta=0 product bit for bit
+        dZ2 = dev(np.zeros_like(C))
+        rt.brgemm(F32, h0, dev(A * np.float32(2)), 0, dB, 0, dZ2, 0, br)
+        assert torch.equal(dZ2, dZ * 2)
+        # the same problem as ONE batch of k = 1024 (stride irrelevant) must agree to rounding
+        h1 = rt.brgemm_dispatch(F32, m, n, 1024, 1024, 1024, 1024, 0, 0, 4)
+        dZ3 = dev(np.zeros_like(C))
+        rt.brgemm(F32, h1, dA, 0, dB, 0, dZ3, 0, 1)
+        assert torch.equal(dZ3, dZ)  # identical chunk order -> identical bits
+
+
+def test_c3_fused_layer_full_size(rt):
+    m, n, k, br = 512, 1024, 64, 16
+    gen = orc.TensorInit("normal", 123)
+    A, W, bias = gen.fill(m * 1024), gen.fill(1024 * n), gen.fill(n)
+    A -= np.float32(0.05)  # make relu actually clip something
+    C = np.full(m * n, np.float32(7.0))
+    ref = C.copy()
+    orc.fused_brgemm_omp(F32, m, n, k, 1024, 1024, 1024, 64, 65536, 4, 5, 1, A, W, ref, bias, br)
+    h = rt.fused_brgemm_dispatch(F32, m, n, k, 1024, 1024, 1024, 64, 65536, 4, 0, 5, 4, 1)
+    dC = dev(C)
+    rt.fused_brgemm(F32, h, dev(A), 0, dev(W), 0, dC, 0, dev(bias), 0, br)
+    got = host(dC, C)
+    check_close(got, ref, F32, "C3 fused layer")
+    assert (got >= 0).all() and (got == 0).any()
+    # relu idempotence: applying xsmm.unary relu to the output changes nothing
+    hr = rt.unary_dispatch(5, F32, m, n, n, n, 0)
+    dC2 = dC.clone()
+    rt.unary(F32, hr, dC2, 0, dC2, 0)
+    import torch
+    assert torch.equal(dC, dC2)
+
+
+def test_c4_mlp_bf16_three_layers(rt):
+    """BASELINE config 4 on one GPU: 3 x (4096x1024x1024 bf16, bias + relu), VNNI-2 weights
+    produced by the runtime's own pack op; oracle on a row sample (rows are independent)."""
+    spec = pkg.MlpSpec()
+    rng = np.random.default_rng(0)
+    N = 1024
+    X = orc.f32_to_bf16(rng.normal(0, 0.5, spec.batch * N).astype(np.float32))
+    Wflat = [orc.f32_to_bf16(rng.normal(0, 0.04, N * N).astype(np.float32)) for _ in range(3)]
+    biases = [orc.f32_to_bf16(rng.normal(0, 0.1, N).astype(np.float32)) for _ in range(3)]
+    hp = rt.unary_dispatch(28, BF16, N, N, N, N, 0)
+    dW = []
+    for w in Wflat:
+        o = dev(np.zeros(N * N, np.uint16))
+        rt.unary(BF16, hp, dev(w), 0, o, 0)
+        dW.append(o)
+    mlp = pkg.ShardedMlp(spec, 0, 1, rt)
+    acts = [dev(np.zeros(spec.batch * N, np.uint16)) for _ in range(3)]
+    out = mlp.forward(dev(X), dW, [dev(b) for b in biases], acts)
+    rt.synchronize()
+    got = host(out, X).reshape(spec.batch, N)
+    rows = np.r_[0:64, 2000:2032, 4064:4096]
+    cur = X.reshape(spec.batch, N)[rows].copy().reshape(-1)
+    for l in range(3):
+        wv = np.zeros(N * N, np.uint16)
+        orc.unary(28, BF16, N, N, N, N, 0, Wflat[l], 0, wv, 0)
+        nxt = np.zeros(len(rows) * N, np.uint16)
+        orc.fused_brgemm(BF16, len(rows), N, 64, N, N, N, 64, 64 * N, 4 | VB, 0, 5, 4, 1, cur, 0, wv, 0, nxt, 0,
+                         biases[l], 0, 16)
+        cur = nxt
+    ref = orc.bf16_to_f32(cur).reshape(len(rows), N).astype(np.float64)
+    g = orc.bf16_to_f32(got[rows].reshape(-1)).reshape(len(rows), N).astype(np.float64)
+    # three chained bf16 layers: a one-ulp flip in layer l perturbs layer l+1; reference tolerance
+    # for bf16 differential tests is fpcmp -r 0.01 (vnni-xsmm-vs-loops.mlir:13)
+    denom = np.maximum(np.abs(ref), 1e-2)
+    assert (np.abs(g - ref) / denom).max() <= 0.01, float((np.abs(g - ref) / denom).max())
+    assert np.mean(g == ref) > 0.5  # and most outputs are bit-identical
+
+
+def test_async_mode_and_stream(rt):
+    import torch
+    X = rand(np.random.default_rng(8), 256 * 256, F32)
+    h = rt.brgemm_dispatch(F32, 256, 256, 64, 256, 256, 256, 64, 64 * 256, 4)
+    dA, dB = dev(X), dev(X[::-1].copy())
+    sync_out = dev(np.zeros(256 * 256, np.float32))
+    rt.brgemm(F32, h, dA, 0, dB, 0, sync_out, 0, 4)
+    s = torch.cuda.Stream()
+    prev = rt.set_async(True)
+    try:
+        rt.set_stream(s)
+        outs = [dev(np.zeros(256 * 256, np.float32)) for _ in range(8)]
+        torch.cuda.synchronize()
+        t0 = rt.perf_start_timer()
+        for o in outs:
+            rt.brgemm(F32, h, dA, 0, dB, 0, o, 0, 4)
+        dt = rt.perf_stop_timer(t0)  # drains the stream
+        assert dt > 0
+        for o in outs:
+            assert torch.equal(o, sync_out)
+    finally:
+        rt.set_stream(None)
+        rt.set_async(prev)
+
+
+def test_concurrent_invokes_on_disjoint_tiles(rt):
+    """invoke is re-entrant: the reference calls it from OpenMP workers on disjoint output
+    tiles with one shared handle (pass-convert-mlp-to-parallel-tile.mlir:80-88)."""
+    rng = np.random.default_rng(11)
+    A, B = rand(rng, 8 * 32 * 32 * 4, F32), rand(rng, 8 * 32 * 32 * 4, F32)
+    C = np.zeros(8 * 8 * 32 * 32, np.float32)
+    ref = C.copy()
+    h = rt.brgemm_dispatch(F32, 32, 32, 32, 32, 32, 32, 1024, 1024, 4)
+    tiles = [(i, j) for i in range(8) for j in range(8)]
+    for (i, j) in tiles:
+        orc.brgemm(F32, 32, 32, 32, 32, 32, 32, 1024, 1024, 4, A, i * 4096, B, j * 4096, ref, (i * 8 + j) * 1024, 4)
+
+    def worker(chunk):
+        for (i, j) in chunk:
+            rt.brgemm(F32, h, A, i * 4096, B, j * 4096, C, (i * 8 + j) * 1024, 4)
+    ths = [threading.Thread(target=worker, args=(tiles[w::4],)) for w in range(4)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    check_close(C, ref, F32, "concurrent tiles")

@@ -1,0 +1,66 @@
+"""Builds libtpp_xsmm_runner_utils.so (the drop-in for the reference's library of the
+same name, runtime/Xsmm/CMakeLists.txt:1-11) with hipcc for gfx950, in-tree.
+
+hipcc cross-compiles without a GPU. The built .so is git-ignored but travels with
+the repo snapshot to the GPU box, so nothing is compiled there.
+"""
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+SO_NAME = "libtpp_xsmm_runner_utils.so"
+SO_PATH = os.path.join(HERE, SO_NAME)
+SOURCES = ["runtime.cpp", "brgemm_f32.hip", "brgemm_bf16.hip", "eltwise.hip"]
+HEADERS = ["xsmm_desc.h", "gemm_common.h", os.path.join("..", "..", "include", "tpp_xsmm_abi.h")]
+ARCH = "gfx950"
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found; cannot build the gfx950 runtime")
+    return exe
+
+
+def _stale():
+    if not os.path.exists(SO_PATH):
+        return True
+    t = os.path.getmtime(SO_PATH)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """compile every HIP translation unit for gfx950 and link the shared library"""
+    if not force and not _stale():
+        return SO_PATH
+    cc = hipcc()
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        cmd = [cc] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed on %s:\n%s" % (src, r.stderr))
+        return obj
+
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", SO_PATH] + objs
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n" + r.stderr)
+    return SO_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,404 @@
+// brgemm_f32.hip - f32 batch-reduce GEMM for gfx950 on v_mfma_f32_32x32x2_f32.
+//
+// Semantics (reference: xsmm.brgemm / xsmm.fused_brgemm, XsmmOps.td:128-181,281-308;
+// runtime/Xsmm/XsmmRunnerUtils.cpp:288-457):
+//   C[m x n] = relu?( (beta0 ? 0 : C) + sum_{b<br} A_b[m x k] * B_b[k x n]  (+ bias[n]) )
+// row-major, A_b = A + b*stride_a, B_b = B + b*stride_b (elements).
+//
+// Kernel structure (one workgroup per output tile; no split-K across workgroups,
+// so results are deterministic and each element is an f32 fma chain):
+//   * workgroup tile (32*WM) x (32*WN), WM*WN*WK waves; each wave owns one 32x32
+//     accumulator tile (16 VGPRs) and 1/WK of every K chunk; WK>1 partial sums are
+//     combined once through LDS at the end.
+//   * the batch-reduce loop IS the K loop: chunk t = (batch t / (k/64), 64 columns of
+//     k). A/B panels go HBM -> VGPR (global_load_dwordx4, issued 1.5 chunks ahead)
+//     -> LDS (ds_write_b128) -> MFMA fragments, through a 3-slot LDS ring.
+//   * ONE barrier per chunk, placed in the MIDDLE of the chunk's MFMA stream: chunk
+//     t+1 is published while chunk t still has MFMAs to issue, so no wave ever
+//     waits for data at a chunk boundary.
+//   * A is stored in LDS as [row][64 k] with the 16-byte column index XOR (row&15):
+//     the per-lane ds_read_b128 of 4 consecutive k is bank-conflict free. A lane's
+//     4 values feed 4 successive MFMAs; lane-half h therefore covers k = 8q+4h+s at
+//     step s (a fixed permutation of k inside each block of 8 - any order is a valid
+//     summation order). B is stored [k][n] linear and read with ds_read_b32
+//     (conflict free: 32 consecutive columns per lane group).
+#include "gemm_common.h"
+#include "xsmm_desc.h"
+#include <stdio.h>
+#include <string.h>
+#include <type_traits>
+
+namespace tpp {
+
+constexpr int BK = 64;     // k columns per chunk
+constexpr int NSTAGE = 3;  // LDS ring slots
+
+template <int WM, int WN, int WK, int NACC>
+__global__ __launch_bounds__(64 * WM * WN * WK) void brgemm_f32_fast(GemmArgs p) {
+  constexpr int BM = 32 * WM, BN = 32 * WN, NT = 64 * WM * WN * WK;
+  constexpr int A_STAGE = BM * BK, B_STAGE = BK * BN; // floats
+  constexpr int LA = (BM * BK / 4) / NT, LB = (BK * BN / 4) / NT;
+  constexpr int KB_PER_WAVE = 8 / WK;                  // k-blocks (of 8) per wave per chunk
+  constexpr int KB_HALF = KB_PER_WAVE / 2;
+  static_assert(LA >= 1 && LB >= 1 && KB_HALF >= 1, "tile too small for this thread count");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *As = smem;
+  float *Bs = smem + NSTAGE * A_STAGE;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wk = wave / (WM * WN), wmn = wave % (WM * WN), wm = wmn / WN, wn = wmn % WN;
+  const int li = lane & 31, lh = lane >> 5;
+  int tm, tn;
+  tile_of_block(blockIdx.x, p.tiles_m, p.tiles_n, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const float *__restrict__ A = (const float *)p.A;
+  const float *__restrict__ B = (const float *)p.B;
+  float *__restrict__ C = (float *)p.C;
+  const int kchunks = p.k / BK;
+  const int T = p.br * kchunks;
+
+  // accumulators: wk == 0 starts from C (beta = 1) so the chain is C + sum, as in
+  // the reference; other K groups start from zero.
+  f32x16 acc[NACC];
+#pragma unroll
+  for (int a = 0; a < NACC; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[a][r] = 0.0f;
+  const int crow0 = m0 + wm * 32 + 4 * lh, ccol = n0 + wn * 32 + li;
+  if (!(p.ep & EP_BETA0) && wk == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      acc[0][r] = C[(int64_t)(crow0 + (r & 3) + 8 * (r >> 2)) * p.ldc + ccol];
+  }
+
+  // staging registers of the chunk in flight (HBM -> VGPR -> LDS). Items 0..LA-1 are
+  // A pieces, LA..LA+LB-1 are B pieces; `part` p of 4 handles items u with u % 4 == p so
+  // the loads / LDS writes can be spread between the MFMAs of one k-block step.
+  f32x4 rs[LA + LB];
+  const float *gA = nullptr, *gB = nullptr;
+  auto gaddr = [&](int t) {
+    const int b = t / kchunks, kk0 = (t - b * kchunks) * BK;
+    gA = A + (int64_t)b * p.stride_a + (int64_t)m0 * p.lda + kk0;
+    gB = B + (int64_t)b * p.stride_b + (int64_t)kk0 * p.ldb + n0;
+  };
+  auto gload_part = [&](int part) {
+#pragma unroll
+    for (int u = 0; u < LA + LB; ++u) {
+      if ((u & 3) != part) continue;
+      if (u < LA) {
+        const int q = tid + u * NT, row = q >> 4, c = q & 15;
+        rs[u] = *(const f32x4 *)(gA + (int64_t)row * p.lda + 4 * c);
+      } else {
+        const int q = tid + (u - LA) * NT, krow = q / (BN / 4), c = q % (BN / 4);
+        rs[u] = *(const f32x4 *)(gB + (int64_t)krow * p.ldb + 4 * c);
+      }
+    }
+  };
+  auto swrite_part = [&](int stage, int part) {
+    float *as = As + stage * A_STAGE, *bs = Bs + stage * B_STAGE;
+#pragma unroll
+    for (int u = 0; u < LA + LB; ++u) {
+      if ((u & 3) != part) continue;
+      if (u < LA) {
+        const int q = tid + u * NT, row = q >> 4, c = q & 15;
+        *(f32x4 *)(as + row * BK + ((c ^ (row & 15)) << 2)) = rs[u];
+      } else {
+        const int q = tid + (u - LA) * NT, krow = q / (BN / 4), c = q % (BN / 4);
+        *(f32x4 *)(bs + krow * BN + 4 * c) = rs[u];
+      }
+    }
+  };
+  // MFMA fragments of one k-block (8 k): 4 A values (one ds_read_b128) and 4 B values
+  // per lane; double-buffered so block q+1 is read while block q multiplies.
+  f32x4 fa[2];
+  float fb[2][4];
+  const int a_off = (wm * 32 + li) * BK, b_off = wn * 32 + li;
+  auto frag_load = [&](int buf, int stage, int kb) {
+    const float *as = As + stage * A_STAGE + a_off;
+    const float *bs = Bs + stage * B_STAGE + b_off;
+    fa[buf] = *(const f32x4 *)(as + (((2 * kb + lh) ^ (li & 15)) << 2));
+#pragma unroll
+    for (int s = 0; s < 4; ++s) fb[buf][s] = bs[(8 * kb + 4 * lh + s) * BN];
+  };
+
+  const int kbw = wk * KB_PER_WAVE;
+  // one chunk: KB_PER_WAVE k-block steps of 4 MFMAs. HAS_NEXT: chunk t+1 exists (its
+  // registers are written to the next ring slot during step KB_HALF-1, then ONE barrier
+  // publishes it). HAS_NEXT2: chunk t+2 exists (its global loads are issued during step
+  // KB_HALF). The last step prefetches the first fragments of chunk t+1.
+  auto chunk = [&](int stage, int nstage, auto has_next, auto has_next2) {
+    constexpr bool HAS_NEXT = decltype(has_next)::value, HAS_NEXT2 = decltype(has_next2)::value;
+#pragma unroll
+    for (int q = 0; q < KB_PER_WAVE; ++q) {
+      const int cur = q & 1, nxt = cur ^ 1;
+      if (q + 1 < KB_PER_WAVE) frag_load(nxt, stage, kbw + q + 1);
+      else if (HAS_NEXT) frag_load(nxt, nstage, kbw);
+      // pin the issue order: the fragment reads of step q+1 stay ABOVE the MFMAs of
+      // step q, and each piece of staging work sits in the shadow of one MFMA (the
+      // wave is in-order: it idles at the next MFMA until the matrix pipe frees up).
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        acc[s % NACC] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][s], fb[cur][s], acc[s % NACC], 0, 0, 0);
+        if (HAS_NEXT && q == KB_HALF - 1) swrite_part(nstage, s);
+        if (HAS_NEXT2 && q == KB_HALF) gload_part(s);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (q == KB_HALF - 1) __syncthreads();
+    }
+  };
+  using yes = std::integral_constant<bool, true>;
+  using no = std::integral_constant<bool, false>;
+
+  if (T > 0) {
+    gaddr(0);
+#pragma unroll
+    for (int part = 0; part < 4; ++part) gload_part(part);
+#pragma unroll
+    for (int part = 0; part < 4; ++part) swrite_part(0, part);
+    if (T > 1) {
+      gaddr(1);
+#pragma unroll
+      for (int part = 0; part < 4; ++part) gload_part(part);
+    }
+  }
+  __syncthreads();
+  if (T > 0) frag_load(0, 0, kbw);
+  int stage = 0, t = 0;
+  for (; t + 2 < T; ++t) {
+    const int nstage = stage + 1 == NSTAGE ? 0 : stage + 1;
+    gaddr(t + 2);
+    chunk(stage, nstage, yes{}, yes{});
+    stage = nstage;
+  }
+  if (t + 1 < T) {
+    const int nstage = stage + 1 == NSTAGE ? 0 : stage + 1;
+    chunk(stage, nstage, yes{}, no{});
+    stage = nstage;
+    ++t;
+  }
+  if (t < T) chunk(stage, stage, no{}, no{});
+
+#pragma unroll
+  for (int a = 1; a < NACC; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][r] += acc[a][r];
+
+  if constexpr (WK > 1) {
+    // combine the K groups through LDS: group g>0 parks its 32x32 partial, group 0 adds
+    __syncthreads();
+    float *red = smem; // (WK-1) * WM*WN * 16 * 64 floats, fits in the ring
+    if (wk > 0) {
+      float *dst = red + ((wk - 1) * (WM * WN) + wmn) * 1024 + lane;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[r * 64] = acc[0][r];
+    }
+    __syncthreads();
+    if (wk > 0) return;
+#pragma unroll
+    for (int g = 1; g < WK; ++g) {
+      const float *src = red + ((g - 1) * (WM * WN) + wmn) * 1024 + lane;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[0][r] += src[r * 64];
+    }
+  }
+
+  const float bias = (p.ep & EP_BIAS) ? ((const float *)p.D)[ccol] : 0.0f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float v = acc[0][r] + bias;
+    if (p.ep & EP_RELU) v = v > 0.0f ? v : 0.0f;
+    C[(int64_t)(crow0 + (r & 3) + 8 * (r >> 2)) * p.ldc + ccol] = v;
+  }
+}
+
+// ---- generic kernel: any m/n/k/ld/alignment, f32 or bf16 storage, flat or VNNI-2 B.
+// Elements are widened to f32 on the way into LDS and the same f32 MFMA core runs
+// (bf16 x bf16 products are exact in f32, accumulation is f32: the reference's
+// "f32 compute for bf16" rule, XsmmRunnerUtils.cpp:127-129). One rounding at the store.
+template <typename T, bool VNNI, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void brgemm_generic(GemmArgs p) {
+  constexpr int BM = 32 * WM, BN = 32 * WN, NT = 64 * WM * WN;
+  __shared__ __attribute__((aligned(16))) float As[BM * BK];
+  __shared__ __attribute__((aligned(16))) float Bs[BK * BN];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int tm = blockIdx.x / p.tiles_n, tn = blockIdx.x % p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int kchunks = (p.k + BK - 1) / BK;
+  const int nchunk = p.br * kchunks;
+
+  f32x16 acc;
+  const int crow0 = m0 + wm * 32 + 4 * lh, ccol = n0 + wn * 32 + li;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = crow0 + (r & 3) + 8 * (r >> 2);
+    acc[r] = (!(p.ep & EP_BETA0) && row < p.m && ccol < p.n) ? Elem<T>::load(p.C, (int64_t)row * p.ldc + ccol) : 0.0f;
+  }
+
+  for (int t = 0; t < nchunk; ++t) {
+    const int b = t / kchunks, kk0 = (t - b * kchunks) * BK;
+    const int64_t abase = (int64_t)b * p.stride_a, bbase = (int64_t)b * p.stride_b;
+    __syncthreads();
+    for (int e = tid; e < BM * BK; e += NT) {
+      const int row = e / BK, kk = e % BK;
+      const int gr = m0 + row, gk = kk0 + kk;
+      const float v = (gr < p.m && gk < p.k) ? Elem<T>::load(p.A, abase + (int64_t)gr * p.lda + gk) : 0.0f;
+      As[row * BK + ((((kk >> 2) ^ (row & 15)) << 2) | (kk & 3))] = v;
+    }
+    for (int e = tid; e < BK * BN; e += NT) {
+      const int krow = e / BN, j = e % BN;
+      const int gk = kk0 + krow, gj = n0 + j;
+      float v = 0.0f;
+      if (gk < p.k && gj < p.n) {
+        const int64_t idx = VNNI ? (int64_t)(gk >> 1) * (2 * p.ldb) + 2 * (int64_t)gj + (gk & 1)
+                                 : (int64_t)gk * p.ldb + gj;
+        v = Elem<T>::load(p.B, bbase + idx);
+      }
+      Bs[krow * BN + j] = v;
+    }
+    __syncthreads();
+    const float *as = As + (wm * 32 + li) * BK;
+    const float *bs = Bs + wn * 32 + li;
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+      const f32x4 a4 = *(const f32x4 *)(as + (((2 * kb + lh) ^ (li & 15)) << 2));
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s], bs[(8 * kb + 4 * lh + s) * BN], acc, 0, 0, 0);
+    }
+  }
+
+  const float bias = ((p.ep & EP_BIAS) && ccol < p.n) ? Elem<T>::load(p.D, ccol) : 0.0f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = crow0 + (r & 3) + 8 * (r >> 2);
+    if (row < p.m && ccol < p.n) {
+      float v = acc[r] + bias;
+      if (p.ep & EP_RELU) v = v > 0.0f ? v : 0.0f;
+      Elem<T>::store(p.C, (int64_t)row * p.ldc + ccol, v);
+    }
+  }
+}
+
+// ---- host side ---------------------------------------------------------------
+enum GemmVariant : int {
+  V_F32_64x64 = 0,   // 4 waves 2x2x1
+  V_F32_64x32K2 = 1, // 4 waves 2x1x2
+  V_F32_32x32K4 = 2, // 4 waves 1x1x4
+  V_F32_128x64 = 3,  // 8 waves 4x2x1
+  V_GENERIC = 8,     // chosen per invoke when the fast preconditions fail
+  V_BF16_FAST = 16,  // brgemm_bf16.hip
+};
+
+template <int WM, int WN, int WK, int NACC>
+static hipError_t launch_fast(const GemmArgs &a, hipStream_t s) {
+  constexpr int BM = 32 * WM, BN = 32 * WN, NT = 64 * WM * WN * WK;
+  constexpr size_t lds = (size_t)NSTAGE * (BM * BK + BK * BN) * sizeof(float);
+  static bool attr_set = false;
+  auto kern = brgemm_f32_fast<WM, WN, WK, NACC>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  GemmArgs args = a;
+  args.tiles_m = a.m / BM;
+  args.tiles_n = a.n / BN;
+  hipLaunchKernelGGL(kern, dim3(args.tiles_m * args.tiles_n), dim3(NT), lds, s, args);
+  return hipGetLastError();
+}
+
+template <typename T, bool VNNI>
+static hipError_t launch_generic(const GemmArgs &a, hipStream_t s) {
+  GemmArgs args = a;
+  if (a.m <= 32 && a.n <= 32) {
+    args.tiles_m = (a.m + 31) / 32;
+    args.tiles_n = (a.n + 31) / 32;
+    hipLaunchKernelGGL((brgemm_generic<T, VNNI, 1, 1>), dim3(args.tiles_m * args.tiles_n), dim3(64), 0, s, args);
+  } else {
+    args.tiles_m = (a.m + 63) / 64;
+    args.tiles_n = (a.n + 63) / 64;
+    hipLaunchKernelGGL((brgemm_generic<T, VNNI, 2, 2>), dim3(args.tiles_m * args.tiles_n), dim3(256), 0, s, args);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_gemm_bf16_fast(const GemmDesc &d, const GemmArgs &a, hipStream_t s); // brgemm_bf16.hip
+bool bf16_fast_eligible(const GemmDesc &d);
+
+static int g_num_cus = 256;
+
+static int pick_f32_variant(const GemmDesc &d) {
+  if (d.k <= 0 || d.k % BK) return V_GENERIC;
+  if ((d.lda | d.ldb | d.stride_a | d.stride_b) & 3) return V_GENERIC;
+  const int64_t m = d.m, n = d.n;
+  auto tiles = [&](int bm, int bn) { return (m % bm == 0 && n % bn == 0) ? (m / bm) * (n / bn) : 0; };
+  // largest tile that still gives every CU a workgroup; else the smallest tile
+  if (tiles(128, 64) >= 2 * g_num_cus) return V_F32_128x64;
+  if (tiles(64, 64) >= g_num_cus) return V_F32_64x64;
+  if (tiles(64, 32) >= g_num_cus) return V_F32_64x32K2;
+  if (tiles(32, 32) > 0 && tiles(32, 32) >= tiles(64, 64) * 2 && tiles(64, 32) < g_num_cus) return V_F32_32x32K4;
+  if (tiles(64, 64) > 0) return V_F32_64x64;
+  if (tiles(64, 32) > 0) return V_F32_64x32K2;
+  if (tiles(32, 32) > 0) return V_F32_32x32K4;
+  return V_GENERIC;
+}
+
+static const char *variant_name(int v) {
+  switch (v) {
+  case V_F32_64x64: return "brgemm_f32_fast<64x64,k1>";
+  case V_F32_64x32K2: return "brgemm_f32_fast<64x32,k2>";
+  case V_F32_32x32K4: return "brgemm_f32_fast<32x32,k4>";
+  case V_F32_128x64: return "brgemm_f32_fast<128x64,k1>";
+  case V_BF16_FAST: return "brgemm_bf16_fast";
+  default: return "brgemm_generic";
+  }
+}
+
+bool plan_gemm(GemmDesc &d, int forced_variant) {
+  int v = V_GENERIC;
+  if (d.dtype == DT_F32 && !d.vnni_b) v = pick_f32_variant(d);
+  else if (d.dtype == DT_BF16 && bf16_fast_eligible(d)) v = V_BF16_FAST;
+  if (forced_variant >= 0 && d.dtype == DT_F32 && v != V_GENERIC) {
+    // honour the forced tile only if the shape divides it
+    const int bm[] = {64, 64, 32, 128}, bn[] = {64, 32, 32, 64};
+    if (forced_variant <= 3 && d.m % bm[forced_variant] == 0 && d.n % bn[forced_variant] == 0) v = forced_variant;
+    if (forced_variant == V_GENERIC) v = V_GENERIC;
+  } else if (forced_variant == V_GENERIC) {
+    v = V_GENERIC;
+  }
+  d.variant = v;
+  strncpy(d.name, variant_name(v), sizeof(d.name) - 1);
+  d.name[sizeof(d.name) - 1] = 0;
+  return true;
+}
+
+hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C, const void *D, int64_t br,
+                       hipStream_t stream) {
+  if (d.m <= 0 || d.n <= 0) return hipSuccess;
+  GemmArgs a;
+  a.A = A; a.B = B; a.C = C; a.D = D;
+  a.lda = d.lda; a.ldb = d.ldb; a.ldc = d.ldc; a.stride_a = d.stride_a; a.stride_b = d.stride_b;
+  a.m = (int)d.m; a.n = (int)d.n; a.k = (int)d.k; a.br = (int)(br < 0 ? 0 : br);
+  a.ep = (d.beta0 ? EP_BETA0 : 0) | (d.bias ? EP_BIAS : 0) | (d.relu ? EP_RELU : 0);
+  a.tiles_m = a.tiles_n = 0;
+  int v = d.variant;
+  const bool aligned16 = ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0;
+  if (v != V_GENERIC && !aligned16) v = V_GENERIC;
+  switch (v) {
+  case V_F32_64x64: return launch_fast<2, 2, 1, 2>(a, stream);
+  case V_F32_64x32K2: return launch_fast<2, 1, 2, 2>(a, stream);
+  case V_F32_32x32K4: return launch_fast<1, 1, 4, 2>(a, stream);
+  case V_F32_128x64: return launch_fast<4, 2, 1, 2>(a, stream);
+  case V_BF16_FAST: return launch_gemm_bf16_fast(d, a, stream);
+  default: break;
+  }
+  if (d.dtype == DT_F32) return launch_generic<float, false>(a, stream);
+  if (d.vnni_b) return launch_generic<unsigned short, true>(a, stream);
+  return launch_generic<unsigned short, false>(a, stream);
+}
+
+} // namespace tpp

@@ -1,0 +1,236 @@
+// eltwise.hip - the HBM-bound members of the xsmm op set for gfx950:
+//   unary  IDENTITY / ZERO / RELU with row / column / scalar broadcast
+//          (xsmm.unary, XsmmOps.td:30-70; XsmmUtils.cpp:105-126,254-288)
+//   unary  TRANSPOSE (m, n = INPUT dims, ConvertLinalgToXsmm.cpp:147-148)
+//   unary  VNNI2 pack [m][n] -> [m/2][n][2]  (ConvertLinalgToXsmm.cpp:1036-1083)
+//   binary ADD / MUL / SUB / DIV with per-operand broadcast
+//          (xsmm.binary, XsmmOps.td:72-120; XsmmUtils.cpp:193-252,290-352)
+// These kernels move 16 bytes per lane per access whenever shape/stride/alignment
+// allow (coalesced 1 KiB per wave-instruction) and fall back to element accesses
+// otherwise. bf16 arithmetic is done in f32 with one RNE rounding at the store;
+// IDENTITY / ZERO / TRANSPOSE / VNNI2 are bit-exact moves in the storage type
+// (XsmmRunnerUtils.cpp:29-59).
+#include "gemm_common.h"
+#include "xsmm_desc.h"
+
+namespace tpp {
+
+enum : int64_t { U_IDENTITY = 1, U_ZERO = 2, U_RELU = 5, U_VNNI2 = 28, U_TRANSPOSE = 29 };
+enum : int64_t { UF_ROW = 2, UF_COL = 4, UF_SCALAR = 8 };
+enum : int64_t { B_ADD = 1, B_MUL = 2, B_SUB = 3, B_DIV = 4 };
+enum : int64_t { BF_ROW0 = 1, BF_ROW1 = 2, BF_COL0 = 4, BF_COL1 = 8, BF_SC0 = 16, BF_SC1 = 32 };
+enum : int { BC_NONE = 0, BC_ROW = 1, BC_COL = 2, BC_SCALAR = 3 };
+
+template <typename T> struct Bits;
+template <> struct Bits<float> {
+  static __device__ __forceinline__ float to_f32(float v) { return v; }
+  static __device__ __forceinline__ float from_f32(float v) { return v; }
+};
+template <> struct Bits<unsigned short> {
+  static __device__ __forceinline__ float to_f32(unsigned short v) { return bf16_bits_to_f32(v); }
+  static __device__ __forceinline__ unsigned short from_f32(float v) { return f32_to_bf16_bits(v); }
+};
+
+template <typename T, int VEC> struct alignas(sizeof(T) * VEC) Pack { T v[VEC]; };
+
+template <typename T, int VEC>
+__device__ __forceinline__ Pack<T, VEC> load_operand(const T *p, int bc, int64_t i, int64_t j, int64_t ld) {
+  Pack<T, VEC> r;
+  if (bc == BC_NONE) {
+    r = *(const Pack<T, VEC> *)(p + i * ld + j);
+  } else if (bc == BC_COL) {
+    r = *(const Pack<T, VEC> *)(p + j);
+  } else {
+    const T s = bc == BC_ROW ? p[i * ld] : p[0];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) r.v[e] = s;
+  }
+  return r;
+}
+
+// IDENTITY / ZERO / RELU. Each thread owns VEC consecutive columns of one row.
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void unary_kernel(int op, int bc, int64_t m, int64_t n, int64_t ldi, int64_t ldo,
+                                                    const T *in, T *out, float scalar,
+                                                    int use_scalar) {
+  const int64_t nv = n / VEC, total = m * nv;
+  const T sc = use_scalar ? Bits<T>::from_f32(scalar) : T(0);
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = idx / nv, j = (idx - i * nv) * VEC;
+    Pack<T, VEC> x;
+    if (op == (int)U_ZERO) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) x.v[e] = T(0);
+    } else {
+      if (use_scalar) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) x.v[e] = sc;
+      } else {
+        x = load_operand<T, VEC>(in, bc, i, j, ldi);
+      }
+      if (op == (int)U_RELU) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const float f = Bits<T>::to_f32(x.v[e]);
+          x.v[e] = Bits<T>::from_f32(f > 0.0f ? f : 0.0f);
+        }
+      }
+    }
+    *(Pack<T, VEC> *)(out + i * ldo + j) = x;
+  }
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void binary_kernel(int op, int bc0, int bc1, int64_t m, int64_t n, int64_t ldl,
+                                                     int64_t ldr, int64_t ldo, const T *lhs, const T *rhs, T *out) {
+  const int64_t nv = n / VEC, total = m * nv;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = idx / nv, j = (idx - i * nv) * VEC;
+    const Pack<T, VEC> l = load_operand<T, VEC>(lhs, bc0, i, j, ldl);
+    const Pack<T, VEC> r = load_operand<T, VEC>(rhs, bc1, i, j, ldr);
+    Pack<T, VEC> o;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float a = Bits<T>::to_f32(l.v[e]), b = Bits<T>::to_f32(r.v[e]);
+      float c;
+      switch (op) {
+      case (int)B_ADD: c = a + b; break;
+      case (int)B_MUL: c = a * b; break;
+      case (int)B_SUB: c = a - b; break;
+      default: c = a / b; break;
+      }
+      o.v[e] = Bits<T>::from_f32(c);
+    }
+    *(Pack<T, VEC> *)(out + i * ldo + j) = o;
+  }
+}
+
+// out[j][i] = in[i][j], i < m, j < n. 64x64 tiles through LDS (row padded by one
+// element: column reads are bank-conflict free); both global sides are coalesced.
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(int64_t m, int64_t n, int64_t ldi, int64_t ldo,
+                                                        const T *__restrict__ in, T *__restrict__ out) {
+  __shared__ T tile[64][65];
+  const int64_t tiles_n = (n + 63) / 64;
+  const int64_t i0 = (blockIdx.x / tiles_n) * 64, j0 = (blockIdx.x % tiles_n) * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6; // 64 x 4
+#pragma unroll 4
+  for (int r = ty; r < 64; r += 4)
+    if (i0 + r < m && j0 + tx < n) tile[r][tx] = in[(i0 + r) * ldi + j0 + tx];
+  __syncthreads();
+#pragma unroll 4
+  for (int r = ty; r < 64; r += 4)
+    if (j0 + r < n && i0 + tx < m) out[(j0 + r) * ldo + i0 + tx] = tile[tx][r];
+}
+
+// VNNI-2 pack of 16-bit elements: out[(i/2)*(2*ldo) + 2*j + (i&1)] = in[i*ldi + j].
+// Vector path: a thread takes 8 columns of a row pair (2 x 16 B in, 2 x 16 B out).
+template <int VEC>
+__global__ __launch_bounds__(256) void vnni2_kernel(int64_t m, int64_t n, int64_t ldi, int64_t ldo,
+                                                    const unsigned short *__restrict__ in,
+                                                    unsigned short *__restrict__ out) {
+  const int64_t nv = n / VEC, total = (m / 2) * nv;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = idx / nv, j = (idx - r * nv) * VEC;
+    const Pack<unsigned short, VEC> e = *(const Pack<unsigned short, VEC> *)(in + (2 * r) * ldi + j);
+    const Pack<unsigned short, VEC> o = *(const Pack<unsigned short, VEC> *)(in + (2 * r + 1) * ldi + j);
+    Pack<unsigned int, VEC> w;
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) w.v[q] = (unsigned int)e.v[q] | ((unsigned int)o.v[q] << 16);
+    unsigned int *dst = (unsigned int *)(out + r * (2 * ldo) + 2 * j);
+    if constexpr (VEC == 8) {
+      *(Pack<unsigned int, 4> *)dst = *(const Pack<unsigned int, 4> *)&w.v[0];
+      *(Pack<unsigned int, 4> *)(dst + 4) = *(const Pack<unsigned int, 4> *)&w.v[VEC / 2];
+    } else {
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) {
+        out[r * (2 * ldo) + 2 * (j + q)] = e.v[q];
+        out[r * (2 * ldo) + 2 * (j + q) + 1] = o.v[q];
+      }
+    }
+  }
+}
+
+static inline int grid_for(int64_t total) {
+  int64_t blocks = (total + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048; // 256 CUs x 8 resident blocks, grid-stride the rest
+  return (int)blocks;
+}
+static inline bool aligned(const void *p, size_t a) { return (((uintptr_t)p) & (a - 1)) == 0; }
+
+template <typename T>
+static hipError_t launch_unary_t(const UnaryDesc &d, const void *in, float scalar, bool use_scalar, void *out,
+                                 hipStream_t s) {
+  constexpr int V = 16 / sizeof(T);
+  const int op = (int)d.op;
+  int bc = BC_NONE;
+  if (d.flags & UF_SCALAR) bc = BC_SCALAR;
+  else if (d.flags & UF_ROW) bc = BC_ROW;
+  else if (d.flags & UF_COL) bc = BC_COL;
+  if (op == (int)U_TRANSPOSE) {
+    const int64_t tiles = ((d.m + 63) / 64) * ((d.n + 63) / 64);
+    hipLaunchKernelGGL((transpose_kernel<T>), dim3((unsigned)tiles), dim3(256), 0, s, d.m, d.n, d.ldi, d.ldo,
+                       (const T *)in, (T *)out);
+    return hipGetLastError();
+  }
+  const bool reads = op != (int)U_ZERO && !use_scalar;
+  bool vec = d.n % V == 0 && d.ldo % V == 0 && aligned(out, 16);
+  if (reads && (bc == BC_NONE || bc == BC_COL)) vec = vec && aligned(in, 16) && (bc == BC_COL || d.ldi % V == 0);
+  if (vec)
+    hipLaunchKernelGGL((unary_kernel<T, V>), dim3(grid_for(d.m * (d.n / V))), dim3(256), 0, s, op, bc, d.m, d.n,
+                       d.ldi, d.ldo, (const T *)in, (T *)out, scalar, (int)use_scalar);
+  else
+    hipLaunchKernelGGL((unary_kernel<T, 1>), dim3(grid_for(d.m * d.n)), dim3(256), 0, s, op, bc, d.m, d.n, d.ldi,
+                       d.ldo, (const T *)in, (T *)out, scalar, (int)use_scalar);
+  return hipGetLastError();
+}
+
+hipError_t launch_unary(const UnaryDesc &d, const void *in, float scalar, bool use_scalar, void *out,
+                        hipStream_t s) {
+  if (d.m <= 0 || d.n <= 0) return hipSuccess;
+  if (d.op == U_VNNI2) {
+    const bool vec = d.n % 8 == 0 && d.ldi % 8 == 0 && (2 * d.ldo) % 8 == 0 && aligned(in, 16) && aligned(out, 16);
+    if (vec)
+      hipLaunchKernelGGL((vnni2_kernel<8>), dim3(grid_for((d.m / 2) * (d.n / 8))), dim3(256), 0, s, d.m, d.n, d.ldi,
+                         d.ldo, (const unsigned short *)in, (unsigned short *)out);
+    else
+      hipLaunchKernelGGL((vnni2_kernel<1>), dim3(grid_for((d.m / 2) * d.n)), dim3(256), 0, s, d.m, d.n, d.ldi, d.ldo,
+                         (const unsigned short *)in, (unsigned short *)out);
+    return hipGetLastError();
+  }
+  if (d.dtype == DT_F32) return launch_unary_t<float>(d, in, scalar, use_scalar, out, s);
+  return launch_unary_t<unsigned short>(d, in, scalar, use_scalar, out, s);
+}
+
+template <typename T>
+static hipError_t launch_binary_t(const BinaryDesc &d, const void *lhs, const void *rhs, void *out, hipStream_t s) {
+  constexpr int V = 16 / sizeof(T);
+  auto mode = [](int64_t f, int64_t row, int64_t col, int64_t sc) {
+    return (f & sc) ? BC_SCALAR : (f & row) ? BC_ROW : (f & col) ? BC_COL : BC_NONE;
+  };
+  const int bc0 = mode(d.flags, BF_ROW0, BF_COL0, BF_SC0), bc1 = mode(d.flags, BF_ROW1, BF_COL1, BF_SC1);
+  auto ok = [&](const void *p, int bc, int64_t ld) {
+    if (bc == BC_ROW || bc == BC_SCALAR) return true;
+    return aligned(p, 16) && (bc == BC_COL || ld % V == 0);
+  };
+  const bool vec = d.n % V == 0 && d.ldo % V == 0 && aligned(out, 16) && ok(lhs, bc0, d.ldi_lhs) && ok(rhs, bc1, d.ldi_rhs);
+  if (vec)
+    hipLaunchKernelGGL((binary_kernel<T, V>), dim3(grid_for(d.m * (d.n / V))), dim3(256), 0, s, (int)d.op, bc0, bc1,
+                       d.m, d.n, d.ldi_lhs, d.ldi_rhs, d.ldo, (const T *)lhs, (const T *)rhs, (T *)out);
+  else
+    hipLaunchKernelGGL((binary_kernel<T, 1>), dim3(grid_for(d.m * d.n)), dim3(256), 0, s, (int)d.op, bc0, bc1, d.m,
+                       d.n, d.ldi_lhs, d.ldi_rhs, d.ldo, (const T *)lhs, (const T *)rhs, (T *)out);
+  return hipGetLastError();
+}
+
+hipError_t launch_binary(const BinaryDesc &d, const void *lhs, const void *rhs, void *out, hipStream_t s) {
+  if (d.m <= 0 || d.n <= 0) return hipSuccess;
+  if (d.dtype == DT_F32) return launch_binary_t<float>(d, lhs, rhs, out, s);
+  return launch_binary_t<unsigned short>(d, lhs, rhs, out, s);
+}
+
+} // namespace tpp

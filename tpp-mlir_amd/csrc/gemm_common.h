@@ -1,0 +1,69 @@
+// gemm_common.h - device-side helpers shared by the BRGEMM kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tpp {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+enum : int { EP_BETA0 = 1, EP_BIAS = 2, EP_RELU = 4 };
+
+struct GemmArgs {
+  const void *A;
+  const void *B;
+  void *C;
+  const void *D;       // bias row (length n) when EP_BIAS
+  int64_t lda, ldb, ldc, stride_a, stride_b; // elements
+  int m, n, k, br;
+  int ep;              // EP_* bits
+  int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short h) {
+  return __uint_as_float(((unsigned int)h) << 16);
+}
+// round-to-nearest-even, NaN -> quiet NaN (same bit recipe as the oracle)
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
+  unsigned int u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static __device__ __forceinline__ float load(const void *p, int64_t i) { return ((const float *)p)[i]; }
+  static __device__ __forceinline__ void store(void *p, int64_t i, float v) { ((float *)p)[i] = v; }
+};
+template <> struct Elem<unsigned short> {
+  static __device__ __forceinline__ float load(const void *p, int64_t i) {
+    return bf16_bits_to_f32(((const unsigned short *)p)[i]);
+  }
+  static __device__ __forceinline__ void store(void *p, int64_t i, float v) {
+    ((unsigned short *)p)[i] = f32_to_bf16_bits(v);
+  }
+};
+
+// Workgroup id -> output tile, XCD-aware. Workgroup b is observed to run on XCD
+// b % 8 (each XCD has a private 4 MiB L2); give every XCD a compact 2-D block of
+// tiles so the A row-panels and B column-panels it touches are shared in its L2.
+// Pure speed choice: any bijection is correct.
+__device__ __forceinline__ void tile_of_block(int b, int tiles_m, int tiles_n, int &tm, int &tn) {
+  const int nt = tiles_m * tiles_n;
+  if ((nt & 7) == 0 && (tiles_m & 3) == 0 && (tiles_n & 1) == 0) {
+    const int xcd = b & 7, idx = b >> 3;          // idx in [0, nt/8)
+    const int bm = tiles_m >> 2, bn = tiles_n >> 1; // XCD grid 4 (M) x 2 (N), blocks bm x bn
+    const int xm = xcd >> 1, xn = xcd & 1;
+    tm = xm * bm + idx / bn;
+    tn = xn * bn + idx % bn;
+  } else {
+    tm = b / tiles_n;
+    tn = b % tiles_n;
+  }
+}
+
+} // namespace tpp

@@ -1,0 +1,474 @@
+// runtime.cpp - the dispatch/invoke C-ABI of tpp-mlir's runtime/Xsmm, served by
+// gfx950 HIP kernels. Mirrors /root/reference/runtime/Xsmm/XsmmRunnerUtils.cpp entry
+// point by entry point (same names, argument order and error behaviour:
+// message on stderr + exit(-1)); see include/tpp_xsmm_abi.h for the citations.
+//
+// Differences that follow from running on a discrete GPU (documented in DESIGN.md):
+//  * a handle is a pointer to an immutable descriptor (hash-consed, never freed)
+//    instead of a JIT'd function pointer;
+//  * data pointers are classified per invoke: device memory is used in place; host
+//    memory is mirrored (H2D, kernel, D2H) so host callers keep the reference's
+//    "results visible on return" contract;
+//  * there is NO CPU fallback: without a HIP device every invoke fails loudly.
+#include "../../include/tpp_xsmm_abi.h"
+#include "xsmm_desc.h"
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <vector>
+
+using namespace tpp;
+
+namespace {
+
+[[noreturn]] void die(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vfprintf(stderr, fmt, ap);
+  va_end(ap);
+  fputc('\n', stderr);
+  fflush(stderr);
+  exit(-1); // XsmmRunnerUtils.cpp:132-137 convention
+}
+
+#define HIP_OK(expr)                                                                               \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess) die("tpp-xsmm-hip: %s failed: %s (no CPU fallback exists)", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+struct Config {
+  std::atomic<int> async{0};
+  std::atomic<hipStream_t> stream{nullptr};
+  std::atomic<int> forced_variant{-1};
+  bool trace = false;
+  Config() {
+    if (const char *e = getenv("TPP_HIP_ASYNC")) async = atoi(e) != 0;
+    if (const char *e = getenv("TPP_HIP_TRACE")) trace = atoi(e) != 0;
+    if (const char *e = getenv("TPP_HIP_VARIANT")) forced_variant = atoi(e);
+  }
+};
+Config &cfg() {
+  static Config c;
+  return c;
+}
+
+// ---- handle registry: hash-cons descriptors by their dispatch tuple -----------------
+std::mutex g_mu;
+std::map<std::vector<int64_t>, void *> g_registry;
+
+template <typename Make> void *intern(const std::vector<int64_t> &key, Make make) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_registry.find(key);
+  if (it != g_registry.end()) return it->second;
+  void *p = make();
+  g_registry.emplace(key, p);
+  return p;
+}
+
+size_t esize(int64_t dtype) { return dtype == DT_F32 ? 4 : 2; }
+
+void check_dtype(const char *who, int64_t dtype) {
+  if (dtype != DT_F32 && dtype != DT_BF16) die("%s: unhandled data type %ld", who, (long)dtype);
+}
+
+// ---- device scratch for mirroring host operands (per thread, grow only) -------------
+struct Arena {
+  char *base = nullptr;
+  size_t cap = 0, used = 0;
+  char *alloc(size_t bytes) {
+    used = (used + 255) & ~size_t(255);
+    char *p = base + used;
+    used += bytes;
+    return p;
+  }
+  void reserve(size_t bytes, hipStream_t s) {
+    used = 0;
+    if (bytes <= cap) return;
+    if (base) {
+      HIP_OK(hipStreamSynchronize(s));
+      HIP_OK(hipFree(base));
+    }
+    cap = std::max(bytes, cap * 2);
+    HIP_OK(hipMalloc((void **)&base, cap));
+  }
+};
+thread_local Arena t_arena;
+
+bool is_device_ptr(const void *p) {
+  if (!p) return true; // nothing to mirror
+  hipPointerAttribute_t attr;
+  memset(&attr, 0, sizeof(attr));
+  hipError_t e = hipPointerGetAttributes(&attr, p);
+  if (e != hipSuccess) {
+    (void)hipGetLastError(); // plain malloc'd memory on older runtimes: invalid value
+    return false;
+  }
+  return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged || attr.type == hipMemoryTypeArray;
+}
+
+// One operand of an invoke: [ptr, ptr + bytes), read and/or written by the kernel.
+struct Operand {
+  void *ptr;
+  size_t bytes;
+  bool written;
+  void *dev; // resolved device pointer
+};
+
+// Resolve every operand to a device pointer. Device memory is used in place. Host
+// ranges are merged when they overlap (in-place relu, binary with out == lhs, C tiles
+// inside one buffer), mirrored into the arena and uploaded; the returned list says
+// what to download afterwards.
+struct Mirror {
+  char *host;
+  size_t bytes;
+  char *dev;
+  bool written;
+};
+std::vector<Mirror> stage_in(std::vector<Operand *> &ops, hipStream_t s) {
+  std::vector<Mirror> mirrors;
+  std::vector<Operand *> host_ops;
+  for (Operand *o : ops) {
+    if (!o->ptr || o->bytes == 0 || is_device_ptr(o->ptr)) o->dev = o->ptr;
+    else host_ops.push_back(o);
+  }
+  if (host_ops.empty()) return mirrors;
+  std::sort(host_ops.begin(), host_ops.end(), [](Operand *a, Operand *b) { return a->ptr < b->ptr; });
+  for (Operand *o : host_ops) {
+    char *b = (char *)o->ptr;
+    if (!mirrors.empty() && b < mirrors.back().host + mirrors.back().bytes) {
+      Mirror &m = mirrors.back();
+      m.bytes = std::max(m.bytes, (size_t)(b + o->bytes - m.host));
+      m.written |= o->written;
+    } else {
+      mirrors.push_back({b, o->bytes, nullptr, o->written});
+    }
+  }
+  size_t total = 0;
+  for (Mirror &m : mirrors) total += m.bytes + 512;
+  t_arena.reserve(total, s);
+  for (Mirror &m : mirrors) {
+    // keep the host address's offset within 256 B so alignment-dependent kernel
+    // choices see the caller's real alignment
+    m.dev = t_arena.alloc(m.bytes + 256) + (((uintptr_t)m.host) & 255);
+    HIP_OK(hipMemcpyAsync(m.dev, m.host, m.bytes, hipMemcpyHostToDevice, s));
+  }
+  for (Operand *o : host_ops)
+    for (Mirror &m : mirrors)
+      if ((char *)o->ptr >= m.host && (char *)o->ptr < m.host + m.bytes) {
+        o->dev = m.dev + ((char *)o->ptr - m.host);
+        break;
+      }
+  return mirrors;
+}
+
+void finish(std::vector<Mirror> &mirrors, hipStream_t s) {
+  if (!mirrors.empty()) {
+    for (Mirror &m : mirrors)
+      if (m.written) HIP_OK(hipMemcpyAsync(m.host, m.dev, m.bytes, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    return;
+  }
+  if (!cfg().async.load(std::memory_order_relaxed)) HIP_OK(hipStreamSynchronize(s));
+}
+
+template <typename D> const D *as_desc(int64_t handle, int kind, const char *who) {
+  const D *d = reinterpret_cast<const D *>(handle);
+  if (!d || d->kind != kind) die("%s: handle %ld was not produced by the matching dispatch", who, (long)handle);
+  return d;
+}
+
+size_t span(int64_t rows, int64_t ld, int64_t cols) { // elements of a rows x cols view
+  return rows <= 0 || cols <= 0 ? 0 : (size_t)((rows - 1) * ld + cols);
+}
+
+int64_t gemm_dispatch_common(const char *who, int has_batch, int fused, int64_t dtype, int64_t m, int64_t n,
+                             int64_t k, int64_t lda, int64_t ldb, int64_t ldc, int64_t stride_a,
+                             int64_t stride_b, int64_t flags, int64_t unary_flags, int64_t unary_kind,
+                             int64_t binary_flags, int64_t binary_kind) {
+  check_dtype(who, dtype);
+  if (m < 0 || n < 0 || k < 0 || lda < 0 || ldb < 0 || ldc < 0 || stride_a < 0 || stride_b < 0)
+    die("%s: negative dimension (m %ld n %ld k %ld lda %ld ldb %ld ldc %ld)", who, (long)m, (long)n, (long)k,
+        (long)lda, (long)ldb, (long)ldc);
+  // XsmmOps.cpp:335-340: lda >= k, ldb >= n, ldc >= n
+  if (lda < k || ldb < n || ldc < n)
+    die("%s: failed to generate func: expect lda >= k, ldb >= n, ldc >= n (M: %ld N: %ld K: %ld lda: %ld ldb: %ld ldc: %ld)",
+        who, (long)m, (long)n, (long)k, (long)lda, (long)ldb, (long)ldc);
+  const int64_t known = XSMM_GEMM_FLAG_BETA_0 | XSMM_GEMM_FLAG_NO_RESET_TILECONFIG |
+                        XSMM_GEMM_FLAG_NO_SETUP_TILECONFIG | XSMM_GEMM_WIRE_VNNI_B;
+  if (flags & ~known)
+    die("%s: unsupported gemm flags %ld (VNNI_A / VNNI_C operands and unknown bits are not implemented)", who,
+        (long)flags);
+  const bool vnni_b = (flags & XSMM_GEMM_WIRE_VNNI_B) != 0;
+  if (vnni_b && dtype != DT_BF16) die("%s: VNNI flags require bf16 (XsmmOps.cpp:292-298)", who);
+  if (vnni_b && (k & 1)) die("%s: VNNI-2 B operand needs an even k, got %ld", who, (long)k);
+  if (fused) {
+    if (unary_flags != 0) die("%s: unsupported unary flags %ld on a fused brgemm", who, (long)unary_flags);
+    if (unary_kind != XSMM_UNARY_NONE && unary_kind != XSMM_UNARY_RELU)
+      die("%s: unsupported fused unary kind %ld (only none/relu reach the runtime)", who, (long)unary_kind);
+    // ConvertXsmmToFunc.cpp:405-421: fused ADD is only lowered with bcast_col_in0
+    if (binary_kind == XSMM_BINARY_NONE) {
+      if (binary_flags != 0) die("%s: binary flags %ld without a binary op", who, (long)binary_flags);
+    } else if (!(binary_kind == XSMM_BINARY_ADD && binary_flags == XSMM_BINARY_FLAG_BCAST_COL_IN_0)) {
+      die("%s: unsupported fused binary op %ld with flags %ld (only add + bcast_col_in0)", who, (long)binary_kind,
+          (long)binary_flags);
+    }
+  }
+  std::vector<int64_t> key = {KIND_GEMM, has_batch, fused, dtype, m, n, k, lda, ldb, ldc, stride_a, stride_b,
+                              flags & (XSMM_GEMM_FLAG_BETA_0 | XSMM_GEMM_WIRE_VNNI_B), unary_kind, binary_kind,
+                              cfg().forced_variant.load()};
+  void *h = intern(key, [&]() {
+    GemmDesc *d = new GemmDesc();
+    memset(d, 0, sizeof(*d));
+    d->kind = KIND_GEMM;
+    d->has_batch = has_batch;
+    d->fused = fused;
+    d->dtype = dtype; d->m = m; d->n = n; d->k = k; d->lda = lda; d->ldb = ldb; d->ldc = ldc;
+    d->stride_a = stride_a; d->stride_b = stride_b; d->wire_flags = flags;
+    d->beta0 = (flags & XSMM_GEMM_FLAG_BETA_0) != 0;
+    d->vnni_b = vnni_b;
+    d->bias = fused && binary_kind == XSMM_BINARY_ADD;
+    d->relu = fused && unary_kind == XSMM_UNARY_RELU;
+    plan_gemm(*d, cfg().forced_variant.load());
+    if (cfg().trace)
+      fprintf(stderr, "[tpp-xsmm-hip] %s dtype %ld m %ld n %ld k %ld lda %ld ldb %ld ldc %ld sa %ld sb %ld flags %ld -> %s\n",
+              who, (long)dtype, (long)m, (long)n, (long)k, (long)lda, (long)ldb, (long)ldc, (long)stride_a,
+              (long)stride_b, (long)flags, d->name);
+    return (void *)d;
+  });
+  return reinterpret_cast<int64_t>(h);
+}
+
+void gemm_invoke_common(const char *who, bool want_fused, int64_t dtype, int64_t handle, void *a, int64_t off_a,
+                        void *b, int64_t off_b, void *c, int64_t off_c, void *dptr, int64_t off_d, int64_t br) {
+  const GemmDesc *d = as_desc<GemmDesc>(handle, KIND_GEMM, who);
+  if (d->dtype != dtype) die("%s: invoke dtype %ld != dispatch dtype %ld", who, (long)dtype, (long)d->dtype);
+  if (want_fused != (d->fused != 0)) die("%s: handle dispatched for a different gemm flavour", who);
+  if (br < 0) die("%s: negative batch count %ld", who, (long)br);
+  if (d->m == 0 || d->n == 0) return;
+  const size_t es = esize(dtype);
+  const int64_t kk = br > 0 ? d->k : 0;
+  Operand A{(char *)a + off_a * es, 0, false, nullptr}, B{(char *)b + off_b * es, 0, false, nullptr},
+      C{(char *)c + off_c * es, span(d->m, d->ldc, d->n) * es, true, nullptr},
+      D{dptr ? (char *)dptr + off_d * es : nullptr, d->bias ? (size_t)d->n * es : 0, false, nullptr};
+  if (kk > 0) {
+    A.bytes = ((size_t)(br - 1) * d->stride_a + span(d->m, d->lda, d->k)) * es;
+    const size_t bspan = d->vnni_b ? span((d->k + 1) / 2, 2 * d->ldb, 2 * d->n) : span(d->k, d->ldb, d->n);
+    B.bytes = ((size_t)(br - 1) * d->stride_b + bspan) * es;
+  }
+  if (d->bias && !dptr) die("%s: fused bias operand is null", who);
+  hipStream_t s = cfg().stream.load(std::memory_order_relaxed);
+  std::vector<Operand *> ops = {&A, &B, &C, &D};
+  std::vector<Mirror> mirrors = stage_in(ops, s);
+  HIP_OK(launch_gemm(*d, A.dev, B.dev, C.dev, D.dev, br, s));
+  finish(mirrors, s);
+}
+
+} // namespace
+
+// =============================== dispatch ==========================================
+extern "C" int64_t xsmm_gemm_dispatch(int64_t dtype, int64_t m, int64_t n, int64_t k, int64_t lda, int64_t ldb,
+                                      int64_t ldc, int64_t flags) {
+  return gemm_dispatch_common("xsmm_gemm_dispatch", 0, 0, dtype, m, n, k, lda, ldb, ldc, 0, 0, flags, 0, 0, 0, 0);
+}
+
+extern "C" int64_t xsmm_brgemm_dispatch(int64_t dtype, int64_t m, int64_t n, int64_t k, int64_t lda, int64_t ldb,
+                                        int64_t ldc, int64_t stride_a, int64_t stride_b, int64_t flags) {
+  return gemm_dispatch_common("xsmm_brgemm_dispatch", 1, 0, dtype, m, n, k, lda, ldb, ldc, stride_a, stride_b,
+                              flags, 0, 0, 0, 0);
+}
+
+extern "C" int64_t xsmm_fused_brgemm_dispatch(int64_t dtype, int64_t m, int64_t n, int64_t k, int64_t lda,
+                                              int64_t ldb, int64_t ldc, int64_t stride_a, int64_t stride_b,
+                                              int64_t gemm_flags, int64_t unary_flags, int64_t unary_kind,
+                                              int64_t binary_flags, int64_t binary_kind) {
+  return gemm_dispatch_common("xsmm_fused_brgemm_dispatch", 1, 1, dtype, m, n, k, lda, ldb, ldc, stride_a,
+                              stride_b, gemm_flags, unary_flags, unary_kind, binary_flags, binary_kind);
+}
+
+extern "C" int64_t xsmm_unary_dispatch(int64_t kind, int64_t dtype, int64_t m, int64_t n, int64_t ldi,
+                                       int64_t ldo, int64_t flags) {
+  const char *who = "xsmm_unary_dispatch";
+  check_dtype(who, dtype);
+  if (m < 0 || n < 0 || ldi < 0 || ldo < 0) die("%s: negative dimension", who);
+  switch (kind) {
+  case XSMM_UNARY_IDENTITY: case XSMM_UNARY_ZERO: case XSMM_UNARY_RELU:
+    if (flags != 0 && flags != XSMM_UNARY_FLAG_BCAST_ROW && flags != XSMM_UNARY_FLAG_BCAST_COL &&
+        flags != XSMM_UNARY_FLAG_BCAST_SCALAR)
+      die("failed to generate unary func\nop_type: %ld\nflags: %ld", (long)kind, (long)flags);
+    if (ldo < n) die("%s: ldo %ld < n %ld", who, (long)ldo, (long)n);
+    if (flags == 0 && kind != XSMM_UNARY_ZERO && ldi < n) die("%s: ldi %ld < n %ld", who, (long)ldi, (long)n);
+    break;
+  case XSMM_UNARY_TRANSPOSE: // m, n are the INPUT dims; output is n x m
+    if (flags != 0) die("%s: transpose takes no broadcast flags", who);
+    if (ldi < n || ldo < m) die("%s: transpose expects ldi >= n and ldo >= m (m %ld n %ld ldi %ld ldo %ld)", who,
+                               (long)m, (long)n, (long)ldi, (long)ldo);
+    break;
+  case XSMM_UNARY_VNNI2:
+    if (dtype != DT_BF16) die("%s: VNNI-2 packing is defined for bf16 only", who);
+    if (flags != 0) die("%s: vnni_2 takes no broadcast flags", who);
+    if (m & 1) die("%s: VNNI-2 packing needs an even number of rows, got %ld", who, (long)m);
+    if (ldi < n || ldo < n) die("%s: vnni_2 expects ldi >= n and ldo >= n", who);
+    break;
+  default:
+    die("failed to generate unary func\nop_type: %ld\nflags: %ld", (long)kind, (long)flags);
+  }
+  std::vector<int64_t> key = {KIND_UNARY, kind, dtype, m, n, ldi, ldo, flags};
+  void *h = intern(key, [&]() {
+    UnaryDesc *d = new UnaryDesc{KIND_UNARY, kind, dtype, m, n, ldi, ldo, flags};
+    return (void *)d;
+  });
+  return reinterpret_cast<int64_t>(h);
+}
+
+extern "C" int64_t xsmm_binary_dispatch(int64_t kind, int64_t dtype, int64_t m, int64_t n, int64_t ldi_lhs,
+                                        int64_t ldi_rhs, int64_t ldo, int64_t flags) {
+  const char *who = "xsmm_binary_dispatch";
+  check_dtype(who, dtype);
+  if (kind < XSMM_BINARY_ADD || kind > XSMM_BINARY_DIV)
+    die("failed to generate binary func\nop_type: %ld\nflags: %ld", (long)kind, (long)flags);
+  if (m < 0 || n < 0 || ldi_lhs < 0 || ldi_rhs < 0 || ldo < 0) die("%s: negative dimension", who);
+  if (flags & ~int64_t(63)) die("failed to generate binary func\nop_type: %ld\nflags: %ld", (long)kind, (long)flags);
+  auto one = [&](int64_t f) { return (f & (f - 1)) == 0; }; // at most one broadcast per operand
+  const int64_t f0 = flags & (1 | 4 | 16), f1 = flags & (2 | 8 | 32);
+  if (!one(f0) || !one(f1)) die("%s: conflicting broadcast flags %ld", who, (long)flags);
+  if (ldo < n) die("%s: ldo %ld < n %ld", who, (long)ldo, (long)n);
+  if (f0 == 0 && ldi_lhs < n) die("%s: ldi lhs %ld < n %ld", who, (long)ldi_lhs, (long)n);
+  if (f1 == 0 && ldi_rhs < n) die("%s: ldi rhs %ld < n %ld", who, (long)ldi_rhs, (long)n);
+  std::vector<int64_t> key = {KIND_BINARY, kind, dtype, m, n, ldi_lhs, ldi_rhs, ldo, flags};
+  void *h = intern(key, [&]() {
+    BinaryDesc *d = new BinaryDesc{KIND_BINARY, kind, dtype, m, n, ldi_lhs, ldi_rhs, ldo, flags};
+    return (void *)d;
+  });
+  return reinterpret_cast<int64_t>(h);
+}
+
+extern "C" int64_t xsmm_intel_amx_tile_config_dispatch(int64_t, int64_t, int64_t, int64_t, int64_t, int64_t,
+                                                       int64_t, int64_t, int64_t, int64_t) {
+  // AMX tile configuration has no meaning on CDNA4; the compiler emits these calls
+  // around every bf16 brgemm (IntelAMXTileConfig.cpp:36-118), so they must exist.
+  static AmxDesc amx{KIND_AMX};
+  return reinterpret_cast<int64_t>(&amx);
+}
+
+// =============================== invoke ============================================
+extern "C" void xsmm_gemm_invoke(int64_t dtype, int64_t handle, void *a, int64_t off_a, void *b, int64_t off_b,
+                                 void *c, int64_t off_c) {
+  gemm_invoke_common("xsmm_gemm_invoke", false, dtype, handle, a, off_a, b, off_b, c, off_c, nullptr, 0, 1);
+}
+
+extern "C" void xsmm_brgemm_invoke(int64_t dtype, int64_t handle, void *a, int64_t off_a, void *b, int64_t off_b,
+                                   void *c, int64_t off_c, int64_t num_batches) {
+  gemm_invoke_common("xsmm_brgemm_invoke", false, dtype, handle, a, off_a, b, off_b, c, off_c, nullptr, 0,
+                     num_batches);
+}
+
+extern "C" void xsmm_fused_brgemm_invoke(int64_t dtype, int64_t handle, void *a, int64_t off_a, void *b,
+                                         int64_t off_b, void *c, int64_t off_c, void *d, int64_t off_d,
+                                         int64_t num_batches) {
+  gemm_invoke_common("xsmm_fused_brgemm_invoke", true, dtype, handle, a, off_a, b, off_b, c, off_c, d, off_d,
+                     num_batches);
+}
+
+static void unary_invoke_common(const char *who, int64_t dtype, int64_t handle, void *in, int64_t off_in,
+                                float scalar, bool use_scalar, void *out, int64_t off_out) {
+  const UnaryDesc *d = as_desc<UnaryDesc>(handle, KIND_UNARY, who);
+  if (d->dtype != dtype) die("%s: invoke dtype %ld != dispatch dtype %ld", who, (long)dtype, (long)d->dtype);
+  if (d->m == 0 || d->n == 0) return;
+  const size_t es = esize(dtype);
+  Operand I{nullptr, 0, false, nullptr}, O{(char *)out + off_out * es, 0, true, nullptr};
+  if (use_scalar && (d->op == XSMM_UNARY_TRANSPOSE || d->op == XSMM_UNARY_VNNI2))
+    die("%s: scalar input is meaningless for op %ld", who, (long)d->op);
+  if (d->op == XSMM_UNARY_TRANSPOSE) O.bytes = span(d->n, d->ldo, d->m) * es;
+  else if (d->op == XSMM_UNARY_VNNI2) O.bytes = span(d->m / 2, 2 * d->ldo, 2 * d->n) * es;
+  else O.bytes = span(d->m, d->ldo, d->n) * es;
+  if (!use_scalar && d->op != XSMM_UNARY_ZERO) {
+    I.ptr = (char *)in + off_in * es;
+    if (d->flags & XSMM_UNARY_FLAG_BCAST_SCALAR) I.bytes = es;
+    else if (d->flags & XSMM_UNARY_FLAG_BCAST_ROW) I.bytes = span(d->m, d->ldi, 1) * es;
+    else if (d->flags & XSMM_UNARY_FLAG_BCAST_COL) I.bytes = (size_t)d->n * es;
+    else I.bytes = span(d->m, d->ldi, d->n) * es;
+  }
+  hipStream_t s = cfg().stream.load(std::memory_order_relaxed);
+  std::vector<Operand *> ops = {&I, &O};
+  std::vector<Mirror> mirrors = stage_in(ops, s);
+  HIP_OK(launch_unary(*d, I.dev, scalar, use_scalar, O.dev, s));
+  finish(mirrors, s);
+}
+
+extern "C" void xsmm_unary_invoke(int64_t dtype, int64_t handle, void *in, int64_t off_in, void *out,
+                                  int64_t off_out) {
+  unary_invoke_common("xsmm_unary_invoke", dtype, handle, in, off_in, 0.0f, false, out, off_out);
+}
+
+extern "C" void xsmm_unary_scalar_invoke(int64_t dtype, int64_t handle, float scalar, void *out, int64_t off_out) {
+  unary_invoke_common("xsmm_unary_scalar_invoke", dtype, handle, nullptr, 0, scalar, true, out, off_out);
+}
+
+extern "C" void xsmm_binary_invoke(int64_t dtype, int64_t handle, void *lhs, int64_t off_lhs, void *rhs,
+                                   int64_t off_rhs, void *out, int64_t off_out) {
+  const char *who = "xsmm_binary_invoke";
+  const BinaryDesc *d = as_desc<BinaryDesc>(handle, KIND_BINARY, who);
+  if (d->dtype != dtype) die("%s: invoke dtype %ld != dispatch dtype %ld", who, (long)dtype, (long)d->dtype);
+  if (d->m == 0 || d->n == 0) return;
+  const size_t es = esize(dtype);
+  auto in_bytes = [&](int64_t row, int64_t col, int64_t sc, int64_t ld) -> size_t {
+    if (d->flags & sc) return es;
+    if (d->flags & row) return span(d->m, ld, 1) * es;
+    if (d->flags & col) return (size_t)d->n * es;
+    return span(d->m, ld, d->n) * es;
+  };
+  Operand L{(char *)lhs + off_lhs * es, in_bytes(1, 4, 16, d->ldi_lhs), false, nullptr},
+      R{(char *)rhs + off_rhs * es, in_bytes(2, 8, 32, d->ldi_rhs), false, nullptr},
+      O{(char *)out + off_out * es, span(d->m, d->ldo, d->n) * es, true, nullptr};
+  hipStream_t s = cfg().stream.load(std::memory_order_relaxed);
+  std::vector<Operand *> ops = {&L, &R, &O};
+  std::vector<Mirror> mirrors = stage_in(ops, s);
+  HIP_OK(launch_binary(*d, L.dev, R.dev, O.dev, s));
+  finish(mirrors, s);
+}
+
+extern "C" void xsmm_intel_amx_tile_config_invoke(int64_t, int64_t, void *, int64_t) {}
+
+// =============================== timers ============================================
+// runtime/PerfRunnerUtils.cpp:23-35, plus a device drain so queued launches count.
+extern "C" int64_t perf_start_timer(void) {
+  return std::chrono::duration_cast<std::chrono::nanoseconds>(
+             std::chrono::high_resolution_clock::now().time_since_epoch())
+      .count();
+}
+
+extern "C" double perf_stop_timer(int64_t start) {
+  if (cfg().async.load()) (void)hipStreamSynchronize(cfg().stream.load());
+  const int64_t now = std::chrono::duration_cast<std::chrono::nanoseconds>(
+                          std::chrono::high_resolution_clock::now().time_since_epoch())
+                          .count();
+  return (double)(now - start) * 1e-9;
+}
+
+// =============================== extensions ========================================
+extern "C" int xsmm_hip_set_async(int enable) { return cfg().async.exchange(enable != 0); }
+extern "C" void xsmm_hip_set_stream(void *s) { cfg().stream.store((hipStream_t)s); }
+extern "C" void *xsmm_hip_get_stream(void) { return (void *)cfg().stream.load(); }
+extern "C" void xsmm_hip_synchronize(void) { HIP_OK(hipStreamSynchronize(cfg().stream.load())); }
+extern "C" int xsmm_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+extern "C" const char *xsmm_hip_kernel_name(int64_t handle) {
+  const GemmDesc *d = reinterpret_cast<const GemmDesc *>(handle);
+  return (d && d->kind == KIND_GEMM) ? d->name : "";
+}
+extern "C" void xsmm_hip_force_variant(int v) { cfg().forced_variant.store(v); }
+extern "C" const char *xsmm_hip_version(void) { return "tpp-xsmm-hip 0.1 (gfx950)"; }

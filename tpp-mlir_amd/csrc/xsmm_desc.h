@@ -1,0 +1,52 @@
+// xsmm_desc.h - immutable kernel descriptors behind the i64 handles of the C-ABI,
+// and the launch interface between the ABI layer (runtime.cpp) and the gfx950
+// kernels (*.hip). Not part of the public ABI (that is include/tpp_xsmm_abi.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tpp {
+
+enum : int { KIND_GEMM = 0x47454d4d /*'GEMM'*/, KIND_UNARY = 0x554e4152, KIND_BINARY = 0x42494e41,
+             KIND_AMX = 0x414d5843 };
+enum : int64_t { DT_F32 = 1, DT_BF16 = 2 };
+
+// One descriptor type for gemm / brgemm / fused_brgemm (a gemm is a brgemm with
+// one batch and no strides; a brgemm is a fused_brgemm with no epilogue).
+struct GemmDesc {
+  int kind;             // KIND_GEMM
+  int has_batch;        // 0: dispatched through xsmm_gemm_dispatch
+  int fused;            // dispatched through xsmm_fused_brgemm_dispatch (invoke takes D)
+  int64_t dtype, m, n, k, lda, ldb, ldc, stride_a, stride_b;
+  int64_t wire_flags;   // as received (BETA_0 = 4, VNNI_B wire = 2048, ...)
+  int beta0, vnni_b, bias, relu;
+  int variant;          // kernel variant chosen at dispatch (see gemm_variants.h), -1 = by invoke
+  char name[64];        // kernel name for profiles
+};
+
+struct UnaryDesc {
+  int kind;             // KIND_UNARY
+  int64_t op, dtype, m, n, ldi, ldo, flags;
+};
+
+struct BinaryDesc {
+  int kind;             // KIND_BINARY
+  int64_t op, dtype, m, n, ldi_lhs, ldi_rhs, ldo, flags;
+};
+
+struct AmxDesc {
+  int kind;             // KIND_AMX (no-op on this hardware)
+};
+
+// ---- kernel launchers (all enqueue on `stream`, never synchronise) --------------
+// pointers are device pointers with element offsets already applied.
+hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C, const void *D,
+                       int64_t br, hipStream_t stream);
+// fills d.variant / d.name; returns false if no kernel can run the descriptor
+bool plan_gemm(GemmDesc &d, int forced_variant);
+hipError_t launch_unary(const UnaryDesc &d, const void *in, float scalar, bool use_scalar, void *out,
+                        hipStream_t stream);
+hipError_t launch_binary(const BinaryDesc &d, const void *lhs, const void *rhs, void *out,
+                         hipStream_t stream);
+
+} // namespace tpp
