@@ -61,8 +61,11 @@ def check_close(got, ref, dt, what):
     if dt == F32:
         tol = 1e-5 * max(1.0, float(np.abs(r).max()) if r.size else 1.0)
         bad = diff > tol
-    else:  # one bf16 ulp of the reference value (2^-8 relative spacing, so 2^-7 covers a flip) + tiny abs
-        tol = np.abs(r) * 2.0 ** -7 + 1e-30
+    else:
+        # one bf16 ulp of the reference value (a rounding flip: 2^-7 relative covers it) plus the
+        # f32-accumulation floor of the f32 bar: where products cancel, |ref| is far below the
+        # magnitude of the summands and only the absolute f32 error of the sum is meaningful
+        tol = np.abs(r) * 2.0 ** -7 + 1e-5 * max(1.0, float(np.abs(r).max()) if r.size else 1.0)
         bad = diff > tol
     assert not bad.any(), "%s: %d/%d mismatches, max abs diff %g (max |ref| %g)" % (
         what, int(bad.sum()), bad.size, float(diff.max()), float(np.abs(r).max()))
@@ -401,7 +404,7 @@ def test_c3_fused_layer_full_size(rt):
     m, n, k, br = 512, 1024, 64, 16
     gen = orc.TensorInit("normal", 123)
     A, W, bias = gen.fill(m * 1024), gen.fill(1024 * n), gen.fill(n)
-    A -= np.float32(0.05)  # make relu actually clip something
+    A -= np.float32(0.08)  # the normal init is clamped to [0, 1]: shift it so relu clips about half the outputs
     C = np.full(m * n, np.float32(7.0))
     ref = C.copy()
     orc.fused_brgemm_omp(F32, m, n, k, 1024, 1024, 1024, 64, 65536, 4, 5, 1, A, W, ref, bias, br)
@@ -452,8 +455,10 @@ def test_c4_mlp_bf16_three_layers(rt):
     g = orc.bf16_to_f32(got[rows].reshape(-1)).reshape(len(rows), N).astype(np.float64)
     # three chained bf16 layers: a one-ulp flip in layer l perturbs layer l+1; reference tolerance
     # for bf16 differential tests is fpcmp -r 0.01 (vnni-xsmm-vs-loops.mlir:13)
-    denom = np.maximum(np.abs(ref), 1e-2)
-    assert (np.abs(g - ref) / denom).max() <= 0.01, float((np.abs(g - ref) / denom).max())
+    # (relative 0.01 as fpcmp -r 0.01, plus an absolute floor of one bf16 ulp of the output scale:
+    # near-zero post-relu outputs inherit the absolute perturbation of the flipped inputs)
+    err = np.abs(g - ref) - 0.01 * np.abs(ref) - 2.0 ** -8 * np.abs(ref).max()
+    assert err.max() <= 0, float(err.max())
     assert np.mean(g == ref) > 0.5  # and most outputs are bit-identical
 
 

@@ -1,0 +1,12 @@
+#!/bin/bash
+set -e
+cd "$(dirname "$0")/.."
+C=tpp-mlir_amd/csrc; B=tpp-mlir_amd/build; mkdir -p $B
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC"
+rm -f $B/libabl_*.so
+for m in $1; do
+  ( hipcc $FLAGS -DTPP_ABLATE=$m -c $C/brgemm_bf16.hip -o $B/abl_bf16_$m.o &&
+    hipcc --offload-arch=gfx950 -shared -fPIC -o $B/libabl_h$m.so $B/abl_bf16_$m.o $B/runtime.o $B/brgemm_f32.o $B/eltwise.o ) &
+done
+wait
+ls $B/libabl_*.so

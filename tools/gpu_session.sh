@@ -16,7 +16,7 @@ timeout 600 python bench.py --steps 200 --warmup 20 > $OUT/bench.json 2> $OUT/be
 echo "bench rc=$?" >> $OUT/bench.err
 timeout 600 python bench.py --steps 200 --warmup 20 --graph --no-cpu-baseline > $OUT/bench_graph.json 2> $OUT/bench_graph.err
 echo "bench graph rc=$?" >> $OUT/bench_graph.err
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/rocprof_bench.log 2>&1 )
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/rocprof_bench.log 2>&1 )
 find /tmp/prof_$TAG -name "*stats*" -exec cp {} $OUT/ \; 2>/dev/null
 find /tmp/prof_$TAG -name "*kernel_trace*" -exec sh -c 'head -400 "$1" > '"$OUT"'/kernel_trace_head.csv' _ {} \; 2>/dev/null
 ls -la /tmp/prof_$TAG/* >> $OUT/rocprof_bench.log 2>&1

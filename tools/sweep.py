@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""GPU-side sweep: TFLOP/s of the BRGEMM kernels over shapes / forced tile variants.
+Prints one line per case. Not a test: a measurement aid for kernel work."""
+import importlib
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pkg = importlib.import_module("tpp-mlir_amd")
+rt = pkg.get_runtime()
+rt.set_async(True)
+F32, BF16 = 1, 2
+
+
+def time_it(fn, iters=50, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = 1e9
+    for _ in range(3):
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) * 1e-3 / iters)
+    return best
+
+
+def f32_case(m, n, k, br, force=None, beta0=True, tag=""):
+    K = k * max(br, 1)
+    A = torch.rand(m, K, device="cuda") * 2 - 1
+    B = torch.rand(K, n, device="cuda") * 2 - 1
+    C = torch.zeros(m, n, device="cuda")
+    if force is not None:
+        rt.force_variant(force)
+    h = rt.brgemm_dispatch(F32, m, n, k, K, n, n, k, k * n, 4 if beta0 else 0)
+    rt.force_variant(-1)
+    t = time_it(lambda: rt.brgemm(F32, h, A, 0, B, 0, C, 0, br))
+    fl = 2.0 * m * n * k * br
+    print("f32  m%-5d n%-5d k%-5d br%-3d %-28s %8.2f us %8.1f TF  %5.1f%% %s" % (
+        m, n, k, br, rt.kernel_name(h), t * 1e6, fl / t / 1e12, fl / t / 1.573e12, tag), flush=True)
+
+
+def bf16_case(m, n, k, br, tag=""):
+    K = k * br
+    A = (torch.rand(m, K, device="cuda") * 2 - 1).to(torch.bfloat16)
+    B = (torch.rand(K // 2, n, 2, device="cuda") * 2 - 1).to(torch.bfloat16)
+    C = torch.zeros(m, n, device="cuda", dtype=torch.bfloat16)
+    h = rt.brgemm_dispatch(BF16, m, n, k, K, n, n, k, k * n, 4 | 2048)
+    t = time_it(lambda: rt.brgemm(BF16, h, A, 0, B, 0, C, 0, br))
+    fl = 2.0 * m * n * K
+    print("bf16 m%-5d n%-5d k%-5d br%-3d %-28s %8.2f us %8.1f TF  %5.1f%% %s" % (
+        m, n, k, br, rt.kernel_name(h), t * 1e6, fl / t / 1e12, fl / t / 25e12, tag), flush=True)
+
+
+if __name__ == "__main__":
+    f32_case(64, 64, 64, 0, tag="launch floor (empty batch)")
+    f32_case(1024, 1024, 64, 0, tag="epilogue only")
+    f32_case(1024, 1024, 64, 1, tag="1 chunk")
+    f32_case(1024, 1024, 64, 2, tag="2 chunks")
+    f32_case(1024, 1024, 64, 4)
+    f32_case(1024, 1024, 64, 8)
+    f32_case(1024, 1024, 64, 16, tag="C2")
+    f32_case(1024, 1024, 64, 16, beta0=False, tag="C2 beta=1")
+    f32_case(1024, 1024, 64, 64)
+    f32_case(1024, 1024, 1024, 16, tag="C2 large variant")
+    for v in (0, 1, 2, 3):
+        f32_case(1024, 1024, 64, 16, force=v, tag="forced v%d" % v)
+    f32_case(512, 1024, 64, 16, tag="C3 shape")
+    for v in (0, 1, 2):
+        f32_case(512, 1024, 64, 16, force=v, tag="C3 forced v%d" % v)
+    f32_case(256, 1024, 64, 16)
+    f32_case(2048, 2048, 64, 32)
+    f32_case(4096, 4096, 64, 64, tag="4096^3")
+    bf16_case(4096, 1024, 64, 16, tag="C4 layer")
+    bf16_case(2048, 2048, 128, 16, tag="C5")
+    bf16_case(4096, 4096, 64, 64, tag="4096^3")
+    bf16_case(8192, 8192, 64, 128, tag="8192^3")
+    bf16_case(1024, 1024, 64, 16)

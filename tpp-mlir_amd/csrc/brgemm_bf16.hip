@@ -18,13 +18,20 @@
 //             global_load_dwordx4 and the ds_write_b128.
 #include "gemm_common.h"
 #include "xsmm_desc.h"
+#include <type_traits>
 
 namespace tpp {
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
+#ifndef TPP_ABLATE
+#define TPP_ABLATE 0
+#endif
+constexpr int HABL_NO_GLOAD = 1, HABL_NO_SWRITE = 2, HABL_NO_BARRIER = 4, HABL_NO_FRAG = 8, HABL_NO_TRANSPOSE = 16;
+
 constexpr int BKH = 64;     // k per chunk
 constexpr int NSTAGE_H = 3;
+constexpr int NSET_H = 3;  // staging register sets (chunks of global loads in flight per lane)
 
 template <int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(64 * WM * WN) void brgemm_bf16_fast(GemmArgs p) {
@@ -70,88 +77,184 @@ __global__ __launch_bounds__(64 * WM * WN) void brgemm_bf16_fast(GemmArgs p) {
               C[(int64_t)(crow0 + 32 * i + (r & 3) + 8 * (r >> 2)) * p.ldc + ccol0 + 32 * j]);
   }
 
-  u32x4 ra[LA], rb[LB][4];
-  auto gload = [&](int t) {
-    const int b = t / kchunks, kk0 = (t - b * kchunks) * BKH;
-    const unsigned short *Ab = A + (int64_t)b * p.stride_a + (int64_t)m0 * p.lda + kk0;
-    // pair-row r of this chunk starts at B_b + (kk0/2 + r) * 2*ldb; column c at +2c
-    const unsigned short *Bb = B + (int64_t)b * p.stride_b + (int64_t)(kk0 >> 1) * (2 * p.ldb) + 2 * (int64_t)n0;
+  // staging: A pieces are 16-byte row segments; a B piece is a 4x4 dword block (4 pair-rows
+  // x 4 columns) that is transposed in registers on its way to LDS. Buffer loads with
+  // per-lane constant byte offsets; the wave-uniform panel bases advance by scalar adds.
+  u32x4 ra[NSET_H][LA], rb[NSET_H][LB][4];
+  unsigned voffA[LA], voffB[LB];
 #pragma unroll
-    for (int u = 0; u < LA; ++u) {
-      const int q = tid + u * NT, row = q >> 3, c = q & 7;
-      if (A_ITEMS % NT == 0 || q < A_ITEMS) ra[u] = *(const u32x4 *)(Ab + (int64_t)row * p.lda + 8 * c);
-    }
+  for (int u = 0; u < LA; ++u) {
+    const int q = tid + u * NT, row = q >> 3, c = q & 7;
+    voffA[u] = (unsigned)((row * (int)p.lda + 8 * c) * 2);
+  }
 #pragma unroll
-    for (int u = 0; u < LB; ++u) {
-      const int q = tid + u * NT, g = q & 7, jq = q >> 3;
-      if (B_ITEMS % NT == 0 || q < B_ITEMS) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          rb[u][r] = *(const u32x4 *)(Bb + (int64_t)(4 * g + r) * (2 * p.ldb) + 8 * jq);
+  for (int u = 0; u < LB; ++u) {
+    const int q = tid + u * NT, g = q & 7, jq = q >> 3;
+    voffB[u] = (unsigned)((4 * g * 2 * (int)p.ldb + 8 * jq) * 2);
+  }
+  const unsigned rowB = (unsigned)(2 * (int)p.ldb * 2); // bytes between pair-rows
+  const unsigned short *gA = A + (int64_t)m0 * p.lda, *gB = B + 2 * (int64_t)n0;
+  int kc = 0;
+  const int64_t dA_wrap = p.stride_a - (int64_t)(kchunks - 1) * BKH;
+  const int64_t dB_in = (int64_t)(BKH / 2) * 2 * p.ldb, dB_wrap = p.stride_b - (int64_t)(kchunks - 1) * dB_in;
+  constexpr int NLOAD = LA + 4 * LB, NWRITE = LA + 4 * LB; // instruction counts per chunk per lane
+  auto gload_item = [&](int set, int it) __attribute__((always_inline)) {
+    if (it < LA) {
+      if (A_ITEMS % NT == 0 || tid + it * NT < A_ITEMS) {
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)gA, 0, 0x7fffffff, 0x00020000);
+        ra[set][it] = __builtin_amdgcn_raw_buffer_load_b128(r, voffA[it], 0, 0);
+      }
+    } else {
+      const int u = (it - LA) >> 2, rr = (it - LA) & 3;
+      if (B_ITEMS % NT == 0 || tid + u * NT < B_ITEMS) {
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)gB, 0, 0x7fffffff, 0x00020000);
+        rb[set][u][rr] = __builtin_amdgcn_raw_buffer_load_b128(r, voffB[u] + rr * rowB, 0, 0);
       }
     }
   };
-  auto swrite = [&](int stage) {
+  auto swrite_item = [&](int stage, int it) __attribute__((always_inline)) {
     unsigned char *as = As + stage * A_STAGE, *bs = Bs + stage * B_STAGE;
-#pragma unroll
-    for (int u = 0; u < LA; ++u) {
-      const int q = tid + u * NT, row = q >> 3, c = q & 7;
-      if (A_ITEMS % NT == 0 || q < A_ITEMS) *(u32x4 *)(as + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = ra[u];
-    }
-#pragma unroll
-    for (int u = 0; u < LB; ++u) {
+    if (it < LA) {
+      const int q = tid + it * NT, row = q >> 3, c = q & 7;
+      if (A_ITEMS % NT == 0 || q < A_ITEMS) *(u32x4 *)(as + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = ra[stage][it];
+    } else {
+      const int u = (it - LA) >> 2, e = (it - LA) & 3;
       const int q = tid + u * NT, g = q & 7, jq = q >> 3;
-      if (B_ITEMS % NT == 0 || q < B_ITEMS) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { // column 4*jq+e: its 4 pair-rows, transposed in registers
-          u32x4 v = {rb[u][0][e], rb[u][1][e], rb[u][2][e], rb[u][3][e]};
-          *(u32x4 *)(bs + g * B_GROW + ((4 * jq + e) << 4)) = v;
-        }
+      if (B_ITEMS % NT == 0 || q < B_ITEMS) { // column 4*jq+e: its 4 pair-rows, transposed in registers
+        u32x4 v = {rb[stage][u][0][e], rb[stage][u][1][e], rb[stage][u][2][e], rb[stage][u][3][e]};
+        if (TPP_ABLATE & HABL_NO_TRANSPOSE) v = rb[stage][u][e];
+        *(u32x4 *)(bs + g * B_GROW + ((4 * jq + e) << 4)) = v;
       }
     }
   };
-  auto compute = [&](int stage, int ks0, int nks) {
+  bf16x8_t af[2][TM], bfr[2][TN];
+  auto frag_load = [&](int buf, int stage, int ks) __attribute__((always_inline)) {
     const unsigned char *as = As + stage * A_STAGE;
     const unsigned char *bs = Bs + stage * B_STAGE;
 #pragma unroll
-    for (int q = 0; q < nks; ++q) {
-      const int ks = ks0 + q;
-      bf16x8_t af[TM], bfr[TN];
+    for (int i = 0; i < TM; ++i) {
+      const int row = (wm * TM + i) * 32 + li;
+      af[buf][i] = *(const bf16x8_t *)(as + row * 128 + (((2 * ks + lh) ^ ((row >> 1) & 7)) << 4));
+    }
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int row = (wm * TM + i) * 32 + li;
-        af[i] = *(const bf16x8_t *)(as + row * 128 + (((2 * ks + lh) ^ ((row >> 1) & 7)) << 4));
-      }
+    for (int j = 0; j < TN; ++j) {
+      const int col = (wn * TN + j) * 32 + li;
+      bfr[buf][j] = *(const bf16x8_t *)(bs + (2 * ks + lh) * B_GROW + (col << 4));
+    }
+  };
+  // one chunk: 4 k-steps of TM*TN MFMAs; same pipeline as the f32 kernel (ring slot known
+  // at compile time, writes of chunk t+1 in the first half + ONE barrier, loads of chunk
+  // t+2 in the second half, fragments of step q+1 read while step q multiplies).
+  constexpr int SLOTS = 2 * TM * TN; // MFMA slots per half chunk
+  auto gadvance = [&]() __attribute__((always_inline)) {
+    if (++kc == kchunks) {
+      kc = 0;
+      gA += dA_wrap;
+      gB += dB_wrap;
+    } else {
+      gA += BKH;
+      gB += dB_in;
+    }
+  };
+  auto chunk = [&](auto stage_c, auto has_next, auto has_load) __attribute__((always_inline)) {
+    constexpr int STAGE = decltype(stage_c)::value, NSTG = (STAGE + 1) % NSTAGE_H;
+    constexpr bool HAS_NEXT = decltype(has_next)::value, HAS_LOAD = decltype(has_load)::value;
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int col = (wn * TN + j) * 32 + li;
-        bfr[j] = *(const bf16x8_t *)(bs + (2 * ks + lh) * B_GROW + (col << 4));
+    for (int q = 0; q < 4; ++q) {
+      const int cur = q & 1, nxt = cur ^ 1;
+      if (!(TPP_ABLATE & HABL_NO_FRAG)) {
+        if (q + 1 < 4) frag_load(nxt, STAGE, q + 1);
+        else if (HAS_NEXT) frag_load(nxt, NSTG, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][i], bfr[cur][j], acc[i][j], 0, 0, 0);
+          const int slot = (q & 1) * TM * TN + i * TN + j; // slot inside the half chunk
+          if (HAS_LOAD && q == 1 && i == TM - 1 && j == TN - 1) { // next panel base: scalar work
+            if (++kc == kchunks) {
+              kc = 0;
+              gA += dA_wrap;
+              gB += dB_wrap;
+            } else {
+              gA += BKH;
+              gB += dB_in;
+            }
+          }
+#pragma unroll
+          for (int it = 0; it < NWRITE; ++it)
+            if (HAS_NEXT && !(TPP_ABLATE & HABL_NO_SWRITE) && q < 2 && (it * SLOTS) / NWRITE == slot) swrite_item(NSTG, it);
+#pragma unroll
+          for (int it = 0; it < NLOAD; ++it)
+            if (HAS_LOAD && !(TPP_ABLATE & HABL_NO_GLOAD) && q >= 2 && (it * SLOTS) / NLOAD == slot) gload_item(NSTG, it);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      if (q == 1 && !(TPP_ABLATE & HABL_NO_BARRIER)) __syncthreads();
     }
   };
+  using yes = std::integral_constant<bool, true>;
+  using no = std::integral_constant<bool, false>;
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>;
+  static_assert(NSET_H == NSTAGE_H && NSTAGE_H == 3, "schedule written for 3 slots / 3 sets");
 
+  // prologue: chunk 0 -> set 0 -> slot 0; chunks 1, 2, 3 -> sets 1, 2, 0 (in flight)
   if (T > 0) {
-    gload(0);
-    swrite(0);
-    if (T > 1) gload(1);
+#pragma unroll
+    for (int it = 0; it < NLOAD; ++it) gload_item(0, it);
+#pragma unroll
+    for (int c = 1; c <= NSET_H; ++c) {
+      if (c == NSET_H) {
+#pragma unroll
+        for (int it = 0; it < NWRITE; ++it) swrite_item(0, it);
+      }
+      if (c < T) {
+        gadvance();
+#pragma unroll
+        for (int it = 0; it < NLOAD; ++it) gload_item(c % NSET_H, it);
+      }
+    }
   }
   __syncthreads();
-  int stage = 0;
-  for (int t = 0; t < T; ++t) {
-    const int nstage = stage + 1 == NSTAGE_H ? 0 : stage + 1;
-    compute(stage, 0, 2);
-    if (t + 1 < T) swrite(nstage);
-    __syncthreads();
-    if (t + 2 < T) gload(t + 2);
-    compute(stage, 2, 2);
-    stage = nstage;
+  if (T > 0) frag_load(0, 0, 0);
+  int t = 0;
+  for (; t + 2 + NSET_H + 1 < T; t += 3) {
+    chunk(S0{}, yes{}, yes{});
+    chunk(S1{}, yes{}, yes{});
+    chunk(S2{}, yes{}, yes{});
+  }
+  auto tail = [&](auto stage_c) __attribute__((always_inline)) {
+    const int left = T - t;
+    if (left > NSET_H + 1) chunk(stage_c, yes{}, yes{});
+    else if (left >= 2) chunk(stage_c, yes{}, no{});
+    else chunk(stage_c, no{}, no{});
+    ++t;
+  };
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    if (t < T) tail(S0{});
+    if (t < T) tail(S1{});
+    if (t < T) tail(S2{});
   }
 
+  if (TPP_ABLATE) {
+#pragma unroll
+    for (int st = 0; st < NSET_H; ++st) {
+#pragma unroll
+      for (int u = 0; u < LA; ++u) asm volatile("" ::"v"(ra[st][u]));
+#pragma unroll
+      for (int u = 0; u < LB; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) asm volatile("" ::"v"(rb[st][u][r]));
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(af[0][i]), "v"(af[1][i]));
+#pragma unroll
+    for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(bfr[0][j]), "v"(bfr[1][j]));
+  }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = ccol0 + 32 * j;

@@ -30,8 +30,19 @@
 
 namespace tpp {
 
+// Timing-only ablation switches for kernel work (tools/ablate.sh builds side libraries
+// with -DTPP_ABLATE=mask; the shipped library is always built with 0 = full kernel).
+#ifndef TPP_ABLATE
+#define TPP_ABLATE 0
+#endif
+#ifndef TPP_NACC
+#define TPP_NACC 2
+#endif
+constexpr int ABL_NO_GLOAD = 1, ABL_NO_SWRITE = 2, ABL_NO_BARRIER = 4, ABL_NO_FRAG = 8;
+
 constexpr int BK = 64;     // k columns per chunk
 constexpr int NSTAGE = 3;  // LDS ring slots
+constexpr int NSET = 3;    // staging register sets = chunks of global loads in flight per lane
 
 template <int WM, int WN, int WK, int NACC>
 __global__ __launch_bounds__(64 * WM * WN * WK) void brgemm_f32_fast(GemmArgs p) {
@@ -40,6 +51,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void brgemm_f32_fast(GemmArgs p)
   constexpr int LA = (BM * BK / 4) / NT, LB = (BK * BN / 4) / NT;
   constexpr int KB_PER_WAVE = 8 / WK;                  // k-blocks (of 8) per wave per chunk
   constexpr int KB_HALF = KB_PER_WAVE / 2;
+  constexpr int NP = LA + LB;                          // staging pieces per thread per chunk
   static_assert(LA >= 1 && LB >= 1 && KB_HALF >= 1, "tile too small for this thread count");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *As = smem;
@@ -72,41 +84,55 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void brgemm_f32_fast(GemmArgs p)
       acc[0][r] = C[(int64_t)(crow0 + (r & 3) + 8 * (r >> 2)) * p.ldc + ccol];
   }
 
-  // staging registers of the chunk in flight (HBM -> VGPR -> LDS). Items 0..LA-1 are
-  // A pieces, LA..LA+LB-1 are B pieces; `part` p of 4 handles items u with u % 4 == p so
-  // the loads / LDS writes can be spread between the MFMAs of one k-block step.
-  f32x4 rs[LA + LB];
-  const float *gA = nullptr, *gB = nullptr;
-  auto gaddr = [&](int t) {
-    const int b = t / kchunks, kk0 = (t - b * kchunks) * BK;
-    gA = A + (int64_t)b * p.stride_a + (int64_t)m0 * p.lda + kk0;
-    gB = B + (int64_t)b * p.stride_b + (int64_t)kk0 * p.ldb + n0;
-  };
-  auto gload_part = [&](int part) {
+  // staging registers of the chunk in flight (HBM -> VGPR -> LDS). Pieces 0..LA-1 are
+  // A, LA..LA+LB-1 are B (16 bytes per lane each). The LDS writes of a chunk are spread
+  // over the MFMA slots of the FIRST half of the previous chunk's steps and its global
+  // loads over the SECOND half, so neither the LDS nor the vector-memory path sees a
+  // burst. Loads are buffer loads: wave-uniform 64-bit panel base in the descriptor
+  // (advanced by scalar adds once per chunk), per-lane byte offset constant for the
+  // whole kernel -> one instruction per 16 bytes, no per-load vector address math.
+  f32x4 rs[NSET][NP];
+  unsigned voff[NP];
 #pragma unroll
-    for (int u = 0; u < LA + LB; ++u) {
-      if ((u & 3) != part) continue;
-      if (u < LA) {
-        const int q = tid + u * NT, row = q >> 4, c = q & 15;
-        rs[u] = *(const f32x4 *)(gA + (int64_t)row * p.lda + 4 * c);
-      } else {
-        const int q = tid + (u - LA) * NT, krow = q / (BN / 4), c = q % (BN / 4);
-        rs[u] = *(const f32x4 *)(gB + (int64_t)krow * p.ldb + 4 * c);
-      }
+  for (int u = 0; u < NP; ++u) {
+    if (u < LA) {
+      const int q = tid + u * NT, row = q >> 4, c = q & 15;
+      voff[u] = (unsigned)((row * (int)p.lda + 4 * c) * 4);
+    } else {
+      const int q = tid + (u - LA) * NT, krow = q / (BN / 4), c = q % (BN / 4);
+      voff[u] = (unsigned)((krow * (int)p.ldb + 4 * c) * 4);
+    }
+  }
+  // panel base of the chunk being loaded (wave-uniform) and its position in the batch
+  const float *gA = A + (int64_t)m0 * p.lda, *gB = B + n0;
+  int kc = 0; // chunk index inside the current batch element
+  const int64_t dA_wrap = p.stride_a - (int64_t)(kchunks - 1) * BK;
+  const int64_t dB_in = (int64_t)BK * p.ldb, dB_wrap = p.stride_b - (int64_t)(kchunks - 1) * BK * p.ldb;
+  auto gadvance = [&]() __attribute__((always_inline)) { // next chunk: +64 k inside a batch element, else next batch element
+    if (++kc == kchunks) {
+      kc = 0;
+      gA += dA_wrap;
+      gB += dB_wrap;
+    } else {
+      gA += BK;
+      gB += dB_in;
     }
   };
-  auto swrite_part = [&](int stage, int part) {
+  auto gload_piece = [&](int set, int u) __attribute__((always_inline)) {
+    // descriptor built from wave-uniform scalars right at the load (kept in SGPRs)
+    const __amdgpu_buffer_rsrc_t r =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(u < LA ? gA : gB), 0, 0x7fffffff, 0x00020000);
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff[u], 0, 0);
+    rs[set][u] = __builtin_bit_cast(f32x4, v);
+  };
+  auto swrite_piece = [&](int stage, int u) __attribute__((always_inline)) {
     float *as = As + stage * A_STAGE, *bs = Bs + stage * B_STAGE;
-#pragma unroll
-    for (int u = 0; u < LA + LB; ++u) {
-      if ((u & 3) != part) continue;
-      if (u < LA) {
-        const int q = tid + u * NT, row = q >> 4, c = q & 15;
-        *(f32x4 *)(as + row * BK + ((c ^ (row & 15)) << 2)) = rs[u];
-      } else {
-        const int q = tid + (u - LA) * NT, krow = q / (BN / 4), c = q % (BN / 4);
-        *(f32x4 *)(bs + krow * BN + 4 * c) = rs[u];
-      }
+    if (u < LA) {
+      const int q = tid + u * NT, row = q >> 4, c = q & 15;
+      *(f32x4 *)(as + row * BK + ((c ^ (row & 15)) << 2)) = rs[stage][u];
+    } else {
+      const int q = tid + (u - LA) * NT, krow = q / (BN / 4), c = q % (BN / 4);
+      *(f32x4 *)(bs + krow * BN + 4 * c) = rs[stage][u];
     }
   };
   // MFMA fragments of one k-block (8 k): 4 A values (one ds_read_b128) and 4 B values
@@ -114,7 +140,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void brgemm_f32_fast(GemmArgs p)
   f32x4 fa[2];
   float fb[2][4];
   const int a_off = (wm * 32 + li) * BK, b_off = wn * 32 + li;
-  auto frag_load = [&](int buf, int stage, int kb) {
+  auto frag_load = [&](int buf, int stage, int kb) __attribute__((always_inline)) {
     const float *as = As + stage * A_STAGE + a_off;
     const float *bs = Bs + stage * B_STAGE + b_off;
     fa[buf] = *(const f32x4 *)(as + (((2 * kb + lh) ^ (li & 15)) << 2));
@@ -123,17 +149,23 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void brgemm_f32_fast(GemmArgs p)
   };
 
   const int kbw = wk * KB_PER_WAVE;
-  // one chunk: KB_PER_WAVE k-block steps of 4 MFMAs. HAS_NEXT: chunk t+1 exists (its
-  // registers are written to the next ring slot during step KB_HALF-1, then ONE barrier
-  // publishes it). HAS_NEXT2: chunk t+2 exists (its global loads are issued during step
-  // KB_HALF). The last step prefetches the first fragments of chunk t+1.
-  auto chunk = [&](int stage, int nstage, auto has_next, auto has_next2) {
-    constexpr bool HAS_NEXT = decltype(has_next)::value, HAS_NEXT2 = decltype(has_next2)::value;
+  // One chunk = KB_PER_WAVE k-block steps of 4 MFMAs, ring slot STAGE known at compile
+  // time (every LDS address is base VGPR + immediate). Register set s holds the chunk
+  // that goes to ring slot s (NSET == NSTAGE). HAS_NEXT: chunk t+1 exists: set STAGE+1
+  // is written to slot STAGE+1 during the first half of the steps, then ONE barrier
+  // publishes it. HAS_LOAD: chunk t+1+NSET exists: its global loads refill the set just
+  // written, during the second half - they have NSET-0.5 chunks of MFMAs to land. The
+  // last step prefetches the first fragments of chunk t+1.
+  auto chunk = [&](auto stage_c, auto has_next, auto has_load) __attribute__((always_inline)) {
+    constexpr int STAGE = decltype(stage_c)::value, NSTG = (STAGE + 1) % NSTAGE;
+    constexpr bool HAS_NEXT = decltype(has_next)::value, HAS_LOAD = decltype(has_load)::value;
 #pragma unroll
     for (int q = 0; q < KB_PER_WAVE; ++q) {
       const int cur = q & 1, nxt = cur ^ 1;
-      if (q + 1 < KB_PER_WAVE) frag_load(nxt, stage, kbw + q + 1);
-      else if (HAS_NEXT) frag_load(nxt, nstage, kbw);
+      if (!(TPP_ABLATE & ABL_NO_FRAG)) {
+        if (q + 1 < KB_PER_WAVE) frag_load(nxt, STAGE, kbw + q + 1);
+        else if (HAS_NEXT) frag_load(nxt, NSTG, kbw);
+      }
       // pin the issue order: the fragment reads of step q+1 stay ABOVE the MFMAs of
       // step q, and each piece of staging work sits in the shadow of one MFMA (the
       // wave is in-order: it idles at the next MFMA until the matrix pipe frees up).
@@ -141,45 +173,79 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void brgemm_f32_fast(GemmArgs p)
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         acc[s % NACC] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][s], fb[cur][s], acc[s % NACC], 0, 0, 0);
-        if (HAS_NEXT && q == KB_HALF - 1) swrite_part(nstage, s);
-        if (HAS_NEXT2 && q == KB_HALF) gload_part(s);
+        if (HAS_LOAD && !(TPP_ABLATE & ABL_NO_GLOAD) && q == KB_HALF - 1 && s == 3) {
+          // panel base of the next chunk to load: scalar work in the shadow of the MFMA above
+          if (++kc == kchunks) {
+            kc = 0;
+            gA += dA_wrap;
+            gB += dB_wrap;
+          } else {
+            gA += BK;
+            gB += dB_in;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+          if (HAS_NEXT && !(TPP_ABLATE & ABL_NO_SWRITE) && (u * 4 * KB_HALF) / NP == q * 4 + s) swrite_piece(NSTG, u);
+          if (HAS_LOAD && !(TPP_ABLATE & ABL_NO_GLOAD) && (u * 4 * (KB_PER_WAVE - KB_HALF)) / NP == (q - KB_HALF) * 4 + s)
+            gload_piece(NSTG, u);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (q == KB_HALF - 1) __syncthreads();
+      if (q == KB_HALF - 1 && !(TPP_ABLATE & ABL_NO_BARRIER)) __syncthreads();
     }
   };
   using yes = std::integral_constant<bool, true>;
   using no = std::integral_constant<bool, false>;
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>;
+  static_assert(NSET == NSTAGE && NSTAGE == 3, "the chunk schedule below is written for 3 slots / 3 sets");
 
+  // prologue: chunk 0 -> set 0 -> slot 0; chunks 1, 2, 3 -> sets 1, 2, 0 (in flight)
   if (T > 0) {
-    gaddr(0);
 #pragma unroll
-    for (int part = 0; part < 4; ++part) gload_part(part);
+    for (int u = 0; u < NP; ++u) gload_piece(0, u);
 #pragma unroll
-    for (int part = 0; part < 4; ++part) swrite_part(0, part);
-    if (T > 1) {
-      gaddr(1);
+    for (int c = 1; c <= NSET; ++c) {
+      if (c == NSET) { // set 0 is reused for chunk NSET: chunk 0 must be in LDS first
 #pragma unroll
-      for (int part = 0; part < 4; ++part) gload_part(part);
+        for (int u = 0; u < NP; ++u) swrite_piece(0, u);
+      }
+      if (c < T) {
+        gadvance();
+#pragma unroll
+        for (int u = 0; u < NP; ++u) gload_piece(c % NSET, u);
+      }
     }
   }
   __syncthreads();
   if (T > 0) frag_load(0, 0, kbw);
-  int stage = 0, t = 0;
-  for (; t + 2 < T; ++t) {
-    const int nstage = stage + 1 == NSTAGE ? 0 : stage + 1;
-    gaddr(t + 2);
-    chunk(stage, nstage, yes{}, yes{});
-    stage = nstage;
+  int t = 0;
+  for (; t + 2 + NSET + 1 < T; t += 3) { // steady state: three chunks per trip, ring slots 0, 1, 2
+    chunk(S0{}, yes{}, yes{});
+    chunk(S1{}, yes{}, yes{});
+    chunk(S2{}, yes{}, yes{});
   }
-  if (t + 1 < T) {
-    const int nstage = stage + 1 == NSTAGE ? 0 : stage + 1;
-    chunk(stage, nstage, yes{}, no{});
-    stage = nstage;
+  auto tail = [&](auto stage_c) __attribute__((always_inline)) { // last chunks: same bodies minus what no longer exists
+    const int left = T - t;
+    if (left > NSET + 1) chunk(stage_c, yes{}, yes{});
+    else if (left >= 2) chunk(stage_c, yes{}, no{});
+    else chunk(stage_c, no{}, no{});
     ++t;
+  };
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    if (t < T) tail(S0{});
+    if (t < T) tail(S1{});
+    if (t < T) tail(S2{});
   }
-  if (t < T) chunk(stage, stage, no{}, no{});
 
+  if (TPP_ABLATE & (ABL_NO_SWRITE | ABL_NO_FRAG)) { // keep ablated producers alive
+#pragma unroll
+    for (int u = 0; u < LA + LB; ++u) asm volatile("" ::"v"(rs[0][u]), "v"(rs[1][u]), "v"(rs[2][u]));
+    asm volatile("" ::"v"(fa[0]), "v"(fa[1]));
+  }
 #pragma unroll
   for (int a = 1; a < NACC; ++a)
 #pragma unroll
@@ -389,10 +455,10 @@ hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C,
   const bool aligned16 = ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0;
   if (v != V_GENERIC && !aligned16) v = V_GENERIC;
   switch (v) {
-  case V_F32_64x64: return launch_fast<2, 2, 1, 2>(a, stream);
-  case V_F32_64x32K2: return launch_fast<2, 1, 2, 2>(a, stream);
-  case V_F32_32x32K4: return launch_fast<1, 1, 4, 2>(a, stream);
-  case V_F32_128x64: return launch_fast<4, 2, 1, 2>(a, stream);
+  case V_F32_64x64: return launch_fast<2, 2, 1, TPP_NACC>(a, stream);
+  case V_F32_64x32K2: return launch_fast<2, 1, 2, TPP_NACC>(a, stream);
+  case V_F32_32x32K4: return launch_fast<1, 1, 4, TPP_NACC>(a, stream);
+  case V_F32_128x64: return launch_fast<4, 2, 1, TPP_NACC>(a, stream);
   case V_BF16_FAST: return launch_gemm_bf16_fast(d, a, stream);
   default: break;
   }
