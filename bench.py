@@ -35,13 +35,16 @@ F32, BF16 = 1, 2
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mlp", action="store_true")
     ap.add_argument("--graph", action="store_true",
                     help="also time a hipGraph replay of the step and report the faster of the two launch modes")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--init", choices=["reference", "uniform"], default="reference",
+                    help="reference: tpp-run's normal init stream (what the reference benchmarks run on); "
+                         "uniform: U[-1,1) (sign cancellation, highest switching power)")
     return ap.parse_args()
 
 
@@ -60,6 +63,17 @@ def timed(fn, steps, sync, barrier):
     barrier()
     wall = time.perf_counter() - t0
     return wall, e0.elapsed_time(e1) * 1e-3
+
+
+def warm(fn, steps, sync):
+    """untimed warm-up: W steps, with two launch->synchronize cycles so that lazy module loading,
+    clock ramp-up and the runtime's first blocking wait are all outside the timed region"""
+    for _ in range(max(1, steps // 2)):
+        fn()
+    sync()
+    for _ in range(steps - max(1, steps // 2)):
+        fn()
+    sync()
 
 
 def graph_of(fn, warm=3):
@@ -143,10 +157,17 @@ def main():
     # ------------------------------------------------------------ C2: fp32 BRGEMM 1024^3, br = 16
     m = n = 1024
     k, br = 64, 16
-    rng = np.random.default_rng(1234 + rank)
-    hA = rng.uniform(-1, 1, m * 1024).astype(np.float32)
-    hB = rng.uniform(-1, 1, 1024 * n).astype(np.float32)
-    hC = rng.uniform(-1, 1, m * n).astype(np.float32)
+    if args.init == "reference":
+        # the reference harness' inputs: tpp-run --seed 123 --init-type normal (benchmarks/harness/
+        # controller.py:149-154): N(0, 0.2) clamped to [0, 1], ONE stream over the arguments in order
+        from oracle import pyoracle as orc  # input generation only (restated TensorInit stream)
+        gen = orc.TensorInit("normal", 123 + rank)
+        hA, hB, hC = gen.fill(m * 1024), gen.fill(1024 * n), gen.fill(m * n)
+    else:
+        rng = np.random.default_rng(1234 + rank)
+        hA = rng.uniform(-1, 1, m * 1024).astype(np.float32)
+        hB = rng.uniform(-1, 1, 1024 * n).astype(np.float32)
+        hC = rng.uniform(-1, 1, m * n).astype(np.float32)
     dA, dB, dC = (torch.from_numpy(x).cuda() for x in (hA, hB, hC))
     h = rt.brgemm_dispatch(F32, m, n, k, 1024, 1024, 1024, 64, 65536, pkg.GemmFlags.BETA_0)
     flops = 2.0 * m * n * k * br
@@ -154,9 +175,7 @@ def main():
     def step():
         rt.brgemm(F32, h, dA, 0, dB, 0, dC, 0, br)
 
-    for _ in range(W):
-        step()
-    sync()
+    warm(step, W, sync)
     wall, devs = timed(step, K, sync, barrier)
     mode = "invoke-loop"
     replay = graph_of(step) if args.graph else None
@@ -200,9 +219,7 @@ def main():
             if world > 1:
                 pkg.all_gather_rows(out, full, spec, world)
 
-        for _ in range(W):
-            mlp_step()
-        sync()
+        warm(mlp_step, W, sync)
         mwall, mdev = timed(mlp_step, K, sync, barrier)
         tm = torch.tensor([mwall], dtype=torch.float64, device="cuda")
         if world > 1:
@@ -227,7 +244,9 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BRGEMM 1024x1024x1024 fp32, batch-reduce=16 (m=n=1024 k=64 lda=ldb=ldc=1024 "
                                    "stride_a=64 stride_b=65536 BETA_0), one independent problem per GPU",
-                       "launch": mode, "kernel": rt.kernel_name(h), "flops_per_step_per_gpu": flops},
+                       "launch": mode, "kernel": rt.kernel_name(h), "flops_per_step_per_gpu": flops,
+                       "inputs": "tpp-run normal init, seed 123 (N(0,0.2) clamped to [0,1])" if args.init == "reference"
+                       else "uniform [-1,1)"},
             "roofline": {"bound": "mfma", "achieved": round(achieved_tf, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved_tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
                          "kernel_us": round(kernel_s * 1e6, 3),

@@ -68,10 +68,12 @@ if __name__ == "__main__":
     f32_case(1024, 1024, 64, 16, beta0=False, tag="C2 beta=1")
     f32_case(1024, 1024, 64, 64)
     f32_case(1024, 1024, 1024, 16, tag="C2 large variant")
-    for v in (0, 1, 2, 3):
+    for v in (0, 1, 2, 3, 4):
         f32_case(1024, 1024, 64, 16, force=v, tag="forced v%d" % v)
+    f32_case(1024, 1024, 64, 128, force=4, tag="forced v4 K=8192")
+    f32_case(1024, 1024, 64, 128, force=0, tag="forced v0 K=8192")
     f32_case(512, 1024, 64, 16, tag="C3 shape")
-    for v in (0, 1, 2):
+    for v in (0, 1, 2, 4):
         f32_case(512, 1024, 64, 16, force=v, tag="C3 forced v%d" % v)
     f32_case(256, 1024, 64, 16)
     f32_case(2048, 2048, 64, 32)

@@ -27,7 +27,7 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 #ifndef TPP_ABLATE
 #define TPP_ABLATE 0
 #endif
-constexpr int HABL_NO_GLOAD = 1, HABL_NO_SWRITE = 2, HABL_NO_BARRIER = 4, HABL_NO_FRAG = 8, HABL_NO_TRANSPOSE = 16;
+constexpr int HABL_NO_GLOAD = 1, HABL_NO_SWRITE = 2, HABL_NO_BARRIER = 4, HABL_NO_FRAG = 8, HABL_NO_TRANSPOSE = 16, HABL_STAMP = 32;
 
 constexpr int BKH = 64;     // k per chunk
 constexpr int NSTAGE_H = 3;
@@ -45,11 +45,14 @@ __global__ __launch_bounds__(64 * WM * WN) void brgemm_bf16_fast(GemmArgs p) {
   unsigned char *As = smem_h;
   unsigned char *Bs = smem_h + NSTAGE_H * A_STAGE;
 
+  unsigned long long stamp[6] = {0, 0, 0, 0, 0, 0};
+  if (TPP_ABLATE & HABL_STAMP) { stamp[0] = __builtin_readcyclecounter(); stamp[4] = wall_clock64(); }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int li = lane & 31, lh = lane >> 5;
-  int tm, tn;
-  tile_of_block(blockIdx.x, p.tiles_m, p.tiles_n, tm, tn);
+  // tile from the 3-D grid (see brgemm_f32.hip): (8, bn, bm) XCD-blocked or (1, tiles_n, tiles_m)
+  const int tm = (int)(blockIdx.x >> 1) * p.tiles_m + (int)blockIdx.z;
+  const int tn = (int)(blockIdx.x & 1) * p.tiles_n + (int)blockIdx.y;
   const int m0 = tm * BM, n0 = tn * BN;
 
   const unsigned short *__restrict__ A = (const unsigned short *)p.A;
@@ -58,24 +61,7 @@ __global__ __launch_bounds__(64 * WM * WN) void brgemm_bf16_fast(GemmArgs p) {
   const int kchunks = p.k / BKH;
   const int T = p.br * kchunks;
 
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-  const int crow0 = m0 + wm * 32 * TM + 4 * lh, ccol0 = n0 + wn * 32 * TN + li;
-  if (!(p.ep & EP_BETA0)) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          acc[i][j][r] = bf16_bits_to_f32(
-              C[(int64_t)(crow0 + 32 * i + (r & 3) + 8 * (r >> 2)) * p.ldc + ccol0 + 32 * j]);
-  }
+  f32x16 acc[TM][TN]; // initialised after the first loads are on their way
 
   // staging: A pieces are 16-byte row segments; a B piece is a 4x4 dword block (4 pair-rows
   // x 4 columns) that is transposed in registers on its way to LDS. Buffer loads with
@@ -202,9 +188,36 @@ __global__ __launch_bounds__(64 * WM * WN) void brgemm_bf16_fast(GemmArgs p) {
   static_assert(NSET_H == NSTAGE_H && NSTAGE_H == 3, "schedule written for 3 slots / 3 sets");
 
   // prologue: chunk 0 -> set 0 -> slot 0; chunks 1, 2, 3 -> sets 1, 2, 0 (in flight)
-  if (T > 0) {
+  if (T > 0) { // first thing the kernel does: get chunk 0 moving
 #pragma unroll
     for (int it = 0; it < NLOAD; ++it) gload_item(0, it);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  // C tile through buffer ops: tile base in the descriptor, per-lane offset constant, the
+  // (tile row i, register r) row as a scalar offset, the tile column j as an immediate
+  const int ccol0 = n0 + wn * 32 * TN + li;
+  const __amdgpu_buffer_rsrc_t rsrcC =
+      __builtin_amdgcn_make_buffer_rsrc((void *)(C + (int64_t)m0 * p.ldc + n0), 0, 0x7fffffff, 0x00020000);
+  const unsigned voffC = (unsigned)(((wm * 32 * TM + 4 * lh) * (int)p.ldc + wn * 32 * TN + li) * 2);
+  const unsigned ldcb = (unsigned)((int)p.ldc * 2);
+  if (!(p.ep & EP_BETA0)) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          acc[i][j][r] = bf16_bits_to_f32(__builtin_amdgcn_raw_buffer_load_b16(
+              rsrcC, voffC + 64 * j, (unsigned)(32 * i + (r & 3) + 8 * (r >> 2)) * ldcb, 0));
+  }
+
+  if (T > 0) {
 #pragma unroll
     for (int c = 1; c <= NSET_H; ++c) {
       if (c == NSET_H) {
@@ -220,6 +233,7 @@ __global__ __launch_bounds__(64 * WM * WN) void brgemm_bf16_fast(GemmArgs p) {
   }
   __syncthreads();
   if (T > 0) frag_load(0, 0, 0);
+  if (TPP_ABLATE & HABL_STAMP) stamp[1] = __builtin_readcyclecounter();
   int t = 0;
   for (; t + 2 + NSET_H + 1 < T; t += 3) {
     chunk(S0{}, yes{}, yes{});
@@ -240,7 +254,8 @@ __global__ __launch_bounds__(64 * WM * WN) void brgemm_bf16_fast(GemmArgs p) {
     if (t < T) tail(S2{});
   }
 
-  if (TPP_ABLATE) {
+  if (TPP_ABLATE & HABL_STAMP) stamp[2] = __builtin_readcyclecounter();
+  if (TPP_ABLATE & ~HABL_STAMP) {
 #pragma unroll
     for (int st = 0; st < NSET_H; ++st) {
 #pragma unroll
@@ -265,8 +280,16 @@ __global__ __launch_bounds__(64 * WM * WN) void brgemm_bf16_fast(GemmArgs p) {
       for (int r = 0; r < 16; ++r) {
         float v = acc[i][j][r] + bias;
         if (p.ep & EP_RELU) v = v > 0.0f ? v : 0.0f;
-        C[(int64_t)(crow0 + 32 * i + (r & 3) + 8 * (r >> 2)) * p.ldc + col] = f32_to_bf16_bits(v);
+        __builtin_amdgcn_raw_buffer_store_b16(f32_to_bf16_bits(v), rsrcC, voffC + 64 * j,
+                                              (unsigned)(32 * i + (r & 3) + 8 * (r >> 2)) * ldcb, 0);
       }
+  }
+  if ((TPP_ABLATE & HABL_STAMP) && p.D && !(p.ep & EP_BIAS) && tid == 0) {
+    stamp[3] = __builtin_readcyclecounter();
+    const size_t lin = blockIdx.x + gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z);
+    unsigned long long *dbg = (unsigned long long *)p.D + lin * 8;
+    for (int e = 0; e < 5; ++e) dbg[e] = stamp[e];
+    dbg[5] = wall_clock64();
   }
 }
 
@@ -282,9 +305,18 @@ static hipError_t launch_bf16(const GemmArgs &a, hipStream_t s) {
     attr_set = true;
   }
   GemmArgs args = a;
-  args.tiles_m = a.m / BM;
-  args.tiles_n = a.n / BN;
-  hipLaunchKernelGGL(kern, dim3(args.tiles_m * args.tiles_n), dim3(NT), lds, s, args);
+  const int tiles_m = a.m / BM, tiles_n = a.n / BN;
+  dim3 grid;
+  if ((tiles_m & 3) == 0 && (tiles_n & 1) == 0 && tiles_m / 4 <= 65535 && tiles_n / 2 <= 65535) {
+    args.tiles_m = tiles_m / 4; // XCD-blocked: 4 (M) x 2 (N) XCD blocks of tiles_m/4 x tiles_n/2 tiles
+    args.tiles_n = tiles_n / 2;
+    grid = dim3(8, args.tiles_n, args.tiles_m);
+  } else {
+    args.tiles_m = args.tiles_n = 0;
+    if (tiles_m > 65535 || tiles_n > 65535) return hipErrorInvalidValue;
+    grid = dim3(1, tiles_n, tiles_m);
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, args);
   return hipGetLastError();
 }
 
@@ -293,6 +325,7 @@ bool bf16_fast_eligible(const GemmDesc &d) {
   if (d.k <= 0 || d.k % BKH) return false;
   if (d.m % 64 || d.n % 64) return false;
   if ((d.lda & 7) || (d.ldb & 3) || (d.stride_a & 7) || (d.stride_b & 7)) return false;
+  if (d.lda >= (1 << 22) || d.ldb >= (1 << 21) || d.ldc >= (1 << 22)) return false; // 32-bit lane offsets
   return true;
 }
 

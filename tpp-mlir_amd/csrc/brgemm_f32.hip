@@ -38,7 +38,7 @@ namespace tpp {
 #ifndef TPP_NACC
 #define TPP_NACC 2
 #endif
-constexpr int ABL_NO_GLOAD = 1, ABL_NO_SWRITE = 2, ABL_NO_BARRIER = 4, ABL_NO_FRAG = 8;
+constexpr int ABL_NO_GLOAD = 1, ABL_NO_SWRITE = 2, ABL_NO_BARRIER = 4, ABL_NO_FRAG = 8, ABL_STAMP = 32;
 
 constexpr int BK = 64;     // k columns per chunk
 constexpr int NSTAGE = 3;  // LDS ring slots
@@ -52,16 +52,28 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void brgemm_f32_fast(GemmArgs p)
   constexpr int KB_PER_WAVE = 8 / WK;                  // k-blocks (of 8) per wave per chunk
   constexpr int KB_HALF = KB_PER_WAVE / 2;
   constexpr int NP = LA + LB;                          // staging pieces per thread per chunk
+  // MFMA slots that carry the LDS writes: they end one step before the barrier so the
+  // barrier's lgkmcnt(0) finds them retired
+  constexpr int WSLOTS = KB_HALF >= 2 ? 4 * (KB_HALF - 1) : 4 * KB_HALF;
   static_assert(LA >= 1 && LB >= 1 && KB_HALF >= 1, "tile too small for this thread count");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *As = smem;
   float *Bs = smem + NSTAGE * A_STAGE;
 
+  unsigned long long stamp[5] = {0, 0, 0, 0, 0};
+  unsigned long long step_stamp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long pro_stamp[4] = {0, 0, 0, 0};
+  if (TPP_ABLATE & ABL_STAMP) { stamp[0] = __builtin_readcyclecounter(); stamp[4] = wall_clock64(); }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wk = wave / (WM * WN), wmn = wave % (WM * WN), wm = wmn / WN, wn = wmn % WN;
   const int li = lane & 31, lh = lane >> 5;
-  int tm, tn;
-  tile_of_block(blockIdx.x, p.tiles_m, p.tiles_n, tm, tn);
+  // Output tile from the 3-D grid, no divisions (launch_fast picks the shape): XCD-blocked
+  // grids are (8, bn, bm): blockIdx.x is the XCD slot (workgroups go to XCDs round-robin in
+  // linear-id order, x fastest), and each XCD owns a compact bm x bn block of tiles so the
+  // A row-panels / B column-panels it streams are shared in its private L2. Plain grids are
+  // (1, tiles_n, tiles_m) with the same formula (blockIdx.x == 0).
+  const int tm = (int)(blockIdx.x >> 1) * p.tiles_m + (int)blockIdx.z;
+  const int tn = (int)(blockIdx.x & 1) * p.tiles_n + (int)blockIdx.y;
   const int m0 = tm * BM, n0 = tn * BN;
 
   const float *__restrict__ A = (const float *)p.A;
@@ -70,19 +82,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void brgemm_f32_fast(GemmArgs p)
   const int kchunks = p.k / BK;
   const int T = p.br * kchunks;
 
-  // accumulators: wk == 0 starts from C (beta = 1) so the chain is C + sum, as in
-  // the reference; other K groups start from zero.
-  f32x16 acc[NACC];
-#pragma unroll
-  for (int a = 0; a < NACC; ++a)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[a][r] = 0.0f;
-  const int crow0 = m0 + wm * 32 + 4 * lh, ccol = n0 + wn * 32 + li;
-  if (!(p.ep & EP_BETA0) && wk == 0) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-      acc[0][r] = C[(int64_t)(crow0 + (r & 3) + 8 * (r >> 2)) * p.ldc + ccol];
-  }
+  f32x16 acc[NACC]; // initialised after the first loads are on their way
 
   // staging registers of the chunk in flight (HBM -> VGPR -> LDS). Pieces 0..LA-1 are
   // A, LA..LA+LB-1 are B (16 bytes per lane each). The LDS writes of a chunk are spread
@@ -162,6 +162,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void brgemm_f32_fast(GemmArgs p)
 #pragma unroll
     for (int q = 0; q < KB_PER_WAVE; ++q) {
       const int cur = q & 1, nxt = cur ^ 1;
+      if ((TPP_ABLATE & ABL_STAMP) && STAGE == 0 && HAS_LOAD) step_stamp[q] = __builtin_readcyclecounter();
       if (!(TPP_ABLATE & ABL_NO_FRAG)) {
         if (q + 1 < KB_PER_WAVE) frag_load(nxt, STAGE, kbw + q + 1);
         else if (HAS_NEXT) frag_load(nxt, NSTG, kbw);
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void brgemm_f32_fast(GemmArgs p)
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         acc[s % NACC] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][s], fb[cur][s], acc[s % NACC], 0, 0, 0);
-        if (HAS_LOAD && !(TPP_ABLATE & ABL_NO_GLOAD) && q == KB_HALF - 1 && s == 3) {
+        if (HAS_LOAD && !(TPP_ABLATE & ABL_NO_GLOAD) && q == 0 && s == 0) {
           // panel base of the next chunk to load: scalar work in the shadow of the MFMA above
           if (++kc == kchunks) {
             kc = 0;
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void brgemm_f32_fast(GemmArgs p)
         }
 #pragma unroll
         for (int u = 0; u < NP; ++u) {
-          if (HAS_NEXT && !(TPP_ABLATE & ABL_NO_SWRITE) && (u * 4 * KB_HALF) / NP == q * 4 + s) swrite_piece(NSTG, u);
+          if (HAS_NEXT && !(TPP_ABLATE & ABL_NO_SWRITE) && (u * WSLOTS) / NP == q * 4 + s) swrite_piece(NSTG, u);
           if (HAS_LOAD && !(TPP_ABLATE & ABL_NO_GLOAD) && (u * 4 * (KB_PER_WAVE - KB_HALF)) / NP == (q - KB_HALF) * 4 + s)
             gload_piece(NSTG, u);
         }
@@ -194,6 +195,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void brgemm_f32_fast(GemmArgs p)
       }
       if (q == KB_HALF - 1 && !(TPP_ABLATE & ABL_NO_BARRIER)) __syncthreads();
     }
+    if ((TPP_ABLATE & ABL_STAMP) && STAGE == 0 && HAS_LOAD) step_stamp[8] = __builtin_readcyclecounter();
   };
   using yes = std::integral_constant<bool, true>;
   using no = std::integral_constant<bool, false>;
@@ -203,14 +205,41 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void brgemm_f32_fast(GemmArgs p)
   static_assert(NSET == NSTAGE && NSTAGE == 3, "the chunk schedule below is written for 3 slots / 3 sets");
 
   // prologue: chunk 0 -> set 0 -> slot 0; chunks 1, 2, 3 -> sets 1, 2, 0 (in flight)
-  if (T > 0) {
+  if (T > 0) { // first thing the kernel does: get chunk 0 moving
+    if (TPP_ABLATE & ABL_STAMP) pro_stamp[0] = __builtin_readcyclecounter();
 #pragma unroll
     for (int u = 0; u < NP; ++u) gload_piece(0, u);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // accumulators: wk == 0 starts from C (beta = 1) so the chain is C + sum, as in
+  // the reference; other K groups start from zero.
+#pragma unroll
+  for (int a = 0; a < NACC; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[a][r] = 0.0f;
+  // C tile through buffer ops: wave-uniform tile base in the descriptor, per-lane offset
+  // constant, the row of accumulator register r as a scalar offset -> one instruction per
+  // register, no 64-bit vector address math in the epilogue.
+  const int ccol = n0 + wn * 32 + li;
+  const __amdgpu_buffer_rsrc_t rsrcC =
+      __builtin_amdgcn_make_buffer_rsrc((void *)(C + (int64_t)m0 * p.ldc + n0), 0, 0x7fffffff, 0x00020000);
+  const unsigned voffC = (unsigned)(((wm * 32 + 4 * lh) * (int)p.ldc + wn * 32 + li) * 4);
+  const unsigned ldcb = (unsigned)((int)p.ldc * 4);
+  if (!(p.ep & EP_BETA0) && wk == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      acc[0][r] = __builtin_bit_cast(
+          float, __builtin_amdgcn_raw_buffer_load_b32(rsrcC, voffC, (unsigned)((r & 3) + 8 * (r >> 2)) * ldcb, 0));
+  }
+
+  if (T > 0) {
 #pragma unroll
     for (int c = 1; c <= NSET; ++c) {
       if (c == NSET) { // set 0 is reused for chunk NSET: chunk 0 must be in LDS first
+        if (TPP_ABLATE & ABL_STAMP) pro_stamp[1] = __builtin_readcyclecounter();
 #pragma unroll
         for (int u = 0; u < NP; ++u) swrite_piece(0, u);
+        if (TPP_ABLATE & ABL_STAMP) pro_stamp[2] = __builtin_readcyclecounter();
       }
       if (c < T) {
         gadvance();
@@ -220,7 +249,9 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void brgemm_f32_fast(GemmArgs p)
     }
   }
   __syncthreads();
+  if (TPP_ABLATE & ABL_STAMP) pro_stamp[3] = __builtin_readcyclecounter();
   if (T > 0) frag_load(0, 0, kbw);
+  if (TPP_ABLATE & ABL_STAMP) stamp[1] = __builtin_readcyclecounter();
   int t = 0;
   for (; t + 2 + NSET + 1 < T; t += 3) { // steady state: three chunks per trip, ring slots 0, 1, 2
     chunk(S0{}, yes{}, yes{});
@@ -241,6 +272,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void brgemm_f32_fast(GemmArgs p)
     if (t < T) tail(S2{});
   }
 
+  if (TPP_ABLATE & ABL_STAMP) stamp[2] = __builtin_readcyclecounter();
   if (TPP_ABLATE & (ABL_NO_SWRITE | ABL_NO_FRAG)) { // keep ablated producers alive
 #pragma unroll
     for (int u = 0; u < LA + LB; ++u) asm volatile("" ::"v"(rs[0][u]), "v"(rs[1][u]), "v"(rs[2][u]));
@@ -275,7 +307,21 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void brgemm_f32_fast(GemmArgs p)
   for (int r = 0; r < 16; ++r) {
     float v = acc[0][r] + bias;
     if (p.ep & EP_RELU) v = v > 0.0f ? v : 0.0f;
-    C[(int64_t)(crow0 + (r & 3) + 8 * (r >> 2)) * p.ldc + ccol] = v;
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrcC, voffC,
+                                          (unsigned)((r & 3) + 8 * (r >> 2)) * ldcb, 0);
+  }
+  if ((TPP_ABLATE & ABL_STAMP) && p.D && !(p.ep & EP_BIAS) && tid == 0) {
+    stamp[3] = __builtin_readcyclecounter();
+    const size_t lin = blockIdx.x + gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z);
+    const size_t nblk = (size_t)gridDim.x * gridDim.y * gridDim.z;
+    unsigned long long *dbg = (unsigned long long *)p.D + lin * 8;
+    for (int e = 0; e < 5; ++e) dbg[e] = stamp[e];
+    dbg[5] = wall_clock64();
+    unsigned long long *dbg2 = (unsigned long long *)p.D + nblk * 8 + lin * 16;
+    for (int e = 0; e < 9; ++e) dbg2[e] = step_stamp[e];
+    for (int e = 0; e < 4; ++e) dbg2[9 + e] = pro_stamp[e];
+    dbg[6] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); // HW_REG_XCC_ID
+    dbg[7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_REG_HW_ID
   }
 }
 
@@ -355,6 +401,7 @@ enum GemmVariant : int {
   V_F32_64x32K2 = 1, // 4 waves 2x1x2
   V_F32_32x32K4 = 2, // 4 waves 1x1x4
   V_F32_128x64 = 3,  // 8 waves 4x2x1
+  V_F32_64x64K2 = 4, // 8 waves 2x2x2 (two waves per SIMD share every K chunk)
   V_GENERIC = 8,     // chosen per invoke when the fast preconditions fail
   V_BF16_FAST = 16,  // brgemm_bf16.hip
 };
@@ -371,9 +418,18 @@ static hipError_t launch_fast(const GemmArgs &a, hipStream_t s) {
     attr_set = true;
   }
   GemmArgs args = a;
-  args.tiles_m = a.m / BM;
-  args.tiles_n = a.n / BN;
-  hipLaunchKernelGGL(kern, dim3(args.tiles_m * args.tiles_n), dim3(NT), lds, s, args);
+  const int tiles_m = a.m / BM, tiles_n = a.n / BN;
+  dim3 grid;
+  if ((tiles_m & 3) == 0 && (tiles_n & 1) == 0 && tiles_m / 4 <= 65535 && tiles_n / 2 <= 65535) {
+    args.tiles_m = tiles_m / 4; // XCD-blocked: 4 (M) x 2 (N) XCD blocks of tiles_m/4 x tiles_n/2 tiles
+    args.tiles_n = tiles_n / 2;
+    grid = dim3(8, args.tiles_n, args.tiles_m);
+  } else {
+    args.tiles_m = args.tiles_n = 0;
+    if (tiles_m > 65535 || tiles_n > 65535) return hipErrorInvalidValue;
+    grid = dim3(1, tiles_n, tiles_m);
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, args);
   return hipGetLastError();
 }
 
@@ -400,6 +456,7 @@ static int g_num_cus = 256;
 static int pick_f32_variant(const GemmDesc &d) {
   if (d.k <= 0 || d.k % BK) return V_GENERIC;
   if ((d.lda | d.ldb | d.stride_a | d.stride_b) & 3) return V_GENERIC;
+  if (d.lda >= (1 << 22) || d.ldb >= (1 << 22) || d.ldc >= (1 << 22)) return V_GENERIC; // 32-bit lane offsets
   const int64_t m = d.m, n = d.n;
   auto tiles = [&](int bm, int bn) { return (m % bm == 0 && n % bn == 0) ? (m / bm) * (n / bn) : 0; };
   // largest tile that still gives every CU a workgroup; else the smallest tile
@@ -419,6 +476,7 @@ static const char *variant_name(int v) {
   case V_F32_64x32K2: return "brgemm_f32_fast<64x32,k2>";
   case V_F32_32x32K4: return "brgemm_f32_fast<32x32,k4>";
   case V_F32_128x64: return "brgemm_f32_fast<128x64,k1>";
+  case V_F32_64x64K2: return "brgemm_f32_fast<64x64,k2>";
   case V_BF16_FAST: return "brgemm_bf16_fast";
   default: return "brgemm_generic";
   }
@@ -430,8 +488,8 @@ bool plan_gemm(GemmDesc &d, int forced_variant) {
   else if (d.dtype == DT_BF16 && bf16_fast_eligible(d)) v = V_BF16_FAST;
   if (forced_variant >= 0 && d.dtype == DT_F32 && v != V_GENERIC) {
     // honour the forced tile only if the shape divides it
-    const int bm[] = {64, 64, 32, 128}, bn[] = {64, 32, 32, 64};
-    if (forced_variant <= 3 && d.m % bm[forced_variant] == 0 && d.n % bn[forced_variant] == 0) v = forced_variant;
+    const int bm[] = {64, 64, 32, 128, 64}, bn[] = {64, 32, 32, 64, 64};
+    if (forced_variant <= 4 && d.m % bm[forced_variant] == 0 && d.n % bn[forced_variant] == 0) v = forced_variant;
     if (forced_variant == V_GENERIC) v = V_GENERIC;
   } else if (forced_variant == V_GENERIC) {
     v = V_GENERIC;
@@ -459,6 +517,7 @@ hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C,
   case V_F32_64x32K2: return launch_fast<2, 1, 2, TPP_NACC>(a, stream);
   case V_F32_32x32K4: return launch_fast<1, 1, 4, TPP_NACC>(a, stream);
   case V_F32_128x64: return launch_fast<4, 2, 1, TPP_NACC>(a, stream);
+  case V_F32_64x64K2: return launch_fast<2, 2, 2, TPP_NACC>(a, stream);
   case V_BF16_FAST: return launch_gemm_bf16_fast(d, a, stream);
   default: break;
   }
