@@ -105,6 +105,28 @@ def graph_of(fn, warm=3):
         return None
 
 
+def pmc_traffic(kernel_substr):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/*_pmc_hbm.txt, one counter per run). FETCH_SIZE / WRITE_SIZE are KiB; on gfx950
+    FETCH_SIZE reports half of a 16 B/lane streaming read (MI355X_MICROARCH.md, HBM) -> doubled."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.txt")))
+    if not files:
+        return None
+    fetch = write = None
+    for line in open(files[-1]):
+        if kernel_substr in line:
+            m = re.search(r"mean\s+([0-9.]+)", line)
+            if m and "FETCH_SIZE" in line:
+                fetch = float(m.group(1))
+            if m and "WRITE_SIZE" in line:
+                write = float(m.group(1))
+    if fetch is None or write is None:
+        return None
+    return (2.0 * fetch + write) * 1024.0
+
+
 def cpu_baseline(seconds, A, B, C):
     """the CPU restatement (oracle, OpenMP over row blocks of output tiles) on the same C2 inputs"""
     from oracle import pyoracle as orc
@@ -248,7 +270,9 @@ def main():
                        "inputs": "tpp-run normal init, seed 123 (N(0,0.2) clamped to [0,1])" if args.init == "reference"
                        else "uniform [-1,1)"},
             "roofline": {"bound": "mfma", "achieved": round(achieved_tf, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved_tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(achieved_tf / PEAK_F32_MFMA_TFLOPS, 4),
+                         "traffic": pmc_traffic("brgemm_f32_fast<2, 2, 1"), "traffic_unit": "bytes/launch (HBM side, PMC)",
+                         "algorithmic_bytes": 3 * 4 * 1024 * 1024,
                          "kernel_us": round(kernel_s * 1e6, 3),
                          "note": "achieved = 2*m*n*k*br / (HIP-event time of the K timed launches / K) on the launch stream"},
             "cpu_baseline": cpu,
