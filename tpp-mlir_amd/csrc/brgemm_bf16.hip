@@ -19,6 +19,7 @@
 #include "gemm_common.h"
 #include "xsmm_desc.h"
 #include <type_traits>
+#include <stdlib.h>
 
 namespace tpp {
 
@@ -46,6 +47,7 @@ __global__ __launch_bounds__(64 * WM * WN) void brgemm_bf16_fast(GemmArgs p) {
   unsigned char *Bs = smem_h + NSTAGE_H * A_STAGE;
 
   unsigned long long stamp[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long step_stamp[5] = {0, 0, 0, 0, 0};
   if (TPP_ABLATE & HABL_STAMP) { stamp[0] = __builtin_readcyclecounter(); stamp[4] = wall_clock64(); }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -148,6 +150,7 @@ __global__ __launch_bounds__(64 * WM * WN) void brgemm_bf16_fast(GemmArgs p) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int cur = q & 1, nxt = cur ^ 1;
+      if ((TPP_ABLATE & HABL_STAMP) && STAGE == 0 && HAS_LOAD) step_stamp[q] = __builtin_readcyclecounter();
       if (!(TPP_ABLATE & HABL_NO_FRAG)) {
         if (q + 1 < 4) frag_load(nxt, STAGE, q + 1);
         else if (HAS_NEXT) frag_load(nxt, NSTG, 0);
@@ -157,7 +160,8 @@ __global__ __launch_bounds__(64 * WM * WN) void brgemm_bf16_fast(GemmArgs p) {
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][i], bfr[cur][j], acc[i][j], 0, 0, 0);
+          // operands swapped (D = B^T A^T tile): lane&31 = output ROW, registers = columns - see the epilogue
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[cur][j], af[cur][i], acc[i][j], 0, 0, 0);
           const int slot = (q & 1) * TM * TN + i * TN + j; // slot inside the half chunk
           if (HAS_LOAD && q == 1 && i == TM - 1 && j == TN - 1) { // next panel base: scalar work
             if (++kc == kchunks) {
@@ -179,6 +183,7 @@ __global__ __launch_bounds__(64 * WM * WN) void brgemm_bf16_fast(GemmArgs p) {
         }
       if (q == 1 && !(TPP_ABLATE & HABL_NO_BARRIER)) __syncthreads();
     }
+    if ((TPP_ABLATE & HABL_STAMP) && STAGE == 0 && HAS_LOAD) step_stamp[4] = __builtin_readcyclecounter();
   };
   using yes = std::integral_constant<bool, true>;
   using no = std::integral_constant<bool, false>;
@@ -199,22 +204,30 @@ __global__ __launch_bounds__(64 * WM * WN) void brgemm_bf16_fast(GemmArgs p) {
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-  // C tile through buffer ops: tile base in the descriptor, per-lane offset constant, the
-  // (tile row i, register r) row as a scalar offset, the tile column j as an immediate
-  const int ccol0 = n0 + wn * 32 * TN + li;
+  // Output fragment layout (MFMA operands are swapped: the B fragment is the "A" operand):
+  // lane (li, lh) owns output row wm*32*TM + 32*i + li of tile (i, j) and, in registers
+  // 4g..4g+3, the four consecutive columns 32*j + 8*g + 4*lh + (0..3). The C tile is
+  // addressed through a buffer descriptor (tile base) + per-lane byte offset (row) + an
+  // immediate/scalar column offset.
   const __amdgpu_buffer_rsrc_t rsrcC =
       __builtin_amdgcn_make_buffer_rsrc((void *)(C + (int64_t)m0 * p.ldc + n0), 0, 0x7fffffff, 0x00020000);
-  const unsigned voffC = (unsigned)(((wm * 32 * TM + 4 * lh) * (int)p.ldc + wn * 32 * TN + li) * 2);
   const unsigned ldcb = (unsigned)((int)p.ldc * 2);
-  if (!(p.ep & EP_BETA0)) {
+  const unsigned voffC = (unsigned)(wm * 32 * TM + li) * ldcb + (unsigned)((wn * 32 * TN + 4 * lh) * 2);
+  if (!(p.ep & EP_BETA0)) { // beta = 1: start the accumulator chain from C (8-byte loads, 4 columns each)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          acc[i][j][r] = bf16_bits_to_f32(__builtin_amdgcn_raw_buffer_load_b16(
-              rsrcC, voffC + 64 * j, (unsigned)(32 * i + (r & 3) + 8 * (r >> 2)) * ldcb, 0));
+        for (int g = 0; g < 4; ++g) {
+          typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+          const u32x2 c2 = __builtin_amdgcn_raw_buffer_load_b64(rsrcC, voffC + (unsigned)((32 * j + 8 * g) * 2),
+                                                              (unsigned)(32 * i) * ldcb, 0);
+          acc[i][j][4 * g + 0] = __uint_as_float(c2[0] << 16);
+          acc[i][j][4 * g + 1] = __uint_as_float(c2[0] & 0xffff0000u);
+          acc[i][j][4 * g + 2] = __uint_as_float(c2[1] << 16);
+          acc[i][j][4 * g + 3] = __uint_as_float(c2[1] & 0xffff0000u);
+        }
   }
 
   if (T > 0) {
@@ -270,19 +283,53 @@ __global__ __launch_bounds__(64 * WM * WN) void brgemm_bf16_fast(GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(bfr[0][j]), "v"(bfr[1][j]));
   }
+  // epilogue: (+bias[col]) (relu) -> bf16 (RNE, v_cvt_pk_bf16_f32) -> 16-byte stores. A lane
+  // holds 4 consecutive columns per register quad and its partner lane (lh ^ 1) the next 4;
+  // one v_permlane32_swap per dword gives the lower half-wave columns 8g..8g+7 of quad g and
+  // the upper half-wave the same of quad g+1: 2 stores of 16 bytes per 32x32 tile per lane.
+  typedef unsigned int u32x2e __attribute__((ext_vector_type(2)));
+  const bool relu = (p.ep & EP_RELU) != 0;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    const int col = ccol0 + 32 * j;
-    const float bias = (p.ep & EP_BIAS) ? bf16_bits_to_f32(((const unsigned short *)p.D)[col]) : 0.0f;
+    float bias[4][4];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int g = 0; g < 4; ++g) {
+      u32x2e b2 = {0u, 0u};
+      if (p.ep & EP_BIAS)
+        b2 = *(const u32x2e *)((const unsigned short *)p.D + n0 + wn * 32 * TN + 32 * j + 8 * g + 4 * lh);
+      bias[g][0] = __uint_as_float(b2[0] << 16);
+      bias[g][1] = __uint_as_float(b2[0] & 0xffff0000u);
+      bias[g][2] = __uint_as_float(b2[1] << 16);
+      bias[g][3] = __uint_as_float(b2[1] & 0xffff0000u);
+    }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = acc[i][j][r] + bias;
-        if (p.ep & EP_RELU) v = v > 0.0f ? v : 0.0f;
-        __builtin_amdgcn_raw_buffer_store_b16(f32_to_bf16_bits(v), rsrcC, voffC + 64 * j,
-                                              (unsigned)(32 * i + (r & 3) + 8 * (r >> 2)) * ldcb, 0);
+    for (int i = 0; i < TM; ++i) {
+      unsigned int pk[4][2]; // quad g -> two dwords of packed bf16
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          float v0 = acc[i][j][4 * g + 2 * h2] + bias[g][2 * h2];
+          float v1 = acc[i][j][4 * g + 2 * h2 + 1] + bias[g][2 * h2 + 1];
+          if (relu) { // wave-uniform; max(x, 0) == (x > 0 ? x : 0) incl. NaN -> 0
+            v0 = __builtin_fmaxf(v0, 0.0f);
+            v1 = __builtin_fmaxf(v1, 0.0f);
+          }
+          typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+          typedef float f32x2_t __attribute__((ext_vector_type(2)));
+          const f32x2_t vv = {v0, v1};
+          pk[g][h2] = __builtin_bit_cast(unsigned int, __builtin_convertvector(vv, bf16x2_t)); // one v_cvt_pk_bf16_f32 (RNE)
+        }
+#pragma unroll
+      for (int g = 0; g < 4; g += 2) {
+        const auto s0 = __builtin_amdgcn_permlane32_swap(pk[g][0], pk[g + 1][0], false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(pk[g][1], pk[g + 1][1], false, false);
+        const u32x4 out = {s0[0], s1[0], s0[1], s1[1]};
+        // lower half: columns 32j + 8g .. +7 ; upper half: columns 32j + 8(g+1) .. +7
+        const unsigned colb = (unsigned)((32 * j + 8 * g) * 2) + (lh ? 16u - 8u : 0u);
+        __builtin_amdgcn_raw_buffer_store_b128(out, rsrcC, voffC + colb, (unsigned)(32 * i) * ldcb, 0);
       }
+    }
   }
   if ((TPP_ABLATE & HABL_STAMP) && p.D && !(p.ep & EP_BIAS) && tid == 0) {
     stamp[3] = __builtin_readcyclecounter();
@@ -290,6 +337,9 @@ __global__ __launch_bounds__(64 * WM * WN) void brgemm_bf16_fast(GemmArgs p) {
     unsigned long long *dbg = (unsigned long long *)p.D + lin * 8;
     for (int e = 0; e < 5; ++e) dbg[e] = stamp[e];
     dbg[5] = wall_clock64();
+    const size_t nblk = (size_t)gridDim.x * gridDim.y * gridDim.z;
+    unsigned long long *dbg2 = (unsigned long long *)p.D + nblk * 8 + lin * 8;
+    for (int e = 0; e < 5; ++e) dbg2[e] = step_stamp[e];
   }
 }
 
@@ -320,18 +370,353 @@ static hipError_t launch_bf16(const GemmArgs &a, hipStream_t s) {
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------
+// brgemm_bf16_dma128: 128x128 tile, 4 waves (2x2) of 64x64, every panel byte goes
+// HBM -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds): no staging VGPRs, no ds_write, no
+// transpose moves. Measured on the register-staged kernel above, the ds_write path (13
+// cycles per 16 bytes per wave-instruction, 32 per chunk per CU) was the critical
+// resource of the first half of every chunk; the DMA path does not use it.
+//   ring : 4 slots of (A 16 KiB | B 16 KiB); the DMA of chunk t+3 is issued right after the
+//          mid-chunk barrier of chunk t (2.5 chunks of MFMAs ahead of its first use).
+//   A    : LDS image [128 rows][8 x 16 B], lane-linear per DMA instruction (8 rows x 128 B);
+//          the bank swizzle (16-byte column XOR ((row>>1)&7)) is applied to the SOURCE
+//          address, the fragment read applies the same XOR (involution).
+//   B    : LDS image = the VNNI-2 rows as they are, [32 pair-rows][128 dwords]; a lane's
+//          fragment (8 consecutive k of one column) is 4 dwords one row apart, read by two
+//          ds_read2st64_b32 (row stride 512 B = 2 x 64 dwords).
+//   sync : per chunk ONE s_waitcnt vmcnt(N) (own DMA of chunk t+1 landed) + ONE raw s_barrier,
+//          in the middle of the chunk's MFMAs; never __syncthreads (it would drain the DMA).
+//   out  : accumulators (lane = row, registers = columns, operands swapped) -> bias/relu ->
+//          bf16 -> per-wave LDS tile -> row-contiguous 16-byte reads -> fully coalesced
+//          128-byte-per-row stores.
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+__global__ __launch_bounds__(256) void brgemm_bf16_dma128(GemmArgs p) {
+  constexpr int BM = 128, BN = 128, NSLOT = 4, TM = 2, TN = 2;
+  constexpr int A_SLOT = BM * BKH * 2, B_SLOT = (BKH / 2) * BN * 4, SLOT = A_SLOT + B_SLOT;
+  constexpr int DMA_PER_CHUNK = 8; // per wave: 4 x 1 KiB of A + 4 x 1 KiB of B
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_d[];
+
+  unsigned long long stamp[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long step_stamp[5] = {0, 0, 0, 0, 0};
+  if (TPP_ABLATE & HABL_STAMP) { stamp[0] = __builtin_readcyclecounter(); stamp[4] = wall_clock64(); }
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int tm = (int)(blockIdx.x >> 1) * p.tiles_m + (int)blockIdx.z;
+  const int tn = (int)(blockIdx.x & 1) * p.tiles_n + (int)blockIdx.y;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const unsigned short *__restrict__ A = (const unsigned short *)p.A;
+  const unsigned short *__restrict__ B = (const unsigned short *)p.B;
+  unsigned short *__restrict__ C = (unsigned short *)p.C;
+  const int kchunks = p.k / BKH;
+  const int T = p.br * kchunks;
+
+  // per-lane source offsets of this wave's 8 DMA instructions (constant for the kernel)
+  unsigned voffA[4], voffB[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int v = wave * 4 + u;
+    const int row = 8 * v + (lane >> 3), pos = lane & 7;
+    voffA[u] = (unsigned)(row * (int)p.lda * 2 + ((pos ^ ((row >> 1) & 7)) << 4));
+    const int rowb = 2 * v + (lane >> 5);
+    voffB[u] = (unsigned)(rowb * (int)p.ldb * 4 + ((lane & 31) << 4));
+  }
+  // K rotation: every tile walks the same (batch, k) chunks but starts at a different one
+  // (and wraps), so the workgroups of one XCD do not all ask its L2 for the same lines at
+  // the same moment. The sum is over the same terms in a rotated order (still fixed per tile).
+#ifndef TPP_BF16_ROTATE
+#define TPP_BF16_ROTATE 0
+#endif
+  const int rot = (TPP_BF16_ROTATE && T > 1) ? (int)((blockIdx.y * 5u + blockIdx.z * 3u + blockIdx.x) % (unsigned)T) : 0;
+  const int rb = rot / kchunks, rk = rot - rb * kchunks; // first chunk = (batch rb, k-chunk rk)
+  const unsigned short *const gA0 = A + (int64_t)m0 * p.lda, *const gB0 = B + 2 * (int64_t)n0;
+  const unsigned short *gA = gA0 + (int64_t)rb * p.stride_a + (int64_t)rk * BKH;
+  const unsigned short *gB = gB0 + (int64_t)rb * p.stride_b + (int64_t)rk * (BKH / 2) * 2 * p.ldb;
+  int kc = rk, cabs = rot; // k-chunk inside the batch element / absolute chunk index (wraps at T)
+  const int64_t dA_wrap = p.stride_a - (int64_t)(kchunks - 1) * BKH;
+  const int64_t dB_in = (int64_t)(BKH / 2) * 2 * p.ldb, dB_wrap = p.stride_b - (int64_t)(kchunks - 1) * dB_in;
+  // one of this wave's 8 DMA instructions of the chunk at (gA, gB): pieces 0-3 A, 4-7 B
+  auto dma_piece = [&](int slot, int u) __attribute__((always_inline)) {
+    unsigned char *base = smem_d + slot * SLOT + wave * 4096;
+    if (u < 4) {
+      const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void *)gA, 0, 0x7fffffff, 0x00020000);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t *)(base + u * 1024), 16, voffA[u], 0, 0, 0);
+    } else {
+      const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)gB, 0, 0x7fffffff, 0x00020000);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_t *)(base + A_SLOT + (u - 4) * 1024), 16, voffB[u - 4], 0, 0, 0);
+    }
+  };
+  auto dma_chunk = [&](int slot) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) dma_piece(slot, u);
+  };
+#define TPP_DMA_ADVANCE()         \
+  do {                            \
+    if (++cabs == T) {            \
+      cabs = 0;                   \
+      kc = 0;                     \
+      gA = gA0;                   \
+      gB = gB0;                   \
+    } else if (++kc == kchunks) { \
+      kc = 0;                     \
+      gA += dA_wrap;              \
+      gB += dB_wrap;              \
+    } else {                      \
+      gA += BKH;                  \
+      gB += dB_in;                \
+    }                             \
+  } while (0)
+
+  f32x16 acc[TM][TN];
+  constexpr int NFB = 4; // fragment buffers: step q+2 is read while step q multiplies
+  bf16x8_t af[NFB][TM], bfr[NFB][TN];
+  int b_lane[TN]; // dword index of this lane's column in tile j, row 4*lh of a k-step
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    b_lane[j] = (4 * lh) * BN + (wn * TN + j) * 32 + li;
+    asm volatile("" : "+v"(b_lane[j]));
+  }
+  auto frag_load = [&](int buf, int slot, int ks) __attribute__((always_inline)) {
+    const unsigned char *as = smem_d + slot * SLOT;
+    const unsigned int *bs = (const unsigned int *)(as + A_SLOT);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int row = (wm * TM + i) * 32 + li;
+      af[buf][i] = *(const bf16x8_t *)(as + row * 128 + (((2 * ks + lh) ^ ((row >> 1) & 7)) << 4));
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      // one base VGPR per column tile (made opaque) so the 4 row reads pair up as
+      // ds_read2st64_b32 (rows r, r+1) straight into 4 consecutive registers
+      const unsigned int *bp = bs + b_lane[j] + (8 * ks) * BN;
+      const u32x4 v = {bp[0], bp[BN], bp[2 * BN], bp[3 * BN]};
+      bfr[buf][j] = __builtin_bit_cast(bf16x8_t, v);
+    }
+  };
+  // one chunk in ring slot S. H1/H2/H3: chunk t+1 / t+2 / t+3 exist. Step q multiplies the
+  // fragments in buffer q (4 steps per chunk, 4 buffers) while the fragments of step q+2 are
+  // read (steps 2, 3 read the first two steps of chunk t+1, published by the mid barrier).
+  // The 8 DMA instructions of chunk t+3 ride one per MFMA in steps 2 and 3.
+  auto chunk = [&](auto slot_c, auto h1, auto h2, auto h3) __attribute__((always_inline)) {
+    constexpr int S = decltype(slot_c)::value;
+    constexpr bool H1 = decltype(h1)::value, H2 = decltype(h2)::value, H3 = decltype(h3)::value;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if ((TPP_ABLATE & HABL_STAMP) && S == 0 && H3) step_stamp[q] = __builtin_readcyclecounter();
+      if (!(TPP_ABLATE & HABL_NO_FRAG)) {
+        if (q + 2 < 4) frag_load(q + 2, S, q + 2);
+        else if (H1) frag_load(q - 2, (S + 1) % NSLOT, q - 2);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[q][j], af[q][i], acc[i][j], 0, 0, 0);
+          if (H3 && q >= 2 && !(TPP_ABLATE & HABL_NO_GLOAD)) {
+            dma_piece((S + 3) % NSLOT, (q - 2) * 4 + i * TN + j); // slot of chunk t-1: every wave is past it
+            if (q == 3 && i == TM - 1 && j == TN - 1) TPP_DMA_ADVANCE();
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      if (q == 1 && H1) {
+        // chunk t+1: this wave's DMA has landed (chunk t+2's may still fly), then everybody's
+        if (H2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_CHUNK) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if ((TPP_ABLATE & HABL_STAMP) && S == 0 && H3) step_stamp[4] = __builtin_readcyclecounter();
+  };
+  using yes = std::integral_constant<bool, true>;
+  using no = std::integral_constant<bool, false>;
+
+  // prologue: chunks 0, 1, 2 in flight at once
+  if (T > 0) {
+    dma_chunk(0);
+    TPP_DMA_ADVANCE();
+  }
+  if (T > 1) {
+    dma_chunk(1);
+    TPP_DMA_ADVANCE();
+  }
+  if (T > 2) {
+    dma_chunk(2);
+    TPP_DMA_ADVANCE();
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  if (T > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DMA_PER_CHUNK) : "memory");
+  else if (T > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_CHUNK) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  if (T > 0) {
+    frag_load(0, 0, 0);
+    frag_load(1, 0, 1);
+  }
+  if (TPP_ABLATE & HABL_STAMP) stamp[1] = __builtin_readcyclecounter();
+  int t = 0;
+  for (; t + 6 < T; t += 4) {
+    chunk(std::integral_constant<int, 0>{}, yes{}, yes{}, yes{});
+    chunk(std::integral_constant<int, 1>{}, yes{}, yes{}, yes{});
+    chunk(std::integral_constant<int, 2>{}, yes{}, yes{}, yes{});
+    chunk(std::integral_constant<int, 3>{}, yes{}, yes{}, yes{});
+  }
+  auto tail = [&](auto slot_c) __attribute__((always_inline)) {
+    const int left = T - t;
+    if (left >= 4) chunk(slot_c, yes{}, yes{}, yes{});
+    else if (left == 3) chunk(slot_c, yes{}, yes{}, no{});
+    else if (left == 2) chunk(slot_c, yes{}, no{}, no{});
+    else chunk(slot_c, no{}, no{}, no{});
+    ++t;
+  };
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    if (t < T) tail(std::integral_constant<int, 0>{});
+    if (t < T) tail(std::integral_constant<int, 1>{});
+    if (t < T) tail(std::integral_constant<int, 2>{});
+    if (t < T) tail(std::integral_constant<int, 3>{});
+  }
+
+  if (TPP_ABLATE & HABL_STAMP) stamp[2] = __builtin_readcyclecounter();
+  if (TPP_ABLATE & HABL_NO_FRAG) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(af[0][i]), "v"(af[1][i]), "v"(af[2][i]), "v"(af[3][i]));
+#pragma unroll
+    for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(bfr[0][j]), "v"(bfr[1][j]), "v"(bfr[2][j]), "v"(bfr[3][j]));
+  }
+  // ---- epilogue ------------------------------------------------------------------------
+  // lane (li, lh) owns row 32*i + li of wave-tile row block i and, in registers 4g..4g+3 of
+  // tile (i, j), columns 32*j + 8*g + 4*lh + (0..3)
+  typedef unsigned int u32x2d __attribute__((ext_vector_type(2)));
+  const __amdgpu_buffer_rsrc_t rsrcC = __builtin_amdgcn_make_buffer_rsrc(
+      (void *)(C + (int64_t)(m0 + wm * 64) * p.ldc + n0 + wn * 64), 0, 0x7fffffff, 0x00020000);
+  const unsigned ldcb = (unsigned)((int)p.ldc * 2);
+  if (!(p.ep & EP_BETA0)) { // beta = 1: add C before the single rounding (8-byte loads, rare path)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const u32x2d c2 = __builtin_amdgcn_raw_buffer_load_b64(
+              rsrcC, (unsigned)(32 * i + li) * ldcb + (unsigned)((32 * j + 8 * g + 4 * lh) * 2), 0, 0);
+          acc[i][j][4 * g + 0] += __uint_as_float(c2[0] << 16);
+          acc[i][j][4 * g + 1] += __uint_as_float(c2[0] & 0xffff0000u);
+          acc[i][j][4 * g + 2] += __uint_as_float(c2[1] << 16);
+          acc[i][j][4 * g + 3] += __uint_as_float(c2[1] & 0xffff0000u);
+        }
+  }
+  __syncthreads(); // every wave is done with the ring: reuse it as per-wave output tiles
+  const bool relu = (p.ep & EP_RELU) != 0;
+  constexpr int ES = 144; // bytes per staged row: 64 bf16 + 16 B pad (conflict-free 16-byte accesses)
+  unsigned char *ot = smem_d + wave * (64 * ES);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    float bias[4][4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      u32x2d b2 = {0u, 0u};
+      if (p.ep & EP_BIAS)
+        b2 = *(const u32x2d *)((const unsigned short *)p.D + n0 + wn * 64 + 32 * j + 8 * g + 4 * lh);
+      bias[g][0] = __uint_as_float(b2[0] << 16);
+      bias[g][1] = __uint_as_float(b2[0] & 0xffff0000u);
+      bias[g][2] = __uint_as_float(b2[1] << 16);
+      bias[g][3] = __uint_as_float(b2[1] & 0xffff0000u);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      unsigned int pk[4][2];
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          float v0 = acc[i][j][4 * g + 2 * h2] + bias[g][2 * h2];
+          float v1 = acc[i][j][4 * g + 2 * h2 + 1] + bias[g][2 * h2 + 1];
+          if (relu) { // wave-uniform; max(x, 0) == (x > 0 ? x : 0) incl. NaN -> 0
+            v0 = __builtin_fmaxf(v0, 0.0f);
+            v1 = __builtin_fmaxf(v1, 0.0f);
+          }
+          typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+          typedef float f32x2_t __attribute__((ext_vector_type(2)));
+          const f32x2_t vv = {v0, v1};
+          pk[g][h2] = __builtin_bit_cast(unsigned int, __builtin_convertvector(vv, bf16x2_t)); // one v_cvt_pk_bf16_f32 (RNE)
+        }
+#pragma unroll
+      for (int g = 0; g < 4; g += 2) {
+        const auto s0 = __builtin_amdgcn_permlane32_swap(pk[g][0], pk[g + 1][0], false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(pk[g][1], pk[g + 1][1], false, false);
+        const u32x4 out = {s0[0], s1[0], s0[1], s1[1]};
+        // lower half-wave: columns 32j + 8g .. +7 ; upper: 32j + 8(g+1) .. +7
+        *(u32x4 *)(ot + (32 * i + li) * ES + (32 * j + 8 * g + 8 * lh) * 2) = out;
+      }
+    }
+  }
+  // same wave reads its tile back row-contiguously: 8 lanes x 16 B = one 128-byte row
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int row = it * 8 + (lane >> 3), ch = lane & 7;
+    const u32x4 v = *(const u32x4 *)(ot + row * ES + ch * 16);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrcC, (unsigned)(lane >> 3) * ldcb + (unsigned)(ch * 16),
+                                           (unsigned)(it * 8) * ldcb, 0);
+  }
+  if ((TPP_ABLATE & HABL_STAMP) && p.D && !(p.ep & EP_BIAS) && tid == 0) {
+    stamp[3] = __builtin_readcyclecounter();
+    const size_t lin = blockIdx.x + gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z);
+    const size_t nblk = (size_t)gridDim.x * gridDim.y * gridDim.z;
+    unsigned long long *dbg = (unsigned long long *)p.D + lin * 8;
+    for (int e = 0; e < 5; ++e) dbg[e] = stamp[e];
+    dbg[5] = wall_clock64();
+    unsigned long long *dbg2 = (unsigned long long *)p.D + nblk * 8 + lin * 8;
+    for (int e = 0; e < 5; ++e) dbg2[e] = step_stamp[e];
+  }
+}
+
+static hipError_t launch_bf16_dma128(const GemmArgs &a, hipStream_t s) {
+  constexpr size_t lds = 4 * 32768;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void *)brgemm_bf16_dma128, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  GemmArgs args = a;
+  const int tiles_m = a.m / 128, tiles_n = a.n / 128;
+  dim3 grid;
+  if ((tiles_m & 3) == 0 && (tiles_n & 1) == 0 && tiles_m / 4 <= 65535 && tiles_n / 2 <= 65535) {
+    args.tiles_m = tiles_m / 4;
+    args.tiles_n = tiles_n / 2;
+    grid = dim3(8, args.tiles_n, args.tiles_m);
+  } else {
+    args.tiles_m = args.tiles_n = 0;
+    if (tiles_m > 65535 || tiles_n > 65535) return hipErrorInvalidValue;
+    grid = dim3(1, tiles_n, tiles_m);
+  }
+  hipLaunchKernelGGL(brgemm_bf16_dma128, grid, dim3(256), lds, s, args);
+  return hipGetLastError();
+}
+
 bool bf16_fast_eligible(const GemmDesc &d) {
   if (d.dtype != DT_BF16 || !d.vnni_b) return false;
   if (d.k <= 0 || d.k % BKH) return false;
   if (d.m % 64 || d.n % 64) return false;
-  if ((d.lda & 7) || (d.ldb & 3) || (d.stride_a & 7) || (d.stride_b & 7)) return false;
+  if ((d.lda & 7) || (d.ldb & 3) || (d.ldc & 7) || (d.stride_a & 7) || (d.stride_b & 7)) return false;
   if (d.lda >= (1 << 22) || d.ldb >= (1 << 21) || d.ldc >= (1 << 22)) return false; // 32-bit lane offsets
   return true;
 }
 
 hipError_t launch_gemm_bf16_fast(const GemmDesc &d, const GemmArgs &a, hipStream_t s) {
   const int64_t t128 = (d.m % 128 == 0 && d.n % 128 == 0) ? (d.m / 128) * (d.n / 128) : 0;
-  if (t128 >= 192) return launch_bf16<2, 2, 2, 2>(a, s);
+  static const int legacy = getenv("TPP_HIP_BF16_LEGACY") ? atoi(getenv("TPP_HIP_BF16_LEGACY")) : 0;
+  if (t128 >= 192) return legacy ? launch_bf16<2, 2, 2, 2>(a, s) : launch_bf16_dma128(a, s);
   return launch_bf16<2, 2, 1, 1>(a, s);
 }
 

@@ -512,6 +512,8 @@ hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C,
   int v = d.variant;
   const bool aligned16 = ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0;
   if (v != V_GENERIC && !aligned16) v = V_GENERIC;
+  // the bf16 kernel stores 16-byte row pieces and reads the bias 8 bytes at a time
+  if (v == V_BF16_FAST && ((((uintptr_t)C) & 15) || (d.bias && (((uintptr_t)D) & 7)))) v = V_GENERIC;
   switch (v) {
   case V_F32_64x64: return launch_fast<2, 2, 1, TPP_NACC>(a, stream);
   case V_F32_64x32K2: return launch_fast<2, 1, 2, TPP_NACC>(a, stream);
