@@ -254,6 +254,51 @@ def main():
                "frac_of_bf16_mfma_peak": round(spec.flops() * K / mwall / 1e12 / (PEAK_BF16_MFMA_TFLOPS * world), 4),
                "kernel": rt.kernel_name(sh.handles[0][0]) if sh.rows else ""}
 
+    # ------------------------------------------------------------ the other BASELINE configs (N=1 only, short)
+    others = None
+    if world == 1 and not args.no_mlp:
+        others = []
+        Ko, Wo = max(50, K // 10), max(20, W // 10)
+        # C3: fp32 fused_brgemm + bias + relu, MLP layer 1024->1024, bs=512
+        A3 = torch.rand(512, 1024, device="cuda") - 0.4
+        W3 = torch.rand(1024, 1024, device="cuda") - 0.5
+        b3 = torch.rand(1024, device="cuda")
+        C3 = torch.empty(512, 1024, device="cuda")
+        h3 = rt.fused_brgemm_dispatch(F32, 512, 1024, 64, 1024, 1024, 1024, 64, 65536, 4, 0, 5, 4, 1)
+
+        def c3_step():
+            rt.fused_brgemm(F32, h3, A3, 0, W3, 0, C3, 0, b3, 0, 16)
+        warm(c3_step, Wo, sync)
+        w3, _ = timed(c3_step, Ko, sync, barrier)
+        f3 = 2.0 * 512 * 1024 * 1024 + 2.0 * 512 * 1024  # MLIRGen.cpp:328-334
+        others.append({"workload": "C3 fused_brgemm+bias+relu fp32 512x1024x1024", "kernel": rt.kernel_name(h3),
+                       "value": round(f3 * Ko / w3 / 1e9, 1), "unit": "GFLOP/s", "us_per_step": round(w3 / Ko * 1e6, 2),
+                       "frac_of_f32_mfma_peak": round(f3 * Ko / w3 / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)})
+        # C5: xsmm.unary VNNI-2 pack of B (2048^2 bf16) + bf16 BRGEMM 2048^3 (k=128, br=16, VNNI_B|BETA_0)
+        M5 = 2048
+        A5 = (torch.rand(M5, M5, device="cuda") - 0.5).to(torch.bfloat16)
+        B5 = (torch.rand(M5, M5, device="cuda") - 0.5).to(torch.bfloat16)
+        B5v = torch.empty_like(B5)
+        C5 = torch.empty(M5, M5, device="cuda", dtype=torch.bfloat16)
+        hp5 = rt.unary_dispatch(pkg.UnaryKind.VNNI2, BF16, M5, M5, M5, M5, 0)
+        h5 = rt.brgemm_dispatch(BF16, M5, M5, 128, M5, M5, M5, 128, 128 * M5, 4 | 2048)
+
+        def c5_pack():
+            rt.unary(BF16, hp5, B5, 0, B5v, 0)
+
+        def c5_gemm():
+            rt.brgemm(BF16, h5, A5, 0, B5v, 0, C5, 0, 16)
+        warm(c5_pack, Wo, sync)
+        wp, _ = timed(c5_pack, Ko, sync, barrier)
+        warm(c5_gemm, Wo, sync)
+        wg, _ = timed(c5_gemm, Ko, sync, barrier)
+        pack_bytes = 2.0 * M5 * M5 * 2
+        others.append({"workload": "C5 VNNI-2 pack prologue 2048x2048 bf16 (bit-exact move)", "value": round(pack_bytes * Ko / wp / 1e9, 1),
+                       "unit": "GB/s", "us_per_step": round(wp / Ko * 1e6, 2), "frac_of_hbm_8TBps": round(pack_bytes * Ko / wp / 8e12, 4)})
+        others.append({"workload": "C5 bf16 BRGEMM 2048^3 VNNI_B (k=128, br=16)", "kernel": rt.kernel_name(h5),
+                       "value": round(2.0 * M5 ** 3 * Ko / wg / 1e9, 1), "unit": "GFLOP/s", "us_per_step": round(wg / Ko * 1e6, 2),
+                       "frac_of_bf16_mfma_peak": round(2.0 * M5 ** 3 * Ko / wg / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)})
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.cpu_seconds, hA, hB, hC)
@@ -279,6 +324,8 @@ def main():
         }
         if mlp is not None:
             line["mlp"] = mlp
+        if others:
+            line["other_configs"] = others
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

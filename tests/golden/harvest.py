@@ -318,6 +318,38 @@ def main():
                              ["A", 0], ["W", 0], ["C", 0], ["bias", 0], 8)],
         "expect": [expect("C", 128, 512, 512, fill=257, tol="exact")]})
 
+    # ---- BASELINE config 1 ("plumbing"): the call script the default pipeline produces for
+    # `mlir-gen --kernel=args --float-type=f32 --batch=256 --layers=256,256`:
+    # A / W / C relayout into 32x32 blocks ([8][8][32][32], pack-matmul default tiles,
+    # ToBlockLayoutAndBack.cpp:460-471; blocks moved by 2-D copies, LowerPacksAndUnpacks.cpp:45-49),
+    # ONE brgemm dispatch [32,32,32,32,32,32,1024,1024], 8x8 invokes with batch 8, un-pack of C.
+    # Inputs const 1.0 (seed 0), C argument initialised 1.0, beta = 1 -> every element 256 + 1 = 257
+    # (same closed form as test/Integration/mlir-gen.mlir:17,28 where 10*1 + 1 = 11).
+    calls = []
+    ident = [1, F32, 32, 32, 256, 32, 0]      # xsmm.unary identity: 32x32 block, ldi 256 -> ldo 32
+    for bi in range(8):
+        for bj in range(8):
+            blk = (bi * 8 + bj) * 1024
+            calls.append(unary_call(ident, ["A", bi * 32 * 256 + bj * 32], ["Ap", blk]))     # A  [M/32][K/32][32][32]
+            calls.append(unary_call(ident, ["W", bj * 32 * 256 + bi * 32], ["Wp", blk]))     # W  [N/32][K/32][32 k][32 n]
+            calls.append(unary_call(ident, ["C", bi * 32 * 256 + bj * 32], ["Cp", blk]))     # C  [M/32][N/32][32][32]
+    for bi in range(8):
+        for bj in range(8):
+            calls.append(brgemm_call([F32, 32, 32, 32, 32, 32, 32, 1024, 1024, 0],
+                                     ["Ap", bi * 8 * 1024], ["Wp", bj * 8 * 1024], ["Cp", (bi * 8 + bj) * 1024], 8))
+    unpack = [1, F32, 32, 32, 32, 256, 0]
+    for bi in range(8):
+        for bj in range(8):
+            calls.append(unary_call(unpack, ["Cp", (bi * 8 + bj) * 1024], ["C", bi * 32 * 256 + bj * 32]))
+    dump("c1_mlir_gen_matmul_256", {
+        "source": ["BASELINE.json configs[0]; SURVEY.md section 8d (C1)", T + "mlir-gen.mlir:14-30 (closed form)",
+                   "lib/TPP/Transforms/ToBlockLayoutAndBack.cpp:460-471 (32x32x32 blocks)"],
+        "buffers": {"A": buf(F32, size=65536, const=1), "W": buf(F32, size=65536, const=1),
+                    "C": buf(F32, size=65536, const=1), "Ap": buf(F32, size=65536, const=0),
+                    "Wp": buf(F32, size=65536, const=0), "Cp": buf(F32, size=65536, const=0)},
+        "calls": calls,
+        "expect": [expect("C", 256, 256, 256, fill=257, tol="exact")]})
+
     # ---- bf16 -------------------------------------------------------------------
     VB = 2048  # wire value of dialect vnni_b (ConvertXsmmToFunc.cpp:251-265)
     dump("xsmm_brgemm_bf16", {
