@@ -139,6 +139,13 @@ TPP_XSMM_EXPORT double perf_stop_timer(int64_t start);
  * xsmm_hip_synchronize() or perf_stop_timer() to drain. Returns previous mode.
  * Also settable with env TPP_HIP_ASYNC=1. */
 TPP_XSMM_EXPORT int xsmm_hip_set_async(int enable);
+/* Tile queue (async mode only, device pointers only): invokes of one small-tile GEMM handle
+ * (m, n <= 64: the compiler's native 32x32x32 call pattern) are collected and run as ONE
+ * grouped launch at the next flush point (other handle / other op / data dependence on a
+ * queued output / xsmm_hip_flush / xsmm_hip_synchronize / perf_stop_timer). Program order is
+ * preserved. Returns the previous setting. Also env TPP_HIP_TILE_QUEUE=1. */
+TPP_XSMM_EXPORT int xsmm_hip_set_tile_queue(int enable);
+TPP_XSMM_EXPORT void xsmm_hip_flush(void);
 /* Stream the kernels are launched on (a hipStream_t). NULL = default stream. */
 TPP_XSMM_EXPORT void xsmm_hip_set_stream(void *hip_stream);
 TPP_XSMM_EXPORT void *xsmm_hip_get_stream(void);

@@ -1,0 +1,6 @@
+#!/bin/bash
+TAG=${1:-q}; OUT=gpurun_out/$TAG; mkdir -p $OUT
+timeout 600 python -m pytest tests/test_tile_queue_gpu.py -m gpu -q -p no:cacheprovider -x 2>&1 | tail -12
+for q in 0 1; do ./tools/tpp_replay --batch 256 --layers 1024,1024,1024,1024 --tiles 32 --bias --relu --queue $q -n 100 --print 2>&1 | grep -v amdgpu.ids; done | tee $OUT/replay.log
+./tools/tpp_replay --batch 256 --layers 1024,1024,1024,1024 --whole-layer --bias --relu -n 1000 --print 2>&1 | grep -v amdgpu.ids | tee -a $OUT/replay.log
+./tools/tpp_replay --batch 256 --layers 1024,1024,1024,1024 --tiles 32 --queue 1 -n 100 2>&1 | grep -v amdgpu.ids | tee -a $OUT/replay.log

@@ -1,0 +1,113 @@
+// tpp_replay - replays the dispatch/invoke call sequence that tpp-run's JIT'd code issues for
+// the reference's mlir-gen kernels, against libtpp_xsmm_runner_utils.so, with the reference's
+// timing definition (lib/TPP/Runner/TppRunnerWrapper.cpp:115-130: warm-up max(1, min(50, N/100))
+// iterations, then ONE perf_start_timer/perf_stop_timer pair around N back-to-back kernel calls,
+// mean = delta / N) and its metric (benchmarks/harness/controller.py:187-192:
+// gflops = BENCH_TOTAL_FLOPS / mean / 1e9, FLOPs per tools/mlir-gen/MLIRGen.cpp:313-334).
+//
+// It is the stand-in for tpp-run (which needs MLIR) on the hot path only: buffers live in HBM
+// (hipMalloc), filled like `--init-type const`; the calls are exactly the wire tuples of
+// test/Passes/pass-convert-mlp-to-parallel-tile.mlir:80-88 (packed 32x32x32 tiles) or one
+// whole-layer dispatch per layer.
+//
+//   tpp_replay --batch 256 --layers 1024,1024,1024,1024 --tiles 32 [--bias --relu] [--queue 1] [-n 100]
+//   tpp_replay --batch 256 --layers 1024,1024,1024,1024 --whole-layer ...
+#include "../include/tpp_xsmm_abi.h"
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#define CHECK(x)                                                                   \
+  do {                                                                             \
+    hipError_t e = (x);                                                            \
+    if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1); } \
+  } while (0)
+
+static std::vector<int64_t> parse_list(const char *s) {
+  std::vector<int64_t> v;
+  for (char *p = strdup(s), *t = strtok(p, ","); t; t = strtok(nullptr, ",")) v.push_back(atoll(t));
+  return v;
+}
+
+int main(int argc, char **argv) {
+  int64_t batch = 256, tile = 32, n_iter = 100;
+  std::vector<int64_t> layers = {1024, 1024, 1024, 1024};
+  bool bias = false, relu = false, whole = false, print = false;
+  int queue = 1;
+  for (int i = 1; i < argc; ++i) {
+    std::string a = argv[i];
+    auto next = [&]() { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(2); } return argv[++i]; };
+    if (a == "--batch") batch = atoll(next());
+    else if (a == "--layers") layers = parse_list(next());
+    else if (a == "--tiles") tile = atoll(next());
+    else if (a == "-n") n_iter = atoll(next());
+    else if (a == "--queue") queue = atoi(next());
+    else if (a == "--bias") bias = true;
+    else if (a == "--relu") relu = true;
+    else if (a == "--whole-layer") whole = true;
+    else if (a == "--print") print = true;
+    else { fprintf(stderr, "unknown flag %s\n", a.c_str()); return 2; }
+  }
+  if (xsmm_hip_device_count() < 1) { fprintf(stderr, "tpp_replay: no HIP device (there is no CPU fallback)\n"); return 1; }
+  const int L = (int)layers.size() - 1;
+  const int64_t gflags = XSMM_GEMM_FLAG_BETA_0; // mlir-gen --kernel=const: zero fill folded into BETA_0
+  const int64_t ukind = relu ? XSMM_UNARY_RELU : XSMM_UNARY_NONE;
+  const int64_t bkind = bias ? XSMM_BINARY_ADD : XSMM_BINARY_NONE, bflags = bias ? XSMM_BINARY_FLAG_BCAST_COL_IN_0 : 0;
+  double flops = 0;
+  for (int l = 0; l < L; ++l) flops += 2.0 * batch * layers[l] * layers[l + 1] + (bias ? batch * layers[l + 1] : 0) + (relu ? batch * layers[l + 1] : 0);
+
+  // buffers: activations [l] (batch x layers[l]), weights, biases; const 1.0 / 0.01 fills
+  std::vector<float *> act(L + 1), W(L), B(L);
+  auto dalloc = [](size_t n, float v) {
+    float *d; CHECK(hipMalloc((void **)&d, n * sizeof(float)));
+    std::vector<float> h(n, v); CHECK(hipMemcpy(d, h.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    return d;
+  };
+  for (int l = 0; l <= L; ++l) act[l] = dalloc((size_t)batch * layers[l], 1.0f);
+  for (int l = 0; l < L; ++l) { W[l] = dalloc((size_t)layers[l] * layers[l + 1], 1.0f / (float)layers[l]); B[l] = dalloc((size_t)layers[l + 1], 0.5f); }
+
+  xsmm_hip_set_async(1);
+  xsmm_hip_set_tile_queue(queue);
+  std::vector<int64_t> handle(L);
+  for (int l = 0; l < L; ++l) {
+    const int64_t K = layers[l], N = layers[l + 1];
+    if (whole) // one dispatch per layer on the flat row-major tensors
+      handle[l] = xsmm_fused_brgemm_dispatch(1, batch, N, 64, K, N, N, 64, 64 * N, gflags, 0, ukind, bflags, bkind);
+    else       // packed tiles: [MB][KB][t][t] x [NB][KB][t][t] -> [MB][NB][t][t]
+      handle[l] = xsmm_fused_brgemm_dispatch(1, tile, tile, tile, tile, tile, tile, tile * tile, tile * tile, gflags, 0, ukind, bflags, bkind);
+  }
+  auto kernel = [&]() {
+    for (int l = 0; l < L; ++l) {
+      const int64_t K = layers[l], N = layers[l + 1];
+      if (whole) {
+        xsmm_fused_brgemm_invoke(1, handle[l], act[l], 0, W[l], 0, act[l + 1], 0, B[l], 0, K / 64);
+      } else {
+        const int64_t MB = batch / tile, NB = N / tile, KB = K / tile, tt = tile * tile;
+        for (int64_t i = 0; i < MB; ++i)
+          for (int64_t j = 0; j < NB; ++j)
+            xsmm_fused_brgemm_invoke(1, handle[l], act[l], i * KB * tt, W[l], j * KB * tt, act[l + 1], (i * NB + j) * tt,
+                                     B[l], j * tile, KB);
+      }
+    }
+  };
+  const int64_t warm = n_iter / 100 < 1 ? 1 : (n_iter / 100 > 50 ? 50 : n_iter / 100);
+  for (int64_t i = 0; i < warm; ++i) kernel();
+  xsmm_hip_synchronize();
+  const int64_t t0 = perf_start_timer();
+  for (int64_t i = 0; i < n_iter; ++i) kernel();
+  const double dt = perf_stop_timer(t0); // flushes the tile queue and drains the stream
+  const double mean = dt / (double)n_iter;
+  printf("%g\n", mean); // tpp-run prints the mean seconds (MLIRBench.cpp:297-300)
+  fprintf(stderr, "tpp_replay: %s, batch %ld, %d layer(s), queue %d: mean %.3f us, %.1f GFLOP/s (BENCH_TOTAL_FLOPS %.0f), kernel %s\n",
+          whole ? "whole-layer dispatch" : "packed 32x32x32 tile invokes", (long)batch, L, queue, mean * 1e6, flops / mean / 1e9, flops,
+          xsmm_hip_kernel_name(handle[0]));
+  if (print) {
+    std::vector<float> h(8);
+    CHECK(hipMemcpy(h.data(), act[L], 8 * sizeof(float), hipMemcpyDeviceToHost));
+    printf("( %g, %g, %g, %g, %g, %g, %g, %g )\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+  }
+  return 0;
+}

@@ -9,4 +9,4 @@ it with importlib.import_module("tpp-mlir_amd").
 from .runtime import (BinaryFlags, BinaryKind, DataType, GemmFlags, REFERENCE_SYMBOLS, UnaryFlags,  # noqa: F401
                       UnaryKind, XsmmRuntime, get_runtime, library_path, load_library)
 from .mlp import MlpSpec, ShardedMlp, all_gather_rows, layer_dispatch_args, row_partition  # noqa: F401
-from .build import build  # noqa: F401
+from .build import build, build_tools  # noqa: F401

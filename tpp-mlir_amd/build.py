@@ -62,5 +62,25 @@ def build(force=False, verbose=False):
     return SO_PATH
 
 
+def build_tools(verbose=False):
+    """tools/tpp_replay: the native stand-in for tpp-run's timing loop on this path (links the .so)"""
+    root = os.path.dirname(HERE)
+    src = os.path.join(root, "tools", "tpp_replay.cpp")
+    out = os.path.join(root, "tools", "tpp_replay")
+    if not os.path.exists(src):
+        return None
+    if os.path.exists(out) and os.path.getmtime(out) > max(os.path.getmtime(src), os.path.getmtime(SO_PATH)):
+        return out
+    cmd = [hipcc(), "-O2", "-std=c++17", src, "-o", out, "-L", HERE, "-ltpp_xsmm_runner_utils",
+           "-Wl,-rpath,$ORIGIN/../tpp-mlir_amd"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building tpp_replay failed:\n" + r.stderr)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_tools(verbose=True))

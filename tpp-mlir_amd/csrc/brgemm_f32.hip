@@ -395,6 +395,125 @@ __global__ __launch_bounds__(64 * WM * WN) void brgemm_generic(GemmArgs p) {
   }
 }
 
+// ---- grouped kernel: many invokes of one small-tile descriptor in ONE launch ----------
+// The compiler's native call pattern is hundreds of invokes per layer on 32x32x32 tiles with
+// batch 32 from OpenMP workers (test/Passes/pass-convert-mlp-to-parallel-tile.mlir:80-88); one
+// GPU launch per invoke would be pure launch latency. The runtime's tile queue (runtime.cpp)
+// collects such invokes and runs them here: grid = (32x32 tiles per item, items), one
+// workgroup of 4 waves per tile; wave w takes the K chunks (32 k of one batch element)
+// c = w, w+4, ... so all four SIMDs of a CU work on the tile, each with a private
+// double-buffered LDS panel pair (no workgroup barrier in the K loop); the four partial
+// accumulators are combined through LDS once. Same element semantics as brgemm_generic
+// (any m/n/k/ld, f32/bf16, flat or VNNI-2 B); VEC selects 16-byte loads when shape,
+// strides and pointers allow.
+constexpr int GK = 32; // k per chunk of the grouped kernel
+
+template <typename T, bool VNNI, bool VEC>
+__global__ __launch_bounds__(256) void brgemm_grouped(GemmArgs p, const WorkItem *__restrict__ items) {
+  extern __shared__ __attribute__((aligned(16))) float smem_g[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const WorkItem it = items[blockIdx.y];
+  const int tm = blockIdx.x / p.tiles_n, tn = blockIdx.x % p.tiles_n;
+  const int m0 = tm * 32, n0 = tn * 32;
+  const int kchunks = (p.k + GK - 1) / GK;
+  const int nchunk = (int)it.br * kchunks;
+  // per-wave LDS: 2 buffers x (A 32x32 + B 32x32) floats
+  float *wl = smem_g + wave * (2 * 2 * 32 * GK);
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+
+  // staging registers: A tile rows [m0, m0+32) x k [kk0, kk0+32); B tile k x n
+  f32x4 ra[4], rb[4]; // 32 x 32 floats = 256 pieces of 16 B per panel, 4 per lane
+  auto gload = [&](int c) __attribute__((always_inline)) {
+    const int b = c / kchunks, kk0 = (c - b * kchunks) * GK;
+    const int64_t abase = (int64_t)b * p.stride_a, bbase = (int64_t)b * p.stride_b;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int q = lane + 64 * u, row = q >> 3, c4 = q & 7; // 32 rows x 8 pieces of 4 floats
+      if (VEC) {
+        ra[u] = *(const f32x4 *)((const float *)it.A + abase + (int64_t)(m0 + row) * p.lda + kk0 + 4 * c4);
+        rb[u] = *(const f32x4 *)((const float *)it.B + bbase + (int64_t)(kk0 + row) * p.ldb + n0 + 4 * c4);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int gr = m0 + row, gk = kk0 + 4 * c4 + e;
+          ra[u][e] = (gr < p.m && gk < p.k) ? Elem<T>::load(it.A, abase + (int64_t)gr * p.lda + gk) : 0.0f;
+          const int bk = kk0 + row, bj = n0 + 4 * c4 + e;
+          float v = 0.0f;
+          if (bk < p.k && bj < p.n) {
+            const int64_t idx = VNNI ? (int64_t)(bk >> 1) * (2 * p.ldb) + 2 * (int64_t)bj + (bk & 1)
+                                     : (int64_t)bk * p.ldb + bj;
+            v = Elem<T>::load(it.B, bbase + idx);
+          }
+          rb[u][e] = v;
+        }
+      }
+    }
+  };
+  auto swrite = [&](int buf) __attribute__((always_inline)) {
+    float *as = wl + buf * (2 * 32 * GK), *bs = as + 32 * GK;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int q = lane + 64 * u, row = q >> 3, c4 = q & 7;
+      *(f32x4 *)(as + row * GK + ((c4 ^ ((row >> 1) & 7)) << 2)) = ra[u]; // 128-byte rows: XOR on (row>>1)
+      *(f32x4 *)(bs + row * 32 + 4 * c4) = rb[u];
+    }
+  };
+  auto compute = [&](int buf) __attribute__((always_inline)) {
+    const float *as = wl + buf * (2 * 32 * GK) + li * GK, *bs = wl + buf * (2 * 32 * GK) + 32 * GK + li;
+#pragma unroll
+    for (int kb = 0; kb < GK / 8; ++kb) {
+      const f32x4 a4 = *(const f32x4 *)(as + (((2 * kb + lh) ^ ((li >> 1) & 7)) << 2));
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s], bs[(8 * kb + 4 * lh + s) * 32], acc, 0, 0, 0);
+    }
+  };
+  // wave-private pipeline: loads of the next chunk fly while the current one multiplies
+  int c = wave, buf = 0;
+  if (c < nchunk) {
+    gload(c);
+    swrite(0);
+  }
+  for (; c < nchunk; c += 4) {
+    const bool more = c + 4 < nchunk;
+    if (more) gload(c + 4);
+    compute(buf);
+    if (more) swrite(buf ^ 1);
+    buf ^= 1;
+  }
+  // combine the four waves' partial sums (waves 1..3 park theirs), then wave 0 finishes
+  __syncthreads();
+  float *red = smem_g;
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wave - 1) * 1024 + r * 64 + lane] = acc[r];
+  }
+  __syncthreads();
+  if (wave > 0) return;
+#pragma unroll
+  for (int g = 0; g < 3; ++g)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += red[g * 1024 + r * 64 + lane];
+  const int col = n0 + li;
+  const float bias = ((p.ep & EP_BIAS) && col < p.n) ? Elem<T>::load(it.D, col) : 0.0f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = m0 + 4 * lh + (r & 3) + 8 * (r >> 2);
+    if (row < p.m && col < p.n) {
+      float v = acc[r];
+      if (!(p.ep & EP_BETA0)) v += Elem<T>::load(it.C, (int64_t)row * p.ldc + col);
+      v += bias;
+      if (p.ep & EP_RELU) v = v > 0.0f ? v : 0.0f;
+      Elem<T>::store(it.C, (int64_t)row * p.ldc + col, v);
+    }
+  }
+}
+
 // ---- host side ---------------------------------------------------------------
 enum GemmVariant : int {
   V_F32_64x64 = 0,   // 4 waves 2x2x1
@@ -450,6 +569,43 @@ static hipError_t launch_generic(const GemmArgs &a, hipStream_t s) {
 
 hipError_t launch_gemm_bf16_fast(const GemmDesc &d, const GemmArgs &a, hipStream_t s); // brgemm_bf16.hip
 bool bf16_fast_eligible(const GemmDesc &d);
+
+template <typename T, bool VNNI, bool VEC>
+static hipError_t launch_grouped_t(const GemmArgs &a, const WorkItem *items, int n_items, hipStream_t s) {
+  constexpr size_t lds = 4 * 2 * 2 * 32 * GK * sizeof(float); // 64 KiB: 4 waves x 2 buffers x (A + B)
+  static bool attr_set = false;
+  auto kern = brgemm_grouped<T, VNNI, VEC>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  GemmArgs args = a;
+  args.tiles_m = (a.m + 31) / 32;
+  args.tiles_n = (a.n + 31) / 32;
+  for (int done = 0; done < n_items; done += 65535) { // gridDim.y limit
+    const int n = n_items - done < 65535 ? n_items - done : 65535;
+    hipLaunchKernelGGL(kern, dim3(args.tiles_m * args.tiles_n, n), dim3(256), lds, s, args, items + done);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_items, bool vec_ok,
+                               hipStream_t stream) {
+  if (d.m <= 0 || d.n <= 0 || n_items <= 0) return hipSuccess;
+  GemmArgs a;
+  a.A = a.B = a.D = nullptr; a.C = nullptr;
+  a.lda = d.lda; a.ldb = d.ldb; a.ldc = d.ldc; a.stride_a = d.stride_a; a.stride_b = d.stride_b;
+  a.m = (int)d.m; a.n = (int)d.n; a.k = (int)d.k; a.br = 0;
+  a.ep = (d.beta0 ? EP_BETA0 : 0) | (d.bias ? EP_BIAS : 0) | (d.relu ? EP_RELU : 0);
+  a.tiles_m = a.tiles_n = 0;
+  const bool vec = vec_ok && d.dtype == DT_F32 && !d.vnni_b && d.m % 32 == 0 && d.n % 32 == 0 && d.k % GK == 0 &&
+                   !((d.lda | d.ldb | d.stride_a | d.stride_b) & 3);
+  if (d.dtype == DT_F32) return vec ? launch_grouped_t<float, false, true>(a, items, n_items, stream)
+                                    : launch_grouped_t<float, false, false>(a, items, n_items, stream);
+  if (d.vnni_b) return launch_grouped_t<unsigned short, true, false>(a, items, n_items, stream);
+  return launch_grouped_t<unsigned short, false, false>(a, items, n_items, stream);
+}
 
 static int g_num_cus = 256;
 

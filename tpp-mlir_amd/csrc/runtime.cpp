@@ -48,11 +48,13 @@ struct Config {
   std::atomic<int> async{0};
   std::atomic<hipStream_t> stream{nullptr};
   std::atomic<int> forced_variant{-1};
+  std::atomic<int> tile_queue{0};
   bool trace = false;
   Config() {
     if (const char *e = getenv("TPP_HIP_ASYNC")) async = atoi(e) != 0;
     if (const char *e = getenv("TPP_HIP_TRACE")) trace = atoi(e) != 0;
     if (const char *e = getenv("TPP_HIP_VARIANT")) forced_variant = atoi(e);
+    if (const char *e = getenv("TPP_HIP_TILE_QUEUE")) tile_queue = atoi(e) != 0;
   }
 };
 Config &cfg() {
@@ -246,6 +248,149 @@ int64_t gemm_dispatch_common(const char *who, int has_batch, int fused, int64_t 
   return reinterpret_cast<int64_t>(h);
 }
 
+// ---- tile queue -------------------------------------------------------------------
+// The compiler's native granularity is hundreds of invokes per layer on 32x32 tiles from
+// OpenMP workers; one launch per invoke would be pure launch latency on a GPU. In async
+// mode with the tile queue on, invokes of ONE small-tile GEMM handle on device pointers are
+// appended to a work list and run as ONE grouped launch (brgemm_grouped) when something
+// forces a flush: another handle or op, a data dependence on a queued output, capacity, a
+// synchronize / perf_stop_timer, or leaving async mode. Program order is preserved: a new
+// invoke that reads or overwrites anything a queued invoke writes (or overwrites anything a
+// queued invoke reads) flushes first, so queued invokes are always mutually independent.
+struct Range {
+  uintptr_t b, e;
+};
+// union of half-open intervals with O(log n) insert / overlap query
+struct IntervalSet {
+  std::map<uintptr_t, uintptr_t> iv; // begin -> end, disjoint
+  void clear() { iv.clear(); }
+  bool overlaps(const Range &r) const {
+    if (r.b >= r.e || iv.empty()) return false;
+    auto it = iv.lower_bound(r.e); // first interval starting at/after r.e: cannot overlap
+    if (it == iv.begin()) return false;
+    --it;
+    return it->second > r.b;
+  }
+  void insert(Range r) {
+    if (r.b >= r.e) return;
+    auto it = iv.lower_bound(r.b);
+    if (it != iv.begin()) {
+      auto pv = std::prev(it);
+      if (pv->second >= r.b) it = pv;
+    }
+    while (it != iv.end() && it->first <= r.e) {
+      r.b = std::min(r.b, it->first);
+      r.e = std::max(r.e, it->second);
+      it = iv.erase(it);
+    }
+    iv.emplace(r.b, r.e);
+  }
+};
+
+// Device allocations seen so far ([base, base+size) from hipMemGetAddressRange). Only used
+// by the tile queue: its callers issue hundreds of invokes per layer on the same few
+// allocations, and one driver query per operand per invoke would dominate the host time.
+struct DeviceRanges {
+  std::vector<Range> known;
+  bool contains(const void *p) const {
+    const uintptr_t a = (uintptr_t)p;
+    for (const Range &r : known)
+      if (a >= r.b && a < r.e) return true;
+    return false;
+  }
+  bool is_device(const void *p) {
+    if (!p || contains(p)) return true;
+    if (!is_device_ptr(p)) return false;
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)p) == hipSuccess && size) {
+      if (known.size() >= 64) known.erase(known.begin());
+      known.push_back(Range{(uintptr_t)base, (uintptr_t)base + size});
+    } else {
+      (void)hipGetLastError();
+    }
+    return true;
+  }
+};
+
+struct TileQueue {
+  static constexpr int CAP = 4096, SLOTS = 4;
+  std::mutex mu;
+  const GemmDesc *desc = nullptr;
+  bool vec_ok = true;
+  int n = 0;
+  IntervalSet reads, writes;
+  DeviceRanges devmem;
+  WorkItem *pinned[SLOTS] = {nullptr, nullptr, nullptr, nullptr}; // host-pinned, read by the kernel over PCIe once per workgroup
+  hipEvent_t done[SLOTS];
+  bool used[SLOTS] = {false, false, false, false};
+  int slot = 0;
+  hipStream_t stream = nullptr;
+
+  void ensure_slot() {
+    if (!pinned[slot]) {
+      HIP_OK(hipHostMalloc((void **)&pinned[slot], sizeof(WorkItem) * CAP, hipHostMallocDefault));
+      HIP_OK(hipEventCreateWithFlags(&done[slot], hipEventDisableTiming));
+    } else if (used[slot] && n == 0) {
+      HIP_OK(hipEventSynchronize(done[slot])); // the launch that read this slot has finished
+      used[slot] = false;
+    }
+  }
+  // caller holds mu
+  void flush_locked() {
+    if (n == 0) return;
+    HIP_OK(launch_gemm_grouped(*desc, pinned[slot], n, vec_ok, stream));
+    HIP_OK(hipEventRecord(done[slot], stream));
+    used[slot] = true;
+    slot = (slot + 1) % SLOTS;
+    n = 0;
+    desc = nullptr;
+    vec_ok = true;
+    reads.clear();
+    writes.clear();
+  }
+  void flush() {
+    std::lock_guard<std::mutex> lk(mu);
+    flush_locked();
+  }
+};
+TileQueue &tq() {
+  static TileQueue q;
+  return q;
+}
+void flush_tile_queue() {
+  if (cfg().tile_queue.load(std::memory_order_relaxed)) tq().flush();
+}
+
+// true if the invoke was queued (nothing launched yet)
+bool try_enqueue(const GemmDesc *d, const Operand &A, const Operand &B, const Operand &C, const Operand &D, int64_t br,
+                 hipStream_t s) {
+  if (d->m > 64 || d->n > 64) return false; // big descriptors fill the chip on their own
+  TileQueue &q = tq();
+  std::lock_guard<std::mutex> lk(q.mu);
+  const Range ra{(uintptr_t)A.ptr, (uintptr_t)A.ptr + A.bytes}, rb{(uintptr_t)B.ptr, (uintptr_t)B.ptr + B.bytes},
+      rc{(uintptr_t)C.ptr, (uintptr_t)C.ptr + C.bytes}, rd{(uintptr_t)D.ptr, (uintptr_t)D.ptr + D.bytes};
+  if (!q.devmem.is_device(A.ptr) || !q.devmem.is_device(B.ptr) || !q.devmem.is_device(C.ptr) ||
+      !q.devmem.is_device(D.ptr))
+    return false; // a host operand: the caller flushes and takes the mirrored path
+  bool conflict = q.n > 0 && (q.desc != d || q.stream != s || q.n >= TileQueue::CAP);
+  if (!conflict && q.n > 0)
+    conflict = q.writes.overlaps(ra) || q.writes.overlaps(rb) || q.writes.overlaps(rc) || q.writes.overlaps(rd) ||
+               q.reads.overlaps(rc);
+  if (conflict) q.flush_locked();
+  q.ensure_slot();
+  q.desc = d;
+  q.stream = s;
+  const uintptr_t al = (uintptr_t)A.ptr | (uintptr_t)B.ptr;
+  q.vec_ok = q.vec_ok && (al & 15) == 0;
+  q.pinned[q.slot][q.n++] = WorkItem{A.ptr, B.ptr, C.ptr, D.ptr, br};
+  q.reads.insert(ra);
+  q.reads.insert(rb);
+  q.reads.insert(rd);
+  q.writes.insert(rc);
+  return true;
+}
+
 void gemm_invoke_common(const char *who, bool want_fused, int64_t dtype, int64_t handle, void *a, int64_t off_a,
                         void *b, int64_t off_b, void *c, int64_t off_c, void *dptr, int64_t off_d, int64_t br) {
   const GemmDesc *d = as_desc<GemmDesc>(handle, KIND_GEMM, who);
@@ -265,6 +410,10 @@ void gemm_invoke_common(const char *who, bool want_fused, int64_t dtype, int64_t
   }
   if (d->bias && !dptr) die("%s: fused bias operand is null", who);
   hipStream_t s = cfg().stream.load(std::memory_order_relaxed);
+  if (cfg().tile_queue.load(std::memory_order_relaxed)) {
+    if (cfg().async.load(std::memory_order_relaxed) && try_enqueue(d, A, B, C, D, br, s)) return;
+    flush_tile_queue();
+  }
   std::vector<Operand *> ops = {&A, &B, &C, &D};
   std::vector<Mirror> mirrors = stage_in(ops, s);
   HIP_OK(launch_gemm(*d, A.dev, B.dev, C.dev, D.dev, br, s));
@@ -396,6 +545,7 @@ static void unary_invoke_common(const char *who, int64_t dtype, int64_t handle, 
     else if (d->flags & XSMM_UNARY_FLAG_BCAST_COL) I.bytes = (size_t)d->n * es;
     else I.bytes = span(d->m, d->ldi, d->n) * es;
   }
+  flush_tile_queue();
   hipStream_t s = cfg().stream.load(std::memory_order_relaxed);
   std::vector<Operand *> ops = {&I, &O};
   std::vector<Mirror> mirrors = stage_in(ops, s);
@@ -428,6 +578,7 @@ extern "C" void xsmm_binary_invoke(int64_t dtype, int64_t handle, void *lhs, int
   Operand L{(char *)lhs + off_lhs * es, in_bytes(1, 4, 16, d->ldi_lhs), false, nullptr},
       R{(char *)rhs + off_rhs * es, in_bytes(2, 8, 32, d->ldi_rhs), false, nullptr},
       O{(char *)out + off_out * es, span(d->m, d->ldo, d->n) * es, true, nullptr};
+  flush_tile_queue();
   hipStream_t s = cfg().stream.load(std::memory_order_relaxed);
   std::vector<Operand *> ops = {&L, &R, &O};
   std::vector<Mirror> mirrors = stage_in(ops, s);
@@ -446,6 +597,7 @@ extern "C" int64_t perf_start_timer(void) {
 }
 
 extern "C" double perf_stop_timer(int64_t start) {
+  flush_tile_queue();
   if (cfg().async.load()) (void)hipStreamSynchronize(cfg().stream.load());
   const int64_t now = std::chrono::duration_cast<std::chrono::nanoseconds>(
                           std::chrono::high_resolution_clock::now().time_since_epoch())
@@ -454,10 +606,24 @@ extern "C" double perf_stop_timer(int64_t start) {
 }
 
 // =============================== extensions ========================================
-extern "C" int xsmm_hip_set_async(int enable) { return cfg().async.exchange(enable != 0); }
-extern "C" void xsmm_hip_set_stream(void *s) { cfg().stream.store((hipStream_t)s); }
+extern "C" int xsmm_hip_set_async(int enable) {
+  flush_tile_queue();
+  return cfg().async.exchange(enable != 0);
+}
+extern "C" void xsmm_hip_set_stream(void *s) {
+  flush_tile_queue();
+  cfg().stream.store((hipStream_t)s);
+}
+extern "C" int xsmm_hip_set_tile_queue(int enable) {
+  flush_tile_queue();
+  return cfg().tile_queue.exchange(enable != 0);
+}
+extern "C" void xsmm_hip_flush(void) { flush_tile_queue(); }
 extern "C" void *xsmm_hip_get_stream(void) { return (void *)cfg().stream.load(); }
-extern "C" void xsmm_hip_synchronize(void) { HIP_OK(hipStreamSynchronize(cfg().stream.load())); }
+extern "C" void xsmm_hip_synchronize(void) {
+  flush_tile_queue();
+  HIP_OK(hipStreamSynchronize(cfg().stream.load()));
+}
 extern "C" int xsmm_hip_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) {

@@ -38,10 +38,23 @@ struct AmxDesc {
   int kind;             // KIND_AMX (no-op on this hardware)
 };
 
+// One queued invoke of a GEMM-family handle (tile queue, runtime.cpp): operands with
+// element offsets applied + its batch count. An array of these lives in device memory.
+struct WorkItem {
+  const void *A;
+  const void *B;
+  void *C;
+  const void *D;
+  int64_t br;
+};
+
 // ---- kernel launchers (all enqueue on `stream`, never synchronise) --------------
 // pointers are device pointers with element offsets already applied.
 hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C, const void *D,
                        int64_t br, hipStream_t stream);
+// n_items invokes of ONE descriptor in one launch (items: device array of WorkItem)
+hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_items, bool vec_ok,
+                               hipStream_t stream);
 // fills d.variant / d.name; returns false if no kernel can run the descriptor
 bool plan_gemm(GemmDesc &d, int forced_variant);
 hipError_t launch_unary(const UnaryDesc &d, const void *in, float scalar, bool use_scalar, void *out,

@@ -75,6 +75,8 @@ _SIGNATURES = {
     # extensions (not in the reference ABI)
     "xsmm_hip_set_async": (ctypes.c_int, [ctypes.c_int]),
     "xsmm_hip_set_stream": (None, [VP]),
+    "xsmm_hip_set_tile_queue": (ctypes.c_int, [ctypes.c_int]),
+    "xsmm_hip_flush": (None, []),
     "xsmm_hip_get_stream": (VP, []),
     "xsmm_hip_synchronize": (None, []),
     "xsmm_hip_device_count": (ctypes.c_int, []),
@@ -189,6 +191,12 @@ class XsmmRuntime:
     def set_stream(self, stream):
         """stream: raw hipStream_t value, or a torch.cuda.Stream"""
         self.lib.xsmm_hip_set_stream(getattr(stream, "cuda_stream", stream) or None)
+
+    def set_tile_queue(self, enable):
+        return bool(self.lib.xsmm_hip_set_tile_queue(1 if enable else 0))
+
+    def flush(self):
+        self.lib.xsmm_hip_flush()
 
     def synchronize(self):
         self.lib.xsmm_hip_synchronize()
