@@ -391,7 +391,11 @@ static hipError_t launch_bf16(const GemmArgs &a, hipStream_t s) {
 //          128-byte-per-row stores.
 typedef __attribute__((address_space(3))) void lds_void_t;
 
-__global__ __launch_bounds__(256) void brgemm_bf16_dma128(GemmArgs p) {
+// LW = true adds two LOADER waves (wave 4 streams A, wave 5 streams B: 16 DMA instructions per
+// chunk each) so the four MFMA waves never stall on vector-memory issue; the per-chunk barrier is
+// shared by all six waves (the loaders wait for their own DMA to land before they arrive).
+template <bool LW>
+__global__ __launch_bounds__(LW ? 384 : 256) void brgemm_bf16_dma128(GemmArgs p) {
   constexpr int BM = 128, BN = 128, NSLOT = 4, TM = 2, TN = 2;
   constexpr int A_SLOT = BM * BKH * 2, B_SLOT = (BKH / 2) * BN * 4, SLOT = A_SLOT + B_SLOT;
   constexpr int DMA_PER_CHUNK = 8; // per wave: 4 x 1 KiB of A + 4 x 1 KiB of B
@@ -469,6 +473,46 @@ __global__ __launch_bounds__(256) void brgemm_bf16_dma128(GemmArgs p) {
     }                             \
   } while (0)
 
+  if (LW && wave >= 4) {
+    // ---- loader waves ------------------------------------------------------------------
+    const bool isA = wave == 4;
+    // A: instruction v covers rows 8v..8v+7; swizzle term ((row>>1)&7) = 4*(v&1) + (lane>>4)
+    const unsigned rowoffA = (unsigned)((lane >> 3) * (int)p.lda * 2);
+    const unsigned voA0 = rowoffA + (unsigned)((((lane & 7) ^ (lane >> 4))) << 4);
+    const unsigned voA1 = rowoffA + (unsigned)((((lane & 7) ^ (4 + (lane >> 4)))) << 4);
+    const unsigned voB = (unsigned)((lane >> 5) * (int)p.ldb * 4 + ((lane & 31) << 4));
+    const unsigned stepA = (unsigned)(8 * (int)p.lda * 2), stepB = (unsigned)(2 * (int)p.ldb * 4);
+    auto issue = [&](int slot) __attribute__((always_inline)) {
+      unsigned char *base = smem_d + slot * SLOT + (isA ? 0 : A_SLOT);
+      if (isA) {
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)gA, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+        for (int v = 0; v < 16; ++v)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_t *)(base + v * 1024), 16, (v & 1) ? voA1 : voA0, v * stepA, 0, 0);
+      } else {
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)gB, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+        for (int v = 0; v < 16; ++v)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_t *)(base + v * 1024), 16, voB, v * stepB, 0, 0);
+      }
+      TPP_DMA_ADVANCE();
+    };
+    if (T > 0) issue(0);
+    if (T > 1) issue(1);
+    if (T > 2) issue(2);
+    if (T > 2) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    else if (T > 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier(); // chunk 0 published
+    for (int t = 0; t + 1 < T; ++t) {
+      if (t + 2 < T) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier(); // = the MFMA waves' mid-chunk barrier of chunk t: chunk t+1 published
+      if (t + 3 < T) issue((t + 3) & 3);
+    }
+    return; // ended waves do not take part in later barriers
+  }
+
   f32x16 acc[TM][TN];
   constexpr int NFB = 4; // fragment buffers: step q+2 is read while step q multiplies
   bf16x8_t af[NFB][TM], bfr[NFB][TN];
@@ -515,7 +559,7 @@ __global__ __launch_bounds__(256) void brgemm_bf16_dma128(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[q][j], af[q][i], acc[i][j], 0, 0, 0);
-          if (H3 && q >= 2 && !(TPP_ABLATE & HABL_NO_GLOAD)) {
+          if (!LW && H3 && q >= 2 && !(TPP_ABLATE & HABL_NO_GLOAD)) {
             dma_piece((S + 3) % NSLOT, (q - 2) * 4 + i * TN + j); // slot of chunk t-1: every wave is past it
             if (q == 3 && i == TM - 1 && j == TN - 1) TPP_DMA_ADVANCE();
           }
@@ -523,8 +567,10 @@ __global__ __launch_bounds__(256) void brgemm_bf16_dma128(GemmArgs p) {
         }
       if (q == 1 && H1) {
         // chunk t+1: this wave's DMA has landed (chunk t+2's may still fly), then everybody's
-        if (H2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_CHUNK) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!LW) {
+          if (H2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_CHUNK) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -535,17 +581,19 @@ __global__ __launch_bounds__(256) void brgemm_bf16_dma128(GemmArgs p) {
   using no = std::integral_constant<bool, false>;
 
   // prologue: chunks 0, 1, 2 in flight at once
-  if (T > 0) {
-    dma_chunk(0);
-    TPP_DMA_ADVANCE();
-  }
-  if (T > 1) {
-    dma_chunk(1);
-    TPP_DMA_ADVANCE();
-  }
-  if (T > 2) {
-    dma_chunk(2);
-    TPP_DMA_ADVANCE();
+  if (!LW) {
+    if (T > 0) {
+      dma_chunk(0);
+      TPP_DMA_ADVANCE();
+    }
+    if (T > 1) {
+      dma_chunk(1);
+      TPP_DMA_ADVANCE();
+    }
+    if (T > 2) {
+      dma_chunk(2);
+      TPP_DMA_ADVANCE();
+    }
   }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -553,9 +601,11 @@ __global__ __launch_bounds__(256) void brgemm_bf16_dma128(GemmArgs p) {
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-  if (T > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DMA_PER_CHUNK) : "memory");
-  else if (T > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_CHUNK) : "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (!LW) {
+    if (T > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DMA_PER_CHUNK) : "memory");
+    else if (T > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_CHUNK) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
   if (T > 0) {
@@ -680,11 +730,11 @@ __global__ __launch_bounds__(256) void brgemm_bf16_dma128(GemmArgs p) {
   }
 }
 
-static hipError_t launch_bf16_dma128(const GemmArgs &a, hipStream_t s) {
+template <bool LW> static hipError_t launch_bf16_dma128(const GemmArgs &a, hipStream_t s) {
   constexpr size_t lds = 4 * 32768;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)brgemm_bf16_dma128, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void *)brgemm_bf16_dma128<LW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
@@ -700,7 +750,7 @@ static hipError_t launch_bf16_dma128(const GemmArgs &a, hipStream_t s) {
     if (tiles_m > 65535 || tiles_n > 65535) return hipErrorInvalidValue;
     grid = dim3(1, tiles_n, tiles_m);
   }
-  hipLaunchKernelGGL(brgemm_bf16_dma128, grid, dim3(256), lds, s, args);
+  hipLaunchKernelGGL(brgemm_bf16_dma128<LW>, grid, dim3(LW ? 384 : 256), lds, s, args);
   return hipGetLastError();
 }
 
@@ -716,7 +766,7 @@ bool bf16_fast_eligible(const GemmDesc &d) {
 hipError_t launch_gemm_bf16_fast(const GemmDesc &d, const GemmArgs &a, hipStream_t s) {
   const int64_t t128 = (d.m % 128 == 0 && d.n % 128 == 0) ? (d.m / 128) * (d.n / 128) : 0;
   static const int legacy = getenv("TPP_HIP_BF16_LEGACY") ? atoi(getenv("TPP_HIP_BF16_LEGACY")) : 0;
-  if (t128 >= 192) return legacy ? launch_bf16<2, 2, 2, 2>(a, s) : launch_bf16_dma128(a, s);
+  if (t128 >= 192) return legacy == 1 ? launch_bf16<2, 2, 2, 2>(a, s) : legacy == 2 ? launch_bf16_dma128<false>(a, s) : launch_bf16_dma128<true>(a, s);
   return launch_bf16<2, 2, 1, 1>(a, s);
 }
 
