@@ -325,76 +325,6 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void brgemm_f32_fast(GemmArgs p)
   }
 }
 
-// ---- generic kernel: any m/n/k/ld/alignment, f32 or bf16 storage, flat or VNNI-2 B.
-// Elements are widened to f32 on the way into LDS and the same f32 MFMA core runs
-// (bf16 x bf16 products are exact in f32, accumulation is f32: the reference's
-// "f32 compute for bf16" rule, XsmmRunnerUtils.cpp:127-129). One rounding at the store.
-template <typename T, bool VNNI, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN) void brgemm_generic(GemmArgs p) {
-  constexpr int BM = 32 * WM, BN = 32 * WN, NT = 64 * WM * WN;
-  __shared__ __attribute__((aligned(16))) float As[BM * BK];
-  __shared__ __attribute__((aligned(16))) float Bs[BK * BN];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
-  const int li = lane & 31, lh = lane >> 5;
-  const int tm = blockIdx.x / p.tiles_n, tn = blockIdx.x % p.tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int kchunks = (p.k + BK - 1) / BK;
-  const int nchunk = p.br * kchunks;
-
-  f32x16 acc;
-  const int crow0 = m0 + wm * 32 + 4 * lh, ccol = n0 + wn * 32 + li;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = crow0 + (r & 3) + 8 * (r >> 2);
-    acc[r] = (!(p.ep & EP_BETA0) && row < p.m && ccol < p.n) ? Elem<T>::load(p.C, (int64_t)row * p.ldc + ccol) : 0.0f;
-  }
-
-  for (int t = 0; t < nchunk; ++t) {
-    const int b = t / kchunks, kk0 = (t - b * kchunks) * BK;
-    const int64_t abase = (int64_t)b * p.stride_a, bbase = (int64_t)b * p.stride_b;
-    __syncthreads();
-    for (int e = tid; e < BM * BK; e += NT) {
-      const int row = e / BK, kk = e % BK;
-      const int gr = m0 + row, gk = kk0 + kk;
-      const float v = (gr < p.m && gk < p.k) ? Elem<T>::load(p.A, abase + (int64_t)gr * p.lda + gk) : 0.0f;
-      As[row * BK + ((((kk >> 2) ^ (row & 15)) << 2) | (kk & 3))] = v;
-    }
-    for (int e = tid; e < BK * BN; e += NT) {
-      const int krow = e / BN, j = e % BN;
-      const int gk = kk0 + krow, gj = n0 + j;
-      float v = 0.0f;
-      if (gk < p.k && gj < p.n) {
-        const int64_t idx = VNNI ? (int64_t)(gk >> 1) * (2 * p.ldb) + 2 * (int64_t)gj + (gk & 1)
-                                 : (int64_t)gk * p.ldb + gj;
-        v = Elem<T>::load(p.B, bbase + idx);
-      }
-      Bs[krow * BN + j] = v;
-    }
-    __syncthreads();
-    const float *as = As + (wm * 32 + li) * BK;
-    const float *bs = Bs + wn * 32 + li;
-#pragma unroll
-    for (int kb = 0; kb < 8; ++kb) {
-      const f32x4 a4 = *(const f32x4 *)(as + (((2 * kb + lh) ^ (li & 15)) << 2));
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s], bs[(8 * kb + 4 * lh + s) * BN], acc, 0, 0, 0);
-    }
-  }
-
-  const float bias = ((p.ep & EP_BIAS) && ccol < p.n) ? Elem<T>::load(p.D, ccol) : 0.0f;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = crow0 + (r & 3) + 8 * (r >> 2);
-    if (row < p.m && ccol < p.n) {
-      float v = acc[r] + bias;
-      if (p.ep & EP_RELU) v = v > 0.0f ? v : 0.0f;
-      Elem<T>::store(p.C, (int64_t)row * p.ldc + ccol, v);
-    }
-  }
-}
-
 // ---- grouped kernel: many invokes of one small-tile descriptor in ONE launch ----------
 // The compiler's native call pattern is hundreds of invokes per layer on 32x32x32 tiles with
 // batch 32 from OpenMP workers (test/Passes/pass-convert-mlp-to-parallel-tile.mlir:80-88); one
@@ -403,9 +333,12 @@ __global__ __launch_bounds__(64 * WM * WN) void brgemm_generic(GemmArgs p) {
 // workgroup of 4 waves per tile; wave w takes the K chunks (32 k of one batch element)
 // c = w, w+4, ... so all four SIMDs of a CU work on the tile, each with a private
 // double-buffered LDS panel pair (no workgroup barrier in the K loop); the four partial
-// accumulators are combined through LDS once. Same element semantics as brgemm_generic
-// (any m/n/k/ld, f32/bf16, flat or VNNI-2 B); VEC selects 16-byte loads when shape,
-// strides and pointers allow.
+// accumulators are combined through LDS once. It is also the GENERIC kernel of the runtime
+// (items == nullptr: one invoke described by the arguments themselves): any m/n/k/ld and
+// alignment, f32 or bf16 storage (elements are widened to f32 on the way into LDS, bf16 x
+// bf16 products are exact in f32, accumulation is f32 - the reference's "f32 compute for
+// bf16" rule, XsmmRunnerUtils.cpp:127-129 - one rounding at the store), flat or VNNI-2 B.
+// VEC selects 16-byte loads when shape, strides and pointers allow.
 constexpr int GK = 32; // k per chunk of the grouped kernel
 
 template <typename T, bool VNNI, bool VEC>
@@ -414,7 +347,7 @@ __global__ __launch_bounds__(256) void brgemm_grouped(GemmArgs p, const WorkItem
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
-  const WorkItem it = items[blockIdx.y];
+  const WorkItem it = items ? items[blockIdx.y] : WorkItem{p.A, p.B, p.C, p.D, (int64_t)p.br};
   const int tm = blockIdx.x / p.tiles_n, tn = blockIdx.x % p.tiles_n;
   const int m0 = tm * 32, n0 = tn * 32;
   const int kchunks = (p.k + GK - 1) / GK;
@@ -552,21 +485,6 @@ static hipError_t launch_fast(const GemmArgs &a, hipStream_t s) {
   return hipGetLastError();
 }
 
-template <typename T, bool VNNI>
-static hipError_t launch_generic(const GemmArgs &a, hipStream_t s) {
-  GemmArgs args = a;
-  if (a.m <= 32 && a.n <= 32) {
-    args.tiles_m = (a.m + 31) / 32;
-    args.tiles_n = (a.n + 31) / 32;
-    hipLaunchKernelGGL((brgemm_generic<T, VNNI, 1, 1>), dim3(args.tiles_m * args.tiles_n), dim3(64), 0, s, args);
-  } else {
-    args.tiles_m = (a.m + 63) / 64;
-    args.tiles_n = (a.n + 63) / 64;
-    hipLaunchKernelGGL((brgemm_generic<T, VNNI, 2, 2>), dim3(args.tiles_m * args.tiles_n), dim3(256), 0, s, args);
-  }
-  return hipGetLastError();
-}
-
 hipError_t launch_gemm_bf16_fast(const GemmDesc &d, const GemmArgs &a, hipStream_t s); // brgemm_bf16.hip
 bool bf16_fast_eligible(const GemmDesc &d);
 
@@ -585,7 +503,7 @@ static hipError_t launch_grouped_t(const GemmArgs &a, const WorkItem *items, int
   args.tiles_n = (a.n + 31) / 32;
   for (int done = 0; done < n_items; done += 65535) { // gridDim.y limit
     const int n = n_items - done < 65535 ? n_items - done : 65535;
-    hipLaunchKernelGGL(kern, dim3(args.tiles_m * args.tiles_n, n), dim3(256), lds, s, args, items + done);
+    hipLaunchKernelGGL(kern, dim3(args.tiles_m * args.tiles_n, n), dim3(256), lds, s, args, items ? items + done : items);
   }
   return hipGetLastError();
 }
@@ -634,7 +552,7 @@ static const char *variant_name(int v) {
   case V_F32_128x64: return "brgemm_f32_fast<128x64,k1>";
   case V_F32_64x64K2: return "brgemm_f32_fast<64x64,k2>";
   case V_BF16_FAST: return "brgemm_bf16_fast";
-  default: return "brgemm_generic";
+  default: return "brgemm_grouped(generic)";
   }
 }
 
@@ -679,9 +597,13 @@ hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C,
   case V_BF16_FAST: return launch_gemm_bf16_fast(d, a, stream);
   default: break;
   }
-  if (d.dtype == DT_F32) return launch_generic<float, false>(a, stream);
-  if (d.vnni_b) return launch_generic<unsigned short, true>(a, stream);
-  return launch_generic<unsigned short, false>(a, stream);
+  // everything else: the grouped kernel with a single, inline work item
+  const bool vec = aligned16 && d.dtype == DT_F32 && !d.vnni_b && d.m % 32 == 0 && d.n % 32 == 0 && d.k % GK == 0 &&
+                   !((d.lda | d.ldb | d.stride_a | d.stride_b) & 3);
+  if (d.dtype == DT_F32) return vec ? launch_grouped_t<float, false, true>(a, nullptr, 1, stream)
+                                    : launch_grouped_t<float, false, false>(a, nullptr, 1, stream);
+  if (d.vnni_b) return launch_grouped_t<unsigned short, true, false>(a, nullptr, 1, stream);
+  return launch_grouped_t<unsigned short, false, false>(a, nullptr, 1, stream);
 }
 
 } // namespace tpp
