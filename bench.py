@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--graph", action="store_true",
                     help="also time a hipGraph replay of the step and report the faster of the two launch modes")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise RCCL and run the collectives even with one rank (exercises the N>1 code path)")
     ap.add_argument("--init", choices=["reference", "uniform"], default="reference",
                     help="reference: tpp-run's normal init stream (what the reference benchmarks run on); "
                          "uniform: U[-1,1) (sign cancellation, highest switching power)")
@@ -159,13 +161,15 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no HIP device visible); there is no CPU fallback")
     torch.cuda.set_device(local)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local))
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     def sync():
@@ -209,7 +213,7 @@ def main():
         if wall_g < wall:
             wall, devs, mode = wall_g, devs_g, "hipGraph-replay"
     t = torch.tensor([wall, devs], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall, devs = float(t[0]), float(t[1])
     value = world * flops * K / wall / 1e9
@@ -238,17 +242,17 @@ def main():
 
         def mlp_step():
             out = sh.forward(X, Wv, Bs, acts)
-            if world > 1:
+            if use_dist:
                 pkg.all_gather_rows(out, full, spec, world)
 
         warm(mlp_step, W, sync)
         mwall, mdev = timed(mlp_step, K, sync, barrier)
         tm = torch.tensor([mwall], dtype=torch.float64, device="cuda")
-        if world > 1:
+        if use_dist:
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         mwall = float(tm[0])
         mlp = {"workload": "3-layer MLP 1024x3 bf16 bs=4096 bias+relu, rows sharded over %d GPU(s)%s" % (
-                   world, " + RCCL all-gather of the output" if world > 1 else ""),
+                   world, " + RCCL all-gather of the output" if use_dist else ""),
                "value": round(spec.flops() * K / mwall / 1e9, 1), "unit": "GFLOP/s", "scaling": "strong",
                "ms_per_step": round(mwall / K * 1e3, 5), "flops_per_step": spec.flops(),
                "frac_of_bf16_mfma_peak": round(spec.flops() * K / mwall / 1e12 / (PEAK_BF16_MFMA_TFLOPS * world), 4),
@@ -344,7 +348,7 @@ def main():
         if others:
             line["other_configs"] = others
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -766,7 +766,8 @@ bool bf16_fast_eligible(const GemmDesc &d) {
 hipError_t launch_gemm_bf16_fast(const GemmDesc &d, const GemmArgs &a, hipStream_t s) {
   const int64_t t128 = (d.m % 128 == 0 && d.n % 128 == 0) ? (d.m / 128) * (d.n / 128) : 0;
   static const int legacy = getenv("TPP_HIP_BF16_LEGACY") ? atoi(getenv("TPP_HIP_BF16_LEGACY")) : 0;
-  if (t128 >= 192) return legacy == 1 ? launch_bf16<2, 2, 2, 2>(a, s) : legacy == 2 ? launch_bf16_dma128<false>(a, s) : launch_bf16_dma128<true>(a, s);
+  // TPP_HIP_BF16_LEGACY=2 drops the loader waves (A/B measurement knob)
+  if (t128 >= 192) return legacy == 2 ? launch_bf16_dma128<false>(a, s) : launch_bf16_dma128<true>(a, s);
   return launch_bf16<2, 2, 1, 1>(a, s);
 }
 

@@ -48,22 +48,4 @@ template <> struct Elem<unsigned short> {
   }
 };
 
-// Workgroup id -> output tile, XCD-aware. Workgroup b is observed to run on XCD
-// b % 8 (each XCD has a private 4 MiB L2); give every XCD a compact 2-D block of
-// tiles so the A row-panels and B column-panels it touches are shared in its L2.
-// Pure speed choice: any bijection is correct.
-__device__ __forceinline__ void tile_of_block(int b, int tiles_m, int tiles_n, int &tm, int &tn) {
-  const int nt = tiles_m * tiles_n;
-  if ((nt & 7) == 0 && (tiles_m & 3) == 0 && (tiles_n & 1) == 0) {
-    const int xcd = b & 7, idx = b >> 3;          // idx in [0, nt/8)
-    const int bm = tiles_m >> 2, bn = tiles_n >> 1; // XCD grid 4 (M) x 2 (N), blocks bm x bn
-    const int xm = xcd >> 1, xn = xcd & 1;
-    tm = xm * bm + idx / bn;
-    tn = xn * bn + idx % bn;
-  } else {
-    tm = b / tiles_n;
-    tn = b % tiles_n;
-  }
-}
-
 } // namespace tpp
