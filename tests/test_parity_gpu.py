@@ -508,3 +508,26 @@ def test_concurrent_invokes_on_disjoint_tiles(rt):
     for t in ths:
         t.join()
     check_close(C, ref, F32, "concurrent tiles")
+
+
+def test_c5_pack_prologue_then_vnni_brgemm_full_size(rt):
+    """BASELINE config 5 end to end: xsmm.unary VNNI-2 pack of a flat bf16 B[2048x2048] on the GPU,
+    then the bf16 BRGEMM 2048^3 on the packed operand (wire flags VNNI_B|BETA_0 = 2052). Checked
+    against the oracle working on the FLAT B (no VNNI anywhere on the oracle side), on row samples
+    - so the pack layout and the kernel's VNNI addressing must agree with the reference definition
+    out[(k/2)][n][k%2] = in[k][n] (VNNIUtils.cpp:75-77), not merely with each other."""
+    M = 2048
+    rng = np.random.default_rng(55)
+    A = orc.f32_to_bf16(rng.uniform(-1, 1, M * M).astype(np.float32))
+    B = orc.f32_to_bf16(rng.uniform(-1, 1, M * M).astype(np.float32))
+    hp = rt.unary_dispatch(28, BF16, M, M, M, M, 0)
+    hg = rt.brgemm_dispatch(BF16, M, M, 128, M, M, M, 128, 128 * M, 4 | VB)
+    dB, dBv, dC = dev(B), dev(np.zeros(M * M, np.uint16)), dev(np.zeros(M * M, np.uint16))
+    rt.unary(BF16, hp, dB, 0, dBv, 0)
+    rt.brgemm(BF16, hg, dev(A), 0, dBv, 0, dC, 0, 16)
+    got = host(dC, A).reshape(M, M)
+    for (r0, rr) in ((0, 32), (1000, 24), (2040, 8)):
+        ref = np.zeros(rr * M, np.uint16)
+        # flat B: batch b covers k in [128 b, 128 b + 128): stride_b = 128 rows of the flat matrix
+        orc.brgemm(BF16, rr, M, 128, M, M, M, 128, 128 * M, 4, A, r0 * M, B, 0, ref, 0, 16)
+        check_close(got[r0:r0 + rr].reshape(-1), ref, BF16, "C5 rows %d..%d" % (r0, r0 + rr))
