@@ -513,6 +513,11 @@ __global__ __launch_bounds__(LW ? 384 : 256) void brgemm_bf16_dma128(GemmArgs p)
     return; // ended waves do not take part in later barriers
   }
 
+#ifndef TPP_BF16_SETPRIO
+#define TPP_BF16_SETPRIO 0
+#endif
+  // optional static priority of the MFMA waves over the loader waves (A/B measured: no effect)
+  if (LW && TPP_BF16_SETPRIO) __builtin_amdgcn_s_setprio(2);
   f32x16 acc[TM][TN];
   constexpr int NFB = 4; // fragment buffers: step q+2 is read while step q multiplies
   bf16x8_t af[NFB][TM], bfr[NFB][TN];
