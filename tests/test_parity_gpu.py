@@ -225,6 +225,50 @@ def test_brgemm_bf16_flat_b_generic(rt):
     gemm_case(rt, BF16, 48, 40, 24, 3, vnni=False, seed=3, bias=True)
 
 
+def _random_gemm_case(rng, dt):
+    """one random dispatch the compiler could emit: half the draws are shaped for the fast kernels
+    (multiples of 64, 16-byte-aligned leading dimensions and offsets), half are ragged; leading
+    dimensions, batch strides, offsets and the epilogue are drawn independently"""
+    aligned = rng.random() < 0.5
+    if aligned:
+        m, n = int(rng.integers(1, 7)) * 64, int(rng.integers(1, 7)) * 64
+        k = int(rng.integers(1, 4)) * 64
+        q = 8
+    else:
+        m, n, k = int(rng.integers(1, 150)), int(rng.integers(1, 150)), int(rng.integers(1, 100))
+        q = 1
+    vnni = dt == BF16 and (k % 2 == 0) and rng.random() < 0.8
+    br = int(rng.integers(0, 6))
+    lda = k + q * int(rng.integers(0, 5))
+    ldb = n + q * int(rng.integers(0, 5))
+    ldc = n + q * int(rng.integers(0, 5))
+    kp2 = ((k + 1) // 2) * 2
+    choice = rng.random()
+    if choice < 0.4:      # batch along k inside one row-major matrix (mlir-gen whole-layer form)
+        lda = k * max(br, 1) + q * int(rng.integers(0, 3))
+        sa, sb = k, (kp2 if vnni else k) * ldb
+    elif choice < 0.8:    # packed blocks one after the other
+        sa, sb = m * lda, (kp2 if vnni else k) * ldb
+    else:                 # overlapping / repeated operands (stride smaller than a matrix)
+        sa, sb = q * int(rng.integers(0, 3)), q * int(rng.integers(0, 3))
+    offs = tuple(q * int(rng.integers(0, 4)) for _ in range(4))
+    bias, relu = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    return dict(m=m, n=n, k=k, br=br, lda=lda, ldb=ldb, ldc=ldc, sa=sa, sb=sb, offs=offs, vnni=vnni,
+                beta0=bool(rng.integers(0, 2)), bias=bias, relu=relu, fused=bias or relu or bool(rng.integers(0, 2)))
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("chunk", range(6))
+def test_brgemm_random_dispatches(rt, dt, chunk):
+    """seeded random sweep over the whole dispatch tuple (kernel selection boundaries included)"""
+    rng = np.random.default_rng(1000 * dt + chunk)
+    seen = set()
+    for i in range(14):
+        c = _random_gemm_case(rng, dt)
+        seen.add(gemm_case(rt, dt, seed=chunk * 100 + i, mode="device" if i % 4 else "host", **c))
+    assert seen  # kernel names exercised (both fast and grouped paths occur over the chunks)
+
+
 # ---------------------------------------------------------------- unary / binary
 UNARY = [(1, 0), (1, 2), (1, 4), (1, 8), (5, 0), (5, 2), (5, 4), (5, 8), (2, 0), (2, 8)]
 

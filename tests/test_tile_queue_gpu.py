@@ -176,3 +176,106 @@ def test_concurrent_enqueue_from_threads(rtq):
         t.join()
     rt.synchronize()
     close(host(dC, C), ref, F32)
+
+
+UNARY_Q = [(1, 0), (1, 2), (1, 4), (1, 8), (5, 0), (5, 4), (2, 0), (29, 0), (28, 0)]
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("kind,flags", UNARY_Q)
+def test_queued_unary_tiles_bit_exact(rtq, dt, kind, flags):
+    """pack / unpack / broadcast tiles (LowerPacksAndUnpacks.cpp:45-121 lowers tensor.pack to per-block
+    unary invokes): a grid of tile invokes of ONE dispatch through the queue equals the oracle's replay"""
+    if kind == 28 and dt == F32:
+        pytest.skip("VNNI-2 packs 16-bit elements")
+    rt = rtq
+    rng = np.random.default_rng(kind * 10 + flags)
+    for (m, n, ld_big) in ((32, 32, 256), (13, 40, 97), (64, 64, 64), (6, 10, 12)):
+        m += (m & 1) if kind == 28 else 0  # VNNI-2 packs row pairs
+        gi, gj = 5, 3
+        ldi = {0: ld_big, 2: 1, 4: n, 8: 1}[flags]
+        ldo = m + 3 if kind == 29 else n + 2
+        out_rows = n if kind == 29 else m
+        out_tile = out_rows * ldo + 8
+        src = rng.uniform(-1, 1, gi * 64 * ld_big + gj * 64 + 64 * ld_big).astype(np.float32)
+        X = src if dt == F32 else orc.f32_to_bf16(src)
+        O = np.zeros(gi * gj * out_tile, dtype=X.dtype)
+        ref = O.copy()
+        h = rt.unary_dispatch(kind, dt, m, n, ldi, ldo, flags)
+        dX, dO = dev(X), dev(O)
+        for i in range(gi):
+            for j in range(gj):
+                oi, oo = i * m * ld_big + j * n, (i * gj + j) * out_tile
+                orc.unary(kind, dt, m, n, ldi, ldo, flags, X, oi, ref, oo)
+                rt.unary(dt, h, dX, oi, dO, oo)
+        rt.synchronize()
+        assert host(dO, O).tobytes() == ref.tobytes(), (kind, flags, m, n)
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("kind", [1, 2, 3, 4])
+@pytest.mark.parametrize("flags", [0, 4, 8, 1, 32, 16 | 2])
+def test_queued_binary_tiles(rtq, dt, kind, flags):
+    rt = rtq
+    rng = np.random.default_rng(kind * 100 + flags)
+    m, n, ld = 32, 48, 160
+    f0, f1 = flags & (1 | 4 | 16), flags & (2 | 8 | 32)
+    ldl = 1 if f0 in (1, 16) else (n if f0 == 4 else ld)
+    ldr = 1 if f1 in (2, 32) else (n if f1 == 8 else ld)
+    L = rng.uniform(0.5, 2.0, 4 * m * ld + 64).astype(np.float32)
+    R = rng.uniform(0.5, 2.0, 4 * m * ld + 64).astype(np.float32)
+    if dt == BF16:
+        L, R = orc.f32_to_bf16(L), orc.f32_to_bf16(R)
+    O = np.zeros(4 * 3 * m * n, dtype=L.dtype)
+    ref = O.copy()
+    h = rt.binary_dispatch(kind, dt, m, n, ldl, ldr, n, flags)
+    dL, dR, dO = dev(L), dev(R), dev(O)
+    for i in range(4):
+        for j in range(3):
+            ol, orr, oo = i * m * ld + j * n, i * m * ld + j * n + 5, (i * 3 + j) * m * n
+            orc.binary(kind, dt, m, n, ldl, ldr, n, flags, L, ol, R, orr, ref, oo)
+            rt.binary(dt, h, dL, ol, dR, orr, dO, oo)
+    rt.synchronize()
+    assert host(dO, O).tobytes() == ref.tobytes()
+
+
+def test_queued_in_place_relu_then_dependent_reads(rtq):
+    """in-place tiles (relu on its own input) followed by a consumer of those tiles: the consumer must
+    see the relu'd values (RAW flush), and a later overwrite of the source must not race (WAR flush)"""
+    rt = rtq
+    rng = np.random.default_rng(11)
+    X = rng.uniform(-1, 1, 8 * 1024).astype(np.float32)
+    relu = rt.unary_dispatch(5, F32, 32, 32, 32, 32, 0)
+    copy = rt.unary_dispatch(1, F32, 32, 32, 32, 32, 0)
+    zero = rt.unary_dispatch(2, F32, 32, 32, 32, 32, 0)
+    dX, dY = dev(X), dev(np.zeros_like(X))
+    for b in range(8):
+        rt.unary(F32, relu, dX, b * 1024, dX, b * 1024)
+    for b in range(8):
+        rt.unary(F32, copy, dX, b * 1024, dY, b * 1024)
+    for b in range(8):
+        rt.unary(F32, zero, dX, 0, dX, b * 1024)
+    rt.synchronize()
+    assert np.array_equal(host(dY, X), np.maximum(X, 0))
+    assert not host(dX, X).any()
+
+
+def test_interleaved_and_overlapping_tiles_of_one_buffer(rtq):
+    """tiles of one row-major buffer: neighbours have interleaved rows (no dependence - they must be
+    batched, not flushed one by one) while partially overlapping tiles must keep program order"""
+    rt = rtq
+    rng = np.random.default_rng(21)
+    ld = 256
+    src = rng.uniform(-1, 1, 40 * 1024).astype(np.float32)
+    dst = np.zeros(96 * ld, np.float32)
+    ref = dst.copy()
+    h = rt.unary_dispatch(1, F32, 32, 32, 32, ld, 0)
+    spots = [(0, 0), (0, 32), (0, 64), (32, 0), (32, 32), (16, 16), (16, 48), (8, 8), (40, 40), (0, 224),
+             (63, 100), (64, 0), (64, 32), (50, 90), (20, 200), (21, 201), (22, 202), (0, 0), (33, 33)]
+    dS, dD = dev(src), dev(dst)
+    for rep in range(2):
+        for t, (r, c) in enumerate(spots):
+            orc.unary(1, F32, 32, 32, 32, ld, 0, src, ((t + rep) % 40) * 1024, ref, r * ld + c)
+            rt.unary(F32, h, dS, ((t + rep) % 40) * 1024, dD, r * ld + c)
+    rt.synchronize()
+    assert np.array_equal(host(dD, dst), ref)

@@ -57,6 +57,12 @@ def bf16_case(m, n, k, br, tag=""):
         m, n, k, br, rt.kernel_name(h), t * 1e6, fl / t / 1e12, fl / t / 25e12, tag), flush=True)
 
 
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "shards":
+    # per-rank layer shapes of the row-sharded C4 MLP at 8/4/2/1 GPUs (kernel choice: TPP_HIP_BF16_T128MIN)
+    for m in (512, 1024, 2048, 4096):
+        bf16_case(m, 1024, 64, 16, tag="C4 layer shard, T128MIN=%s" % os.environ.get("TPP_HIP_BF16_T128MIN", "default"))
+    sys.exit(0)
+
 if __name__ == "__main__":
     f32_case(64, 64, 64, 0, tag="launch floor (empty batch)")
     f32_case(1024, 1024, 64, 0, tag="epilogue only")

@@ -12,6 +12,9 @@
 //
 //   tpp_replay --batch 256 --layers 1024,1024,1024,1024 --tiles 32 [--bias --relu] [--queue 1] [-n 100]
 //   tpp_replay --batch 256 --layers 1024,1024,1024,1024 --whole-layer ...
+//   tpp_replay --c1 [--queue 0|1]     BASELINE config 1: mlir-gen --kernel=args --batch=256 --layers=256,256
+//                                     after the default pipeline = 192 block relayout invokes (xsmm.unary
+//                                     identity, ld 256 -> 32), 64 brgemm invokes (32^3, br 8), 64 un-pack invokes
 #include "../include/tpp_xsmm_abi.h"
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -35,7 +38,7 @@ static std::vector<int64_t> parse_list(const char *s) {
 int main(int argc, char **argv) {
   int64_t batch = 256, tile = 32, n_iter = 100;
   std::vector<int64_t> layers = {1024, 1024, 1024, 1024};
-  bool bias = false, relu = false, whole = false, print = false;
+  bool bias = false, relu = false, whole = false, print = false, c1 = false;
   int queue = 1;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
@@ -49,9 +52,55 @@ int main(int argc, char **argv) {
     else if (a == "--relu") relu = true;
     else if (a == "--whole-layer") whole = true;
     else if (a == "--print") print = true;
+    else if (a == "--c1") c1 = true;
     else { fprintf(stderr, "unknown flag %s\n", a.c_str()); return 2; }
   }
   if (xsmm_hip_device_count() < 1) { fprintf(stderr, "tpp_replay: no HIP device (there is no CPU fallback)\n"); return 1; }
+  if (c1) {
+    // A, W, C: 256x256 f32 filled 1.0; packed copies [8][8][32][32]; result 257 everywhere (C += A W)
+    const int64_t N = 256, T = 32, NB = N / T, tt = T * T;
+    float *buf[6];
+    std::vector<float> ones((size_t)N * N, 1.0f);
+    for (int i = 0; i < 6; ++i) {
+      CHECK(hipMalloc((void **)&buf[i], N * N * sizeof(float)));
+      CHECK(hipMemcpy(buf[i], ones.data(), N * N * sizeof(float), hipMemcpyHostToDevice));
+    }
+    float *A = buf[0], *W = buf[1], *C = buf[2], *Ap = buf[3], *Wp = buf[4], *Cp = buf[5];
+    xsmm_hip_set_async(1);
+    xsmm_hip_set_tile_queue(queue);
+    const int64_t pack = xsmm_unary_dispatch(XSMM_UNARY_IDENTITY, 1, T, T, N, T, 0);
+    const int64_t unpack = xsmm_unary_dispatch(XSMM_UNARY_IDENTITY, 1, T, T, T, N, 0);
+    const int64_t hb = xsmm_brgemm_dispatch(1, T, T, T, T, T, T, tt, tt, 0);
+    auto kernel = [&]() {
+      for (int64_t bi = 0; bi < NB; ++bi)
+        for (int64_t bj = 0; bj < NB; ++bj) {
+          const int64_t blk = (bi * NB + bj) * tt;
+          xsmm_unary_invoke(1, pack, A, bi * T * N + bj * T, Ap, blk);
+          xsmm_unary_invoke(1, pack, W, bj * T * N + bi * T, Wp, blk); // W blocks stored [NB][KB]
+          xsmm_unary_invoke(1, pack, C, bi * T * N + bj * T, Cp, blk);
+        }
+      for (int64_t bi = 0; bi < NB; ++bi)
+        for (int64_t bj = 0; bj < NB; ++bj)
+          xsmm_brgemm_invoke(1, hb, Ap, bi * NB * tt, Wp, bj * NB * tt, Cp, (bi * NB + bj) * tt, NB);
+      for (int64_t bi = 0; bi < NB; ++bi)
+        for (int64_t bj = 0; bj < NB; ++bj)
+          xsmm_unary_invoke(1, unpack, Cp, (bi * NB + bj) * tt, C, bi * T * N + bj * T);
+    };
+    kernel();
+    xsmm_hip_synchronize();
+    std::vector<float> h((size_t)N * N);
+    CHECK(hipMemcpy(h.data(), C, N * N * sizeof(float), hipMemcpyDeviceToHost));
+    for (float v : h)
+      if (v != 257.0f) { fprintf(stderr, "tpp_replay --c1: expected 257 everywhere, got %g\n", v); return 1; }
+    const int64_t t0 = perf_start_timer();
+    for (int64_t i = 0; i < n_iter; ++i) kernel();
+    const double mean = perf_stop_timer(t0) / (double)n_iter;
+    const double fl = 2.0 * N * N * N; // 33,554,432 (BENCH_TOTAL_FLOPS of the 256^3 matmul)
+    printf("%g\n", mean);
+    fprintf(stderr, "tpp_replay: C1 call script (320 invokes), queue %d: mean %.3f us, %.1f GFLOP/s, first result 257 checked\n",
+            queue, mean * 1e6, fl / mean / 1e9);
+    return 0;
+  }
   const int L = (int)layers.size() - 1;
   const int64_t gflags = XSMM_GEMM_FLAG_BETA_0; // mlir-gen --kernel=const: zero fill folded into BETA_0
   const int64_t ukind = relu ? XSMM_UNARY_RELU : XSMM_UNARY_NONE;

@@ -772,7 +772,8 @@ hipError_t launch_gemm_bf16_fast(const GemmDesc &d, const GemmArgs &a, hipStream
   const int64_t t128 = (d.m % 128 == 0 && d.n % 128 == 0) ? (d.m / 128) * (d.n / 128) : 0;
   static const int legacy = getenv("TPP_HIP_BF16_LEGACY") ? atoi(getenv("TPP_HIP_BF16_LEGACY")) : 0;
   // TPP_HIP_BF16_LEGACY=2 drops the loader waves (A/B measurement knob)
-  if (t128 >= 192) return legacy == 2 ? launch_bf16_dma128<false>(a, s) : launch_bf16_dma128<true>(a, s);
+  static const int64_t t128_min = getenv("TPP_HIP_BF16_T128MIN") ? atoll(getenv("TPP_HIP_BF16_T128MIN")) : 192;
+  if (t128 >= t128_min) return legacy == 2 ? launch_bf16_dma128<false>(a, s) : launch_bf16_dma128<true>(a, s);
   return launch_bf16<2, 2, 1, 1>(a, s);
 }
 

@@ -154,6 +154,104 @@ __global__ __launch_bounds__(256) void vnni2_kernel(int64_t m, int64_t n, int64_
   }
 }
 
+// ---- grouped variants (tile queue): ONE block per queued invoke of one small-tile descriptor ----
+// The compiler lowers tensor.pack / unpack and bias broadcasts to hundreds of unary / binary invokes
+// on <= 64x64 tiles (LowerPacksAndUnpacks.cpp:45-121); the queue runs them as one launch. Same
+// element arithmetic as the kernels above (bit-identical results), element-granular accesses with
+// consecutive lanes on consecutive columns.
+template <typename T>
+__global__ __launch_bounds__(256) void unary_grouped_kernel(int op, int bc, int m, int n, int64_t ldi, int64_t ldo,
+                                                            const WorkItem *__restrict__ items) {
+  __shared__ T tile[64][65];
+  const T *in = (const T *)items[blockIdx.x].A;
+  T *out = (T *)items[blockIdx.x].C;
+  const int t = threadIdx.x;
+  if (op == (int)U_TRANSPOSE) {
+    for (int idx = t; idx < m * n; idx += 256) {
+      const int i = idx / n, j = idx - i * n;
+      tile[i][j] = in[i * ldi + j];
+    }
+    __syncthreads();
+    for (int idx = t; idx < m * n; idx += 256) {
+      const int j = idx / m, i = idx - j * m;
+      out[j * ldo + i] = tile[i][j];
+    }
+    return;
+  }
+  if (op == (int)U_VNNI2) {
+    const int pairs = m / 2;
+    for (int idx = t; idx < pairs * 2 * n; idx += 256) {
+      const int r = idx / (2 * n), rem = idx - r * 2 * n;
+      out[r * (2 * ldo) + rem] = in[(2 * r + (rem & 1)) * ldi + (rem >> 1)];
+    }
+    return;
+  }
+  for (int idx = t; idx < m * n; idx += 256) {
+    const int i = idx / n, j = idx - i * n;
+    T x = T(0);
+    if (op != (int)U_ZERO) {
+      x = load_operand<T, 1>(in, bc, i, j, ldi).v[0];
+      if (op == (int)U_RELU) {
+        const float f = Bits<T>::to_f32(x);
+        x = Bits<T>::from_f32(f > 0.0f ? f : 0.0f);
+      }
+    }
+    out[i * ldo + j] = x;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void binary_grouped_kernel(int op, int bc0, int bc1, int m, int n, int64_t ldl,
+                                                             int64_t ldr, int64_t ldo,
+                                                             const WorkItem *__restrict__ items) {
+  const T *lhs = (const T *)items[blockIdx.x].A, *rhs = (const T *)items[blockIdx.x].B;
+  T *out = (T *)items[blockIdx.x].C;
+  for (int idx = threadIdx.x; idx < m * n; idx += 256) {
+    const int i = idx / n, j = idx - i * n;
+    const float a = Bits<T>::to_f32(load_operand<T, 1>(lhs, bc0, i, j, ldl).v[0]);
+    const float b = Bits<T>::to_f32(load_operand<T, 1>(rhs, bc1, i, j, ldr).v[0]);
+    float c;
+    switch (op) {
+    case (int)B_ADD: c = a + b; break;
+    case (int)B_MUL: c = a * b; break;
+    case (int)B_SUB: c = a - b; break;
+    default: c = a / b; break;
+    }
+    out[i * ldo + j] = Bits<T>::from_f32(c);
+  }
+}
+
+static inline int unary_bc(int64_t flags) {
+  return (flags & UF_SCALAR) ? BC_SCALAR : (flags & UF_ROW) ? BC_ROW : (flags & UF_COL) ? BC_COL : BC_NONE;
+}
+static inline int binary_bc(int64_t f, int64_t row, int64_t col, int64_t sc) {
+  return (f & sc) ? BC_SCALAR : (f & row) ? BC_ROW : (f & col) ? BC_COL : BC_NONE;
+}
+
+hipError_t launch_unary_grouped(const UnaryDesc &d, const WorkItem *items, int n_items, hipStream_t s) {
+  if (n_items <= 0 || d.m <= 0 || d.n <= 0) return hipSuccess;
+  if (d.m > 64 || d.n > 64) return hipErrorInvalidValue;
+  if (d.dtype == DT_F32)
+    hipLaunchKernelGGL((unary_grouped_kernel<float>), dim3((unsigned)n_items), dim3(256), 0, s, (int)d.op,
+                       unary_bc(d.flags), (int)d.m, (int)d.n, d.ldi, d.ldo, items);
+  else
+    hipLaunchKernelGGL((unary_grouped_kernel<unsigned short>), dim3((unsigned)n_items), dim3(256), 0, s, (int)d.op,
+                       unary_bc(d.flags), (int)d.m, (int)d.n, d.ldi, d.ldo, items);
+  return hipGetLastError();
+}
+
+hipError_t launch_binary_grouped(const BinaryDesc &d, const WorkItem *items, int n_items, hipStream_t s) {
+  if (n_items <= 0 || d.m <= 0 || d.n <= 0) return hipSuccess;
+  const int bc0 = binary_bc(d.flags, BF_ROW0, BF_COL0, BF_SC0), bc1 = binary_bc(d.flags, BF_ROW1, BF_COL1, BF_SC1);
+  if (d.dtype == DT_F32)
+    hipLaunchKernelGGL((binary_grouped_kernel<float>), dim3((unsigned)n_items), dim3(256), 0, s, (int)d.op, bc0, bc1,
+                       (int)d.m, (int)d.n, d.ldi_lhs, d.ldi_rhs, d.ldo, items);
+  else
+    hipLaunchKernelGGL((binary_grouped_kernel<unsigned short>), dim3((unsigned)n_items), dim3(256), 0, s, (int)d.op,
+                       bc0, bc1, (int)d.m, (int)d.n, d.ldi_lhs, d.ldi_rhs, d.ldo, items);
+  return hipGetLastError();
+}
+
 static inline int grid_for(int64_t total) {
   int64_t blocks = (total + 255) / 256;
   if (blocks < 1) blocks = 1;

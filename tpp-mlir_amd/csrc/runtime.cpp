@@ -22,6 +22,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <unordered_map>
 #include <vector>
 
 using namespace tpp;
@@ -122,6 +123,13 @@ struct Operand {
   size_t bytes;
   bool written;
   void *dev; // resolved device pointer
+  // optional 2-D shape of the footprint (rows of row_bytes every pitch bytes); 0 = one flat range.
+  // Only the tile queue's dependence tracking reads it: neighbouring tiles of one row-major buffer
+  // have interleaved rows, so their bounding ranges overlap although the tiles do not.
+  size_t rows = 0, row_bytes = 0, pitch = 0;
+  void shape(int64_t r, size_t rb, size_t p) {
+    if (r > 1 && p > rb) rows = (size_t)r, row_bytes = rb, pitch = p;
+  }
 };
 
 // Resolve every operand to a device pointer. Device memory is used in place. Host
@@ -298,6 +306,12 @@ struct DeviceRanges {
       if (a >= r.b && a < r.e) return true;
     return false;
   }
+  uintptr_t base_of(const void *p) const { // allocation base, 0 if unknown
+    const uintptr_t a = (uintptr_t)p;
+    for (const Range &r : known)
+      if (a >= r.b && a < r.e) return r.b;
+    return 0;
+  }
   bool is_device(const void *p) {
     if (!p || contains(p)) return true;
     if (!is_device_ptr(p)) return false;
@@ -313,13 +327,86 @@ struct DeviceRanges {
   }
 };
 
+// Footprint of the queued invokes' reads (or writes). Flat ranges are kept exactly in an interval
+// set. A 2-D tile (rows x row_bytes, pitch) is kept as a rectangle in the "plane" (allocation base,
+// pitch) it lives in - exact overlap tests between tiles of one row-major buffer, which is what pack /
+// unpack tiles and the C tiles of a flat layer are - with a 64-row x 256-byte cell hash so a test
+// touches a handful of rectangles. Anything that does not fit a plane falls back to its bounding
+// range, and tests across different planes / against flat ranges use bounding ranges: conservative
+// (may flush early), never unsafe.
+struct Footprint {
+  struct Rect { uint32_t r0, r1, c0, c1; };
+  struct Plane {
+    uintptr_t anchor;
+    size_t pitch;
+    IntervalSet bound;
+    std::unordered_multimap<uint64_t, Rect> cells;
+  };
+  IntervalSet flat;
+  std::vector<Plane> planes;
+  void clear() { flat.clear(); planes.clear(); }
+  static Range bounding(const Operand &o) { return Range{(uintptr_t)o.ptr, (uintptr_t)o.ptr + o.bytes}; }
+  // rectangle of o in the plane (anchor, o.pitch); false if o is flat / wraps / is too wide for the hash
+  static bool to_rect(const Operand &o, uintptr_t anchor, Rect &r) {
+    if (!o.rows || !anchor) return false;
+    const uintptr_t off = (uintptr_t)o.ptr - anchor;
+    const uintptr_t r0 = off / o.pitch, c0 = off % o.pitch;
+    if (c0 + o.row_bytes > o.pitch || o.row_bytes > 2048 || o.rows > 512 || r0 + o.rows > 0xffffffffu) return false;
+    r = Rect{(uint32_t)r0, (uint32_t)(r0 + o.rows), (uint32_t)c0, (uint32_t)(c0 + o.row_bytes)};
+    return true;
+  }
+  template <typename F> static void for_cells(const Rect &r, F f) {
+    for (uint32_t cr = r.r0 / 64; cr <= (r.r1 - 1) / 64; ++cr)
+      for (uint32_t cc = r.c0 / 256; cc <= (r.c1 - 1) / 256; ++cc) f(((uint64_t)cr << 32) | cc);
+  }
+  bool overlaps(const Operand &o, uintptr_t anchor) const {
+    if (!o.ptr || !o.bytes) return false;
+    const Range b = bounding(o);
+    if (flat.overlaps(b)) return true;
+    Rect r;
+    const bool is_rect = to_rect(o, anchor, r);
+    for (const Plane &p : planes) {
+      if (!p.bound.overlaps(b)) continue;
+      if (!is_rect || p.anchor != anchor || p.pitch != o.pitch) return true;
+      bool hit = false;
+      for_cells(r, [&](uint64_t key) {
+        auto range = p.cells.equal_range(key);
+        for (auto it = range.first; it != range.second && !hit; ++it) {
+          const Rect &q = it->second;
+          hit = q.r0 < r.r1 && r.r0 < q.r1 && q.c0 < r.c1 && r.c0 < q.c1;
+        }
+      });
+      if (hit) return true;
+    }
+    return false;
+  }
+  void insert(const Operand &o, uintptr_t anchor) {
+    if (!o.ptr || !o.bytes) return;
+    Rect r;
+    if (!to_rect(o, anchor, r)) {
+      flat.insert(bounding(o));
+      return;
+    }
+    Plane *pl = nullptr;
+    for (Plane &p : planes)
+      if (p.anchor == anchor && p.pitch == o.pitch) pl = &p;
+    if (!pl) {
+      planes.push_back(Plane{anchor, o.pitch, {}, {}});
+      pl = &planes.back();
+    }
+    pl->bound.insert(bounding(o));
+    for_cells(r, [&](uint64_t key) { pl->cells.emplace(key, r); });
+  }
+};
+
 struct TileQueue {
   static constexpr int CAP = 4096, SLOTS = 4;
   std::mutex mu;
-  const GemmDesc *desc = nullptr;
+  int kind = 0;               // KIND_GEMM / KIND_UNARY / KIND_BINARY of the queued invokes
+  const void *desc = nullptr; // their (single) descriptor
   bool vec_ok = true;
   int n = 0;
-  IntervalSet reads, writes;
+  Footprint reads, writes;
   DeviceRanges devmem;
   WorkItem *pinned[SLOTS] = {nullptr, nullptr, nullptr, nullptr}; // host-pinned, read by the kernel over PCIe once per workgroup
   hipEvent_t done[SLOTS];
@@ -339,7 +426,9 @@ struct TileQueue {
   // caller holds mu
   void flush_locked() {
     if (n == 0) return;
-    HIP_OK(launch_gemm_grouped(*desc, pinned[slot], n, vec_ok, stream));
+    if (kind == KIND_GEMM) HIP_OK(launch_gemm_grouped(*(const GemmDesc *)desc, pinned[slot], n, vec_ok, stream));
+    else if (kind == KIND_UNARY) HIP_OK(launch_unary_grouped(*(const UnaryDesc *)desc, pinned[slot], n, stream));
+    else HIP_OK(launch_binary_grouped(*(const BinaryDesc *)desc, pinned[slot], n, stream));
     HIP_OK(hipEventRecord(done[slot], stream));
     used[slot] = true;
     slot = (slot + 1) % SLOTS;
@@ -362,33 +451,45 @@ void flush_tile_queue() {
   if (cfg().tile_queue.load(std::memory_order_relaxed)) tq().flush();
 }
 
-// true if the invoke was queued (nothing launched yet)
+// Appends one invoke of (kind, desc) to the queue; true if queued (nothing launched yet), false if an
+// operand is host memory (the caller flushes and takes the mirrored path). `in` are the operands the
+// invoke reads, `out` the one it writes (also read when the op accumulates - a superset is harmless).
+bool enqueue_item(int kind, const void *desc, const WorkItem &item, const Operand *const *in, int n_in,
+                  const Operand &out, bool vec_ok, hipStream_t s) {
+  TileQueue &q = tq();
+  std::lock_guard<std::mutex> lk(q.mu);
+  if (!q.devmem.is_device(out.ptr)) return false;
+  for (int i = 0; i < n_in; ++i)
+    if (!q.devmem.is_device(in[i]->ptr)) return false;
+  auto anchor = [&](const Operand &o) { return o.rows ? q.devmem.base_of(o.ptr) : (uintptr_t)0; };
+  const uintptr_t ao = anchor(out);
+  bool conflict = q.n > 0 && (q.kind != kind || q.desc != desc || q.stream != s || q.n >= TileQueue::CAP);
+  if (!conflict && q.n > 0) {
+    conflict = q.writes.overlaps(out, ao) || q.reads.overlaps(out, ao);
+    for (int i = 0; i < n_in && !conflict; ++i) conflict = q.writes.overlaps(*in[i], anchor(*in[i]));
+  }
+  if (conflict) q.flush_locked();
+  q.ensure_slot();
+  q.kind = kind;
+  q.desc = desc;
+  q.stream = s;
+  q.vec_ok = q.vec_ok && vec_ok;
+  q.pinned[q.slot][q.n++] = item;
+  for (int i = 0; i < n_in; ++i) q.reads.insert(*in[i], anchor(*in[i]));
+  q.writes.insert(out, ao);
+  return true;
+}
+
+bool queue_active() {
+  return cfg().tile_queue.load(std::memory_order_relaxed) && cfg().async.load(std::memory_order_relaxed);
+}
+
 bool try_enqueue(const GemmDesc *d, const Operand &A, const Operand &B, const Operand &C, const Operand &D, int64_t br,
                  hipStream_t s) {
   if (d->m > 64 || d->n > 64) return false; // big descriptors fill the chip on their own
-  TileQueue &q = tq();
-  std::lock_guard<std::mutex> lk(q.mu);
-  const Range ra{(uintptr_t)A.ptr, (uintptr_t)A.ptr + A.bytes}, rb{(uintptr_t)B.ptr, (uintptr_t)B.ptr + B.bytes},
-      rc{(uintptr_t)C.ptr, (uintptr_t)C.ptr + C.bytes}, rd{(uintptr_t)D.ptr, (uintptr_t)D.ptr + D.bytes};
-  if (!q.devmem.is_device(A.ptr) || !q.devmem.is_device(B.ptr) || !q.devmem.is_device(C.ptr) ||
-      !q.devmem.is_device(D.ptr))
-    return false; // a host operand: the caller flushes and takes the mirrored path
-  bool conflict = q.n > 0 && (q.desc != d || q.stream != s || q.n >= TileQueue::CAP);
-  if (!conflict && q.n > 0)
-    conflict = q.writes.overlaps(ra) || q.writes.overlaps(rb) || q.writes.overlaps(rc) || q.writes.overlaps(rd) ||
-               q.reads.overlaps(rc);
-  if (conflict) q.flush_locked();
-  q.ensure_slot();
-  q.desc = d;
-  q.stream = s;
-  const uintptr_t al = (uintptr_t)A.ptr | (uintptr_t)B.ptr;
-  q.vec_ok = q.vec_ok && (al & 15) == 0;
-  q.pinned[q.slot][q.n++] = WorkItem{A.ptr, B.ptr, C.ptr, D.ptr, br};
-  q.reads.insert(ra);
-  q.reads.insert(rb);
-  q.reads.insert(rd);
-  q.writes.insert(rc);
-  return true;
+  const Operand *in[3] = {&A, &B, &D};
+  const bool vec_ok = (((uintptr_t)A.ptr | (uintptr_t)B.ptr) & 15) == 0;
+  return enqueue_item(KIND_GEMM, d, WorkItem{A.ptr, B.ptr, C.ptr, D.ptr, br}, in, 3, C, vec_ok, s);
 }
 
 void gemm_invoke_common(const char *who, bool want_fused, int64_t dtype, int64_t handle, void *a, int64_t off_a,
@@ -403,6 +504,7 @@ void gemm_invoke_common(const char *who, bool want_fused, int64_t dtype, int64_t
   Operand A{(char *)a + off_a * es, 0, false, nullptr}, B{(char *)b + off_b * es, 0, false, nullptr},
       C{(char *)c + off_c * es, span(d->m, d->ldc, d->n) * es, true, nullptr},
       D{dptr ? (char *)dptr + off_d * es : nullptr, d->bias ? (size_t)d->n * es : 0, false, nullptr};
+  C.shape(d->m, (size_t)d->n * es, (size_t)d->ldc * es);
   if (kk > 0) {
     A.bytes = ((size_t)(br - 1) * d->stride_a + span(d->m, d->lda, d->k)) * es;
     const size_t bspan = d->vnni_b ? span((d->k + 1) / 2, 2 * d->ldb, 2 * d->n) : span(d->k, d->ldb, d->n);
@@ -535,18 +637,35 @@ static void unary_invoke_common(const char *who, int64_t dtype, int64_t handle, 
   Operand I{nullptr, 0, false, nullptr}, O{(char *)out + off_out * es, 0, true, nullptr};
   if (use_scalar && (d->op == XSMM_UNARY_TRANSPOSE || d->op == XSMM_UNARY_VNNI2))
     die("%s: scalar input is meaningless for op %ld", who, (long)d->op);
-  if (d->op == XSMM_UNARY_TRANSPOSE) O.bytes = span(d->n, d->ldo, d->m) * es;
-  else if (d->op == XSMM_UNARY_VNNI2) O.bytes = span(d->m / 2, 2 * d->ldo, 2 * d->n) * es;
-  else O.bytes = span(d->m, d->ldo, d->n) * es;
+  if (d->op == XSMM_UNARY_TRANSPOSE) {
+    O.bytes = span(d->n, d->ldo, d->m) * es;
+    O.shape(d->n, (size_t)d->m * es, (size_t)d->ldo * es);
+  } else if (d->op == XSMM_UNARY_VNNI2) {
+    O.bytes = span(d->m / 2, 2 * d->ldo, 2 * d->n) * es;
+    O.shape(d->m / 2, (size_t)2 * d->n * es, (size_t)2 * d->ldo * es);
+  } else {
+    O.bytes = span(d->m, d->ldo, d->n) * es;
+    O.shape(d->m, (size_t)d->n * es, (size_t)d->ldo * es);
+  }
   if (!use_scalar && d->op != XSMM_UNARY_ZERO) {
     I.ptr = (char *)in + off_in * es;
     if (d->flags & XSMM_UNARY_FLAG_BCAST_SCALAR) I.bytes = es;
     else if (d->flags & XSMM_UNARY_FLAG_BCAST_ROW) I.bytes = span(d->m, d->ldi, 1) * es;
     else if (d->flags & XSMM_UNARY_FLAG_BCAST_COL) I.bytes = (size_t)d->n * es;
-    else I.bytes = span(d->m, d->ldi, d->n) * es;
+    else {
+      I.bytes = span(d->m, d->ldi, d->n) * es;
+      I.shape(d->m, (size_t)d->n * es, (size_t)d->ldi * es);
+    }
   }
-  flush_tile_queue();
   hipStream_t s = cfg().stream.load(std::memory_order_relaxed);
+  if (cfg().tile_queue.load(std::memory_order_relaxed)) {
+    // small tiles of tensor.pack / unpack lowering and bias broadcasts: queued like the GEMM tiles
+    if (queue_active() && !use_scalar && d->m <= 64 && d->n <= 64) {
+      const Operand *in[1] = {&I};
+      if (enqueue_item(KIND_UNARY, d, WorkItem{I.ptr, nullptr, O.ptr, nullptr, 0}, in, 1, O, true, s)) return;
+    }
+    flush_tile_queue();
+  }
   std::vector<Operand *> ops = {&I, &O};
   std::vector<Mirror> mirrors = stage_in(ops, s);
   HIP_OK(launch_unary(*d, I.dev, scalar, use_scalar, O.dev, s));
@@ -578,8 +697,17 @@ extern "C" void xsmm_binary_invoke(int64_t dtype, int64_t handle, void *lhs, int
   Operand L{(char *)lhs + off_lhs * es, in_bytes(1, 4, 16, d->ldi_lhs), false, nullptr},
       R{(char *)rhs + off_rhs * es, in_bytes(2, 8, 32, d->ldi_rhs), false, nullptr},
       O{(char *)out + off_out * es, span(d->m, d->ldo, d->n) * es, true, nullptr};
-  flush_tile_queue();
+  O.shape(d->m, (size_t)d->n * es, (size_t)d->ldo * es);
+  if (!(d->flags & (1 | 4 | 16))) L.shape(d->m, (size_t)d->n * es, (size_t)d->ldi_lhs * es);
+  if (!(d->flags & (2 | 8 | 32))) R.shape(d->m, (size_t)d->n * es, (size_t)d->ldi_rhs * es);
   hipStream_t s = cfg().stream.load(std::memory_order_relaxed);
+  if (cfg().tile_queue.load(std::memory_order_relaxed)) {
+    if (queue_active() && d->m <= 64 && d->n <= 64) {
+      const Operand *in[2] = {&L, &R};
+      if (enqueue_item(KIND_BINARY, d, WorkItem{L.ptr, R.ptr, O.ptr, nullptr, 0}, in, 2, O, true, s)) return;
+    }
+    flush_tile_queue();
+  }
   std::vector<Operand *> ops = {&L, &R, &O};
   std::vector<Mirror> mirrors = stage_in(ops, s);
   HIP_OK(launch_binary(*d, L.dev, R.dev, O.dev, s));

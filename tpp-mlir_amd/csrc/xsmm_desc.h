@@ -38,8 +38,9 @@ struct AmxDesc {
   int kind;             // KIND_AMX (no-op on this hardware)
 };
 
-// One queued invoke of a GEMM-family handle (tile queue, runtime.cpp): operands with
-// element offsets applied + its batch count. An array of these lives in device memory.
+// One queued invoke (tile queue, runtime.cpp): operands with element offsets applied. GEMM family:
+// A, B, C, D + batch count; unary: A = in, C = out; binary: A = lhs, B = rhs, C = out. The array is
+// host-pinned and read by the grouped kernels directly.
 struct WorkItem {
   const void *A;
   const void *B;
@@ -61,5 +62,8 @@ hipError_t launch_unary(const UnaryDesc &d, const void *in, float scalar, bool u
                         hipStream_t stream);
 hipError_t launch_binary(const BinaryDesc &d, const void *lhs, const void *rhs, void *out,
                          hipStream_t stream);
+// n_items invokes of ONE unary / binary descriptor with m, n <= 64 in one launch
+hipError_t launch_unary_grouped(const UnaryDesc &d, const WorkItem *items, int n_items, hipStream_t stream);
+hipError_t launch_binary_grouped(const BinaryDesc &d, const WorkItem *items, int n_items, hipStream_t stream);
 
 } // namespace tpp
