@@ -221,6 +221,37 @@ def test_brgemm_bf16_vnni_fast(rt, case):
     assert "bf16" in name, name
 
 
+BF16_FORCED = [
+    # (variant, m, n, k, br, kwargs): every bf16 tile family on small outputs (the tile is normally chosen by
+    # output size; forcing it lets the oracle check whole outputs), all epilogues, ring tails 0..8 chunks
+    (18, 256, 256, 64, 1, dict(beta0=True)),
+    (18, 256, 512, 64, 3, dict(bias=True, relu=True, ldc=520, lda=200, offs=(8, 16, 8, 4))),
+    (18, 512, 256, 128, 2, dict(sa=64, sb=128, lda=512, beta0=True, bias=True)),
+    (18, 1024, 512, 64, 5, dict(lda=320, sa=64, ldb=512, sb=64 * 512, beta0=True, relu=True)),  # XCD-blocked grid
+    (18, 256, 256, 64, 0, dict(beta0=True, bias=True)),                                         # empty batch
+    (18, 256, 256, 64, 0, dict()),
+    (18, 256, 256, 192, 1, dict()),                                                             # beta = 1
+    (17, 128, 256, 64, 3, dict(bias=True, relu=True, ldc=264)),
+    (17, 512, 256, 64, 2, dict(beta0=True)),
+    (16, 64, 192, 64, 3, dict(bias=True)),
+    (16, 256, 256, 128, 1, dict(beta0=True, relu=True)),
+]
+
+
+@pytest.mark.parametrize("case", BF16_FORCED, ids=lambda c: "v%d_m%d_n%d_k%d_br%d" % c[:5])
+def test_brgemm_bf16_forced_tile_families(rt, case):
+    v, m, n, k, br, kw = case
+    name = gemm_case(rt, BF16, m, n, k, br, vnni=True, seed=v * 1000 + m + n + br, force=v, **kw)
+    assert {16: "64x64", 17: "128x128", 18: "256x256"}[v] in name, name
+
+
+def test_brgemm_bf16_large_output_uses_256_tiles(rt):
+    """4096 x 4096 x 512: one 256 x 256 tile per CU; row blocks sampled against the oracle"""
+    name = gemm_case(rt, BF16, 4096, 4096, 64, 8, lda=512, ldb=4096, sa=64, sb=64 * 4096, vnni=True, beta0=True,
+                     bias=True, relu=True, seed=77, row_blocks=[(0, 8), (250, 12), (2047, 6), (4090, 6)])
+    assert "256x256" in name, name
+
+
 def test_brgemm_bf16_flat_b_generic(rt):
     gemm_case(rt, BF16, 48, 40, 24, 3, vnni=False, seed=3, bias=True)
 

@@ -45,17 +45,27 @@ def f32_case(m, n, k, br, force=None, beta0=True, tag=""):
         m, n, k, br, rt.kernel_name(h), t * 1e6, fl / t / 1e12, fl / t / 1.573e12, tag), flush=True)
 
 
-def bf16_case(m, n, k, br, tag=""):
+def bf16_case(m, n, k, br, tag="", force=None):
     K = k * br
     A = (torch.rand(m, K, device="cuda") * 2 - 1).to(torch.bfloat16)
     B = (torch.rand(K // 2, n, 2, device="cuda") * 2 - 1).to(torch.bfloat16)
     C = torch.zeros(m, n, device="cuda", dtype=torch.bfloat16)
+    if force is not None:
+        rt.force_variant(force)
     h = rt.brgemm_dispatch(BF16, m, n, k, K, n, n, k, k * n, 4 | 2048)
+    rt.force_variant(-1)
     t = time_it(lambda: rt.brgemm(BF16, h, A, 0, B, 0, C, 0, br))
     fl = 2.0 * m * n * K
     print("bf16 m%-5d n%-5d k%-5d br%-3d %-28s %8.2f us %8.1f TF  %5.1f%% %s" % (
         m, n, k, br, rt.kernel_name(h), t * 1e6, fl / t / 1e12, fl / t / 25e12, tag), flush=True)
 
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "big":
+    for (m, n, k, br) in ((4096, 4096, 64, 64), (8192, 8192, 64, 128), (4096, 8192, 64, 64), (2048, 2048, 128, 16),
+                          (4096, 1024, 64, 16), (16384, 4096, 64, 64)):
+        for v in (17, 18):
+            bf16_case(m, n, k, br, force=v, tag="forced v%d" % v)
+    sys.exit(0)
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "shards":
     # per-rank layer shapes of the row-sharded C4 MLP at 8/4/2/1 GPUs (kernel choice: TPP_HIP_BF16_T128MIN)

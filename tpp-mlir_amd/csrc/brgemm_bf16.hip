@@ -768,12 +768,30 @@ bool bf16_fast_eligible(const GemmDesc &d) {
   return true;
 }
 
-hipError_t launch_gemm_bf16_fast(const GemmDesc &d, const GemmArgs &a, hipStream_t s) {
+hipError_t launch_bf16_dma256(const GemmArgs &a, hipStream_t s); // brgemm_bf16_dma256.hip
+
+// tile choice for an eligible descriptor: 0 = 64x64 register-staged, 1 = 128x128 DMA, 2 = 256x256 DMA.
+//  * 256 x 256 (LDS / L2 traffic per flop halves: measured 1.31-1.37 vs 0.88-1.03 PFLOP/s on 4096^3 ..
+//    8192^3) when its tile waves fill the 256 CUs well enough to keep that 1.4x: tiles run one per CU,
+//    so a grid of t tiles takes ceil(t / 256) rounds;
+//  * 128 x 128 from ~100 tiles (measured: 128 tiles -> the DMA kernel wins, 64 tiles -> 64x64 wins,
+//    profiles/r01_sweep_shapes.txt);  * 64 x 64 below that, so that more CUs have work.
+int pick_bf16_tile(const GemmDesc &d) {
+  static const int64_t t256_min = getenv("TPP_HIP_BF16_T256MIN") ? atoll(getenv("TPP_HIP_BF16_T256MIN")) : 240;
+  static const int64_t t128_min = getenv("TPP_HIP_BF16_T128MIN") ? atoll(getenv("TPP_HIP_BF16_T128MIN")) : 100;
+  const int64_t t256 = (d.m % 256 == 0 && d.n % 256 == 0) ? (d.m / 256) * (d.n / 256) : 0;
   const int64_t t128 = (d.m % 128 == 0 && d.n % 128 == 0) ? (d.m / 128) * (d.n / 128) : 0;
+  auto fill = [](int64_t t) { return (double)t / (double)(((t + 255) / 256) * 256); }; // CU occupancy over the rounds
+  if (t256 >= t256_min && 1.4 * fill(t256) >= fill(t128)) return 2;
+  if (t128 >= t128_min) return 1;
+  return 0;
+}
+
+hipError_t launch_gemm_bf16_fast(int tile, const GemmArgs &a, hipStream_t s) {
   static const int legacy = getenv("TPP_HIP_BF16_LEGACY") ? atoi(getenv("TPP_HIP_BF16_LEGACY")) : 0;
+  if (tile == 2) return launch_bf16_dma256(a, s);
   // TPP_HIP_BF16_LEGACY=2 drops the loader waves (A/B measurement knob)
-  static const int64_t t128_min = getenv("TPP_HIP_BF16_T128MIN") ? atoll(getenv("TPP_HIP_BF16_T128MIN")) : 192;
-  if (t128 >= t128_min) return legacy == 2 ? launch_bf16_dma128<false>(a, s) : launch_bf16_dma128<true>(a, s);
+  if (tile == 1) return legacy == 2 ? launch_bf16_dma128<false>(a, s) : launch_bf16_dma128<true>(a, s);
   return launch_bf16<2, 2, 1, 1>(a, s);
 }
 

@@ -455,7 +455,9 @@ enum GemmVariant : int {
   V_F32_128x64 = 3,  // 8 waves 4x2x1
   V_F32_64x64K2 = 4, // 8 waves 2x2x2 (two waves per SIMD share every K chunk)
   V_GENERIC = 8,     // chosen per invoke when the fast preconditions fail
-  V_BF16_FAST = 16,  // brgemm_bf16.hip
+  V_BF16_FAST = 16,  // brgemm_bf16.hip: 64x64 register-staged
+  V_BF16_DMA128 = 17, // brgemm_bf16.hip: 128x128, LDS-DMA + loader waves
+  V_BF16_DMA256 = 18, // brgemm_bf16_dma256.hip: 256x256, LDS-DMA
 };
 
 template <int WM, int WN, int WK, int NACC>
@@ -485,7 +487,8 @@ static hipError_t launch_fast(const GemmArgs &a, hipStream_t s) {
   return hipGetLastError();
 }
 
-hipError_t launch_gemm_bf16_fast(const GemmDesc &d, const GemmArgs &a, hipStream_t s); // brgemm_bf16.hip
+hipError_t launch_gemm_bf16_fast(int tile, const GemmArgs &a, hipStream_t s); // brgemm_bf16.hip
+int pick_bf16_tile(const GemmDesc &d);
 bool bf16_fast_eligible(const GemmDesc &d);
 
 template <typename T, bool VNNI, bool VEC>
@@ -551,7 +554,9 @@ static const char *variant_name(int v) {
   case V_F32_32x32K4: return "brgemm_f32_fast<32x32,k4>";
   case V_F32_128x64: return "brgemm_f32_fast<128x64,k1>";
   case V_F32_64x64K2: return "brgemm_f32_fast<64x64,k2>";
-  case V_BF16_FAST: return "brgemm_bf16_fast";
+  case V_BF16_FAST: return "brgemm_bf16_fast<64x64>";
+  case V_BF16_DMA128: return "brgemm_bf16_dma<128x128>";
+  case V_BF16_DMA256: return "brgemm_bf16_dma<256x256>";
   default: return "brgemm_grouped(generic)";
   }
 }
@@ -559,7 +564,11 @@ static const char *variant_name(int v) {
 bool plan_gemm(GemmDesc &d, int forced_variant) {
   int v = V_GENERIC;
   if (d.dtype == DT_F32 && !d.vnni_b) v = pick_f32_variant(d);
-  else if (d.dtype == DT_BF16 && bf16_fast_eligible(d)) v = V_BF16_FAST;
+  else if (d.dtype == DT_BF16 && bf16_fast_eligible(d)) {
+    v = V_BF16_FAST + pick_bf16_tile(d);
+    const int tile = forced_variant - V_BF16_FAST; // a forced bf16 tile is honoured if the shape divides it
+    if (tile >= 0 && tile <= 2 && d.m % (64 << tile) == 0 && d.n % (64 << tile) == 0) v = forced_variant;
+  }
   if (forced_variant >= 0 && d.dtype == DT_F32 && v != V_GENERIC) {
     // honour the forced tile only if the shape divides it
     const int bm[] = {64, 64, 32, 128, 64}, bn[] = {64, 32, 32, 64, 64};
@@ -587,14 +596,16 @@ hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C,
   const bool aligned16 = ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0;
   if (v != V_GENERIC && !aligned16) v = V_GENERIC;
   // the bf16 kernel stores 16-byte row pieces and reads the bias 8 bytes at a time
-  if (v == V_BF16_FAST && ((((uintptr_t)C) & 15) || (d.bias && (((uintptr_t)D) & 7)))) v = V_GENERIC;
+  if (v >= V_BF16_FAST && ((((uintptr_t)C) & 15) || (d.bias && (((uintptr_t)D) & 7)))) v = V_GENERIC;
   switch (v) {
   case V_F32_64x64: return launch_fast<2, 2, 1, TPP_NACC>(a, stream);
   case V_F32_64x32K2: return launch_fast<2, 1, 2, TPP_NACC>(a, stream);
   case V_F32_32x32K4: return launch_fast<1, 1, 4, TPP_NACC>(a, stream);
   case V_F32_128x64: return launch_fast<4, 2, 1, TPP_NACC>(a, stream);
   case V_F32_64x64K2: return launch_fast<2, 2, 2, TPP_NACC>(a, stream);
-  case V_BF16_FAST: return launch_gemm_bf16_fast(d, a, stream);
+  case V_BF16_FAST:
+  case V_BF16_DMA128:
+  case V_BF16_DMA256: return launch_gemm_bf16_fast(v - V_BF16_FAST, a, stream);
   default: break;
   }
   // everything else: the grouped kernel with a single, inline work item

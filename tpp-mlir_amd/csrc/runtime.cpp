@@ -281,10 +281,17 @@ struct IntervalSet {
   }
   void insert(Range r) {
     if (r.b >= r.e) return;
-    auto it = iv.lower_bound(r.b);
+    auto it = iv.upper_bound(r.b); // first interval starting after r.b
     if (it != iv.begin()) {
       auto pv = std::prev(it);
-      if (pv->second >= r.b) it = pv;
+      if (pv->second >= r.b) { // r starts inside (or right at the end of) pv
+        if (pv->second >= r.e) return; // already covered: the common case for re-read operands
+        if (it == iv.end() || it->first > r.e) { // grows pv only: consecutive output tiles
+          pv->second = r.e;
+          return;
+        }
+        it = pv;
+      }
     }
     while (it != iv.end() && it->first <= r.e) {
       r.b = std::min(r.b, it->first);
