@@ -60,6 +60,13 @@ def bf16_case(m, n, k, br, tag="", force=None):
         m, n, k, br, rt.kernel_name(h), t * 1e6, fl / t / 1e12, fl / t / 25e12, tag), flush=True)
 
 
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "bf16":
+    bf16_case(4096, 1024, 64, 16, tag="C4 layer")
+    bf16_case(2048, 2048, 128, 16, tag="C5")
+    bf16_case(4096, 2048, 64, 32, tag="512 tiles of 128")
+    bf16_case(4096, 4096, 64, 64, force=17, tag="4096^3 forced 128x128")
+    sys.exit(0)
+
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "big":
     for (m, n, k, br) in ((4096, 4096, 64, 64), (8192, 8192, 64, 128), (4096, 8192, 64, 64), (2048, 2048, 128, 16),
                           (4096, 1024, 64, 16), (16384, 4096, 64, 64)):

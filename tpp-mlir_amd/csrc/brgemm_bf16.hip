@@ -520,50 +520,64 @@ __global__ __launch_bounds__(LW ? 384 : 256) void brgemm_bf16_dma128(GemmArgs p)
   if (LW && TPP_BF16_SETPRIO) __builtin_amdgcn_s_setprio(2);
   f32x16 acc[TM][TN];
   constexpr int NFB = 4; // fragment buffers: step q+2 is read while step q multiplies
-  bf16x8_t af[NFB][TM], bfr[NFB][TN];
+  bf16x8_t af[NFB][TM];
+  u32x4 bw[NFB][TN]; // B fragments as dwords: a fragment is filled by two 2-dword reads
   int b_lane[TN]; // dword index of this lane's column in tile j, row 4*lh of a k-step
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     b_lane[j] = (4 * lh) * BN + (wn * TN + j) * 32 + li;
     asm volatile("" : "+v"(b_lane[j]));
   }
-  auto frag_load = [&](int buf, int slot, int ks) __attribute__((always_inline)) {
+  // one of the 6 LDS reads of a fragment set, in the order the MFMAs need them: A0, B0 (two halves:
+  // one base VGPR per column tile, made opaque, so that rows r, r+1 pair up as ds_read2st64_b32
+  // straight into consecutive registers), B1, A1
+  auto frag_piece = [&](int buf, int slot, int ks, int idx) __attribute__((always_inline)) {
     const unsigned char *as = smem_d + slot * SLOT;
     const unsigned int *bs = (const unsigned int *)(as + A_SLOT);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    if (idx == 0 || idx == 5) {
+      const int i = idx == 0 ? 0 : 1;
       const int row = (wm * TM + i) * 32 + li;
       af[buf][i] = *(const bf16x8_t *)(as + row * 128 + (((2 * ks + lh) ^ ((row >> 1) & 7)) << 4));
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      // one base VGPR per column tile (made opaque) so the 4 row reads pair up as
-      // ds_read2st64_b32 (rows r, r+1) straight into 4 consecutive registers
+    } else {
+      const int j = (idx - 1) >> 1, h = (idx - 1) & 1;
       const unsigned int *bp = bs + b_lane[j] + (8 * ks) * BN;
-      const u32x4 v = {bp[0], bp[BN], bp[2 * BN], bp[3 * BN]};
-      bfr[buf][j] = __builtin_bit_cast(bf16x8_t, v);
+      bw[buf][j][2 * h] = bp[(2 * h) * BN];
+      bw[buf][j][2 * h + 1] = bp[(2 * h + 1) * BN];
     }
   };
+  auto frag_load = [&](int buf, int slot, int ks) __attribute__((always_inline)) {
+#pragma unroll
+    for (int idx = 0; idx < 6; ++idx) frag_piece(buf, slot, ks, idx);
+  };
+#ifndef TPP_BF16_SPREAD_READS
+#define TPP_BF16_SPREAD_READS 0 // A/B measured: no gain at this tile (it is LDS-throughput-bound, not issue-bound); the 256x256 kernel needs it
+#endif
   // one chunk in ring slot S. H1/H2/H3: chunk t+1 / t+2 / t+3 exist. Step q multiplies the
   // fragments in buffer q (4 steps per chunk, 4 buffers) while the fragments of step q+2 are
-  // read (steps 2, 3 read the first two steps of chunk t+1, published by the mid barrier).
-  // The 8 DMA instructions of chunk t+3 ride one per MFMA in steps 2 and 3.
+  // read (steps 2, 3 read the first two steps of chunk t+1, published by the mid barrier), the six
+  // reads spread over the step's four MFMAs (a burst from four waves at once fills the LDS queue and
+  // holds up the MFMA issue behind it). The 8 DMA instructions of chunk t+3 ride one per MFMA in
+  // steps 2 and 3.
   auto chunk = [&](auto slot_c, auto h1, auto h2, auto h3) __attribute__((always_inline)) {
     constexpr int S = decltype(slot_c)::value;
     constexpr bool H1 = decltype(h1)::value, H2 = decltype(h2)::value, H3 = decltype(h3)::value;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       if ((TPP_ABLATE & HABL_STAMP) && S == 0 && H3) step_stamp[q] = __builtin_readcyclecounter();
-      if (!(TPP_ABLATE & HABL_NO_FRAG)) {
-        if (q + 2 < 4) frag_load(q + 2, S, q + 2);
-        else if (H1) frag_load(q - 2, (S + 1) % NSLOT, q - 2);
-      }
+      const bool reads = !(TPP_ABLATE & HABL_NO_FRAG) && (q + 2 < 4 || H1);
+      const int rbuf = q + 2 < 4 ? q + 2 : q - 2, rslot = q + 2 < 4 ? S : (S + 1) % NSLOT, rks = rbuf;
+      if (reads && !TPP_BF16_SPREAD_READS) frag_load(rbuf, rslot, rks);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[q][j], af[q][i], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bw[q][j]), af[q][i], acc[i][j], 0, 0, 0);
+          if (reads && TPP_BF16_SPREAD_READS) {
+            const int m = i * TN + j; // after MFMA 0: A0, B0 lo | 1: B0 hi, B1 lo | 2: B1 hi | 3: A1
+            frag_piece(rbuf, rslot, rks, m == 0 ? 0 : m == 1 ? 2 : m == 2 ? 4 : 5);
+            if (m < 2) frag_piece(rbuf, rslot, rks, m == 0 ? 1 : 3);
+          }
           if (!LW && H3 && q >= 2 && !(TPP_ABLATE & HABL_NO_GLOAD)) {
             dma_piece((S + 3) % NSLOT, (q - 2) * 4 + i * TN + j); // slot of chunk t-1: every wave is past it
             if (q == 3 && i == TM - 1 && j == TN - 1) TPP_DMA_ADVANCE();
@@ -646,7 +660,7 @@ __global__ __launch_bounds__(LW ? 384 : 256) void brgemm_bf16_dma128(GemmArgs p)
 #pragma unroll
     for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(af[0][i]), "v"(af[1][i]), "v"(af[2][i]), "v"(af[3][i]));
 #pragma unroll
-    for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(bfr[0][j]), "v"(bfr[1][j]), "v"(bfr[2][j]), "v"(bfr[3][j]));
+    for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(bw[0][j]), "v"(bw[1][j]), "v"(bw[2][j]), "v"(bw[3][j]));
   }
   // ---- epilogue ------------------------------------------------------------------------
   // lane (li, lh) owns row 32*i + li of wave-tile row block i and, in registers 4g..4g+3 of
