@@ -135,11 +135,12 @@ __global__ __launch_bounds__(256) void brgemm_bf16_dma256(GemmArgs p) {
 #pragma unroll
     for (int idx = 0; idx < 12; ++idx) frag_piece(buf, slot, ks, idx);
   };
-  // One chunk in ring slot `slot`. STEADY: chunks t+1..t+3 exist (everything unconditional); otherwise
-  // the last three chunks: h1 / h2 say whether chunks t+1 / t+2 exist and nothing is fetched any more.
-  // Two instances only (steady loop, tail loop): all 256 accumulator registers are live across every
-  // path, so there is no room for the copies that merging many specialised paths would need.
-  auto chunk = [&](auto steady_c, int slot, bool h1, bool h2) __attribute__((always_inline)) {
+  // One chunk in ring slot `slot`. STEADY: chunks t+1..t+3 exist (everything unconditional, slot a
+  // literal); otherwise one of the last <= 6 chunks: h1 / h2 / h3 say whether chunks t+1 / t+2 / t+3
+  // exist. Two code paths only (the 4-chunk steady body, the run-time tail): all 256 accumulator
+  // registers are live across every path, so there is no room for the copies that merging many
+  // specialised paths would need.
+  auto chunk = [&](auto steady_c, int slot, bool h1, bool h2, bool h3) __attribute__((always_inline)) {
     constexpr bool STEADY = decltype(steady_c)::value;
     // ---- K step 0 (fragments in set 0); set 1 <- K step 1 of this chunk, one read per MFMA
     if (TPP_STAMP256 && STEADY && slot == 0) stamp[6] = __builtin_readcyclecounter();
@@ -159,8 +160,13 @@ __global__ __launch_bounds__(256) void brgemm_bf16_dma256(GemmArgs p) {
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (!(TPP_ABLATE256 & 4)) __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      if (!STEADY) { // tail chunks: a plain burst, the branch per MFMA would cost more
+      if (!STEADY) { // the last chunks: plain bursts, a branch per MFMA would cost more
         frag_load(0, (slot + 1) & (NSLOT - 1), 0);
+        if (h3) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) dma_piece((slot + 3) & (NSLOT - 1), u);
+          TPP_DMA256_ADVANCE();
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -216,8 +222,13 @@ __global__ __launch_bounds__(256) void brgemm_bf16_dma256(GemmArgs p) {
   }
   if (TPP_STAMP256) stamp[1] = __builtin_readcyclecounter();
   int t = 0;
-  for (; t + 3 < T; ++t) chunk(yes{}, t & (NSLOT - 1), true, true);
-  for (; t < T; ++t) chunk(no{}, t & (NSLOT - 1), t + 1 < T, t + 2 < T);
+  for (; t + 6 < T; t += 4) { // steady state: ring slots are compile-time constants (t % 4 == 0 here)
+    chunk(yes{}, 0, true, true, true);
+    chunk(yes{}, 1, true, true, true);
+    chunk(yes{}, 2, true, true, true);
+    chunk(yes{}, 3, true, true, true);
+  }
+  for (; t < T; ++t) chunk(no{}, t & (NSLOT - 1), t + 1 < T, t + 2 < T, t + 3 < T); // <= 6 chunks
   if (TPP_STAMP256) stamp[2] = __builtin_readcyclecounter();
 
   // ---- epilogue ------------------------------------------------------------------------
