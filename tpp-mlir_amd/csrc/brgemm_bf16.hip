@@ -28,7 +28,8 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 #ifndef TPP_ABLATE
 #define TPP_ABLATE 0
 #endif
-constexpr int HABL_NO_GLOAD = 1, HABL_NO_SWRITE = 2, HABL_NO_BARRIER = 4, HABL_NO_FRAG = 8, HABL_NO_TRANSPOSE = 16, HABL_STAMP = 32;
+constexpr int HABL_NO_GLOAD = 1, HABL_NO_SWRITE = 2, HABL_NO_BARRIER = 4, HABL_NO_FRAG = 8, HABL_NO_TRANSPOSE = 16, HABL_STAMP = 32,
+              HABL_NO_BFRAG = 64 /* dma128: no B fragment reads */, HABL_NO_BDMA = 128 /* dma128: the B loader wave fetches nothing */;
 
 constexpr int BKH = 64;     // k per chunk
 constexpr int NSTAGE_H = 3;
@@ -391,11 +392,13 @@ static hipError_t launch_bf16(const GemmArgs &a, hipStream_t s) {
 //          128-byte-per-row stores.
 typedef __attribute__((address_space(3))) void lds_void_t;
 
-// LW = true adds two LOADER waves (wave 4 streams A, wave 5 streams B: 16 DMA instructions per
+// NLW > 0 adds NLW LOADER waves (the first half stream A, the others B: 32 / NLW DMA instructions per
 // chunk each) so the four MFMA waves never stall on vector-memory issue; the per-chunk barrier is
 // shared by all six waves (the loaders wait for their own DMA to land before they arrive).
-template <bool LW>
-__global__ __launch_bounds__(LW ? 384 : 256) void brgemm_bf16_dma128(GemmArgs p) {
+template <int NLW>
+__global__ __launch_bounds__(256 + 64 * NLW) void brgemm_bf16_dma128(GemmArgs p) {
+  constexpr bool LW = NLW > 0;
+  constexpr int PPL = LW ? 32 / NLW : 0; // DMA instructions per loader wave per chunk
   constexpr int BM = 128, BN = 128, NSLOT = 4, TM = 2, TN = 2;
   constexpr int A_SLOT = BM * BKH * 2, B_SLOT = (BKH / 2) * BN * 4, SLOT = A_SLOT + B_SLOT;
   constexpr int DMA_PER_CHUNK = 8; // per wave: 4 x 1 KiB of A + 4 x 1 KiB of B
@@ -475,7 +478,11 @@ __global__ __launch_bounds__(LW ? 384 : 256) void brgemm_bf16_dma128(GemmArgs p)
 
   if (LW && wave >= 4) {
     // ---- loader waves ------------------------------------------------------------------
-    const bool isA = wave == 4;
+    // loader wave lw of NLW: the first NLW/2 stream A, the others B; each takes a contiguous share of
+    // the 16 DMA instructions of its panel (NLW = 4 halves the per-wave issue burst; measured: no gain).
+    const int lw = wave - 4;
+    const bool isA = lw < NLW / 2;
+    const int v0 = (lw % (NLW > 1 ? NLW / 2 : 1)) * PPL; // first instruction of this wave's share
     // A: instruction v covers rows 8v..8v+7; swizzle term ((row>>1)&7) = 4*(v&1) + (lane>>4)
     const unsigned rowoffA = (unsigned)((lane >> 3) * (int)p.lda * 2);
     const unsigned voA0 = rowoffA + (unsigned)((((lane & 7) ^ (lane >> 4))) << 4);
@@ -483,29 +490,29 @@ __global__ __launch_bounds__(LW ? 384 : 256) void brgemm_bf16_dma128(GemmArgs p)
     const unsigned voB = (unsigned)((lane >> 5) * (int)p.ldb * 4 + ((lane & 31) << 4));
     const unsigned stepA = (unsigned)(8 * (int)p.lda * 2), stepB = (unsigned)(2 * (int)p.ldb * 4);
     auto issue = [&](int slot) __attribute__((always_inline)) {
-      unsigned char *base = smem_d + slot * SLOT + (isA ? 0 : A_SLOT);
+      unsigned char *base = smem_d + slot * SLOT + (isA ? 0 : A_SLOT) + v0 * 1024;
       if (isA) {
         const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)gA, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-        for (int v = 0; v < 16; ++v)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_t *)(base + v * 1024), 16, (v & 1) ? voA1 : voA0, v * stepA, 0, 0);
-      } else {
+        for (int v = 0; v < PPL; ++v)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_t *)(base + v * 1024), 16, (v & 1) ? voA1 : voA0, (v0 + v) * stepA, 0, 0);
+      } else if (!(TPP_ABLATE & HABL_NO_BDMA)) {
         const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)gB, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-        for (int v = 0; v < 16; ++v)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_t *)(base + v * 1024), 16, voB, v * stepB, 0, 0);
+        for (int v = 0; v < PPL; ++v)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_t *)(base + v * 1024), 16, voB, (v0 + v) * stepB, 0, 0);
       }
       TPP_DMA_ADVANCE();
     };
     if (T > 0) issue(0);
     if (T > 1) issue(1);
     if (T > 2) issue(2);
-    if (T > 2) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-    else if (T > 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    if (T > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPL) : "memory");
+    else if (T > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPL) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier(); // chunk 0 published
     for (int t = 0; t + 1 < T; ++t) {
-      if (t + 2 < T) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      if (t + 2 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPL) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier(); // = the MFMA waves' mid-chunk barrier of chunk t: chunk t+1 published
       if (t + 3 < T) issue((t + 3) & 3);
@@ -539,6 +546,7 @@ __global__ __launch_bounds__(LW ? 384 : 256) void brgemm_bf16_dma128(GemmArgs p)
       const int row = (wm * TM + i) * 32 + li;
       af[buf][i] = *(const bf16x8_t *)(as + row * 128 + (((2 * ks + lh) ^ ((row >> 1) & 7)) << 4));
     } else {
+      if (TPP_ABLATE & HABL_NO_BFRAG) return;
       const int j = (idx - 1) >> 1, h = (idx - 1) & 1;
       const unsigned int *bp = bs + b_lane[j] + (8 * ks) * BN;
       bw[buf][j][2 * h] = bp[(2 * h) * BN];
@@ -620,6 +628,15 @@ __global__ __launch_bounds__(LW ? 384 : 256) void brgemm_bf16_dma128(GemmArgs p)
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+#ifndef TPP_BF16_ACC_AGPR
+#define TPP_BF16_ACC_AGPR 0
+#endif
+  if (TPP_BF16_ACC_AGPR) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) asm volatile("" : "+a"(acc[i][j]));
+  }
   if (!LW) {
     if (T > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DMA_PER_CHUNK) : "memory");
     else if (T > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_CHUNK) : "memory");
@@ -749,7 +766,7 @@ __global__ __launch_bounds__(LW ? 384 : 256) void brgemm_bf16_dma128(GemmArgs p)
   }
 }
 
-template <bool LW> static hipError_t launch_bf16_dma128(const GemmArgs &a, hipStream_t s) {
+template <int LW> static hipError_t launch_bf16_dma128(const GemmArgs &a, hipStream_t s) {
   constexpr size_t lds = 4 * 32768;
   static bool attr_set = false;
   if (!attr_set) {
@@ -769,7 +786,7 @@ template <bool LW> static hipError_t launch_bf16_dma128(const GemmArgs &a, hipSt
     if (tiles_m > 65535 || tiles_n > 65535) return hipErrorInvalidValue;
     grid = dim3(1, tiles_n, tiles_m);
   }
-  hipLaunchKernelGGL(brgemm_bf16_dma128<LW>, grid, dim3(LW ? 384 : 256), lds, s, args);
+  hipLaunchKernelGGL(brgemm_bf16_dma128<LW>, grid, dim3(256 + 64 * LW), lds, s, args);
   return hipGetLastError();
 }
 
@@ -804,8 +821,10 @@ int pick_bf16_tile(const GemmDesc &d) {
 hipError_t launch_gemm_bf16_fast(int tile, const GemmArgs &a, hipStream_t s) {
   static const int legacy = getenv("TPP_HIP_BF16_LEGACY") ? atoi(getenv("TPP_HIP_BF16_LEGACY")) : 0;
   if (tile == 2) return launch_bf16_dma256(a, s);
-  // TPP_HIP_BF16_LEGACY=2 drops the loader waves (A/B measurement knob)
-  if (tile == 1) return legacy == 2 ? launch_bf16_dma128<false>(a, s) : launch_bf16_dma128<true>(a, s);
+  // TPP_HIP_BF16_LEGACY: A/B measurement knob - 2 = no loader waves, 4 = four loader waves (default two;
+  // measured equal: the loop is not bound by the DMA issue rate of a wave)
+  if (tile == 1)
+    return legacy == 2 ? launch_bf16_dma128<0>(a, s) : legacy == 4 ? launch_bf16_dma128<4>(a, s) : launch_bf16_dma128<2>(a, s);
   return launch_bf16<2, 2, 1, 1>(a, s);
 }
 
