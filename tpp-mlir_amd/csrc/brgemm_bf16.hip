@@ -558,7 +558,7 @@ __global__ __launch_bounds__(256 + 64 * NLW) void brgemm_bf16_dma128(GemmArgs p)
     for (int idx = 0; idx < 6; ++idx) frag_piece(buf, slot, ks, idx);
   };
 #ifndef TPP_BF16_SPREAD_READS
-#define TPP_BF16_SPREAD_READS 0 // A/B measured: no gain at this tile (it is LDS-throughput-bound, not issue-bound); the 256x256 kernel needs it
+#define TPP_BF16_SPREAD_READS 0 // A/B measured: no gain at this tile (not issue-bound: DESIGN.md 4.2); the 256x256 kernel needs it
 #endif
   // one chunk in ring slot S. H1/H2/H3: chunk t+1 / t+2 / t+3 exist. Step q multiplies the
   // fragments in buffer q (4 steps per chunk, 4 buffers) while the fragments of step q+2 are

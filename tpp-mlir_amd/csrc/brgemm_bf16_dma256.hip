@@ -3,14 +3,12 @@
 // v_mfma_f32_32x32x16_bf16 each), operands streamed global -> LDS by buffer_load ... lds (no
 // staging registers).
 //
-// Why this tile: on a CU the LDS moves 128 B/clk and the 128 x 128 kernel (64 x 64 per wave) needs
-// 96 KiB of LDS traffic (32 KiB of DMA fill + 64 KiB of fragment reads) per 512 MFMA cycles - it is
-// LDS-bound at ~2/3 of the matrix-core rate before anything else. A 128 x 128 wave tile reads half the
-// fragment bytes per MFMA ((4+4) fragments per 16 MFMAs instead of (2+2) per 4), and a 256 x 256
-// workgroup tile halves the fill per flop as well: 192 KiB of LDS traffic per 2048 MFMA cycles (75 %
-// of the LDS rate) and 32 B/clk from the L2 (half of the 64 B/clk a CU can pull). Used when the output
-// has at least ~one such tile per CU (launch_gemm_bf16_fast); smaller outputs keep the 128 x 128 tiles
-// so that every CU has work.
+// Why this tile: a CU pulls at most 50-64 B/clk from the L2 into the LDS (TA busy ~650 cycles per 32 KiB),
+// and the 128 x 128 kernel needs 32 KiB of fill per 512 MFMA cycles - the fill path alone bounds it at
+// ~80 % of the matrix-core rate and in practice it runs at ~50 %. A 256 x 256 workgroup
+// tile halves the fill per flop (32 B/clk), and its 128 x 128 wave tiles read half the fragment bytes per
+// MFMA ((4+4) fragments per 16 MFMAs instead of (2+2) per 4). Used when the output has about one such
+// tile per CU (pick_bf16_tile); smaller outputs keep the 128 x 128 tiles so that every CU has work.
 //
 // Pipeline (per workgroup, 256 threads, 1 wave per SIMD so each lane may use 512 registers: 256
 // accumulators + 2 fragment sets of 32):
