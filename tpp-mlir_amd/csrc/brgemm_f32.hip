@@ -25,6 +25,7 @@
 #include "gemm_common.h"
 #include "xsmm_desc.h"
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <type_traits>
 
@@ -44,7 +45,23 @@ constexpr int BK = 64;     // k columns per chunk
 constexpr int NSTAGE = 3;  // LDS ring slots
 constexpr int NSET = 3;    // staging register sets = chunks of global loads in flight per lane
 
-template <int WM, int WN, int WK, int NACC>
+typedef __attribute__((address_space(3))) void lds_void_f;
+
+// One LDS-DMA instruction: 64 lanes x 16 bytes from (panel base, per-lane offset) to 1 KiB of the
+// dynamic LDS at byte offset lds_off. A plain function on purpose: called from the kernel TEMPLATE with
+// template-dependent operands, the builtin made hipcc drop the kernels' host stubs without a diagnostic.
+static __device__ __forceinline__ void lds_dma_16B(const void *panel, unsigned lds_off, unsigned voff) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds_f32[];
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)panel, 0, 0x7fffffff, 0x00020000);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_f *)(dyn_lds_f32 + lds_off), 16, voff, 0, 0, 0);
+}
+
+// DMA = true: panels go HBM -> LDS directly (buffer_load_dwordx4 ... lds, 1 KiB per wave-instruction):
+// no staging registers and no ds_write_b128 (13 LDS cycles each) competing with the fragment reads.
+// Chunk t+2 is fetched during the second half of chunk t into the ring slot chunk t-1 has left; the
+// A swizzle is applied to the source address. Everything else (fragments, barrier placement,
+// epilogue) is shared with the register-staged path.
+template <int WM, int WN, int WK, int NACC, bool DMA>
 __global__ __launch_bounds__(64 * WM * WN * WK) void brgemm_f32_fast(GemmArgs p) {
   constexpr int BM = 32 * WM, BN = 32 * WN, NT = 64 * WM * WN * WK;
   constexpr int A_STAGE = BM * BK, B_STAGE = BK * BN; // floats
@@ -64,7 +81,8 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void brgemm_f32_fast(GemmArgs p)
   unsigned long long step_stamp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long pro_stamp[4] = {0, 0, 0, 0};
   if (TPP_ABLATE & ABL_STAMP) { stamp[0] = __builtin_readcyclecounter(); stamp[4] = wall_clock64(); }
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wk = wave / (WM * WN), wmn = wave % (WM * WN), wm = wmn / WN, wn = wmn % WN;
   const int li = lane & 31, lh = lane >> 5;
   // Output tile from the 3-D grid, no divisions (launch_fast picks the shape): XCD-blocked
@@ -91,11 +109,22 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void brgemm_f32_fast(GemmArgs p)
   // burst. Loads are buffer loads: wave-uniform 64-bit panel base in the descriptor
   // (advanced by scalar adds once per chunk), per-lane byte offset constant for the
   // whole kernel -> one instruction per 16 bytes, no per-load vector address math.
-  f32x4 rs[NSET][NP];
+  f32x4 rs[DMA ? 1 : NSET][NP];
   unsigned voff[NP];
 #pragma unroll
   for (int u = 0; u < NP; ++u) {
-    if (u < LA) {
+    if (DMA) {
+      // DMA instruction v of this panel fills 1 KiB of the LDS image linearly: lane -> (row, piece)
+      // of the image; the source piece of A is XOR-ed with (row & 15) (the read applies it again)
+      if (u < LA) {
+        const int v = wave * LA + u, row = 4 * v + (lane >> 4), c = lane & 15;
+        voff[u] = (unsigned)((row * (int)p.lda + 4 * (c ^ (row & 15))) * 4);
+      } else {
+        constexpr int RPI = 256 / BN; // B rows per instruction
+        const int v = wave * LB + (u - LA), krow = RPI * v + lane / (BN / 4), c = lane % (BN / 4);
+        voff[u] = (unsigned)((krow * (int)p.ldb + 4 * c) * 4);
+      }
+    } else if (u < LA) {
       const int q = tid + u * NT, row = q >> 4, c = q & 15;
       voff[u] = (unsigned)((row * (int)p.lda + 4 * c) * 4);
     } else {
@@ -124,6 +153,10 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void brgemm_f32_fast(GemmArgs p)
         __builtin_amdgcn_make_buffer_rsrc((void *)(u < LA ? gA : gB), 0, 0x7fffffff, 0x00020000);
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff[u], 0, 0);
     rs[set][u] = __builtin_bit_cast(f32x4, v);
+  };
+  auto dma_piece = [&](int stage, int u) __attribute__((always_inline)) {
+    if (u < LA) lds_dma_16B(gA, (unsigned)((stage * A_STAGE + (wave * LA + u) * 256) * 4), voff[u]);
+    else lds_dma_16B(gB, (unsigned)((NSTAGE * A_STAGE + stage * B_STAGE + (wave * LB + (u - LA)) * 256) * 4), voff[u]);
   };
   auto swrite_piece = [&](int stage, int u) __attribute__((always_inline)) {
     float *as = As + stage * A_STAGE, *bs = Bs + stage * B_STAGE;
@@ -174,7 +207,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void brgemm_f32_fast(GemmArgs p)
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         acc[s % NACC] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][s], fb[cur][s], acc[s % NACC], 0, 0, 0);
-        if (HAS_LOAD && !(TPP_ABLATE & ABL_NO_GLOAD) && q == 0 && s == 0) {
+        if (!DMA && HAS_LOAD && !(TPP_ABLATE & ABL_NO_GLOAD) && q == 0 && s == 0) {
           // panel base of the next chunk to load: scalar work in the shadow of the MFMA above
           if (++kc == kchunks) {
             kc = 0;
@@ -187,13 +220,30 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void brgemm_f32_fast(GemmArgs p)
         }
 #pragma unroll
         for (int u = 0; u < NP; ++u) {
-          if (HAS_NEXT && !(TPP_ABLATE & ABL_NO_SWRITE) && (u * WSLOTS) / NP == q * 4 + s) swrite_piece(NSTG, u);
-          if (HAS_LOAD && !(TPP_ABLATE & ABL_NO_GLOAD) && (u * 4 * (KB_PER_WAVE - KB_HALF)) / NP == (q - KB_HALF) * 4 + s)
-            gload_piece(NSTG, u);
+          if (!DMA && HAS_NEXT && !(TPP_ABLATE & ABL_NO_SWRITE) && (u * WSLOTS) / NP == q * 4 + s) swrite_piece(NSTG, u);
+          if (HAS_LOAD && !(TPP_ABLATE & ABL_NO_GLOAD) && (u * 4 * (KB_PER_WAVE - KB_HALF)) / NP == (q - KB_HALF) * 4 + s) {
+            if (DMA) dma_piece((STAGE + 2) % NSTAGE, u); // chunk t+2 into the slot chunk t-1 has left (after the barrier)
+            else gload_piece(NSTG, u);
+          }
+        }
+        if (DMA && HAS_LOAD && !(TPP_ABLATE & ABL_NO_GLOAD) && q == KB_PER_WAVE - 1 && s == 3) {
+          if (++kc == kchunks) { // panel base of the chunk after the one just requested
+            kc = 0;
+            gA += dA_wrap;
+            gB += dB_wrap;
+          } else {
+            gA += BK;
+            gB += dB_in;
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (q == KB_HALF - 1 && !(TPP_ABLATE & ABL_NO_BARRIER)) __syncthreads();
+      if (q == KB_HALF - 1 && !(TPP_ABLATE & ABL_NO_BARRIER)) {
+        // DMA: this wave's pieces of chunk t+1 have landed in the LDS (the fence of __syncthreads
+        // does not wait for LDS-DMA), then everybody's
+        if (DMA && HAS_NEXT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
     }
     if ((TPP_ABLATE & ABL_STAMP) && STAGE == 0 && HAS_LOAD) step_stamp[8] = __builtin_readcyclecounter();
   };
@@ -208,7 +258,16 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void brgemm_f32_fast(GemmArgs p)
   if (T > 0) { // first thing the kernel does: get chunk 0 moving
     if (TPP_ABLATE & ABL_STAMP) pro_stamp[0] = __builtin_readcyclecounter();
 #pragma unroll
-    for (int u = 0; u < NP; ++u) gload_piece(0, u);
+    for (int u = 0; u < NP; ++u) {
+      if (DMA) dma_piece(0, u);
+      else gload_piece(0, u);
+    }
+    if (DMA && T > 1) { // chunk 1 right behind it; afterwards the panel base points at chunk 2
+      gadvance();
+#pragma unroll
+      for (int u = 0; u < NP; ++u) dma_piece(1, u);
+      gadvance();
+    }
   }
   __builtin_amdgcn_sched_barrier(0);
   // accumulators: wk == 0 starts from C (beta = 1) so the chain is C + sum, as in
@@ -232,7 +291,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void brgemm_f32_fast(GemmArgs p)
           float, __builtin_amdgcn_raw_buffer_load_b32(rsrcC, voffC, (unsigned)((r & 3) + 8 * (r >> 2)) * ldcb, 0));
   }
 
-  if (T > 0) {
+  if (!DMA && T > 0) {
 #pragma unroll
     for (int c = 1; c <= NSET; ++c) {
       if (c == NSET) { // set 0 is reused for chunk NSET: chunk 0 must be in LDS first
@@ -248,19 +307,21 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void brgemm_f32_fast(GemmArgs p)
       }
     }
   }
+  if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (TPP_ABLATE & ABL_STAMP) pro_stamp[3] = __builtin_readcyclecounter();
   if (T > 0) frag_load(0, 0, kbw);
   if (TPP_ABLATE & ABL_STAMP) stamp[1] = __builtin_readcyclecounter();
   int t = 0;
-  for (; t + 2 + NSET + 1 < T; t += 3) { // steady state: three chunks per trip, ring slots 0, 1, 2
+  constexpr int AHEAD = DMA ? 2 : NSET + 1; // chunk t + AHEAD is the one fetched during chunk t
+  for (; t + 2 + AHEAD < T; t += 3) { // steady state: three chunks per trip, ring slots 0, 1, 2
     chunk(S0{}, yes{}, yes{});
     chunk(S1{}, yes{}, yes{});
     chunk(S2{}, yes{}, yes{});
   }
   auto tail = [&](auto stage_c) __attribute__((always_inline)) { // last chunks: same bodies minus what no longer exists
     const int left = T - t;
-    if (left > NSET + 1) chunk(stage_c, yes{}, yes{});
+    if (left > AHEAD) chunk(stage_c, yes{}, yes{});
     else if (left >= 2) chunk(stage_c, yes{}, no{});
     else chunk(stage_c, no{}, no{});
     ++t;
@@ -275,7 +336,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void brgemm_f32_fast(GemmArgs p)
   if (TPP_ABLATE & ABL_STAMP) stamp[2] = __builtin_readcyclecounter();
   if (TPP_ABLATE & (ABL_NO_SWRITE | ABL_NO_FRAG)) { // keep ablated producers alive
 #pragma unroll
-    for (int u = 0; u < LA + LB; ++u) asm volatile("" ::"v"(rs[0][u]), "v"(rs[1][u]), "v"(rs[2][u]));
+    for (int u = 0; u < LA + LB; ++u) asm volatile("" ::"v"(rs[0][u]), "v"(rs[DMA ? 0 : 1][u]), "v"(rs[DMA ? 0 : 2][u]));
     asm volatile("" ::"v"(fa[0]), "v"(fa[1]));
   }
 #pragma unroll
@@ -460,14 +521,17 @@ enum GemmVariant : int {
   V_BF16_DMA256 = 18, // brgemm_bf16_dma256.hip: 256x256, LDS-DMA
 };
 
-template <int WM, int WN, int WK, int NACC>
-static hipError_t launch_fast(const GemmArgs &a, hipStream_t s) {
+#ifndef TPP_F32_DMA
+#define TPP_F32_DMA 1 // 1: LDS-DMA panels (default), 0: register-staged panels
+#endif
+template <int WM, int WN, int WK, int NACC, bool DMA>
+static hipError_t launch_fast_t(const GemmArgs &a, hipStream_t s) {
   constexpr int BM = 32 * WM, BN = 32 * WN, NT = 64 * WM * WN * WK;
   constexpr size_t lds = (size_t)NSTAGE * (BM * BK + BK * BN) * sizeof(float);
   static bool attr_set = false;
-  auto kern = brgemm_f32_fast<WM, WN, WK, NACC>;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void *)brgemm_f32_fast<WM, WN, WK, NACC, DMA>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
@@ -483,8 +547,14 @@ static hipError_t launch_fast(const GemmArgs &a, hipStream_t s) {
     if (tiles_m > 65535 || tiles_n > 65535) return hipErrorInvalidValue;
     grid = dim3(1, tiles_n, tiles_m);
   }
-  hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, args);
+  hipLaunchKernelGGL((brgemm_f32_fast<WM, WN, WK, NACC, DMA>), grid, dim3(NT), lds, s, args);
   return hipGetLastError();
+}
+
+template <int WM, int WN, int WK, int NACC>
+static hipError_t launch_fast(const GemmArgs &a, hipStream_t s) {
+  static const bool use_dma = getenv("TPP_HIP_F32_DMA") ? atoi(getenv("TPP_HIP_F32_DMA")) != 0 : TPP_F32_DMA != 0;
+  return use_dma ? launch_fast_t<WM, WN, WK, NACC, true>(a, s) : launch_fast_t<WM, WN, WK, NACC, false>(a, s);
 }
 
 hipError_t launch_gemm_bf16_fast(int tile, const GemmArgs &a, hipStream_t s); // brgemm_bf16.hip
