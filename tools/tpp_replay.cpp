@@ -38,7 +38,7 @@ static std::vector<int64_t> parse_list(const char *s) {
 int main(int argc, char **argv) {
   int64_t batch = 256, tile = 32, n_iter = 100;
   std::vector<int64_t> layers = {1024, 1024, 1024, 1024};
-  bool bias = false, relu = false, whole = false, print = false, c1 = false;
+  bool bias = false, relu = false, whole = false, print = false, c1 = false, rnd = false;
   int queue = 1;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
@@ -53,6 +53,7 @@ int main(int argc, char **argv) {
     else if (a == "--whole-layer") whole = true;
     else if (a == "--print") print = true;
     else if (a == "--c1") c1 = true;
+    else if (a == "--random") rnd = true; // uniform [-1, 1) * fill instead of constant fills (switching power)
     else { fprintf(stderr, "unknown flag %s\n", a.c_str()); return 2; }
   }
   if (xsmm_hip_device_count() < 1) { fprintf(stderr, "tpp_replay: no HIP device (there is no CPU fallback)\n"); return 1; }
@@ -110,9 +111,11 @@ int main(int argc, char **argv) {
 
   // buffers: activations [l] (batch x layers[l]), weights, biases; const 1.0 / 0.01 fills
   std::vector<float *> act(L + 1), W(L), B(L);
-  auto dalloc = [](size_t n, float v) {
+  auto dalloc = [&](size_t n, float v) {
     float *d; CHECK(hipMalloc((void **)&d, n * sizeof(float)));
-    std::vector<float> h(n, v); CHECK(hipMemcpy(d, h.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    std::vector<float> h(n, v);
+    if (rnd) for (auto &x : h) x = v * (float)(2.0 * rand() / (double)RAND_MAX - 1.0);
+    CHECK(hipMemcpy(d, h.data(), n * sizeof(float), hipMemcpyHostToDevice));
     return d;
   };
   for (int l = 0; l <= L; ++l) act[l] = dalloc((size_t)batch * layers[l], 1.0f);

@@ -521,9 +521,6 @@ enum GemmVariant : int {
   V_BF16_DMA256 = 18, // brgemm_bf16_dma256.hip: 256x256, LDS-DMA
 };
 
-#ifndef TPP_F32_DMA
-#define TPP_F32_DMA 1 // 1: LDS-DMA panels (default), 0: register-staged panels
-#endif
 template <int WM, int WN, int WK, int NACC, bool DMA>
 static hipError_t launch_fast_t(const GemmArgs &a, hipStream_t s) {
   constexpr int BM = 32 * WM, BN = 32 * WN, NT = 64 * WM * WN * WK;
@@ -551,9 +548,10 @@ static hipError_t launch_fast_t(const GemmArgs &a, hipStream_t s) {
   return hipGetLastError();
 }
 
-template <int WM, int WN, int WK, int NACC>
+// DMA_DEFAULT: which panel path the tile uses unless TPP_HIP_F32_DMA=0|1 overrides it (A/B measurements)
+template <int WM, int WN, int WK, int NACC, bool DMA_DEFAULT>
 static hipError_t launch_fast(const GemmArgs &a, hipStream_t s) {
-  static const bool use_dma = getenv("TPP_HIP_F32_DMA") ? atoi(getenv("TPP_HIP_F32_DMA")) != 0 : TPP_F32_DMA != 0;
+  static const bool use_dma = getenv("TPP_HIP_F32_DMA") ? atoi(getenv("TPP_HIP_F32_DMA")) != 0 : DMA_DEFAULT;
   return use_dma ? launch_fast_t<WM, WN, WK, NACC, true>(a, s) : launch_fast_t<WM, WN, WK, NACC, false>(a, s);
 }
 
@@ -668,11 +666,16 @@ hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C,
   // the bf16 kernel stores 16-byte row pieces and reads the bias 8 bytes at a time
   if (v >= V_BF16_FAST && ((((uintptr_t)C) & 15) || (d.bias && (((uintptr_t)D) & 7)))) v = V_GENERIC;
   switch (v) {
-  case V_F32_64x64: return launch_fast<2, 2, 1, TPP_NACC>(a, stream);
-  case V_F32_64x32K2: return launch_fast<2, 1, 2, TPP_NACC>(a, stream);
-  case V_F32_32x32K4: return launch_fast<1, 1, 4, TPP_NACC>(a, stream);
-  case V_F32_128x64: return launch_fast<4, 2, 1, TPP_NACC>(a, stream);
-  case V_F32_64x64K2: return launch_fast<2, 2, 2, TPP_NACC>(a, stream);
+  // LDS-DMA panels for every tile but the smallest: measured C2 +3 %, C3 +8 %, 4096^3 +3 %, 3 x 1024 MLP
+  // at batch 512 / 1024 +5 % / +3 % over register staging. 32x32 tiles with 4 K-split waves have
+  // 512-cycle chunks and short kernels: in a chain of dependent layers (3 x 1024 MLP, batch 256) the DMA
+  // path's 2-chunk lead and slower prologue (an LDS-DMA instruction takes ~60 cycles to issue) cost more
+  // than the ds_write path saves (32.4 vs 29.2 us); deeper rings (5-6 slots) made the prologue worse.
+  case V_F32_64x64: return launch_fast<2, 2, 1, TPP_NACC, true>(a, stream);
+  case V_F32_64x32K2: return launch_fast<2, 1, 2, TPP_NACC, true>(a, stream);
+  case V_F32_32x32K4: return launch_fast<1, 1, 4, TPP_NACC, false>(a, stream);
+  case V_F32_128x64: return launch_fast<4, 2, 1, TPP_NACC, true>(a, stream);
+  case V_F32_64x64K2: return launch_fast<2, 2, 2, TPP_NACC, true>(a, stream);
   case V_BF16_FAST:
   case V_BF16_DMA128:
   case V_BF16_DMA256: return launch_gemm_bf16_fast(v - V_BF16_FAST, a, stream);
