@@ -303,6 +303,22 @@ def main():
                        "value": round(2.0 * M5 ** 3 * Ko / wg / 1e9, 1), "unit": "GFLOP/s", "us_per_step": round(wg / Ko * 1e6, 2),
                        "frac_of_bf16_mfma_peak": round(2.0 * M5 ** 3 * Ko / wg / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)})
 
+        # a large bf16 output (one 256x256 tile per CU): the shape class the 256-tile kernel exists for
+        ML = 4096
+        AL = (torch.rand(ML, ML, device="cuda") - 0.5).to(torch.bfloat16)
+        BL = (torch.rand(ML // 2, ML, 2, device="cuda") - 0.5).to(torch.bfloat16)
+        CL = torch.empty(ML, ML, device="cuda", dtype=torch.bfloat16)
+        hl = rt.brgemm_dispatch(BF16, ML, ML, 64, ML, ML, ML, 64, 64 * ML, 4 | 2048)
+
+        def big_gemm():
+            rt.brgemm(BF16, hl, AL, 0, BL, 0, CL, 0, ML // 64)
+        warm(big_gemm, 30, sync)
+        wl, _ = timed(big_gemm, 100, sync, barrier)
+        others.append({"workload": "bf16 BRGEMM 4096^3 VNNI_B (k=64, br=64), uniform random operands", "kernel": rt.kernel_name(hl),
+                       "value": round(2.0 * ML ** 3 * 100 / wl / 1e9, 1), "unit": "GFLOP/s", "us_per_step": round(wl / 100 * 1e6, 2),
+                       "frac_of_bf16_mfma_peak": round(2.0 * ML ** 3 * 100 / wl / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)})
+        del AL, BL, CL
+
         # the boundary as JIT'd host code sees it: HOST pointers, synchronous invoke (mirror H2D, kernel,
         # D2H per call) - the PCIe-inclusive rate of the C2 BRGEMM; never the headline value
         rt.set_async(False)

@@ -22,4 +22,9 @@ for (k, c), v in sorted(acc.items()):
     print("%s pass: %-70s %-12s dispatches %5d  mean %14.1f  min %14.1f  max %14.1f" % (sys.argv[2], k[:70], c, len(v), sum(v) / len(v), min(v), max(v)))
 PY
 done
+python tools/sweep.py 2>/dev/null | grep -E "^(f32|bf16)" > $OUT/sweep.txt
+python tools/sweep.py big 2>/dev/null | grep -E "^(f32|bf16)" >> $OUT/sweep.txt
+for t in 1 100000; do TPP_HIP_BF16_T128MIN=$t python tools/sweep.py shards 2>/dev/null | grep -E "^bf16" >> $OUT/sweep.txt; done
+bash tools/gpu_queue.sh $TAG/queue > /dev/null 2>&1
+python tools/eltwise_bw.py > $OUT/eltwise_bw.txt 2>/dev/null
 tail -3 $OUT/pytest_gpu.log; tail -1 $OUT/smoke.log; cat $OUT/bench.json; cat $OUT/rocprof_kernel_stats.csv | head -8; cat $OUT/rocprof_pmc_summary.txt
