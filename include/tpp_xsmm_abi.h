@@ -139,11 +139,13 @@ TPP_XSMM_EXPORT double perf_stop_timer(int64_t start);
  * xsmm_hip_synchronize() or perf_stop_timer() to drain. Returns previous mode.
  * Also settable with env TPP_HIP_ASYNC=1. */
 TPP_XSMM_EXPORT int xsmm_hip_set_async(int enable);
-/* Tile queue (async mode only, device pointers only): invokes of one small-tile GEMM handle
- * (m, n <= 64: the compiler's native 32x32x32 call pattern) are collected and run as ONE
- * grouped launch at the next flush point (other handle / other op / data dependence on a
- * queued output / xsmm_hip_flush / xsmm_hip_synchronize / perf_stop_timer). Program order is
- * preserved. Returns the previous setting. Also env TPP_HIP_TILE_QUEUE=1. */
+/* Tile queue (async mode only, device pointers only): invokes of ONE small-tile handle - GEMM
+ * family, unary or binary, m, n <= 64: the compiler's native 32x32x32 call pattern and its per-block
+ * pack / unpack tiles - are collected and run as ONE grouped launch at the next flush point (other
+ * handle / other op / data dependence on a queued output or overwrite of a queued input /
+ * xsmm_hip_flush / xsmm_hip_synchronize / perf_stop_timer). Program order is preserved. Operands
+ * of queued invokes must stay valid until the flush. Returns the previous setting. Also env
+ * TPP_HIP_TILE_QUEUE=1. */
 TPP_XSMM_EXPORT int xsmm_hip_set_tile_queue(int enable);
 TPP_XSMM_EXPORT void xsmm_hip_flush(void);
 /* Stream the kernels are launched on (a hipStream_t). NULL = default stream. */
@@ -154,7 +156,9 @@ TPP_XSMM_EXPORT void xsmm_hip_synchronize(void);
 TPP_XSMM_EXPORT int xsmm_hip_device_count(void);
 /* Name of the HIP kernel variant a GEMM-like handle selected, for profiles. */
 TPP_XSMM_EXPORT const char *xsmm_hip_kernel_name(int64_t handle);
-/* Force a GEMM tile variant for A/B benchmarking (-1 = automatic). */
+/* Force a GEMM tile variant for A/B benchmarking and tests (-1 = automatic): f32 0..4 (64x64,
+ * 64x32+K2, 32x32+K4, 128x64, 64x64+K2), 8 generic, bf16 16 / 17 / 18 (64x64, 128x128, 256x256).
+ * Honoured at dispatch when the shape divides the tile. */
 TPP_XSMM_EXPORT void xsmm_hip_force_variant(int variant);
 /* Library version string. */
 TPP_XSMM_EXPORT const char *xsmm_hip_version(void);
