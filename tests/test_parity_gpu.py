@@ -436,6 +436,73 @@ def test_binary_out_aliases_input(rt):
     assert np.array_equal(Xh, X * X)
 
 
+@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("queue", [False, True])
+@pytest.mark.parametrize("chunk", range(3))
+def test_eltwise_random_dispatches(rt, dt, queue, chunk):
+    """seeded random sweep over unary / binary dispatch tuples (kinds, broadcast flags, leading dimensions,
+    element offsets that break / keep 16-byte alignment, tile-sized and large shapes), bit-exact against
+    the oracle; run once with direct launches and once through the tile queue (async mode)"""
+    rng = np.random.default_rng(7000 + 100 * dt + chunk)
+    prev_async = rt.set_async(queue)
+    prev_queue = rt.set_tile_queue(queue)
+    keep = []
+    try:
+        for i in range(40):
+            small = rng.random() < 0.6
+            m = int(rng.integers(1, 65)) if small else int(rng.integers(65, 300))
+            n = int(rng.integers(1, 65)) if small else int(rng.integers(65, 400))
+            if rng.random() < 0.4:
+                m, n = (m + 7) // 8 * 8, (n + 7) // 8 * 8
+            q = 8 if rng.random() < 0.5 else 1
+            off = [q * int(rng.integers(0, 4)) for _ in range(3)]
+            if rng.random() < 0.55:  # unary
+                kind = int(rng.choice([1, 2, 5, 29, 28] if dt == BF16 else [1, 2, 5, 29]))
+                flags = int(rng.choice([0, 2, 4, 8])) if kind in (1, 5) else 0
+                if kind == 28:
+                    m += m & 1
+                ldi = {0: n + q * int(rng.integers(0, 3)), 2: 1, 4: n, 8: 1}[flags]
+                ldo = (m if kind == 29 else n) + q * int(rng.integers(0, 3))
+                X = rand(rng, off[0] + m * max(ldi, 1) + n + 8, dt)
+                rows_out = n if kind == 29 else m
+                O = rand(rng, off[2] + rows_out * ldo + n + m + 8, dt)
+                ref = O.copy()
+                orc.unary(kind, dt, m, n, ldi, ldo, flags, X, off[0], ref, off[2])
+                h = rt.unary_dispatch(kind, dt, m, n, ldi, ldo, flags)
+                dX, dO = dev(X), dev(O)
+                rt.unary(dt, h, dX, off[0], dO, off[2])
+                keep.append((dO, O, ref, "unary kind %d flags %d m%d n%d ldi%d ldo%d off%s" % (kind, flags, m, n, ldi, ldo, off), True, dX))
+            else:
+                kind = int(rng.integers(1, 5))
+                f0, f1 = int(rng.choice([0, 1, 4, 16])), int(rng.choice([0, 2, 8, 32]))
+                flags = f0 | f1
+                ldl = 1 if f0 in (1, 16) else (n if f0 == 4 else n + q * int(rng.integers(0, 3)))
+                ldr = 1 if f1 in (2, 32) else (n if f1 == 8 else n + q * int(rng.integers(0, 3)))
+                ldo = n + q * int(rng.integers(0, 3))
+                L = rand(rng, off[0] + m * max(ldl, n) + 8, dt, 0.5, 2.0)
+                R = rand(rng, off[1] + m * max(ldr, n) + 8, dt, 0.5, 2.0)
+                O = rand(rng, off[2] + m * ldo + 8, dt)
+                ref = O.copy()
+                orc.binary(kind, dt, m, n, ldl, ldr, ldo, flags, L, off[0], R, off[1], ref, off[2])
+                h = rt.binary_dispatch(kind, dt, m, n, ldl, ldr, ldo, flags)
+                dL, dR, dO = dev(L), dev(R), dev(O)
+                rt.binary(dt, h, dL, off[0], dR, off[1], dO, off[2])
+                keep.append((dO, O, ref, "binary kind %d flags %d m%d n%d ldl%d ldr%d ldo%d off%s" % (kind, flags, m, n, ldl, ldr, ldo, off),
+                             kind != 4, dL, dR))
+        rt.synchronize()
+        for entry in keep:
+            dO, O, ref, what, exact = entry[:5]
+            got = host(dO, O)
+            if exact:
+                assert got.tobytes() == ref.tobytes(), what + (" (queued)" if queue else "")
+            else:
+                check_close(got, ref, dt, what)
+    finally:
+        rt.synchronize()
+        rt.set_tile_queue(prev_queue)
+        rt.set_async(prev_async)
+
+
 # ---------------------------------------------------------------- BASELINE configs, properties
 def test_c2_full_size_and_properties(rt):
     """BASELINE config 2: C[1024x1024] += sum_{b<16} A_b[1024x64] B_b[64x1024], f32, with
