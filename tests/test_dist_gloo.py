@@ -82,6 +82,27 @@ def run_rank(rank, world, port, batch, dtype, out_q):
         dist.destroy_process_group()
 
 
+def run_rank_columns(rank, world, port, batch, dtype, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        spec = pkg.MlpSpec(batch=batch, layers=[128, 256, 128, 256], dtype=dtype)
+        X, Ws, Bs = make_problem(spec)
+        cs = pkg.ColumnShardedMlp(spec, rank, world, OracleRuntime())
+        locals_ = [torch.zeros(batch, n // world, dtype=X.dtype) for n in spec.layers[1:]]
+        gathered = [torch.zeros(world, batch, n // world, dtype=X.dtype) for n in spec.layers[1:]]
+        out = cs.forward(X, Ws, Bs, locals_, gathered, lambda dst, src: dist.all_gather_into_tensor(dst.view(-1, dst.shape[-1]), src))
+        full = pkg.gathered_to_rows(out).contiguous()
+        one = pkg.ShardedMlp(spec, 0, 1, OracleRuntime())
+        acts1 = [torch.zeros(spec.batch, n, dtype=X.dtype) for n in spec.layers[1:]]
+        ref = one.forward(X, Ws, Bs, acts1)
+        ok = torch.equal(full.view(torch.int16) if dtype == 2 else full, ref.view(torch.int16) if dtype == 2 else ref)
+        out_q.put((rank, bool(ok), len(cs.handles), cs.handles[1][1]))
+    finally:
+        dist.destroy_process_group()
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -107,3 +128,23 @@ def test_row_sharded_mlp_with_all_gather_world2(batch, dtype):
     assert all(ok for (_, ok, _, _) in res), res
     rows = sorted((r0, n) for (_, _, r0, n) in res)
     assert rows[0][0] == 0 and rows[0][0] + rows[0][1] == rows[1][0] and rows[1][0] + rows[1][1] == batch
+
+
+@pytest.mark.parametrize("batch,dtype", [(96, 1), (64, 2)])
+def test_column_sharded_mlp_gather_per_layer_world2(batch, dtype):
+    """the per-layer all-gather variant: rank-major gathered activations are consumed by the next layer
+    as a batch-reduce over the rank blocks (br = world); result identical to the unsharded MLP"""
+    orc.lib()
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=run_rank_columns, args=(r, world, port, batch, dtype, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for (_, ok, _, _) in res), res
+    assert all(nl == 3 and br == world for (_, _, nl, br) in res)

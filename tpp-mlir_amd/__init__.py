@@ -8,5 +8,6 @@ it with importlib.import_module("tpp-mlir_amd").
 """
 from .runtime import (BinaryFlags, BinaryKind, DataType, GemmFlags, REFERENCE_SYMBOLS, UnaryFlags,  # noqa: F401
                       UnaryKind, XsmmRuntime, get_runtime, library_path, load_library)
-from .mlp import MlpSpec, ShardedMlp, all_gather_rows, layer_dispatch_args, row_partition  # noqa: F401
+from .mlp import (ColumnShardedMlp, MlpSpec, ShardedMlp, all_gather_rows, gathered_to_rows,  # noqa: F401
+                  layer_dispatch_args, row_partition)
 from .build import build, build_tools  # noqa: F401

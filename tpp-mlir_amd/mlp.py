@@ -95,6 +95,60 @@ class ShardedMlp:
         return cur
 
 
+class ColumnShardedMlp:
+    """The other single-node sharding of the same tile grid ("all-gather of
+    the output of a layer"): rank r computes the COLUMN block [n0, n0 + N/W) of every layer for the
+    whole batch - it reads only its 1/W of each weight matrix - and the activations are all-gathered
+    after EACH layer. The gathered activations keep the collective's natural layout
+    G[W][batch][N/W] (rank-major, exactly what all_gather_into_tensor produces, no re-layout
+    kernel): the next layer consumes it directly, because the rank dimension is a batch-reduce
+    dimension - ONE brgemm dispatch with k = N/W per batch element, lda = N/W,
+    stride_a = batch * N/W, stride_b = (N/W) * N_next, br = W sums over the W column blocks.
+    Per step: L collectives of batch * N / W elements per rank, against one for the row sharding."""
+
+    def __init__(self, spec, rank=0, world=1, rt=None):
+        self.spec, self.rank, self.world, self.rt = spec, rank, world, rt
+        for n in spec.layers[1:]:
+            if n % world or (spec.vnni and (n // world) % 2):
+                raise ValueError("layer width %d cannot be split into %d column blocks" % (n, world))
+        self.handles = []
+        gemm_flags = GemmFlags.BETA_0 | (GemmFlags.VNNI_B if spec.vnni else 0)
+        for l, (k, n) in enumerate(zip(spec.layers[:-1], spec.layers[1:])):
+            nw = n // world
+            if l == 0:  # the input is row-major [batch][k] on every rank: k chunks of 64 as usual
+                assert k % K_CHUNK == 0
+                kk, lda, sa, sb, br = K_CHUNK, k, K_CHUNK, K_CHUNK * n, k // K_CHUNK
+            else:       # gathered layout [W][batch][k/W]: one batch element per rank block
+                kk, lda, sa, sb, br = k // world, k // world, spec.batch * (k // world), (k // world) * n, world
+            h = rt.fused_brgemm_dispatch(
+                dtype=spec.dtype, m=spec.batch, n=nw, k=kk, lda=lda, ldb=n, ldc=nw, stride_a=sa, stride_b=sb,
+                gemm_flags=gemm_flags, unary_flags=0, unary_kind=UnaryKind.RELU if spec.relu else UnaryKind.NONE,
+                binary_flags=BinaryFlags.BCAST_COL_IN_0 if spec.bias else BinaryFlags.NONE,
+                binary_kind=BinaryKind.ADD if spec.bias else BinaryKind.NONE)
+            self.handles.append((h, br, nw))
+
+    def forward(self, x, weights, biases, locals_, gathered, all_gather):
+        """x: [batch, layers[0]] on every rank; weights[l]: the FULL [K][N] (f32) or VNNI-2 [K/2][N][2]
+        (bf16) matrix (only this rank's columns are read); biases[l]: [N]; locals_[l]: this rank's
+        output block [batch, N/W]; gathered[l]: [W, batch, N/W]; all_gather(dst, src) performs the
+        collective (dist.all_gather_into_tensor on RCCL / gloo). Returns gathered[-1]."""
+        cur = x
+        for l, (h, br, nw) in enumerate(self.handles):
+            n0 = self.rank * nw
+            d = biases[l] if self.spec.bias else biases[0]
+            self.rt.fused_brgemm(self.spec.dtype, h, cur, 0, weights[l], (2 if self.spec.vnni else 1) * n0,
+                                 locals_[l], 0, d, n0, br)
+            all_gather(gathered[l], locals_[l])
+            cur = gathered[l]
+        return cur
+
+
+def gathered_to_rows(g):
+    """[W, batch, N/W] (rank-major column blocks) -> row-major [batch, N]; for consumers outside the MLP"""
+    w, b, nw = g.shape
+    return g.permute(1, 0, 2).reshape(b, w * nw)
+
+
 def all_gather_rows(out_local, out_full, spec, world, group=None):
     """all-gather of the row blocks into the full [batch, N] output. Equal blocks use
     one all_gather_into_tensor (a single RCCL collective on GPUs); ragged blocks fall
