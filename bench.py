@@ -377,12 +377,13 @@ def main():
             import re
             import subprocess
             for label, extra in (("tile queue", ["--tiles", "32", "--queue", "1", "-n", "200"]),
+                                 ("tile queue, bf16 + VNNI-2 W", ["--tiles", "32", "--queue", "1", "-n", "200", "--bf16"]),
                                  ("whole-layer dispatch", ["--whole-layer", "-n", "1000"])):
                 r = subprocess.run([replay, "--batch", "256", "--layers", "1024,1024,1024,1024", "--bias", "--relu"] + extra,
                                    capture_output=True, text=True, timeout=300)
                 mm = re.search(r"mean ([0-9.]+) us[^,]*, ([0-9.]+) GFLOP/s", r.stderr)
                 if mm:
-                    others.append({"workload": "mlir-gen mlp fp32 3x1024 bs=256 bias+relu, " + label + " (tools/tpp_replay)",
+                    others.append({"workload": "mlir-gen mlp 3x1024 bs=256 bias+relu (fp32 unless noted), " + label + " (tools/tpp_replay)",
                                    "value": float(mm.group(2)), "unit": "GFLOP/s", "us_per_step": float(mm.group(1))})
 
     cpu = None

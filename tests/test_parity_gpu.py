@@ -252,6 +252,18 @@ def test_brgemm_bf16_large_output_uses_256_tiles(rt):
     assert "256x256" in name, name
 
 
+@pytest.mark.parametrize("shape", [(32, 32, 32, 32), (32, 64, 32, 3), (96, 32, 96, 2), (64, 64, 32, 1), (128, 96, 160, 2)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_brgemm_bf16_vnni_generic_vector_loads(rt, shape):
+    """the compiler-native bf16 tile (32x32x32, VNNI-2 B, packed blocks) and relatives with k not a multiple of
+    64: the grouped kernel's 16-byte-load path (aligned leading dimensions), all epilogues"""
+    m, n, k, br = shape
+    for i, kw in enumerate((dict(beta0=True), dict(bias=True, relu=True), dict(beta0=True, bias=True, ldc=n + 8, lda=k + 8,
+                                                                             ldb=n + 4, offs=(8, 8, 8, 4)))):
+        name = gemm_case(rt, BF16, m, n, k, br, vnni=True, seed=sum(shape) + i, **kw)
+        assert "grouped" in name, name
+
+
 def test_brgemm_bf16_flat_b_generic(rt):
     gemm_case(rt, BF16, 48, 40, 24, 3, vnni=False, seed=3, bias=True)
 

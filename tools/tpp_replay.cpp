@@ -38,7 +38,7 @@ static std::vector<int64_t> parse_list(const char *s) {
 int main(int argc, char **argv) {
   int64_t batch = 256, tile = 32, n_iter = 100;
   std::vector<int64_t> layers = {1024, 1024, 1024, 1024};
-  bool bias = false, relu = false, whole = false, print = false, c1 = false, rnd = false;
+  bool bias = false, relu = false, whole = false, print = false, c1 = false, rnd = false, bf16 = false;
   int queue = 1;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
@@ -53,6 +53,7 @@ int main(int argc, char **argv) {
     else if (a == "--whole-layer") whole = true;
     else if (a == "--print") print = true;
     else if (a == "--c1") c1 = true;
+    else if (a == "--bf16") bf16 = true; // mlir-gen --float-type=bf16 --vnni=2: bf16 storage, W in VNNI-2 blocks
     else if (a == "--random") rnd = true; // uniform [-1, 1) * fill instead of constant fills (switching power)
     else { fprintf(stderr, "unknown flag %s\n", a.c_str()); return 2; }
   }
@@ -103,44 +104,55 @@ int main(int argc, char **argv) {
     return 0;
   }
   const int L = (int)layers.size() - 1;
-  const int64_t gflags = XSMM_GEMM_FLAG_BETA_0; // mlir-gen --kernel=const: zero fill folded into BETA_0
+  int64_t gflags = XSMM_GEMM_FLAG_BETA_0; // mlir-gen --kernel=const: zero fill folded into BETA_0
   const int64_t ukind = relu ? XSMM_UNARY_RELU : XSMM_UNARY_NONE;
   const int64_t bkind = bias ? XSMM_BINARY_ADD : XSMM_BINARY_NONE, bflags = bias ? XSMM_BINARY_FLAG_BCAST_COL_IN_0 : 0;
   double flops = 0;
   for (int l = 0; l < L; ++l) flops += 2.0 * batch * layers[l] * layers[l + 1] + (bias ? batch * layers[l + 1] : 0) + (relu ? batch * layers[l + 1] : 0);
 
-  // buffers: activations [l] (batch x layers[l]), weights, biases; const 1.0 / 0.01 fills
-  std::vector<float *> act(L + 1), W(L), B(L);
+  // buffers: activations [l] (batch x layers[l]), weights, biases; const 1.0 / (1/K) / 0.5 fills. With
+  // constant fills the packed / VNNI-2 / flat layouts of a tensor are the same bytes.
+  const int64_t dt = bf16 ? 2 : 1;
+  const size_t es = bf16 ? 2 : 4;
+  auto to_bf16 = [](float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); };
+  std::vector<void *> act(L + 1), W(L), B(L);
   auto dalloc = [&](size_t n, float v) {
-    float *d; CHECK(hipMalloc((void **)&d, n * sizeof(float)));
+    void *d; CHECK(hipMalloc(&d, n * es));
     std::vector<float> h(n, v);
     if (rnd) for (auto &x : h) x = v * (float)(2.0 * rand() / (double)RAND_MAX - 1.0);
-    CHECK(hipMemcpy(d, h.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    if (bf16) {
+      std::vector<uint16_t> hb(n);
+      for (size_t i = 0; i < n; ++i) hb[i] = to_bf16(h[i]);
+      CHECK(hipMemcpy(d, hb.data(), n * 2, hipMemcpyHostToDevice));
+    } else {
+      CHECK(hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice));
+    }
     return d;
   };
   for (int l = 0; l <= L; ++l) act[l] = dalloc((size_t)batch * layers[l], 1.0f);
   for (int l = 0; l < L; ++l) { W[l] = dalloc((size_t)layers[l] * layers[l + 1], 1.0f / (float)layers[l]); B[l] = dalloc((size_t)layers[l + 1], 0.5f); }
 
+  if (bf16) gflags |= XSMM_GEMM_WIRE_VNNI_B;
   xsmm_hip_set_async(1);
   xsmm_hip_set_tile_queue(queue);
   std::vector<int64_t> handle(L);
   for (int l = 0; l < L; ++l) {
     const int64_t K = layers[l], N = layers[l + 1];
     if (whole) // one dispatch per layer on the flat row-major tensors
-      handle[l] = xsmm_fused_brgemm_dispatch(1, batch, N, 64, K, N, N, 64, 64 * N, gflags, 0, ukind, bflags, bkind);
+      handle[l] = xsmm_fused_brgemm_dispatch(dt, batch, N, 64, K, N, N, 64, 64 * N, gflags, 0, ukind, bflags, bkind);
     else       // packed tiles: [MB][KB][t][t] x [NB][KB][t][t] -> [MB][NB][t][t]
-      handle[l] = xsmm_fused_brgemm_dispatch(1, tile, tile, tile, tile, tile, tile, tile * tile, tile * tile, gflags, 0, ukind, bflags, bkind);
+      handle[l] = xsmm_fused_brgemm_dispatch(dt, tile, tile, tile, tile, tile, tile, tile * tile, tile * tile, gflags, 0, ukind, bflags, bkind);
   }
   auto kernel = [&]() {
     for (int l = 0; l < L; ++l) {
       const int64_t K = layers[l], N = layers[l + 1];
       if (whole) {
-        xsmm_fused_brgemm_invoke(1, handle[l], act[l], 0, W[l], 0, act[l + 1], 0, B[l], 0, K / 64);
+        xsmm_fused_brgemm_invoke(dt, handle[l], act[l], 0, W[l], 0, act[l + 1], 0, B[l], 0, K / 64);
       } else {
         const int64_t MB = batch / tile, NB = N / tile, KB = K / tile, tt = tile * tile;
         for (int64_t i = 0; i < MB; ++i)
           for (int64_t j = 0; j < NB; ++j)
-            xsmm_fused_brgemm_invoke(1, handle[l], act[l], i * KB * tt, W[l], j * KB * tt, act[l + 1], (i * NB + j) * tt,
+            xsmm_fused_brgemm_invoke(dt, handle[l], act[l], i * KB * tt, W[l], j * KB * tt, act[l + 1], (i * NB + j) * tt,
                                      B[l], j * tile, KB);
       }
     }
@@ -151,8 +163,8 @@ int main(int argc, char **argv) {
   const int64_t t0 = perf_start_timer();
   for (int64_t i = 0; i < n_iter; ++i) kernel();
   const double host_dt = (double)(perf_start_timer() - t0) * 1e-9; // all invokes returned (host side only)
-  const double dt = perf_stop_timer(t0); // flushes the tile queue and drains the stream
-  const double mean = dt / (double)n_iter;
+  const double elapsed = perf_stop_timer(t0); // flushes the tile queue and drains the stream
+  const double mean = elapsed / (double)n_iter;
   printf("%g\n", mean); // tpp-run prints the mean seconds (MLIRBench.cpp:297-300)
   fprintf(stderr, "tpp_replay: %s, batch %ld, %d layer(s), queue %d: mean %.3f us (host side of the invokes %.3f us), %.1f GFLOP/s (BENCH_TOTAL_FLOPS %.0f), kernel %s\n",
           whole ? "whole-layer dispatch" : "packed 32x32x32 tile invokes", (long)batch, L, queue, mean * 1e6,
@@ -160,7 +172,13 @@ int main(int argc, char **argv) {
           xsmm_hip_kernel_name(handle[0]));
   if (print) {
     std::vector<float> h(8);
-    CHECK(hipMemcpy(h.data(), act[L], 8 * sizeof(float), hipMemcpyDeviceToHost));
+    if (bf16) {
+      uint16_t hb[8];
+      CHECK(hipMemcpy(hb, act[L], 16, hipMemcpyDeviceToHost));
+      for (int i = 0; i < 8; ++i) { uint32_t u = (uint32_t)hb[i] << 16; memcpy(&h[i], &u, 4); }
+    } else {
+      CHECK(hipMemcpy(h.data(), act[L], 8 * sizeof(float), hipMemcpyDeviceToHost));
+    }
     printf("( %g, %g, %g, %g, %g, %g, %g, %g )\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
   }
   return 0;

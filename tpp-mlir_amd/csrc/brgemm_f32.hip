@@ -425,6 +425,26 @@ __global__ __launch_bounds__(256) void brgemm_grouped(GemmArgs p, const WorkItem
   auto gload = [&](int c) __attribute__((always_inline)) {
     const int b = c / kchunks, kk0 = (c - b * kchunks) * GK;
     const int64_t abase = (int64_t)b * p.stride_a, bbase = (int64_t)b * p.stride_b;
+    if constexpr (VEC && sizeof(T) == 2) {
+      // bf16, VNNI-2 B, 16-byte loads (8 elements), widened to f32 on the way into the staging registers:
+      // A piece (row, 8 k) -> two register quads; B piece (pair-row p, 4 columns x 2 k) -> quad of row 2p
+      // (elements 0, 2, 4, 6) and quad of row 2p+1 (elements 1, 3, 5, 7)
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        const int q = lane + 64 * v;
+        const u32x4 a8 = *(const u32x4 *)((const unsigned short *)it.A + abase + (int64_t)(m0 + (q >> 2)) * p.lda + kk0 + 8 * (q & 3));
+        const u32x4 b8 = *(const u32x4 *)((const unsigned short *)it.B + bbase + (int64_t)((kk0 >> 1) + (q >> 3)) * (2 * p.ldb) +
+                                          2 * (n0 + 4 * (q & 7)));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          ra[2 * v + (e >> 1)][2 * (e & 1)] = __uint_as_float(a8[e] << 16);
+          ra[2 * v + (e >> 1)][2 * (e & 1) + 1] = __uint_as_float(a8[e] & 0xffff0000u);
+          rb[2 * v][e] = __uint_as_float(b8[e] << 16);            // k even, column 4c + e
+          rb[2 * v + 1][e] = __uint_as_float(b8[e] & 0xffff0000u); // k odd
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int q = lane + 64 * u, row = q >> 3, c4 = q & 7; // 32 rows x 8 pieces of 4 floats
@@ -452,9 +472,17 @@ __global__ __launch_bounds__(256) void brgemm_grouped(GemmArgs p, const WorkItem
     float *as = wl + buf * (2 * 32 * GK), *bs = as + 32 * GK;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int q = lane + 64 * u, row = q >> 3, c4 = q & 7;
+      int row, c4, krow, c4b;
+      if constexpr (VEC && sizeof(T) == 2) { // where gload put quad u (see there)
+        const int q = lane + 64 * (u >> 1);
+        row = q >> 2, c4 = 2 * (q & 3) + (u & 1);
+        krow = 2 * (q >> 3) + (u & 1), c4b = q & 7;
+      } else {
+        const int q = lane + 64 * u;
+        row = krow = q >> 3, c4 = c4b = q & 7;
+      }
       *(f32x4 *)(as + row * GK + ((c4 ^ ((row >> 1) & 7)) << 2)) = ra[u]; // 128-byte rows: XOR on (row>>1)
-      *(f32x4 *)(bs + row * 32 + 4 * c4) = rb[u];
+      *(f32x4 *)(bs + krow * 32 + 4 * c4b) = rb[u];
     }
   };
   auto compute = [&](int buf) __attribute__((always_inline)) {
@@ -588,11 +616,14 @@ hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_i
   a.m = (int)d.m; a.n = (int)d.n; a.k = (int)d.k; a.br = 0;
   a.ep = (d.beta0 ? EP_BETA0 : 0) | (d.bias ? EP_BIAS : 0) | (d.relu ? EP_RELU : 0);
   a.tiles_m = a.tiles_n = 0;
-  const bool vec = vec_ok && d.dtype == DT_F32 && !d.vnni_b && d.m % 32 == 0 && d.n % 32 == 0 && d.k % GK == 0 &&
-                   !((d.lda | d.ldb | d.stride_a | d.stride_b) & 3);
+  const bool tiles_ok = vec_ok && d.m % 32 == 0 && d.n % 32 == 0 && d.k % GK == 0;
+  const bool vec = tiles_ok && d.dtype == DT_F32 && !d.vnni_b && !((d.lda | d.ldb | d.stride_a | d.stride_b) & 3);
+  // bf16 + VNNI-2 B with 16-byte loads: 8-element A pieces, pair-rows of B 16-byte aligned
+  const bool vec16 = tiles_ok && d.dtype == DT_BF16 && d.vnni_b && !((d.lda | d.stride_a | d.stride_b) & 7) && !(d.ldb & 3);
   if (d.dtype == DT_F32) return vec ? launch_grouped_t<float, false, true>(a, items, n_items, stream)
                                     : launch_grouped_t<float, false, false>(a, items, n_items, stream);
-  if (d.vnni_b) return launch_grouped_t<unsigned short, true, false>(a, items, n_items, stream);
+  if (d.vnni_b) return vec16 ? launch_grouped_t<unsigned short, true, true>(a, items, n_items, stream)
+                             : launch_grouped_t<unsigned short, true, false>(a, items, n_items, stream);
   return launch_grouped_t<unsigned short, false, false>(a, items, n_items, stream);
 }
 
@@ -682,11 +713,13 @@ hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C,
   default: break;
   }
   // everything else: the grouped kernel with a single, inline work item
-  const bool vec = aligned16 && d.dtype == DT_F32 && !d.vnni_b && d.m % 32 == 0 && d.n % 32 == 0 && d.k % GK == 0 &&
-                   !((d.lda | d.ldb | d.stride_a | d.stride_b) & 3);
+  const bool tiles_ok = aligned16 && d.m % 32 == 0 && d.n % 32 == 0 && d.k % GK == 0;
+  const bool vec = tiles_ok && d.dtype == DT_F32 && !d.vnni_b && !((d.lda | d.ldb | d.stride_a | d.stride_b) & 3);
+  const bool vec16 = tiles_ok && d.dtype == DT_BF16 && d.vnni_b && !((d.lda | d.stride_a | d.stride_b) & 7) && !(d.ldb & 3);
   if (d.dtype == DT_F32) return vec ? launch_grouped_t<float, false, true>(a, nullptr, 1, stream)
                                     : launch_grouped_t<float, false, false>(a, nullptr, 1, stream);
-  if (d.vnni_b) return launch_grouped_t<unsigned short, true, false>(a, nullptr, 1, stream);
+  if (d.vnni_b) return vec16 ? launch_grouped_t<unsigned short, true, true>(a, nullptr, 1, stream)
+                             : launch_grouped_t<unsigned short, true, false>(a, nullptr, 1, stream);
   return launch_grouped_t<unsigned short, false, false>(a, nullptr, 1, stream);
 }
 
