@@ -566,28 +566,36 @@ __global__ __launch_bounds__(256 + 64 * NLW) void brgemm_bf16_dma128(GemmArgs p)
   // reads spread over the step's four MFMAs (a burst from four waves at once fills the LDS queue and
   // holds up the MFMA issue behind it). The 8 DMA instructions of chunk t+3 ride one per MFMA in
   // steps 2 and 3.
-  auto chunk = [&](auto slot_c, auto h1, auto h2, auto h3) __attribute__((always_inline)) {
-    constexpr int S = decltype(slot_c)::value;
-    constexpr bool H1 = decltype(h1)::value, H2 = decltype(h2)::value, H3 = decltype(h3)::value;
+  // One chunk in ring slot S. STEADY: chunks t+1 .. t+3 exist, S is a literal (every LDS address is a
+  // base VGPR + immediate) and nothing is conditional. Otherwise one of the last <= 6 chunks, with
+  // run-time slot and flags h1 / h2 / h3 (chunk t+1 / t+2 / t+3 exists). Exactly TWO code instances: the
+  // tail used to be a chain of specialised variants, each executed once - four instruction-cache cold
+  // misses (~600 cycles each) in a kernel of 16 chunks.
+  // Step q multiplies the fragments in buffer q (4 steps per chunk, 4 buffers) while the fragments of
+  // step q+2 are read (steps 2, 3 read the first two steps of chunk t+1, published by the mid barrier).
+  // Without loader waves the 8 DMA instructions of chunk t+3 ride one per MFMA in steps 2 and 3.
+  auto chunk = [&](auto steady_c, int S, bool h1, bool h2, bool h3) __attribute__((always_inline)) {
+    constexpr bool STEADY = decltype(steady_c)::value;
+    const bool H1 = STEADY || h1, H2 = STEADY || h2, H3 = STEADY || h3;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      if ((TPP_ABLATE & HABL_STAMP) && S == 0 && H3) step_stamp[q] = __builtin_readcyclecounter();
+      if ((TPP_ABLATE & HABL_STAMP) && STEADY && S == 0) step_stamp[q] = __builtin_readcyclecounter();
       const bool reads = !(TPP_ABLATE & HABL_NO_FRAG) && (q + 2 < 4 || H1);
-      const int rbuf = q + 2 < 4 ? q + 2 : q - 2, rslot = q + 2 < 4 ? S : (S + 1) % NSLOT, rks = rbuf;
-      if (reads && !TPP_BF16_SPREAD_READS) frag_load(rbuf, rslot, rks);
+      const int rbuf = q + 2 < 4 ? q + 2 : q - 2, rslot = q + 2 < 4 ? S : (S + 1) & (NSLOT - 1), rks = rbuf;
+      if (reads && !(STEADY && TPP_BF16_SPREAD_READS)) frag_load(rbuf, rslot, rks);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bw[q][j]), af[q][i], acc[i][j], 0, 0, 0);
-          if (reads && TPP_BF16_SPREAD_READS) {
+          if (STEADY && TPP_BF16_SPREAD_READS && reads) {
             const int m = i * TN + j; // after MFMA 0: A0, B0 lo | 1: B0 hi, B1 lo | 2: B1 hi | 3: A1
             frag_piece(rbuf, rslot, rks, m == 0 ? 0 : m == 1 ? 2 : m == 2 ? 4 : 5);
             if (m < 2) frag_piece(rbuf, rslot, rks, m == 0 ? 1 : 3);
           }
-          if (!LW && H3 && q >= 2 && !(TPP_ABLATE & HABL_NO_GLOAD)) {
-            dma_piece((S + 3) % NSLOT, (q - 2) * 4 + i * TN + j); // slot of chunk t-1: every wave is past it
+          if (!LW && STEADY && q >= 2 && !(TPP_ABLATE & HABL_NO_GLOAD)) {
+            dma_piece((S + 3) & (NSLOT - 1), (q - 2) * 4 + i * TN + j); // slot of chunk t-1: every wave is past it
             if (q == 3 && i == TM - 1 && j == TN - 1) TPP_DMA_ADVANCE();
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -600,9 +608,14 @@ __global__ __launch_bounds__(256 + 64 * NLW) void brgemm_bf16_dma128(GemmArgs p)
         }
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        if (!LW && !STEADY && H3 && !(TPP_ABLATE & HABL_NO_GLOAD)) { // the last chunks: one burst
+          dma_chunk((S + 3) & (NSLOT - 1));
+          TPP_DMA_ADVANCE();
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
-    if ((TPP_ABLATE & HABL_STAMP) && S == 0 && H3) step_stamp[4] = __builtin_readcyclecounter();
+    if ((TPP_ABLATE & HABL_STAMP) && STEADY && S == 0) step_stamp[4] = __builtin_readcyclecounter();
   };
   using yes = std::integral_constant<bool, true>;
   using no = std::integral_constant<bool, false>;
@@ -650,27 +663,13 @@ __global__ __launch_bounds__(256 + 64 * NLW) void brgemm_bf16_dma128(GemmArgs p)
   }
   if (TPP_ABLATE & HABL_STAMP) stamp[1] = __builtin_readcyclecounter();
   int t = 0;
-  for (; t + 6 < T; t += 4) {
-    chunk(std::integral_constant<int, 0>{}, yes{}, yes{}, yes{});
-    chunk(std::integral_constant<int, 1>{}, yes{}, yes{}, yes{});
-    chunk(std::integral_constant<int, 2>{}, yes{}, yes{}, yes{});
-    chunk(std::integral_constant<int, 3>{}, yes{}, yes{}, yes{});
+  for (; t + 6 < T; t += 4) { // steady state (t % 4 == 0 here: ring slots are literals)
+    chunk(yes{}, 0, true, true, true);
+    chunk(yes{}, 1, true, true, true);
+    chunk(yes{}, 2, true, true, true);
+    chunk(yes{}, 3, true, true, true);
   }
-  auto tail = [&](auto slot_c) __attribute__((always_inline)) {
-    const int left = T - t;
-    if (left >= 4) chunk(slot_c, yes{}, yes{}, yes{});
-    else if (left == 3) chunk(slot_c, yes{}, yes{}, no{});
-    else if (left == 2) chunk(slot_c, yes{}, no{}, no{});
-    else chunk(slot_c, no{}, no{}, no{});
-    ++t;
-  };
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    if (t < T) tail(std::integral_constant<int, 0>{});
-    if (t < T) tail(std::integral_constant<int, 1>{});
-    if (t < T) tail(std::integral_constant<int, 2>{});
-    if (t < T) tail(std::integral_constant<int, 3>{});
-  }
+  for (; t < T; ++t) chunk(no{}, t & (NSLOT - 1), t + 1 < T, t + 2 < T, t + 3 < T); // the last <= 6 chunks
 
   if (TPP_ABLATE & HABL_STAMP) stamp[2] = __builtin_readcyclecounter();
   if (TPP_ABLATE & HABL_NO_FRAG) {
