@@ -13,6 +13,7 @@
 #include "../../include/tpp_xsmm_abi.h"
 #include "xsmm_desc.h"
 
+#include <sched.h>
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -268,37 +269,49 @@ int64_t gemm_dispatch_common(const char *who, int has_batch, int fused, int64_t 
 struct Range {
   uintptr_t b, e;
 };
-// union of half-open intervals with O(log n) insert / overlap query
+// union of half-open intervals: a sorted vector of disjoint ranges (a handful in practice - queued
+// operands of one layer merge into a few runs - so a contiguous array beats a node-based map; the
+// enqueue path runs 9 of these operations per invoke and is the throughput limit of the tile queue)
 struct IntervalSet {
-  std::map<uintptr_t, uintptr_t> iv; // begin -> end, disjoint
+  std::vector<Range> iv; // sorted by begin, disjoint and non-touching
   void clear() { iv.clear(); }
+  // index of the first interval whose begin is > x
+  size_t upper(uintptr_t x) const {
+    size_t lo = 0, hi = iv.size();
+    if (hi <= 8) { // linear scan from the back: new operands are usually at or near the last run
+      while (hi > 0 && iv[hi - 1].b > x) --hi;
+      return hi;
+    }
+    while (lo < hi) {
+      const size_t mid = (lo + hi) / 2;
+      if (iv[mid].b > x) hi = mid;
+      else lo = mid + 1;
+    }
+    return lo;
+  }
   bool overlaps(const Range &r) const {
     if (r.b >= r.e || iv.empty()) return false;
-    auto it = iv.lower_bound(r.e); // first interval starting at/after r.e: cannot overlap
-    if (it == iv.begin()) return false;
-    --it;
-    return it->second > r.b;
+    const size_t i = upper(r.e - 1); // intervals [0, i) begin before r.e
+    return i > 0 && iv[i - 1].e > r.b;
   }
   void insert(Range r) {
     if (r.b >= r.e) return;
-    auto it = iv.upper_bound(r.b); // first interval starting after r.b
-    if (it != iv.begin()) {
-      auto pv = std::prev(it);
-      if (pv->second >= r.b) { // r starts inside (or right at the end of) pv
-        if (pv->second >= r.e) return; // already covered: the common case for re-read operands
-        if (it == iv.end() || it->first > r.e) { // grows pv only: consecutive output tiles
-          pv->second = r.e;
-          return;
-        }
-        it = pv;
-      }
+    size_t i = upper(r.b); // iv[i-1].b <= r.b < iv[i].b
+    if (i > 0 && iv[i - 1].e >= r.b) { // r starts inside (or right at the end of) its predecessor
+      if (iv[i - 1].e >= r.e) return;  // already covered: the common case for re-read operands
+      --i;
+      r.b = iv[i].b;
     }
-    while (it != iv.end() && it->first <= r.e) {
-      r.b = std::min(r.b, it->first);
-      r.e = std::max(r.e, it->second);
-      it = iv.erase(it);
+    size_t j = i; // [i, j) are swallowed by r
+    while (j < iv.size() && iv[j].b <= r.e) {
+      r.e = std::max(r.e, iv[j].e);
+      ++j;
     }
-    iv.emplace(r.b, r.e);
+    if (j == i) iv.insert(iv.begin() + i, r);
+    else {
+      iv[i] = r;
+      if (j > i + 1) iv.erase(iv.begin() + i + 1, iv.begin() + j);
+    }
   }
 };
 
@@ -307,10 +320,15 @@ struct IntervalSet {
 // allocations, and one driver query per operand per invoke would dominate the host time.
 struct DeviceRanges {
   std::vector<Range> known;
+  mutable size_t mru = 0; // index of the last hit: operands of consecutive invokes share allocations
   bool contains(const void *p) const {
     const uintptr_t a = (uintptr_t)p;
-    for (const Range &r : known)
-      if (a >= r.b && a < r.e) return true;
+    if (mru < known.size() && a >= known[mru].b && a < known[mru].e) return true;
+    for (size_t i = 0; i < known.size(); ++i)
+      if (a >= known[i].b && a < known[i].e) {
+        mru = i;
+        return true;
+      }
     return false;
   }
   uintptr_t base_of(const void *p) const { // allocation base, 0 if unknown
@@ -406,9 +424,22 @@ struct Footprint {
   }
 };
 
+// the queue's critical sections are a few dozen nanoseconds: a spin lock costs half of an uncontended
+// pthread mutex round trip and OpenMP callers never sleep on it
+struct SpinLock {
+  std::atomic_flag f = ATOMIC_FLAG_INIT;
+  void lock() {
+    for (unsigned spins = 0; f.test_and_set(std::memory_order_acquire); ++spins) {
+      if (spins < 2000) __builtin_ia32_pause();
+      else sched_yield(); // the holder may be inside a launch or waiting for a slot: let it run
+    }
+  }
+  void unlock() { f.clear(std::memory_order_release); }
+};
+
 struct TileQueue {
   static constexpr int CAP = 4096, SLOTS = 4;
-  std::mutex mu;
+  SpinLock mu;
   int kind = 0;               // KIND_GEMM / KIND_UNARY / KIND_BINARY of the queued invokes
   const void *desc = nullptr; // their (single) descriptor
   bool vec_ok = true;
@@ -446,7 +477,7 @@ struct TileQueue {
     writes.clear();
   }
   void flush() {
-    std::lock_guard<std::mutex> lk(mu);
+    std::lock_guard<SpinLock> lk(mu);
     flush_locked();
   }
 };
@@ -464,7 +495,7 @@ void flush_tile_queue() {
 bool enqueue_item(int kind, const void *desc, const WorkItem &item, const Operand *const *in, int n_in,
                   const Operand &out, bool vec_ok, hipStream_t s) {
   TileQueue &q = tq();
-  std::lock_guard<std::mutex> lk(q.mu);
+  std::lock_guard<SpinLock> lk(q.mu);
   if (!q.devmem.is_device(out.ptr)) return false;
   for (int i = 0; i < n_in; ++i)
     if (!q.devmem.is_device(in[i]->ptr)) return false;
