@@ -376,8 +376,10 @@ def main():
         if os.path.exists(replay):
             import re
             import subprocess
-            for label, extra in (("tile queue", ["--tiles", "32", "--queue", "1", "-n", "200"]),
-                                 ("tile queue, bf16 + VNNI-2 W", ["--tiles", "32", "--queue", "1", "-n", "200", "--bf16"]),
+            for label, extra in (("tile queue, tiles 32,32,32", ["--tiles", "32", "--queue", "1", "-n", "200"]),
+                                 ("tile queue, tiles 64,64,64", ["--tiles", "64", "--queue", "1", "-n", "200"]),
+                                 ("tile queue, tiles 32,32,32, bf16 + VNNI-2 W", ["--tiles", "32", "--queue", "1", "-n", "200", "--bf16"]),
+                                 ("tile queue, tiles 64,64,64, bf16 + VNNI-2 W", ["--tiles", "64", "--queue", "1", "-n", "200", "--bf16"]),
                                  ("whole-layer dispatch", ["--whole-layer", "-n", "1000"])):
                 r = subprocess.run([replay, "--batch", "256", "--layers", "1024,1024,1024,1024", "--bias", "--relu"] + extra,
                                    capture_output=True, text=True, timeout=300)

@@ -279,3 +279,59 @@ def test_interleaved_and_overlapping_tiles_of_one_buffer(rtq):
             rt.unary(F32, h, dS, ((t + rep) % 40) * 1024, dD, r * ld + c)
     rt.synchronize()
     assert np.array_equal(host(dD, dst), ref)
+
+
+@pytest.mark.parametrize("tiles", [(64, 64, 64), (32, 64, 64), (64, 32, 64), (64, 64, 128)], ids=lambda t: "x".join(map(str, t)))
+@pytest.mark.parametrize("nblk", [(2, 3), (8, 16)], ids=["few", "many"])
+def test_packed_layers_k64_tiles_use_the_fast_families(rtq, tiles, nblk):
+    """mlir-gen --tiles=64,64,64 (the most common setting of the reference's benchmark configs): f32 tiles with
+    k a multiple of 64 run on the fast tile families in grouped mode; few / many items pick different families"""
+    rt = rtq
+    tm, tn, tk = tiles
+    MB, NB = nblk
+    KB = 4
+    rng = np.random.default_rng(tm + tn + tk + MB)
+    X = rng.uniform(-1, 1, MB * KB * tm * tk).astype(np.float32)
+    Wt = rng.uniform(-0.3, 0.3, NB * KB * tk * tn).astype(np.float32)
+    b = rng.uniform(-0.3, 0.3, NB * tn).astype(np.float32)
+    C0 = rng.uniform(-1, 1, MB * NB * tm * tn).astype(np.float32)
+    for (gflags, ukind, bflags, bkind) in ((4, 5, 4, 1), (0, 0, 0, 0)):
+        disp = (F32, tm, tn, tk, tk, tn, tn, tm * tk, tk * tn, gflags, 0, ukind, bflags, bkind)
+        ref = C0.copy()
+        for i in range(MB):
+            for j in range(NB):
+                orc.fused_brgemm(*disp, X, i * KB * tm * tk, Wt, j * KB * tk * tn, ref, (i * NB + j) * tm * tn, b, j * tn, KB)
+        h = rt.fused_brgemm_dispatch(*disp)
+        dX, dW, db, dC = dev(X), dev(Wt), dev(b), dev(C0)
+        for i in range(MB):
+            for j in range(NB):
+                rt.fused_brgemm(F32, h, dX, i * KB * tm * tk, dW, j * KB * tk * tn, dC, (i * NB + j) * tm * tn, db, j * tn, KB)
+        rt.synchronize()
+        close(host(dC, C0), ref, F32)
+
+
+@pytest.mark.parametrize("nblk", [(2, 3), (4, 16)], ids=["few", "many"])
+def test_packed_layers_bf16_64_tiles(rtq, nblk):
+    """bf16 + VNNI-2 W with --tiles=64,64,64: the 64x64 bf16 family in grouped mode"""
+    rt = rtq
+    tm = tn = tk = 64
+    MB, NB = nblk
+    KB = 3
+    rng = np.random.default_rng(MB * 10 + NB)
+    X = orc.f32_to_bf16(rng.uniform(-1, 1, MB * KB * tm * tk).astype(np.float32))
+    Wt = orc.f32_to_bf16(rng.uniform(-0.3, 0.3, NB * KB * tk * tn).astype(np.float32))
+    b = orc.f32_to_bf16(rng.uniform(-0.3, 0.3, NB * tn).astype(np.float32))
+    C0 = orc.f32_to_bf16(rng.uniform(-1, 1, MB * NB * tm * tn).astype(np.float32))
+    for (gflags, ukind, bflags, bkind) in ((4 | 2048, 5, 4, 1), (2048, 0, 0, 0)):
+        disp = (BF16, tm, tn, tk, tk, tn, tn, tm * tk, tk * tn, gflags, 0, ukind, bflags, bkind)
+        ref = C0.copy()
+        for i in range(MB):
+            for j in range(NB):
+                orc.fused_brgemm(*disp, X, i * KB * tm * tk, Wt, j * KB * tk * tn, ref, (i * NB + j) * tm * tn, b, j * tn, KB)
+        h = rt.fused_brgemm_dispatch(*disp)
+        dX, dW, db, dC = dev(X), dev(Wt), dev(b), dev(C0)
+        for i in range(MB):
+            for j in range(NB):
+                rt.fused_brgemm(BF16, h, dX, i * KB * tm * tk, dW, j * KB * tk * tn, dC, (i * NB + j) * tm * tn, db, j * tn, KB)
+        rt.synchronize()
+        close(host(dC, C0), ref, BF16)

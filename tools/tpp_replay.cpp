@@ -36,7 +36,7 @@ static std::vector<int64_t> parse_list(const char *s) {
 }
 
 int main(int argc, char **argv) {
-  int64_t batch = 256, tile = 32, n_iter = 100;
+  int64_t batch = 256, tile = 32, tile_n = 0, tile_k = 0, n_iter = 100;
   std::vector<int64_t> layers = {1024, 1024, 1024, 1024};
   bool bias = false, relu = false, whole = false, print = false, c1 = false, rnd = false, bf16 = false;
   int queue = 1;
@@ -45,7 +45,11 @@ int main(int argc, char **argv) {
     auto next = [&]() { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(2); } return argv[++i]; };
     if (a == "--batch") batch = atoll(next());
     else if (a == "--layers") layers = parse_list(next());
-    else if (a == "--tiles") tile = atoll(next());
+    else if (a == "--tiles") { // m[,n,k] like mlir-gen --tiles=64,48,64
+      std::vector<int64_t> t = parse_list(next());
+      tile = t[0];
+      if (t.size() == 3) { tile_n = t[1]; tile_k = t[2]; }
+    }
     else if (a == "-n") n_iter = atoll(next());
     else if (a == "--queue") queue = atoi(next());
     else if (a == "--bias") bias = true;
@@ -136,12 +140,13 @@ int main(int argc, char **argv) {
   xsmm_hip_set_async(1);
   xsmm_hip_set_tile_queue(queue);
   std::vector<int64_t> handle(L);
+  const int64_t tn = tile_n ? tile_n : tile, tk = tile_k ? tile_k : tile; // blocks: A [MB][KB][tm][tk], W [NB][KB][tk][tn], C [MB][NB][tm][tn]
   for (int l = 0; l < L; ++l) {
     const int64_t K = layers[l], N = layers[l + 1];
     if (whole) // one dispatch per layer on the flat row-major tensors
       handle[l] = xsmm_fused_brgemm_dispatch(dt, batch, N, 64, K, N, N, 64, 64 * N, gflags, 0, ukind, bflags, bkind);
     else       // packed tiles: [MB][KB][t][t] x [NB][KB][t][t] -> [MB][NB][t][t]
-      handle[l] = xsmm_fused_brgemm_dispatch(dt, tile, tile, tile, tile, tile, tile, tile * tile, tile * tile, gflags, 0, ukind, bflags, bkind);
+      handle[l] = xsmm_fused_brgemm_dispatch(dt, tile, tn, tk, tk, tn, tn, tile * tk, tk * tn, gflags, 0, ukind, bflags, bkind);
   }
   auto kernel = [&]() {
     for (int l = 0; l < L; ++l) {
@@ -149,11 +154,11 @@ int main(int argc, char **argv) {
       if (whole) {
         xsmm_fused_brgemm_invoke(dt, handle[l], act[l], 0, W[l], 0, act[l + 1], 0, B[l], 0, K / 64);
       } else {
-        const int64_t MB = batch / tile, NB = N / tile, KB = K / tile, tt = tile * tile;
+        const int64_t MB = batch / tile, NB = N / tn, KB = K / tk;
         for (int64_t i = 0; i < MB; ++i)
           for (int64_t j = 0; j < NB; ++j)
-            xsmm_fused_brgemm_invoke(dt, handle[l], act[l], i * KB * tt, W[l], j * KB * tt, act[l + 1], (i * NB + j) * tt,
-                                     B[l], j * tile, KB);
+            xsmm_fused_brgemm_invoke(dt, handle[l], act[l], i * KB * tile * tk, W[l], j * KB * tk * tn, act[l + 1],
+                                     (i * NB + j) * tile * tn, B[l], j * tn, KB);
       }
     }
   };
@@ -167,7 +172,7 @@ int main(int argc, char **argv) {
   const double mean = elapsed / (double)n_iter;
   printf("%g\n", mean); // tpp-run prints the mean seconds (MLIRBench.cpp:297-300)
   fprintf(stderr, "tpp_replay: %s, batch %ld, %d layer(s), queue %d: mean %.3f us (host side of the invokes %.3f us), %.1f GFLOP/s (BENCH_TOTAL_FLOPS %.0f), kernel %s\n",
-          whole ? "whole-layer dispatch" : "packed 32x32x32 tile invokes", (long)batch, L, queue, mean * 1e6,
+          whole ? "whole-layer dispatch" : "packed tile invokes", (long)batch, L, queue, mean * 1e6,
           host_dt / (double)n_iter * 1e6, flops / mean / 1e9, flops,
           xsmm_hip_kernel_name(handle[0]));
   if (print) {

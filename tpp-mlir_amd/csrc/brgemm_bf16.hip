@@ -35,8 +35,13 @@ constexpr int BKH = 64;     // k per chunk
 constexpr int NSTAGE_H = 3;
 constexpr int NSET_H = 3;  // staging register sets (chunks of global loads in flight per lane)
 
+// items != nullptr: grouped mode (tile queue), grid (items, tiles_n, tiles_m) - see brgemm_f32.hip
 template <int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(64 * WM * WN) void brgemm_bf16_fast(GemmArgs p) {
+__global__ __launch_bounds__(64 * WM * WN) void brgemm_bf16_fast(GemmArgs p, const WorkItem *__restrict__ items) {
+  if (items) {
+    const WorkItem it = items[blockIdx.x];
+    p.A = it.A; p.B = it.B; p.C = it.C; p.D = it.D; p.br = (int)it.br;
+  }
   constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN, NT = 64 * WM * WN;
   constexpr int A_STAGE = BM * BKH * 2;            // bytes
   constexpr int B_GROW = (BN + 1) * 16;            // bytes per pair-row group (padded)
@@ -54,8 +59,8 @@ __global__ __launch_bounds__(64 * WM * WN) void brgemm_bf16_fast(GemmArgs p) {
   const int wm = wave / WN, wn = wave % WN;
   const int li = lane & 31, lh = lane >> 5;
   // tile from the 3-D grid (see brgemm_f32.hip): (8, bn, bm) XCD-blocked or (1, tiles_n, tiles_m)
-  const int tm = (int)(blockIdx.x >> 1) * p.tiles_m + (int)blockIdx.z;
-  const int tn = (int)(blockIdx.x & 1) * p.tiles_n + (int)blockIdx.y;
+  const int tm = items ? (int)blockIdx.z : (int)(blockIdx.x >> 1) * p.tiles_m + (int)blockIdx.z;
+  const int tn = items ? (int)blockIdx.y : (int)(blockIdx.x & 1) * p.tiles_n + (int)blockIdx.y;
   const int m0 = tm * BM, n0 = tn * BN;
 
   const unsigned short *__restrict__ A = (const unsigned short *)p.A;
@@ -367,7 +372,23 @@ static hipError_t launch_bf16(const GemmArgs &a, hipStream_t s) {
     if (tiles_m > 65535 || tiles_n > 65535) return hipErrorInvalidValue;
     grid = dim3(1, tiles_n, tiles_m);
   }
-  hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, args);
+  hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, args, (const WorkItem *)nullptr);
+  return hipGetLastError();
+}
+
+// grouped launch of the 64x64 bf16 tile: one workgroup per (item, 64x64 tile of the item)
+hipError_t launch_bf16_grouped64(const GemmArgs &a, const WorkItem *items, int n_items, hipStream_t s) {
+  constexpr size_t lds = (size_t)NSTAGE_H * (64 * BKH * 2 + 8 * (64 + 1) * 16);
+  static bool attr_set = false;
+  auto kern = brgemm_bf16_fast<2, 2, 1, 1>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  GemmArgs args = a;
+  args.tiles_m = args.tiles_n = 0;
+  hipLaunchKernelGGL(kern, dim3((unsigned)n_items, a.n / 64, a.m / 64), dim3(256), lds, s, args, items);
   return hipGetLastError();
 }
 

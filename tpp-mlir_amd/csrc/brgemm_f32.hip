@@ -61,8 +61,15 @@ static __device__ __forceinline__ void lds_dma_16B(const void *panel, unsigned l
 // Chunk t+2 is fetched during the second half of chunk t into the ring slot chunk t-1 has left; the
 // A swizzle is applied to the source address. Everything else (fragments, barrier placement,
 // epilogue) is shared with the register-staged path.
+// items != nullptr: GROUPED mode (tile queue) - the grid is (items, tiles_n, tiles_m) and workgroup
+// (x, y, z) computes tile (z, y) of queued invoke x, whose operand pointers and batch count come from
+// items[x]; the descriptor fields (m, n, k, leading dimensions, strides, epilogue) are shared.
 template <int WM, int WN, int WK, int NACC, bool DMA>
-__global__ __launch_bounds__(64 * WM * WN * WK) void brgemm_f32_fast(GemmArgs p) {
+__global__ __launch_bounds__(64 * WM * WN * WK) void brgemm_f32_fast(GemmArgs p, const WorkItem *__restrict__ items) {
+  if (items) { // wave-uniform: overwrite the per-invoke fields of the (by-value) argument block
+    const WorkItem it = items[blockIdx.x];
+    p.A = it.A; p.B = it.B; p.C = it.C; p.D = it.D; p.br = (int)it.br;
+  }
   constexpr int BM = 32 * WM, BN = 32 * WN, NT = 64 * WM * WN * WK;
   constexpr int A_STAGE = BM * BK, B_STAGE = BK * BN; // floats
   constexpr int LA = (BM * BK / 4) / NT, LB = (BK * BN / 4) / NT;
@@ -90,8 +97,8 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void brgemm_f32_fast(GemmArgs p)
   // linear-id order, x fastest), and each XCD owns a compact bm x bn block of tiles so the
   // A row-panels / B column-panels it streams are shared in its private L2. Plain grids are
   // (1, tiles_n, tiles_m) with the same formula (blockIdx.x == 0).
-  const int tm = (int)(blockIdx.x >> 1) * p.tiles_m + (int)blockIdx.z;
-  const int tn = (int)(blockIdx.x & 1) * p.tiles_n + (int)blockIdx.y;
+  const int tm = items ? (int)blockIdx.z : (int)(blockIdx.x >> 1) * p.tiles_m + (int)blockIdx.z;
+  const int tn = items ? (int)blockIdx.y : (int)(blockIdx.x & 1) * p.tiles_n + (int)blockIdx.y;
   const int m0 = tm * BM, n0 = tn * BN;
 
   const float *__restrict__ A = (const float *)p.A;
@@ -572,7 +579,26 @@ static hipError_t launch_fast_t(const GemmArgs &a, hipStream_t s) {
     if (tiles_m > 65535 || tiles_n > 65535) return hipErrorInvalidValue;
     grid = dim3(1, tiles_n, tiles_m);
   }
-  hipLaunchKernelGGL((brgemm_f32_fast<WM, WN, WK, NACC, DMA>), grid, dim3(NT), lds, s, args);
+  hipLaunchKernelGGL((brgemm_f32_fast<WM, WN, WK, NACC, DMA>), grid, dim3(NT), lds, s, args, (const WorkItem *)nullptr);
+  return hipGetLastError();
+}
+
+// grouped launch of a fast tile family: one workgroup per (item, tile of the item)
+template <int WM, int WN, int WK, int NACC, bool DMA>
+static hipError_t launch_fast_grouped_t(const GemmArgs &a, const WorkItem *items, int n_items, hipStream_t s) {
+  constexpr int BM = 32 * WM, BN = 32 * WN, NT = 64 * WM * WN * WK;
+  constexpr size_t lds = (size_t)NSTAGE * (BM * BK + BK * BN) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void *)brgemm_f32_fast<WM, WN, WK, NACC, DMA>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  GemmArgs args = a;
+  args.tiles_m = args.tiles_n = 0;
+  hipLaunchKernelGGL((brgemm_f32_fast<WM, WN, WK, NACC, DMA>), dim3((unsigned)n_items, a.n / BN, a.m / BM), dim3(NT), lds, s, args,
+                     items);
   return hipGetLastError();
 }
 
@@ -607,7 +633,11 @@ static hipError_t launch_grouped_t(const GemmArgs &a, const WorkItem *items, int
   return hipGetLastError();
 }
 
-hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_items, bool vec_ok,
+static int g_num_cus = 256;
+
+hipError_t launch_bf16_grouped64(const GemmArgs &a, const WorkItem *items, int n_items, hipStream_t s); // brgemm_bf16.hip
+
+hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_items, bool vec_ok, bool out_ok,
                                hipStream_t stream) {
   if (d.m <= 0 || d.n <= 0 || n_items <= 0) return hipSuccess;
   GemmArgs a;
@@ -618,8 +648,24 @@ hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_i
   a.tiles_m = a.tiles_n = 0;
   const bool tiles_ok = vec_ok && d.m % 32 == 0 && d.n % 32 == 0 && d.k % GK == 0;
   const bool vec = tiles_ok && d.dtype == DT_F32 && !d.vnni_b && !((d.lda | d.ldb | d.stride_a | d.stride_b) & 3);
+  // f32 tiles with k a multiple of 64 (mlir-gen --tiles=64,64,64, the most common setting of the reference's
+  // benchmark configs): the fast tile families in grouped mode, the largest tile that still yields about one
+  // workgroup per CU over the whole work list (the same rule as pick_f32_variant)
+  if (vec && d.k % BK == 0 && d.variant != V_GENERIC && d.lda < (1 << 22) && d.ldb < (1 << 22) && d.ldc < (1 << 22)) {
+    const int64_t t64 = (d.m % 64 == 0 && d.n % 64 == 0) ? (int64_t)n_items * (d.m / 64) * (d.n / 64) : 0;
+    const int64_t t6432 = (d.m % 64 == 0) ? (int64_t)n_items * (d.m / 64) * (d.n / 32) : 0;
+    if (n_items <= 65535 * 32) { // grid.x carries the item index
+      if (t64 >= g_num_cus) return launch_fast_grouped_t<2, 2, 1, TPP_NACC, true>(a, items, n_items, stream);
+      if (t6432 >= g_num_cus) return launch_fast_grouped_t<2, 1, 2, TPP_NACC, true>(a, items, n_items, stream);
+      return launch_fast_grouped_t<1, 1, 4, TPP_NACC, false>(a, items, n_items, stream);
+    }
+  }
   // bf16 + VNNI-2 B with 16-byte loads: 8-element A pieces, pair-rows of B 16-byte aligned
   const bool vec16 = tiles_ok && d.dtype == DT_BF16 && d.vnni_b && !((d.lda | d.stride_a | d.stride_b) & 7) && !(d.ldb & 3);
+  // bf16 tiles of 64x64 with k a multiple of 64: the 64x64 bf16 family in grouped mode (it stores 16-byte
+  // row pieces and reads the bias 8 bytes at a time: checked per item by the queue through out_ok)
+  if (vec16 && out_ok && d.variant >= V_BF16_FAST && bf16_fast_eligible(d))
+    return launch_bf16_grouped64(a, items, n_items, stream);
   if (d.dtype == DT_F32) return vec ? launch_grouped_t<float, false, true>(a, items, n_items, stream)
                                     : launch_grouped_t<float, false, false>(a, items, n_items, stream);
   if (d.vnni_b) return vec16 ? launch_grouped_t<unsigned short, true, true>(a, items, n_items, stream)
@@ -627,7 +673,6 @@ hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_i
   return launch_grouped_t<unsigned short, false, false>(a, items, n_items, stream);
 }
 
-static int g_num_cus = 256;
 
 static int pick_f32_variant(const GemmDesc &d) {
   if (d.k <= 0 || d.k % BK) return V_GENERIC;

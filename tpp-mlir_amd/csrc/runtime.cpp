@@ -442,7 +442,7 @@ struct TileQueue {
   SpinLock mu;
   int kind = 0;               // KIND_GEMM / KIND_UNARY / KIND_BINARY of the queued invokes
   const void *desc = nullptr; // their (single) descriptor
-  bool vec_ok = true;
+  bool vec_ok = true, out_ok = true;
   int n = 0;
   Footprint reads, writes;
   DeviceRanges devmem;
@@ -464,7 +464,7 @@ struct TileQueue {
   // caller holds mu
   void flush_locked() {
     if (n == 0) return;
-    if (kind == KIND_GEMM) HIP_OK(launch_gemm_grouped(*(const GemmDesc *)desc, pinned[slot], n, vec_ok, stream));
+    if (kind == KIND_GEMM) HIP_OK(launch_gemm_grouped(*(const GemmDesc *)desc, pinned[slot], n, vec_ok, out_ok, stream));
     else if (kind == KIND_UNARY) HIP_OK(launch_unary_grouped(*(const UnaryDesc *)desc, pinned[slot], n, stream));
     else HIP_OK(launch_binary_grouped(*(const BinaryDesc *)desc, pinned[slot], n, stream));
     HIP_OK(hipEventRecord(done[slot], stream));
@@ -472,7 +472,7 @@ struct TileQueue {
     slot = (slot + 1) % SLOTS;
     n = 0;
     desc = nullptr;
-    vec_ok = true;
+    vec_ok = out_ok = true;
     reads.clear();
     writes.clear();
   }
@@ -493,7 +493,7 @@ void flush_tile_queue() {
 // operand is host memory (the caller flushes and takes the mirrored path). `in` are the operands the
 // invoke reads, `out` the one it writes (also read when the op accumulates - a superset is harmless).
 bool enqueue_item(int kind, const void *desc, const WorkItem &item, const Operand *const *in, int n_in,
-                  const Operand &out, bool vec_ok, hipStream_t s) {
+                  const Operand &out, bool vec_ok, bool out_ok, hipStream_t s) {
   TileQueue &q = tq();
   std::lock_guard<SpinLock> lk(q.mu);
   if (!q.devmem.is_device(out.ptr)) return false;
@@ -512,6 +512,7 @@ bool enqueue_item(int kind, const void *desc, const WorkItem &item, const Operan
   q.desc = desc;
   q.stream = s;
   q.vec_ok = q.vec_ok && vec_ok;
+  q.out_ok = q.out_ok && out_ok;
   q.pinned[q.slot][q.n++] = item;
   for (int i = 0; i < n_in; ++i) q.reads.insert(*in[i], anchor(*in[i]));
   q.writes.insert(out, ao);
@@ -527,7 +528,8 @@ bool try_enqueue(const GemmDesc *d, const Operand &A, const Operand &B, const Op
   if (d->m > 64 || d->n > 64) return false; // big descriptors fill the chip on their own
   const Operand *in[3] = {&A, &B, &D};
   const bool vec_ok = (((uintptr_t)A.ptr | (uintptr_t)B.ptr) & 15) == 0;
-  return enqueue_item(KIND_GEMM, d, WorkItem{A.ptr, B.ptr, C.ptr, D.ptr, br}, in, 3, C, vec_ok, s);
+  const bool out_ok = (((uintptr_t)C.ptr) & 15) == 0 && (((uintptr_t)D.ptr) & 7) == 0;
+  return enqueue_item(KIND_GEMM, d, WorkItem{A.ptr, B.ptr, C.ptr, D.ptr, br}, in, 3, C, vec_ok, out_ok, s);
 }
 
 void gemm_invoke_common(const char *who, bool want_fused, int64_t dtype, int64_t handle, void *a, int64_t off_a,
@@ -700,7 +702,7 @@ static void unary_invoke_common(const char *who, int64_t dtype, int64_t handle, 
     // small tiles of tensor.pack / unpack lowering and bias broadcasts: queued like the GEMM tiles
     if (queue_active() && !use_scalar && d->m <= 64 && d->n <= 64) {
       const Operand *in[1] = {&I};
-      if (enqueue_item(KIND_UNARY, d, WorkItem{I.ptr, nullptr, O.ptr, nullptr, 0}, in, 1, O, true, s)) return;
+      if (enqueue_item(KIND_UNARY, d, WorkItem{I.ptr, nullptr, O.ptr, nullptr, 0}, in, 1, O, true, true, s)) return;
     }
     flush_tile_queue();
   }
@@ -742,7 +744,7 @@ extern "C" void xsmm_binary_invoke(int64_t dtype, int64_t handle, void *lhs, int
   if (cfg().tile_queue.load(std::memory_order_relaxed)) {
     if (queue_active() && d->m <= 64 && d->n <= 64) {
       const Operand *in[2] = {&L, &R};
-      if (enqueue_item(KIND_BINARY, d, WorkItem{L.ptr, R.ptr, O.ptr, nullptr, 0}, in, 2, O, true, s)) return;
+      if (enqueue_item(KIND_BINARY, d, WorkItem{L.ptr, R.ptr, O.ptr, nullptr, 0}, in, 2, O, true, true, s)) return;
     }
     flush_tile_queue();
   }

@@ -54,7 +54,8 @@ struct WorkItem {
 hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C, const void *D,
                        int64_t br, hipStream_t stream);
 // n_items invokes of ONE descriptor in one launch (items: device array of WorkItem)
-hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_items, bool vec_ok,
+// vec_ok: every item's A and B are 16-byte aligned; out_ok: every item's C is 16-byte and D 8-byte aligned
+hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_items, bool vec_ok, bool out_ok,
                                hipStream_t stream);
 // fills d.variant / d.name; returns false if no kernel can run the descriptor
 bool plan_gemm(GemmDesc &d, int forced_variant);
