@@ -264,6 +264,18 @@ def test_brgemm_bf16_vnni_generic_vector_loads(rt, shape):
         assert "grouped" in name, name
 
 
+@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("shape", [(64, 48, 64, 4), (32, 48, 32, 3), (40, 48, 32, 2), (72, 100, 96, 2), (8, 4, 32, 1)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_brgemm_ragged_tiles_vector_loads(rt, dt, shape):
+    """--tiles=64,48,64 / 32,48,32 of the reference's benchmark configs and other shapes whose m / n are not
+    multiples of 32 (n a multiple of 4, k of 32): the grouped kernel's 16-byte-load path with predicated edges"""
+    m, n, k, br = shape
+    for i, kw in enumerate((dict(beta0=True, bias=True, relu=True), dict(ldc=n + 8, lda=k + 8, ldb=n + 4, offs=(8, 8, 4, 4)))):
+        name = gemm_case(rt, dt, m, n, k, br, vnni=(dt == BF16), seed=sum(shape) + i, force=8, **kw)
+        assert "grouped" in name, name
+
+
 def test_brgemm_bf16_flat_b_generic(rt):
     gemm_case(rt, BF16, 48, 40, 24, 3, vnni=False, seed=3, bias=True)
 

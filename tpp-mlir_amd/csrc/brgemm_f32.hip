@@ -439,9 +439,14 @@ __global__ __launch_bounds__(256) void brgemm_grouped(GemmArgs p, const WorkItem
 #pragma unroll
       for (int v = 0; v < 2; ++v) {
         const int q = lane + 64 * v;
-        const u32x4 a8 = *(const u32x4 *)((const unsigned short *)it.A + abase + (int64_t)(m0 + (q >> 2)) * p.lda + kk0 + 8 * (q & 3));
-        const u32x4 b8 = *(const u32x4 *)((const unsigned short *)it.B + bbase + (int64_t)((kk0 >> 1) + (q >> 3)) * (2 * p.ldb) +
-                                          2 * (n0 + 4 * (q & 7)));
+        // ragged tiles (m not a multiple of 32, n a multiple of 4 only, e.g. --tiles=64,48,64): rows / column
+        // pieces beyond the edge are zero-filled, the epilogue stores nothing there
+        u32x4 a8 = {0u, 0u, 0u, 0u}, b8 = {0u, 0u, 0u, 0u};
+        if (m0 + (q >> 2) < p.m)
+          a8 = *(const u32x4 *)((const unsigned short *)it.A + abase + (int64_t)(m0 + (q >> 2)) * p.lda + kk0 + 8 * (q & 3));
+        if (n0 + 4 * (q & 7) < p.n)
+          b8 = *(const u32x4 *)((const unsigned short *)it.B + bbase + (int64_t)((kk0 >> 1) + (q >> 3)) * (2 * p.ldb) +
+                                2 * (n0 + 4 * (q & 7)));
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           ra[2 * v + (e >> 1)][2 * (e & 1)] = __uint_as_float(a8[e] << 16);
@@ -455,9 +460,11 @@ __global__ __launch_bounds__(256) void brgemm_grouped(GemmArgs p, const WorkItem
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int q = lane + 64 * u, row = q >> 3, c4 = q & 7; // 32 rows x 8 pieces of 4 floats
-      if (VEC) {
-        ra[u] = *(const f32x4 *)((const float *)it.A + abase + (int64_t)(m0 + row) * p.lda + kk0 + 4 * c4);
-        rb[u] = *(const f32x4 *)((const float *)it.B + bbase + (int64_t)(kk0 + row) * p.ldb + n0 + 4 * c4);
+      if (VEC) { // rows / 4-column pieces beyond a ragged edge are zero-filled
+        ra[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        rb[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (m0 + row < p.m) ra[u] = *(const f32x4 *)((const float *)it.A + abase + (int64_t)(m0 + row) * p.lda + kk0 + 4 * c4);
+        if (n0 + 4 * c4 < p.n) rb[u] = *(const f32x4 *)((const float *)it.B + bbase + (int64_t)(kk0 + row) * p.ldb + n0 + 4 * c4);
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -646,12 +653,12 @@ hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_i
   a.m = (int)d.m; a.n = (int)d.n; a.k = (int)d.k; a.br = 0;
   a.ep = (d.beta0 ? EP_BETA0 : 0) | (d.bias ? EP_BIAS : 0) | (d.relu ? EP_RELU : 0);
   a.tiles_m = a.tiles_n = 0;
-  const bool tiles_ok = vec_ok && d.m % 32 == 0 && d.n % 32 == 0 && d.k % GK == 0;
+  const bool tiles_ok = vec_ok && d.n % 4 == 0 && d.k % GK == 0; // 16-byte pieces; ragged m / n edges are predicated
   const bool vec = tiles_ok && d.dtype == DT_F32 && !d.vnni_b && !((d.lda | d.ldb | d.stride_a | d.stride_b) & 3);
   // f32 tiles with k a multiple of 64 (mlir-gen --tiles=64,64,64, the most common setting of the reference's
   // benchmark configs): the fast tile families in grouped mode, the largest tile that still yields about one
   // workgroup per CU over the whole work list (the same rule as pick_f32_variant)
-  if (vec && d.k % BK == 0 && d.variant != V_GENERIC && d.lda < (1 << 22) && d.ldb < (1 << 22) && d.ldc < (1 << 22)) {
+  if (vec && d.m % 32 == 0 && d.n % 32 == 0 && d.k % BK == 0 && d.variant != V_GENERIC && d.lda < (1 << 22) && d.ldb < (1 << 22) && d.ldc < (1 << 22)) {
     const int64_t t64 = (d.m % 64 == 0 && d.n % 64 == 0) ? (int64_t)n_items * (d.m / 64) * (d.n / 64) : 0;
     const int64_t t6432 = (d.m % 64 == 0) ? (int64_t)n_items * (d.m / 64) * (d.n / 32) : 0;
     if (n_items <= 65535 * 32) { // grid.x carries the item index
@@ -758,7 +765,7 @@ hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C,
   default: break;
   }
   // everything else: the grouped kernel with a single, inline work item
-  const bool tiles_ok = aligned16 && d.m % 32 == 0 && d.n % 32 == 0 && d.k % GK == 0;
+  const bool tiles_ok = aligned16 && d.n % 4 == 0 && d.k % GK == 0; // ragged m / n edges are predicated
   const bool vec = tiles_ok && d.dtype == DT_F32 && !d.vnni_b && !((d.lda | d.ldb | d.stride_a | d.stride_b) & 3);
   const bool vec16 = tiles_ok && d.dtype == DT_BF16 && d.vnni_b && !((d.lda | d.stride_a | d.stride_b) & 7) && !(d.ldb & 3);
   if (d.dtype == DT_F32) return vec ? launch_grouped_t<float, false, true>(a, nullptr, 1, stream)
