@@ -464,6 +464,11 @@ struct TileQueue {
   // caller holds mu
   void flush_locked() {
     if (n == 0) return;
+    static const bool dry = getenv("TPP_HIP_QUEUE_DRYRUN") != nullptr; // host-cost measurements: enqueue, never launch
+    if (dry) {
+      n = 0; desc = nullptr; vec_ok = out_ok = true; reads.clear(); writes.clear();
+      return;
+    }
     if (kind == KIND_GEMM) HIP_OK(launch_gemm_grouped(*(const GemmDesc *)desc, pinned[slot], n, vec_ok, out_ok, stream));
     else if (kind == KIND_UNARY) HIP_OK(launch_unary_grouped(*(const UnaryDesc *)desc, pinned[slot], n, stream));
     else HIP_OK(launch_binary_grouped(*(const BinaryDesc *)desc, pinned[slot], n, stream));
