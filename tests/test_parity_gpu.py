@@ -260,8 +260,29 @@ def test_brgemm_bf16_vnni_generic_vector_loads(rt, shape):
     m, n, k, br = shape
     for i, kw in enumerate((dict(beta0=True), dict(bias=True, relu=True), dict(beta0=True, bias=True, ldc=n + 8, lda=k + 8,
                                                                              ldb=n + 4, offs=(8, 8, 8, 4)))):
-        name = gemm_case(rt, BF16, m, n, k, br, vnni=True, seed=sum(shape) + i, **kw)
+        name = gemm_case(rt, BF16, m, n, k, br, vnni=True, seed=sum(shape) + i, force=8, **kw)
         assert "grouped" in name, name
+
+
+BF16_SMALL = [
+    # (m, n, k, br, kwargs): 32x32 tiles, K split over the waves, fragments straight from global memory
+    (32, 32, 32, 32, dict(beta0=True)),                                   # the compiler-native bf16 tile
+    (32, 32, 32, 3, dict(bias=True, relu=True)),
+    (64, 96, 48, 3, dict(beta0=True, bias=True, ldc=104, lda=56, ldb=100, offs=(8, 8, 4, 4))),
+    (96, 32, 16, 5, dict()),                                              # beta = 1, one K step per batch element
+    (32, 64, 64, 1, dict(relu=True)),                                     # fewer K steps than waves x group
+    (256, 1024, 64, 16, dict(lda=1024, ldb=1024, sa=64, sb=65536, beta0=True, bias=True, relu=True)),  # --batch=256 layer
+    (512, 1024, 64, 16, dict(lda=1024, ldb=1024, sa=64, sb=65536, beta0=True)),                        # an 8-GPU shard
+    (64, 64, 64, 0, dict(beta0=True, bias=True)),                         # empty batch: C = bias
+    (160, 224, 80, 7, dict(sa=16, sb=32, lda=320, ldb=224, beta0=True)),  # overlapping batch elements
+]
+
+
+@pytest.mark.parametrize("case", BF16_SMALL, ids=lambda c: "m%d_n%d_k%d_br%d" % c[:4])
+def test_brgemm_bf16_small_outputs(rt, case):
+    m, n, k, br, kw = case
+    name = gemm_case(rt, BF16, m, n, k, br, vnni=True, seed=m + n + k + br, **kw)
+    assert "small" in name, name
 
 
 @pytest.mark.parametrize("dt", [F32, BF16])

@@ -67,6 +67,13 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "bf16":
     bf16_case(4096, 4096, 64, 64, force=17, tag="4096^3 forced 128x128")
     sys.exit(0)
 
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "small":
+    # small bf16 outputs: the reference's --batch=256 layers and the per-rank shards of the MLP, tile families 16 / 19
+    for m in (128, 256, 512, 1024, 2048):
+        for v in (16, 19):
+            bf16_case(m, 1024, 64, 16, force=v, tag="forced v%d" % v)
+    sys.exit(0)
+
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "big":
     for (m, n, k, br) in ((4096, 4096, 64, 64), (8192, 8192, 64, 128), (4096, 8192, 64, 64), (2048, 2048, 128, 16),
                           (4096, 1024, 64, 16), (16384, 4096, 64, 64)):

@@ -1,0 +1,173 @@
+// brgemm_bf16_small.hip - bf16 VNNI-2 BRGEMM for SMALL outputs on gfx950: one workgroup per 32 x 32
+// output tile, its four waves split K, and no LDS in the K loop at all.
+//
+// Why: the reference's own benchmark configs are dominated by --batch=256 (benchmarks/config/*): a layer
+// 256 x 1024 x 1024 has only 64 tiles of 64 x 64, so the 64 x 64 kernel leaves 3/4 of the chip idle and the
+// layer is pure latency (9.5 us, the same as fp32). With 32 x 32 tiles every CU gets a workgroup, and with
+// K split over the four waves of a workgroup NO operand is shared between waves: a wave loads its MFMA
+// fragments straight from global memory into registers -
+//   A fragment of v_mfma_f32_32x32x16_bf16: lane (i, h) holds A[i][k0 + 8h .. +8]  = one 16-byte load,
+//   B fragment: lane (j, h) holds 8 consecutive k of column j = 4 dwords of 4 consecutive VNNI pair-rows
+//               = four 4-byte loads, each coalesced over the 32 columns of the tile -
+// a whole group of K steps per burst (G steps x 8 registers, two register sets), then the MFMAs. The four
+// partial accumulators are combined once through LDS; bias / relu / (+C) / one RNE rounding as elsewhere.
+// The same kernel serves the tile queue (items != nullptr: grid (items, tiles_n, tiles_m)) for the
+// compiler-native bf16 tiles (32 x 32 x 32, 32 x 64 x 64 ...), where a batch element is 2-4 K steps.
+#include "gemm_common.h"
+#include "xsmm_desc.h"
+
+namespace tpp {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+// the operand pointers may come from the work list (generic pointers loaded from memory): say "global" explicitly,
+// or every access becomes a flat_load / flat_store
+typedef __attribute__((address_space(1))) const unsigned short g_cu16;
+typedef __attribute__((address_space(1))) const unsigned int g_cu32;
+typedef __attribute__((address_space(1))) const u32x4 g_cu32x4;
+typedef __attribute__((address_space(1))) unsigned short g_u16;
+
+constexpr int SG = 8; // K steps (of 16) per register set
+
+__global__ __launch_bounds__(256) void brgemm_bf16_small32(GemmArgs p, const WorkItem *__restrict__ items) {
+  if (items) {
+    const WorkItem it = items[blockIdx.x];
+    p.A = it.A; p.B = it.B; p.C = it.C; p.D = it.D; p.br = (int)it.br;
+  }
+  __shared__ float red[3 * 16 * 64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int tm = items ? (int)blockIdx.z : (int)(blockIdx.x >> 1) * p.tiles_m + (int)blockIdx.z;
+  const int tn = items ? (int)blockIdx.y : (int)(blockIdx.x & 1) * p.tiles_n + (int)blockIdx.y;
+  const int m0 = tm * 32, n0 = tn * 32;
+  const int spb = p.k >> 4;                // K steps per batch element
+  const int S = p.br * spb;                // K steps in total
+  const int per = (S + 3) >> 2;            // contiguous share of each wave (consecutive steps walk along cache lines)
+  int s = wave * per;
+  const int s_end = s + per < S ? s + per : S;
+
+  // per-lane operand addresses of K step 0 of batch element 0
+  g_cu16 *a_lane = (g_cu16 *)p.A + (int64_t)(m0 + li) * p.lda + 8 * lh;
+  g_cu32 *b_lane = (g_cu32 *)p.B + (int64_t)(4 * lh) * p.ldb + (n0 + li); // dwords: pair-row stride = ldb
+  // position of step s: batch element b, step kk inside it
+  int b = spb ? s / spb : 0, kk = s - b * spb;
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  u32x4 fa[2][SG], fb[2][SG];
+  // issue the loads of up to SG steps starting at (b, kk) into register set `set`; returns how many
+  auto load_group = [&](int set, int count) __attribute__((always_inline)) {
+#pragma unroll
+    for (int g = 0; g < SG; ++g) {
+      if (g < count) {
+        g_cu16 *ap = a_lane + (int64_t)b * p.stride_a + 16 * kk;
+        g_cu32 *bp = b_lane + (((int64_t)b * p.stride_b) >> 1) + (int64_t)(8 * kk) * p.ldb;
+        fa[set][g] = *(g_cu32x4 *)ap;
+        fb[set][g] = u32x4{bp[0], bp[p.ldb], bp[2 * p.ldb], bp[3 * p.ldb]};
+        if (++kk == spb) {
+          kk = 0;
+          ++b;
+        }
+      }
+    }
+  };
+  auto mul_group = [&](int set, int count) __attribute__((always_inline)) {
+#pragma unroll
+    for (int g = 0; g < SG; ++g)
+      if (g < count)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fb[set][g]), __builtin_bit_cast(bf16x8_t, fa[set][g]),
+                                                      acc, 0, 0, 0);
+  };
+  auto take = [&]() __attribute__((always_inline)) { // size of the next group of this wave's share
+    int c = s_end - s < SG ? s_end - s : SG;
+    c = c < 0 ? 0 : c;
+    s += c;
+    return c;
+  };
+  // two register sets with literal indices (register arrays must not be indexed at run time): the next
+  // group is in flight while the current one multiplies
+  int cur = take();
+  load_group(0, cur);
+  while (cur > 0) {
+    int nxt = take();
+    load_group(1, nxt);
+    mul_group(0, cur);
+    if (nxt == 0) break;
+    cur = take();
+    load_group(0, cur);
+    mul_group(1, nxt);
+  }
+
+  // combine the four K shares: waves 1..3 park theirs, wave 0 finishes
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wave - 1) * 1024 + r * 64 + lane] = acc[r];
+  }
+  __syncthreads();
+  if (wave > 0) return;
+#pragma unroll
+  for (int w = 0; w < 3; ++w)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += red[w * 1024 + r * 64 + lane];
+
+  // operands were swapped (D = B^T A^T): lane (li, lh) owns row li and, in registers 4g..4g+3, columns 8g + 4lh + (0..3)
+  typedef unsigned int u32x2d __attribute__((ext_vector_type(2)));
+  typedef __attribute__((address_space(1))) u32x2d g_u32x2;
+  typedef __attribute__((address_space(1))) const u32x2d g_cu32x2;
+  g_u16 *crow = (g_u16 *)p.C + (int64_t)(m0 + li) * p.ldc + n0 + 4 * lh;
+  g_cu16 *drow = (g_cu16 *)p.D + n0 + 4 * lh;
+  const bool relu = (p.ep & EP_RELU) != 0;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    float v[4] = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+    if (!(p.ep & EP_BETA0)) {
+      const u32x2d c2 = *(g_cu32x2 *)(crow + 8 * g);
+      v[0] += __uint_as_float(c2[0] << 16);
+      v[1] += __uint_as_float(c2[0] & 0xffff0000u);
+      v[2] += __uint_as_float(c2[1] << 16);
+      v[3] += __uint_as_float(c2[1] & 0xffff0000u);
+    }
+    if (p.ep & EP_BIAS) {
+      const u32x2d b2 = *(g_cu32x2 *)(drow + 8 * g);
+      v[0] += __uint_as_float(b2[0] << 16);
+      v[1] += __uint_as_float(b2[0] & 0xffff0000u);
+      v[2] += __uint_as_float(b2[1] << 16);
+      v[3] += __uint_as_float(b2[1] & 0xffff0000u);
+    }
+    if (relu) {
+#pragma unroll
+      for (int x = 0; x < 4; ++x) v[x] = __builtin_fmaxf(v[x], 0.0f);
+    }
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t lo = {v[0], v[1]}, hi = {v[2], v[3]};
+    const u32x2d out = {__builtin_bit_cast(unsigned int, __builtin_convertvector(lo, bf16x2_t)), // v_cvt_pk_bf16_f32 (RNE)
+                        __builtin_bit_cast(unsigned int, __builtin_convertvector(hi, bf16x2_t))};
+    *(g_u32x2 *)(crow + 8 * g) = out;
+  }
+}
+
+// preconditions (checked by the callers): bf16, VNNI-2 B, m % 32 == 0, n % 32 == 0, k % 16 == 0, lda % 8 == 0,
+// stride_a % 8 == 0, stride_b % 2 == 0, ldc % 4 == 0; A 16-byte, B 4-byte, C / D 8-byte aligned
+hipError_t launch_bf16_small32(const GemmArgs &a, const WorkItem *items, int n_items, hipStream_t s) {
+  GemmArgs args = a;
+  const int tiles_m = a.m / 32, tiles_n = a.n / 32;
+  dim3 grid;
+  if (items) {
+    args.tiles_m = args.tiles_n = 0;
+    grid = dim3((unsigned)n_items, tiles_n, tiles_m);
+  } else if ((tiles_m & 3) == 0 && (tiles_n & 1) == 0 && tiles_m / 4 <= 65535 && tiles_n / 2 <= 65535) {
+    args.tiles_m = tiles_m / 4; // XCD-blocked, as the other fast kernels
+    args.tiles_n = tiles_n / 2;
+    grid = dim3(8, args.tiles_n, args.tiles_m);
+  } else {
+    args.tiles_m = args.tiles_n = 0;
+    if (tiles_m > 65535 || tiles_n > 65535) return hipErrorInvalidValue;
+    grid = dim3(1, tiles_n, tiles_m);
+  }
+  hipLaunchKernelGGL(brgemm_bf16_small32, grid, dim3(256), 0, s, args, items);
+  return hipGetLastError();
+}
+
+} // namespace tpp

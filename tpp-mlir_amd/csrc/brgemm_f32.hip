@@ -416,6 +416,12 @@ __global__ __launch_bounds__(256) void brgemm_grouped(GemmArgs p, const WorkItem
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
   const WorkItem it = items ? items[blockIdx.y] : WorkItem{p.A, p.B, p.C, p.D, (int64_t)p.br};
+  g_cvoid *gA = (g_cvoid *)it.A, *gB = (g_cvoid *)it.B, *gD = (g_cvoid *)it.D; // global, not flat, accesses
+  g_void *gC = (g_void *)it.C;
+  typedef __attribute__((address_space(1))) const u32x4 g_cu32x4;
+  typedef __attribute__((address_space(1))) const f32x4 g_cf32x4;
+  typedef __attribute__((address_space(1))) const unsigned short g_cu16;
+  typedef __attribute__((address_space(1))) const float g_cf32;
   const int tm = blockIdx.x / p.tiles_n, tn = blockIdx.x % p.tiles_n;
   const int m0 = tm * 32, n0 = tn * 32;
   const int kchunks = (p.k + GK - 1) / GK;
@@ -443,9 +449,9 @@ __global__ __launch_bounds__(256) void brgemm_grouped(GemmArgs p, const WorkItem
         // pieces beyond the edge are zero-filled, the epilogue stores nothing there
         u32x4 a8 = {0u, 0u, 0u, 0u}, b8 = {0u, 0u, 0u, 0u};
         if (m0 + (q >> 2) < p.m)
-          a8 = *(const u32x4 *)((const unsigned short *)it.A + abase + (int64_t)(m0 + (q >> 2)) * p.lda + kk0 + 8 * (q & 3));
+          a8 = *(g_cu32x4 *)((g_cu16 *)gA + abase + (int64_t)(m0 + (q >> 2)) * p.lda + kk0 + 8 * (q & 3));
         if (n0 + 4 * (q & 7) < p.n)
-          b8 = *(const u32x4 *)((const unsigned short *)it.B + bbase + (int64_t)((kk0 >> 1) + (q >> 3)) * (2 * p.ldb) +
+          b8 = *(g_cu32x4 *)((g_cu16 *)gB + bbase + (int64_t)((kk0 >> 1) + (q >> 3)) * (2 * p.ldb) +
                                 2 * (n0 + 4 * (q & 7)));
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -463,19 +469,19 @@ __global__ __launch_bounds__(256) void brgemm_grouped(GemmArgs p, const WorkItem
       if (VEC) { // rows / 4-column pieces beyond a ragged edge are zero-filled
         ra[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         rb[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        if (m0 + row < p.m) ra[u] = *(const f32x4 *)((const float *)it.A + abase + (int64_t)(m0 + row) * p.lda + kk0 + 4 * c4);
-        if (n0 + 4 * c4 < p.n) rb[u] = *(const f32x4 *)((const float *)it.B + bbase + (int64_t)(kk0 + row) * p.ldb + n0 + 4 * c4);
+        if (m0 + row < p.m) ra[u] = *(g_cf32x4 *)((g_cf32 *)gA + abase + (int64_t)(m0 + row) * p.lda + kk0 + 4 * c4);
+        if (n0 + 4 * c4 < p.n) rb[u] = *(g_cf32x4 *)((g_cf32 *)gB + bbase + (int64_t)(kk0 + row) * p.ldb + n0 + 4 * c4);
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int gr = m0 + row, gk = kk0 + 4 * c4 + e;
-          ra[u][e] = (gr < p.m && gk < p.k) ? Elem<T>::load(it.A, abase + (int64_t)gr * p.lda + gk) : 0.0f;
+          ra[u][e] = (gr < p.m && gk < p.k) ? Elem<T>::load(gA, abase + (int64_t)gr * p.lda + gk) : 0.0f;
           const int bk = kk0 + row, bj = n0 + 4 * c4 + e;
           float v = 0.0f;
           if (bk < p.k && bj < p.n) {
             const int64_t idx = VNNI ? (int64_t)(bk >> 1) * (2 * p.ldb) + 2 * (int64_t)bj + (bk & 1)
                                      : (int64_t)bk * p.ldb + bj;
-            v = Elem<T>::load(it.B, bbase + idx);
+            v = Elem<T>::load(gB, bbase + idx);
           }
           rb[u][e] = v;
         }
@@ -536,16 +542,16 @@ __global__ __launch_bounds__(256) void brgemm_grouped(GemmArgs p, const WorkItem
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] += red[g * 1024 + r * 64 + lane];
   const int col = n0 + li;
-  const float bias = ((p.ep & EP_BIAS) && col < p.n) ? Elem<T>::load(it.D, col) : 0.0f;
+  const float bias = ((p.ep & EP_BIAS) && col < p.n) ? Elem<T>::load(gD, col) : 0.0f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = m0 + 4 * lh + (r & 3) + 8 * (r >> 2);
     if (row < p.m && col < p.n) {
       float v = acc[r];
-      if (!(p.ep & EP_BETA0)) v += Elem<T>::load(it.C, (int64_t)row * p.ldc + col);
+      if (!(p.ep & EP_BETA0)) v += Elem<T>::load((g_cvoid *)gC, (int64_t)row * p.ldc + col);
       v += bias;
       if (p.ep & EP_RELU) v = v > 0.0f ? v : 0.0f;
-      Elem<T>::store(it.C, (int64_t)row * p.ldc + col, v);
+      Elem<T>::store(gC, (int64_t)row * p.ldc + col, v);
     }
   }
 }
@@ -561,6 +567,7 @@ enum GemmVariant : int {
   V_BF16_FAST = 16,  // brgemm_bf16.hip: 64x64 register-staged
   V_BF16_DMA128 = 17, // brgemm_bf16.hip: 128x128, LDS-DMA + loader waves
   V_BF16_DMA256 = 18, // brgemm_bf16_dma256.hip: 256x256, LDS-DMA
+  V_BF16_SMALL32 = 19, // brgemm_bf16_small.hip: 32x32 tiles, 4 waves split K, fragments straight from global memory
 };
 
 template <int WM, int WN, int WK, int NACC, bool DMA>
@@ -643,6 +650,11 @@ static hipError_t launch_grouped_t(const GemmArgs &a, const WorkItem *items, int
 static int g_num_cus = 256;
 
 hipError_t launch_bf16_grouped64(const GemmArgs &a, const WorkItem *items, int n_items, hipStream_t s); // brgemm_bf16.hip
+hipError_t launch_bf16_small32(const GemmArgs &a, const WorkItem *items, int n_items, hipStream_t s); // brgemm_bf16_small.hip
+static bool bf16_small_eligible(const GemmDesc &d) {
+  return d.dtype == DT_BF16 && d.vnni_b && d.m % 32 == 0 && d.n % 32 == 0 && d.k > 0 && d.k % 16 == 0 && !(d.lda & 7) &&
+         !(d.stride_a & 7) && !(d.stride_b & 1) && !(d.ldc & 3);
+}
 
 hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_items, bool vec_ok, bool out_ok,
                                hipStream_t stream) {
@@ -671,8 +683,10 @@ hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_i
   const bool vec16 = tiles_ok && d.dtype == DT_BF16 && d.vnni_b && !((d.lda | d.stride_a | d.stride_b) & 7) && !(d.ldb & 3);
   // bf16 tiles of 64x64 with k a multiple of 64: the 64x64 bf16 family in grouped mode (it stores 16-byte
   // row pieces and reads the bias 8 bytes at a time: checked per item by the queue through out_ok)
-  if (vec16 && out_ok && d.variant >= V_BF16_FAST && bf16_fast_eligible(d))
+  if (vec16 && out_ok && d.variant >= V_BF16_FAST && d.variant != V_BF16_SMALL32 && bf16_fast_eligible(d) &&
+      (int64_t)n_items * (d.m / 64) * (d.n / 64) >= (3 * g_num_cus) / 4)
     return launch_bf16_grouped64(a, items, n_items, stream);
+  if (vec_ok && out_ok && d.variant != V_GENERIC && bf16_small_eligible(d)) return launch_bf16_small32(a, items, n_items, stream);
   if (d.dtype == DT_F32) return vec ? launch_grouped_t<float, false, true>(a, items, n_items, stream)
                                     : launch_grouped_t<float, false, false>(a, items, n_items, stream);
   if (d.vnni_b) return vec16 ? launch_grouped_t<unsigned short, true, true>(a, items, n_items, stream)
@@ -708,6 +722,7 @@ static const char *variant_name(int v) {
   case V_BF16_FAST: return "brgemm_bf16_fast<64x64>";
   case V_BF16_DMA128: return "brgemm_bf16_dma<128x128>";
   case V_BF16_DMA256: return "brgemm_bf16_dma<256x256>";
+  case V_BF16_SMALL32: return "brgemm_bf16_small<32x32,k4>";
   default: return "brgemm_grouped(generic)";
   }
 }
@@ -717,8 +732,15 @@ bool plan_gemm(GemmDesc &d, int forced_variant) {
   if (d.dtype == DT_F32 && !d.vnni_b) v = pick_f32_variant(d);
   else if (d.dtype == DT_BF16 && bf16_fast_eligible(d)) {
     v = V_BF16_FAST + pick_bf16_tile(d);
+    // small outputs (e.g. the reference's --batch=256 layers): 32x32 tiles with K split over the waves give
+    // every CU a workgroup. Measured crossover with the 64x64 family (n = 1024, K = 1024): 5.1 vs 8.4 us at 64
+    // tiles of 64x64, 7.5 vs 8.5 at 128, 12.3 vs 8.9 at 256 (profiles/r01_sweep_shapes.txt)
+    if (v == V_BF16_FAST && bf16_small_eligible(d) && (d.m / 64) * (d.n / 64) < (3 * g_num_cus) / 4) v = V_BF16_SMALL32;
     const int tile = forced_variant - V_BF16_FAST; // a forced bf16 tile is honoured if the shape divides it
     if (tile >= 0 && tile <= 2 && d.m % (64 << tile) == 0 && d.n % (64 << tile) == 0) v = forced_variant;
+    if (forced_variant == V_BF16_SMALL32 && bf16_small_eligible(d)) v = forced_variant;
+  } else if (d.dtype == DT_BF16 && bf16_small_eligible(d)) {
+    v = V_BF16_SMALL32; // k a multiple of 16 only (e.g. the compiler-native 32x32x32 tile), m or n a multiple of 32 only
   }
   if (forced_variant >= 0 && d.dtype == DT_F32 && v != V_GENERIC) {
     // honour the forced tile only if the shape divides it
@@ -747,7 +769,8 @@ hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C,
   const bool aligned16 = ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0;
   if (v != V_GENERIC && !aligned16) v = V_GENERIC;
   // the bf16 kernel stores 16-byte row pieces and reads the bias 8 bytes at a time
-  if (v >= V_BF16_FAST && ((((uintptr_t)C) & 15) || (d.bias && (((uintptr_t)D) & 7)))) v = V_GENERIC;
+  if (v >= V_BF16_FAST && v != V_BF16_SMALL32 && ((((uintptr_t)C) & 15) || (d.bias && (((uintptr_t)D) & 7)))) v = V_GENERIC;
+  if (v == V_BF16_SMALL32 && ((((uintptr_t)C) & 7) || (d.bias && (((uintptr_t)D) & 7)))) v = V_GENERIC;
   switch (v) {
   // LDS-DMA panels for every tile but the smallest: measured C2 +3 %, C3 +8 %, 4096^3 +3 %, 3 x 1024 MLP
   // at batch 512 / 1024 +5 % / +3 % over register staging. 32x32 tiles with 4 K-split waves have
@@ -762,6 +785,7 @@ hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C,
   case V_BF16_FAST:
   case V_BF16_DMA128:
   case V_BF16_DMA256: return launch_gemm_bf16_fast(v - V_BF16_FAST, a, stream);
+  case V_BF16_SMALL32: return launch_bf16_small32(a, nullptr, 1, stream);
   default: break;
   }
   // everything else: the grouped kernel with a single, inline work item

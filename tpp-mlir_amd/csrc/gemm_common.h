@@ -34,10 +34,19 @@ __device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
   return (unsigned short)(u >> 16);
 }
 
+// global-address-space views: operand pointers that come out of a work list are generic pointers loaded
+// from memory; without the explicit address space every access becomes a flat_load / flat_store
+typedef __attribute__((address_space(1))) const void g_cvoid;
+typedef __attribute__((address_space(1))) void g_void;
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
   static __device__ __forceinline__ float load(const void *p, int64_t i) { return ((const float *)p)[i]; }
   static __device__ __forceinline__ void store(void *p, int64_t i, float v) { ((float *)p)[i] = v; }
+  static __device__ __forceinline__ float load(g_cvoid *p, int64_t i) {
+    return ((__attribute__((address_space(1))) const float *)p)[i];
+  }
+  static __device__ __forceinline__ void store(g_void *p, int64_t i, float v) { ((__attribute__((address_space(1))) float *)p)[i] = v; }
 };
 template <> struct Elem<unsigned short> {
   static __device__ __forceinline__ float load(const void *p, int64_t i) {
@@ -45,6 +54,12 @@ template <> struct Elem<unsigned short> {
   }
   static __device__ __forceinline__ void store(void *p, int64_t i, float v) {
     ((unsigned short *)p)[i] = f32_to_bf16_bits(v);
+  }
+  static __device__ __forceinline__ float load(g_cvoid *p, int64_t i) {
+    return bf16_bits_to_f32(((__attribute__((address_space(1))) const unsigned short *)p)[i]);
+  }
+  static __device__ __forceinline__ void store(g_void *p, int64_t i, float v) {
+    ((__attribute__((address_space(1))) unsigned short *)p)[i] = f32_to_bf16_bits(v);
   }
 };
 
