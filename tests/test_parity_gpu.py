@@ -191,6 +191,47 @@ def test_brgemm_generic_ragged(rt, dt, shape, mode):
               vnni=(dt == BF16 and k % 2 == 0))
 
 
+@pytest.mark.parametrize("dt,ld", [(F32, (1 << 22) - 4), (F32, (1 << 22) + 4), (BF16, (1 << 21) - 8), (BF16, (1 << 22) + 8)],
+                         ids=["f32_max_fast_ld", "f32_ld_beyond_fast", "bf16_large_ld", "bf16_ld_beyond_fast"])
+def test_brgemm_huge_leading_dimensions(rt, dt, ld):
+    """leading dimensions at the edge of the fast kernels' 32-bit lane offsets (ld < 2^22) and beyond it (generic
+    kernel, 64-bit addressing): a 64 x 64 x 64 product inside ~1 GiB operands"""
+    import torch
+    m = n = k = 64
+    br = 2
+    rng = np.random.default_rng(ld & 0xffff)
+    vnni = dt == BF16
+    es = np.float32 if dt == F32 else np.uint16
+    A = np.zeros((m - 1) * ld + k * br + 8, dtype=es)
+    B = np.zeros((k * br) * ld // (1 if not vnni else 1) + 2 * ld + 8, dtype=es)
+    C = np.zeros((m - 1) * ld + n + 8, dtype=es)
+    for i in range(m):
+        A[i * ld: i * ld + k * br] = rand(rng, k * br, dt)
+        C[i * ld: i * ld + n] = rand(rng, n, dt)
+    rows_b = k * br if not vnni else (k * br) // 2
+    for r in range(rows_b):
+        w = n if not vnni else 2 * n
+        pitch = ld if not vnni else 2 * ld
+        B[r * pitch: r * pitch + w] = rand(rng, w, dt)
+    ref = C.copy()
+    sb = k * ld  # elements between batch elements of B (flat: k rows; VNNI: k/2 pair-rows of 2*ld)
+    flags = VB if vnni else 0
+    orc.brgemm(dt, m, n, k, ld, ld, ld, k, sb, flags, A, 0, B, 0, ref, 0, br)
+    h = rt.brgemm_dispatch(dt, m, n, k, ld, ld, ld, k, sb, flags)
+    dA, dB, dC = dev(A), dev(B), dev(C)
+    rt.brgemm(dt, h, dA, 0, dB, 0, dC, 0, br)
+    got = host(dC, C)
+    del dA, dB, dC
+    torch.cuda.empty_cache()
+    rows = np.concatenate([np.arange(i * ld, i * ld + n) for i in range(m)])
+    check_close(got[rows], ref[rows], dt, "huge ld %d [%s]" % (ld, rt.kernel_name(h)))
+    mask = np.ones(C.size, dtype=bool)
+    mask[rows] = False
+    assert np.array_equal(got[mask], C[mask]), "wrote outside the output window"
+    if ld >= (1 << 22):  # kernels with 32-bit lane offsets must not have been chosen
+        assert "fast" not in rt.kernel_name(h) and "dma" not in rt.kernel_name(h), rt.kernel_name(h)
+
+
 def test_brgemm_unaligned_pointers_fall_back(rt):
     # fast shape, but A/B offsets break 16-byte alignment: the runtime must pick the generic kernel
     gemm_case(rt, F32, 64, 64, 64, 2, offs=(1, 3, 0, 0), seed=5)
