@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -39,7 +40,7 @@ int main(int argc, char **argv) {
   int64_t batch = 256, tile = 32, tile_n = 0, tile_k = 0, n_iter = 100;
   std::vector<int64_t> layers = {1024, 1024, 1024, 1024};
   bool bias = false, relu = false, whole = false, print = false, c1 = false, rnd = false, bf16 = false;
-  int queue = 1;
+  int queue = 1, threads = 1;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
     auto next = [&]() { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(2); } return argv[++i]; };
@@ -52,6 +53,7 @@ int main(int argc, char **argv) {
     }
     else if (a == "-n") n_iter = atoll(next());
     else if (a == "--queue") queue = atoi(next());
+    else if (a == "--threads") threads = atoi(next()); // the tile loop of a layer is an scf.parallel (OpenMP) in the reference
     else if (a == "--bias") bias = true;
     else if (a == "--relu") relu = true;
     else if (a == "--whole-layer") whole = true;
@@ -155,10 +157,19 @@ int main(int argc, char **argv) {
         xsmm_fused_brgemm_invoke(dt, handle[l], act[l], 0, W[l], 0, act[l + 1], 0, B[l], 0, K / 64);
       } else {
         const int64_t MB = batch / tile, NB = N / tn, KB = K / tk;
-        for (int64_t i = 0; i < MB; ++i)
-          for (int64_t j = 0; j < NB; ++j)
+        auto run = [&](int64_t t0, int64_t t1) { // tiles [t0, t1) of the MB x NB grid, row-major (static schedule)
+          for (int64_t t = t0; t < t1; ++t) {
+            const int64_t i = t / NB, j = t % NB;
             xsmm_fused_brgemm_invoke(dt, handle[l], act[l], i * KB * tile * tk, W[l], j * KB * tk * tn, act[l + 1],
                                      (i * NB + j) * tile * tn, B[l], j * tn, KB);
+          }
+        };
+        if (threads <= 1) run(0, MB * NB);
+        else { // the reference's scf.parallel -> OpenMP parallel-for over the tile grid (static schedule, barrier at the end)
+          const int64_t total = MB * NB;
+#pragma omp parallel for schedule(static) num_threads(threads)
+          for (int64_t t = 0; t < total; ++t) run(t, t + 1);
+        }
       }
     }
   };

@@ -55,7 +55,7 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", SO_PATH] + objs
+    cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-pthread", "-o", SO_PATH] + objs
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stderr)
@@ -71,8 +71,8 @@ def build_tools(verbose=False):
         return None
     if os.path.exists(out) and os.path.getmtime(out) > max(os.path.getmtime(src), os.path.getmtime(SO_PATH)):
         return out
-    cmd = [hipcc(), "-O2", "-std=c++17", src, "-o", out, "-L", HERE, "-ltpp_xsmm_runner_utils",
-           "-Wl,-rpath,$ORIGIN/../tpp-mlir_amd"]
+    cmd = [hipcc(), "-O2", "-std=c++17", "-fopenmp", src, "-o", out, "-L", HERE, "-ltpp_xsmm_runner_utils",
+           "-Wl,-rpath,$ORIGIN/../tpp-mlir_amd", "-Wl,-rpath,/opt/rocm/lib/llvm/lib"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     r = subprocess.run(cmd, capture_output=True, text=True)

@@ -23,6 +23,8 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <thread>
+#include <time.h>
 #include <unordered_map>
 #include <vector>
 
@@ -424,28 +426,13 @@ struct Footprint {
   }
 };
 
-// the queue's critical sections are a few dozen nanoseconds: a spin lock costs half of an uncontended
-// pthread mutex round trip and OpenMP callers never sleep on it
-struct SpinLock {
-  std::atomic_flag f = ATOMIC_FLAG_INIT;
-  void lock() {
-    for (unsigned spins = 0; f.test_and_set(std::memory_order_acquire); ++spins) {
-      if (spins < 2000) __builtin_ia32_pause();
-      else sched_yield(); // the holder may be inside a launch or waiting for a slot: let it run
-    }
-  }
-  void unlock() { f.clear(std::memory_order_release); }
-};
-
 struct TileQueue {
   static constexpr int CAP = 4096, SLOTS = 4;
-  SpinLock mu;
   int kind = 0;               // KIND_GEMM / KIND_UNARY / KIND_BINARY of the queued invokes
   const void *desc = nullptr; // their (single) descriptor
   bool vec_ok = true, out_ok = true;
   int n = 0;
   Footprint reads, writes;
-  DeviceRanges devmem;
   WorkItem *pinned[SLOTS] = {nullptr, nullptr, nullptr, nullptr}; // host-pinned, read by the kernel over PCIe once per workgroup
   hipEvent_t done[SLOTS];
   bool used[SLOTS] = {false, false, false, false};
@@ -461,66 +448,261 @@ struct TileQueue {
       used[slot] = false;
     }
   }
-  // caller holds mu
-  void flush_locked() {
+  void flush() {
     if (n == 0) return;
     static const bool dry = getenv("TPP_HIP_QUEUE_DRYRUN") != nullptr; // host-cost measurements: enqueue, never launch
-    if (dry) {
-      n = 0; desc = nullptr; vec_ok = out_ok = true; reads.clear(); writes.clear();
-      return;
+    if (!dry) {
+      if (kind == KIND_GEMM) HIP_OK(launch_gemm_grouped(*(const GemmDesc *)desc, pinned[slot], n, vec_ok, out_ok, stream));
+      else if (kind == KIND_UNARY) HIP_OK(launch_unary_grouped(*(const UnaryDesc *)desc, pinned[slot], n, stream));
+      else HIP_OK(launch_binary_grouped(*(const BinaryDesc *)desc, pinned[slot], n, stream));
+      HIP_OK(hipEventRecord(done[slot], stream));
+      used[slot] = true;
+      slot = (slot + 1) % SLOTS;
     }
-    if (kind == KIND_GEMM) HIP_OK(launch_gemm_grouped(*(const GemmDesc *)desc, pinned[slot], n, vec_ok, out_ok, stream));
-    else if (kind == KIND_UNARY) HIP_OK(launch_unary_grouped(*(const UnaryDesc *)desc, pinned[slot], n, stream));
-    else HIP_OK(launch_binary_grouped(*(const BinaryDesc *)desc, pinned[slot], n, stream));
-    HIP_OK(hipEventRecord(done[slot], stream));
-    used[slot] = true;
-    slot = (slot + 1) % SLOTS;
     n = 0;
     desc = nullptr;
     vec_ok = out_ok = true;
     reads.clear();
     writes.clear();
   }
-  void flush() {
-    std::lock_guard<SpinLock> lk(mu);
-    flush_locked();
-  }
 };
-TileQueue &tq() {
-  static TileQueue q;
-  return q;
-}
-void flush_tile_queue() {
-  if (cfg().tile_queue.load(std::memory_order_relaxed)) tq().flush();
-}
 
-// Appends one invoke of (kind, desc) to the queue; true if queued (nothing launched yet), false if an
-// operand is host memory (the caller flushes and takes the mirrored path). `in` are the operands the
-// invoke reads, `out` the one it writes (also read when the op accumulates - a superset is harmless).
-bool enqueue_item(int kind, const void *desc, const WorkItem &item, const Operand *const *in, int n_in,
-                  const Operand &out, bool vec_ok, bool out_ok, hipStream_t s) {
-  TileQueue &q = tq();
-  std::lock_guard<SpinLock> lk(q.mu);
-  if (!q.devmem.is_device(out.ptr)) return false;
-  for (int i = 0; i < n_in; ++i)
-    if (!q.devmem.is_device(in[i]->ptr)) return false;
-  auto anchor = [&](const Operand &o) { return o.rows ? q.devmem.base_of(o.ptr) : (uintptr_t)0; };
-  const uintptr_t ao = anchor(out);
-  bool conflict = q.n > 0 && (q.kind != kind || q.desc != desc || q.stream != s || q.n >= TileQueue::CAP);
+// What a caller hands over: one invoke with its footprints (resolved on the caller's thread) - or a fence.
+struct QEntry {
+  int kind = 0; // KIND_GEMM / KIND_UNARY / KIND_BINARY; 0 = fence
+  const void *desc = nullptr;
+  WorkItem w{};
+  Operand out{}, in[3]{};
+  uintptr_t anchor_out = 0, anchor_in[3] = {0, 0, 0};
+  int n_in = 0;
+  bool vec_ok = true, out_ok = true;
+  hipStream_t stream = nullptr;
+  std::atomic<int> *fence = nullptr;
+};
+
+// appends one invoke to the group being collected, launching the group first if the invoke conflicts with it
+inline void process_ops(TileQueue &q, int kind, const void *desc, const WorkItem &w, const Operand &out, uintptr_t anchor_out,
+                        const Operand *const *in, const uintptr_t *anchor_in, int n_in, bool vec_ok, bool out_ok,
+                        hipStream_t stream) {
+  bool conflict = q.n > 0 && (q.kind != kind || q.desc != desc || q.stream != stream || q.n >= TileQueue::CAP);
   if (!conflict && q.n > 0) {
-    conflict = q.writes.overlaps(out, ao) || q.reads.overlaps(out, ao);
-    for (int i = 0; i < n_in && !conflict; ++i) conflict = q.writes.overlaps(*in[i], anchor(*in[i]));
+    conflict = q.writes.overlaps(out, anchor_out) || q.reads.overlaps(out, anchor_out);
+    for (int i = 0; i < n_in && !conflict; ++i) conflict = q.writes.overlaps(*in[i], anchor_in[i]);
   }
-  if (conflict) q.flush_locked();
+  if (conflict) q.flush();
   q.ensure_slot();
   q.kind = kind;
   q.desc = desc;
-  q.stream = s;
+  q.stream = stream;
   q.vec_ok = q.vec_ok && vec_ok;
   q.out_ok = q.out_ok && out_ok;
-  q.pinned[q.slot][q.n++] = item;
-  for (int i = 0; i < n_in; ++i) q.reads.insert(*in[i], anchor(*in[i]));
-  q.writes.insert(out, ao);
+  q.pinned[q.slot][q.n++] = w;
+  for (int i = 0; i < n_in; ++i) q.reads.insert(*in[i], anchor_in[i]);
+  q.writes.insert(out, anchor_out);
+}
+inline void process_entry(TileQueue &q, const QEntry &e) {
+  const Operand *in[3] = {&e.in[0], &e.in[1], &e.in[2]};
+  process_ops(q, e.kind, e.desc, e.w, e.out, e.anchor_out, in, e.anchor_in, e.n_in, e.vec_ok, e.out_ok, e.stream);
+}
+
+// The scheduler. The reference calls invoke from OpenMP workers (scf.parallel over the tile grid): with one
+// lock around the dependence bookkeeping eight callers took 290 us for what one caller did in 45 (lock
+// hand-offs, and interleaved callers defeat the interval merging). Callers therefore only PUSH their invoke
+// into a bounded multi-producer ring (one fetch_add + a 300-byte store); a single scheduler thread pops in
+// ticket order - a linearisation that respects every caller's program order and every happens-before
+// between callers (an OpenMP barrier orders the tickets) - does the dependence bookkeeping without any
+// lock, and launches a group whenever the next invoke conflicts with it. Callers never touch HIP on this
+// path; launches and slot waits happen on the scheduler thread, overlapped with the callers.
+struct Scheduler {
+  static constexpr uint64_t N = 8192, MASK = N - 1;
+  struct alignas(64) Slot {
+    std::atomic<uint64_t> seq;
+    QEntry e;
+  };
+  Slot *ring = nullptr;
+  alignas(64) std::atomic<uint64_t> tail{0};       // next ticket
+  alignas(64) std::atomic<uint64_t> clean_upto{0}; // every ticket below this has been launched (or was a fence)
+  std::atomic<bool> stop{false};
+  std::thread worker;
+  int device = 0;
+  TileQueue q;
+
+  Scheduler() {
+    ring = new Slot[N];
+    for (uint64_t i = 0; i < N; ++i) ring[i].seq.store(i, std::memory_order_relaxed);
+    if (hipGetDevice(&device) != hipSuccess) device = 0;
+    worker = std::thread([this] { run(); });
+  }
+  ~Scheduler() {
+    stop.store(true);
+    if (worker.joinable()) worker.join();
+  }
+  void push(const QEntry &e) {
+    const uint64_t pos = tail.fetch_add(1, std::memory_order_acq_rel);
+    Slot &s = ring[pos & MASK];
+    for (unsigned spins = 0; s.seq.load(std::memory_order_acquire) != pos; ++spins) { // ring full: wait for the scheduler
+      if (spins < 2000) __builtin_ia32_pause();
+      else sched_yield();
+    }
+    s.e = e;
+    s.seq.store(pos + 1, std::memory_order_release);
+  }
+  // everything pushed before this call has been launched on return
+  void drain() {
+    const uint64_t t = tail.load(std::memory_order_acquire);
+    if (clean_upto.load(std::memory_order_acquire) >= t) return;
+    std::atomic<int> flag{0};
+    QEntry f;
+    f.fence = &flag;
+    push(f);
+    for (unsigned spins = 0; !flag.load(std::memory_order_acquire); ++spins) {
+      if (spins < 4000) __builtin_ia32_pause();
+      else sched_yield();
+    }
+  }
+  void process(const QEntry &e) { process_entry(q, e); }
+  void run() {
+    // the creating thread may be pinned (OMP_PROC_BIND, taskset of one core): inheriting that mask would
+    // put the scheduler on the caller's own core. Ask for every CPU the process is allowed to use.
+    cpu_set_t all;
+    CPU_ZERO(&all);
+    for (int c = 0; c < CPU_SETSIZE; ++c) CPU_SET(c, &all);
+    (void)sched_setaffinity(0, sizeof(all), &all);
+    (void)hipSetDevice(device);
+    uint64_t head = 0;
+    unsigned idle = 0;
+    for (;;) {
+      Slot &s = ring[head & MASK];
+      if (s.seq.load(std::memory_order_acquire) == head + 1) {
+        const QEntry e = s.e;
+        s.seq.store(head + N, std::memory_order_release); // the slot is free for the next lap
+        ++head;
+        idle = 0;
+        if (e.kind == 0) {
+          q.flush();
+          clean_upto.store(head, std::memory_order_release);
+          e.fence->store(1, std::memory_order_release);
+        } else {
+          process(e);
+        }
+      } else {
+        if (stop.load(std::memory_order_relaxed)) break;
+        if (++idle < 4000) __builtin_ia32_pause();
+        else if (idle < 20000) sched_yield();
+        else { // nothing for a long while: stop burning a core (a caller that arrives now waits one nap)
+          timespec ts{0, idle < 40000 ? 50000 : 1000000}; // 50 us naps, then 1 ms naps
+          nanosleep(&ts, nullptr);
+          if (idle > 1000000) idle = 40000;
+        }
+      }
+    }
+  }
+};
+std::atomic<Scheduler *> g_sched{nullptr};
+std::mutex g_sched_mu;
+Scheduler &sched() {
+  Scheduler *p = g_sched.load(std::memory_order_acquire);
+  if (!p) {
+    std::lock_guard<std::mutex> lk(g_sched_mu);
+    p = g_sched.load(std::memory_order_relaxed);
+    if (!p) {
+      static Scheduler the_scheduler; // destroyed (worker joined) at process exit
+      p = &the_scheduler;
+      g_sched.store(p, std::memory_order_release);
+    }
+  }
+  return *p;
+}
+// Two ways into the queue state. INLINE (the default): the caller does the bookkeeping itself under a spin
+// lock - the cheapest path for one caller (45 ns per invoke; handing entries to another core costs several
+// cache-line transfers each). SCHEDULED: as soon as a second thread shows up inside one epoch (the reference's
+// OpenMP workers), the process switches - once, for good - to the ring + scheduler thread above.
+struct SpinLock {
+  std::atomic_flag f = ATOMIC_FLAG_INIT;
+  void lock() {
+    for (unsigned spins = 0; f.test_and_set(std::memory_order_acquire); ++spins) {
+      if (spins < 2000) __builtin_ia32_pause();
+      else sched_yield();
+    }
+  }
+  void unlock() { f.clear(std::memory_order_release); }
+};
+struct InlineQueue {
+  SpinLock mu;
+  TileQueue q;
+  std::atomic<bool> scheduled{false}; // one-way switch, flipped under mu after q has been flushed
+  uint64_t owner = 0;                 // thread that queued last (under mu)
+  int foreign = 0;                    // arrivals of other threads since the last flush point
+};
+InlineQueue &inl() {
+  static InlineQueue i;
+  return i;
+}
+inline uint64_t this_thread_tag() {
+  thread_local char tag;
+  return (uint64_t)(uintptr_t)&tag;
+}
+void flush_tile_queue() {
+  if (!cfg().tile_queue.load(std::memory_order_relaxed)) return;
+  InlineQueue &iq = inl();
+  if (!iq.scheduled.load(std::memory_order_acquire)) {
+    std::lock_guard<SpinLock> lk(iq.mu);
+    if (!iq.scheduled.load(std::memory_order_relaxed)) {
+      iq.q.flush();
+      iq.foreign = 0;
+      return;
+    }
+  }
+  if (Scheduler *p = g_sched.load(std::memory_order_acquire)) p->drain();
+}
+
+// Queues one invoke of (kind, desc); true if queued (nothing launched yet), false if an operand is host
+// memory (the caller flushes and takes the mirrored path). `in` are the operands the invoke reads, `out`
+// the one it writes (also read when the op accumulates - a superset is harmless).
+bool enqueue_item(int kind, const void *desc, const WorkItem &item, const Operand *const *in, int n_in,
+                  const Operand &out, bool vec_ok, bool out_ok, hipStream_t s) {
+  thread_local DeviceRanges devmem; // per caller: no sharing, no lock
+  if (!devmem.is_device(out.ptr)) return false;
+  for (int i = 0; i < n_in; ++i)
+    if (!devmem.is_device(in[i]->ptr)) return false;
+  auto anchor = [&](const Operand &o) { return o.rows ? devmem.base_of(o.ptr) : (uintptr_t)0; };
+  const uintptr_t anchor_out = anchor(out);
+  uintptr_t anchor_in[3] = {0, 0, 0};
+  for (int i = 0; i < n_in; ++i) anchor_in[i] = anchor(*in[i]);
+  InlineQueue &iq = inl();
+  if (!iq.scheduled.load(std::memory_order_acquire)) {
+    std::lock_guard<SpinLock> lk(iq.mu);
+    if (!iq.scheduled.load(std::memory_order_relaxed)) {
+      const uint64_t me = this_thread_tag();
+      if (iq.owner != me) {
+        if (iq.owner != 0 && ++iq.foreign > 4) { // several threads are queueing concurrently: hand over to the scheduler
+          iq.q.flush();
+          (void)sched(); // start it
+          iq.scheduled.store(true, std::memory_order_release);
+        }
+        iq.owner = me;
+      }
+      if (!iq.scheduled.load(std::memory_order_relaxed)) {
+        process_ops(iq.q, kind, desc, item, out, anchor_out, in, anchor_in, n_in, vec_ok, out_ok, s);
+        return true;
+      }
+    }
+  }
+  QEntry e;
+  e.kind = kind;
+  e.desc = desc;
+  e.w = item;
+  e.out = out;
+  e.anchor_out = anchor_out;
+  e.n_in = n_in;
+  for (int i = 0; i < n_in; ++i) {
+    e.in[i] = *in[i];
+    e.anchor_in[i] = anchor_in[i];
+  }
+  e.vec_ok = vec_ok;
+  e.out_ok = out_ok;
+  e.stream = s;
+  sched().push(e);
   return true;
 }
 
