@@ -320,8 +320,20 @@ struct IntervalSet {
 // Device allocations seen so far ([base, base+size) from hipMemGetAddressRange). Only used
 // by the tile queue: its callers issue hundreds of invokes per layer on the same few
 // allocations, and one driver query per operand per invoke would dominate the host time.
+// Bumped at the explicit synchronisation points (xsmm_hip_synchronize, perf_stop_timer): the caller may free and
+// re-allocate buffers after those, so cached allocation ranges are only trusted within one such epoch.
+std::atomic<uint64_t> g_devmem_epoch{1};
+
 struct DeviceRanges {
   std::vector<Range> known;
+  uint64_t epoch = 0;
+  void refresh() {
+    const uint64_t e = g_devmem_epoch.load(std::memory_order_relaxed);
+    if (e != epoch) {
+      known.clear();
+      epoch = e;
+    }
+  }
   mutable size_t mru = 0; // index of the last hit: operands of consecutive invokes share allocations
   bool contains(const void *p) const {
     const uintptr_t a = (uintptr_t)p;
@@ -662,6 +674,7 @@ void flush_tile_queue() {
 bool enqueue_item(int kind, const void *desc, const WorkItem &item, const Operand *const *in, int n_in,
                   const Operand &out, bool vec_ok, bool out_ok, hipStream_t s) {
   thread_local DeviceRanges devmem; // per caller: no sharing, no lock
+  devmem.refresh();
   if (!devmem.is_device(out.ptr)) return false;
   for (int i = 0; i < n_in; ++i)
     if (!devmem.is_device(in[i]->ptr)) return false;
@@ -953,6 +966,7 @@ extern "C" int64_t perf_start_timer(void) {
 
 extern "C" double perf_stop_timer(int64_t start) {
   flush_tile_queue();
+  g_devmem_epoch.fetch_add(1, std::memory_order_relaxed);
   if (cfg().async.load()) (void)hipStreamSynchronize(cfg().stream.load());
   const int64_t now = std::chrono::duration_cast<std::chrono::nanoseconds>(
                           std::chrono::high_resolution_clock::now().time_since_epoch())
@@ -977,6 +991,7 @@ extern "C" void xsmm_hip_flush(void) { flush_tile_queue(); }
 extern "C" void *xsmm_hip_get_stream(void) { return (void *)cfg().stream.load(); }
 extern "C" void xsmm_hip_synchronize(void) {
   flush_tile_queue();
+  g_devmem_epoch.fetch_add(1, std::memory_order_relaxed);
   HIP_OK(hipStreamSynchronize(cfg().stream.load()));
 }
 extern "C" int xsmm_hip_device_count(void) {
