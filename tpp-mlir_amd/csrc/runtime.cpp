@@ -120,6 +120,59 @@ bool is_device_ptr(const void *p) {
   return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged || attr.type == hipMemoryTypeArray;
 }
 
+struct Range {
+  uintptr_t b, e;
+};
+
+// Device allocations seen so far ([base, base+size) from hipMemGetAddressRange). Only used
+// by the tile queue: its callers issue hundreds of invokes per layer on the same few
+// allocations, and one driver query per operand per invoke would dominate the host time.
+// Bumped at the explicit synchronisation points (xsmm_hip_synchronize, perf_stop_timer): the caller may free and
+// re-allocate buffers after those, so cached allocation ranges are only trusted within one such epoch.
+std::atomic<uint64_t> g_devmem_epoch{1};
+
+struct DeviceRanges {
+  std::vector<Range> known;
+  uint64_t epoch = 0;
+  void refresh() {
+    const uint64_t e = g_devmem_epoch.load(std::memory_order_relaxed);
+    if (e != epoch) {
+      known.clear();
+      epoch = e;
+    }
+  }
+  mutable size_t mru = 0; // index of the last hit: operands of consecutive invokes share allocations
+  bool contains(const void *p) const {
+    const uintptr_t a = (uintptr_t)p;
+    if (mru < known.size() && a >= known[mru].b && a < known[mru].e) return true;
+    for (size_t i = 0; i < known.size(); ++i)
+      if (a >= known[i].b && a < known[i].e) {
+        mru = i;
+        return true;
+      }
+    return false;
+  }
+  uintptr_t base_of(const void *p) const { // allocation base, 0 if unknown
+    const uintptr_t a = (uintptr_t)p;
+    for (const Range &r : known)
+      if (a >= r.b && a < r.e) return r.b;
+    return 0;
+  }
+  bool is_device(const void *p) {
+    if (!p || contains(p)) return true;
+    if (!is_device_ptr(p)) return false;
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)p) == hipSuccess && size) {
+      if (known.size() >= 64) known.erase(known.begin());
+      known.push_back(Range{(uintptr_t)base, (uintptr_t)base + size});
+    } else {
+      (void)hipGetLastError();
+    }
+    return true;
+  }
+};
+
 // One operand of an invoke: [ptr, ptr + bytes), read and/or written by the kernel.
 struct Operand {
   void *ptr;
@@ -148,8 +201,13 @@ struct Mirror {
 std::vector<Mirror> stage_in(std::vector<Operand *> &ops, hipStream_t s) {
   std::vector<Mirror> mirrors;
   std::vector<Operand *> host_ops;
+  // async mode: device allocations seen in this synchronisation epoch cost one driver query each. In the
+  // (default) synchronous mode every invoke is a point after which the caller may free buffers: query each time.
+  thread_local DeviceRanges devmem;
+  if (cfg().async.load(std::memory_order_relaxed)) devmem.refresh();
+  else devmem.known.clear();
   for (Operand *o : ops) {
-    if (!o->ptr || o->bytes == 0 || is_device_ptr(o->ptr)) o->dev = o->ptr;
+    if (!o->ptr || o->bytes == 0 || devmem.is_device(o->ptr)) o->dev = o->ptr;
     else host_ops.push_back(o);
   }
   if (host_ops.empty()) return mirrors;
@@ -268,9 +326,6 @@ int64_t gemm_dispatch_common(const char *who, int has_batch, int fused, int64_t 
 // synchronize / perf_stop_timer, or leaving async mode. Program order is preserved: a new
 // invoke that reads or overwrites anything a queued invoke writes (or overwrites anything a
 // queued invoke reads) flushes first, so queued invokes are always mutually independent.
-struct Range {
-  uintptr_t b, e;
-};
 // union of half-open intervals: a sorted vector of disjoint ranges (a handful in practice - queued
 // operands of one layer merge into a few runs - so a contiguous array beats a node-based map; the
 // enqueue path runs 9 of these operations per invoke and is the throughput limit of the tile queue)
@@ -314,55 +369,6 @@ struct IntervalSet {
       iv[i] = r;
       if (j > i + 1) iv.erase(iv.begin() + i + 1, iv.begin() + j);
     }
-  }
-};
-
-// Device allocations seen so far ([base, base+size) from hipMemGetAddressRange). Only used
-// by the tile queue: its callers issue hundreds of invokes per layer on the same few
-// allocations, and one driver query per operand per invoke would dominate the host time.
-// Bumped at the explicit synchronisation points (xsmm_hip_synchronize, perf_stop_timer): the caller may free and
-// re-allocate buffers after those, so cached allocation ranges are only trusted within one such epoch.
-std::atomic<uint64_t> g_devmem_epoch{1};
-
-struct DeviceRanges {
-  std::vector<Range> known;
-  uint64_t epoch = 0;
-  void refresh() {
-    const uint64_t e = g_devmem_epoch.load(std::memory_order_relaxed);
-    if (e != epoch) {
-      known.clear();
-      epoch = e;
-    }
-  }
-  mutable size_t mru = 0; // index of the last hit: operands of consecutive invokes share allocations
-  bool contains(const void *p) const {
-    const uintptr_t a = (uintptr_t)p;
-    if (mru < known.size() && a >= known[mru].b && a < known[mru].e) return true;
-    for (size_t i = 0; i < known.size(); ++i)
-      if (a >= known[i].b && a < known[i].e) {
-        mru = i;
-        return true;
-      }
-    return false;
-  }
-  uintptr_t base_of(const void *p) const { // allocation base, 0 if unknown
-    const uintptr_t a = (uintptr_t)p;
-    for (const Range &r : known)
-      if (a >= r.b && a < r.e) return r.b;
-    return 0;
-  }
-  bool is_device(const void *p) {
-    if (!p || contains(p)) return true;
-    if (!is_device_ptr(p)) return false;
-    hipDeviceptr_t base = nullptr;
-    size_t size = 0;
-    if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)p) == hipSuccess && size) {
-      if (known.size() >= 64) known.erase(known.begin());
-      known.push_back(Range{(uintptr_t)base, (uintptr_t)base + size});
-    } else {
-      (void)hipGetLastError();
-    }
-    return true;
   }
 };
 
