@@ -451,18 +451,9 @@ __global__ __launch_bounds__(256 + 64 * NLW) void brgemm_bf16_dma128(GemmArgs p)
     const int rowb = 2 * v + (lane >> 5);
     voffB[u] = (unsigned)(rowb * (int)p.ldb * 4 + ((lane & 31) << 4));
   }
-  // K rotation: every tile walks the same (batch, k) chunks but starts at a different one
-  // (and wraps), so the workgroups of one XCD do not all ask its L2 for the same lines at
-  // the same moment. The sum is over the same terms in a rotated order (still fixed per tile).
-#ifndef TPP_BF16_ROTATE
-#define TPP_BF16_ROTATE 0
-#endif
-  const int rot = (TPP_BF16_ROTATE && T > 1) ? (int)((blockIdx.y * 5u + blockIdx.z * 3u + blockIdx.x) % (unsigned)T) : 0;
-  const int rb = rot / kchunks, rk = rot - rb * kchunks; // first chunk = (batch rb, k-chunk rk)
-  const unsigned short *const gA0 = A + (int64_t)m0 * p.lda, *const gB0 = B + 2 * (int64_t)n0;
-  const unsigned short *gA = gA0 + (int64_t)rb * p.stride_a + (int64_t)rk * BKH;
-  const unsigned short *gB = gB0 + (int64_t)rb * p.stride_b + (int64_t)rk * (BKH / 2) * 2 * p.ldb;
-  int kc = rk, cabs = rot; // k-chunk inside the batch element / absolute chunk index (wraps at T)
+  // panel base of the chunk being fetched (wave-uniform) and its position inside the batch element
+  const unsigned short *gA = A + (int64_t)m0 * p.lda, *gB = B + 2 * (int64_t)n0;
+  int kc = 0;
   const int64_t dA_wrap = p.stride_a - (int64_t)(kchunks - 1) * BKH;
   const int64_t dB_in = (int64_t)(BKH / 2) * 2 * p.ldb, dB_wrap = p.stride_b - (int64_t)(kchunks - 1) * dB_in;
   // one of this wave's 8 DMA instructions of the chunk at (gA, gB): pieces 0-3 A, 4-7 B
@@ -480,21 +471,16 @@ __global__ __launch_bounds__(256 + 64 * NLW) void brgemm_bf16_dma128(GemmArgs p)
 #pragma unroll
     for (int u = 0; u < 8; ++u) dma_piece(slot, u);
   };
-#define TPP_DMA_ADVANCE()         \
-  do {                            \
-    if (++cabs == T) {            \
-      cabs = 0;                   \
-      kc = 0;                     \
-      gA = gA0;                   \
-      gB = gB0;                   \
-    } else if (++kc == kchunks) { \
-      kc = 0;                     \
-      gA += dA_wrap;              \
-      gB += dB_wrap;              \
-    } else {                      \
-      gA += BKH;                  \
-      gB += dB_in;                \
-    }                             \
+#define TPP_DMA_ADVANCE()      \
+  do {                         \
+    if (++kc == kchunks) {     \
+      kc = 0;                  \
+      gA += dA_wrap;           \
+      gB += dB_wrap;           \
+    } else {                   \
+      gA += BKH;               \
+      gB += dB_in;             \
+    }                          \
   } while (0)
 
   if (LW && wave >= 4) {
@@ -541,11 +527,6 @@ __global__ __launch_bounds__(256 + 64 * NLW) void brgemm_bf16_dma128(GemmArgs p)
     return; // ended waves do not take part in later barriers
   }
 
-#ifndef TPP_BF16_SETPRIO
-#define TPP_BF16_SETPRIO 0
-#endif
-  // optional static priority of the MFMA waves over the loader waves (A/B measured: no effect)
-  if (LW && TPP_BF16_SETPRIO) __builtin_amdgcn_s_setprio(2);
   f32x16 acc[TM][TN];
   constexpr int NFB = 4; // fragment buffers: step q+2 is read while step q multiplies
   bf16x8_t af[NFB][TM];
@@ -662,15 +643,6 @@ __global__ __launch_bounds__(256 + 64 * NLW) void brgemm_bf16_dma128(GemmArgs p)
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-#ifndef TPP_BF16_ACC_AGPR
-#define TPP_BF16_ACC_AGPR 0
-#endif
-  if (TPP_BF16_ACC_AGPR) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) asm volatile("" : "+a"(acc[i][j]));
-  }
   if (!LW) {
     if (T > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DMA_PER_CHUNK) : "memory");
     else if (T > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_CHUNK) : "memory");
