@@ -797,11 +797,13 @@ hipError_t launch_bf16_dma256(const GemmArgs &a, hipStream_t s); // brgemm_bf16_
 //  * 256 x 256 (LDS / L2 traffic per flop halves: measured 1.31-1.37 vs 0.88-1.03 PFLOP/s on 4096^3 ..
 //    8192^3) when its tile waves fill the 256 CUs well enough to keep that 1.4x: tiles run one per CU,
 //    so a grid of t tiles takes ceil(t / 256) rounds;
-//  * 128 x 128 from ~100 tiles (measured: 128 tiles -> the DMA kernel wins, 64 tiles -> 64x64 wins,
-//    profiles/r01_sweep_shapes.txt);  * 64 x 64 below that, so that more CUs have work.
+//  * 128 x 128 as soon as the 64 x 64 family would need a second round of workgroups (more than 256 tiles of
+//    64 x 64 = more than 64 of 128 x 128): measured (n = 1024, K = 1024) the DMA kernel takes 9.2-9.4 us from 64
+//    to 256 tiles while the 64 x 64 family jumps from 9.1 to 12.8 us past one tile per CU (tools/mid_probe.py);
+//  * 64 x 64 below that, so that more CUs have work.
 int pick_bf16_tile(const GemmDesc &d) {
   static const int64_t t256_min = getenv("TPP_HIP_BF16_T256MIN") ? atoll(getenv("TPP_HIP_BF16_T256MIN")) : 240;
-  static const int64_t t128_min = getenv("TPP_HIP_BF16_T128MIN") ? atoll(getenv("TPP_HIP_BF16_T128MIN")) : 100;
+  static const int64_t t128_min = getenv("TPP_HIP_BF16_T128MIN") ? atoll(getenv("TPP_HIP_BF16_T128MIN")) : 65;
   const int64_t t256 = (d.m % 256 == 0 && d.n % 256 == 0) ? (d.m / 256) * (d.n / 256) : 0;
   const int64_t t128 = (d.m % 128 == 0 && d.n % 128 == 0) ? (d.m / 128) * (d.n / 128) : 0;
   auto fill = [](int64_t t) { return (double)t / (double)(((t + 255) / 256) * 256); }; // CU occupancy over the rounds
