@@ -701,9 +701,15 @@ static int pick_f32_variant(const GemmDesc &d) {
   if (d.lda >= (1 << 22) || d.ldb >= (1 << 22) || d.ldc >= (1 << 22)) return V_GENERIC; // 32-bit lane offsets
   const int64_t m = d.m, n = d.n;
   auto tiles = [&](int bm, int bn) { return (m % bm == 0 && n % bn == 0) ? (m / bm) * (n / bn) : 0; };
-  // largest tile that still gives every CU a workgroup; else the smallest tile
-  if (tiles(128, 64) >= 2 * g_num_cus) return V_F32_128x64;
-  if (tiles(64, 64) >= g_num_cus) return V_F32_64x64;
+  // Outputs with at least one 64x64 tile per CU: 64x64 or 128x64 tiles, whichever needs less time over its rounds
+  // of workgroups (one per CU at a time). A 128x64 round takes ~1.85x a 64x64 round (measured, K = 1024: 32.7 vs
+  // 17.6 us), so 128x64 wins at 1280-2048 x 1024 (one round instead of two) and for large outputs (0.93x), and
+  // loses e.g. at 3072 x 1024 (two rounds against three; tools/mid_probe.py).
+  if (tiles(64, 64) >= g_num_cus) {
+    const int64_t r64 = (tiles(64, 64) + g_num_cus - 1) / g_num_cus, r128 = (tiles(128, 64) + g_num_cus - 1) / g_num_cus;
+    if (tiles(128, 64) > 0 && 1.85 * (double)r128 < (double)r64) return V_F32_128x64;
+    return V_F32_64x64;
+  }
   if (tiles(64, 32) >= g_num_cus) return V_F32_64x32K2;
   if (tiles(32, 32) > 0 && tiles(32, 32) >= tiles(64, 64) * 2 && tiles(64, 32) < g_num_cus) return V_F32_32x32K4;
   if (tiles(64, 64) > 0) return V_F32_64x64;
