@@ -152,8 +152,24 @@ def cpu_baseline(seconds, A, B, C):
         el = time.perf_counter() - t0
         if el >= seconds or reps >= 2000:
             break
+    # context: a tuned vendor CPU GEMM on the same host (torch.matmul -> MKL / oneDNN, all cores), the same product as
+    # ONE 1024 x 1024 x 1024 matmul; not the reference's libxsmm (not in the image), not the checker
+    vendor = None
+    try:
+        import torch
+        ta = torch.from_numpy(A.reshape(1024, 1024).copy())
+        tb = torch.from_numpy(B.reshape(1024, 1024).copy())
+        for _ in range(3):
+            torch.matmul(ta, tb)
+        n_v, t1 = 0, time.perf_counter()
+        while time.perf_counter() - t1 < 2.0:
+            torch.matmul(ta, tb)
+            n_v += 1
+        vendor = {"torch_cpu_matmul_gflops": round(flops * n_v / (time.perf_counter() - t1) / 1e9, 1), "torch_threads": torch.get_num_threads()}
+    except Exception:
+        pass
     return {"value": round(flops * reps / el / 1e9, 2), "unit": "GFLOP/s", "cores": orc.num_threads(),
-            "kind": "port",
+            "kind": "port", "vendor_cpu_gemm": vendor,
             "sample": "%d full passes of the same BRGEMM 1024^3 br=16 (%.1f s) by oracle/xsmm_oracle.c "
                       "(OpenMP over 32-row output blocks; libxsmm itself is not in the image)" % (reps, el)}
 
