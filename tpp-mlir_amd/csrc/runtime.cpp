@@ -124,11 +124,11 @@ struct Range {
   uintptr_t b, e;
 };
 
-// Device allocations seen so far ([base, base+size) from hipMemGetAddressRange). Only used
-// by the tile queue: its callers issue hundreds of invokes per layer on the same few
-// allocations, and one driver query per operand per invoke would dominate the host time.
-// Bumped at the explicit synchronisation points (xsmm_hip_synchronize, perf_stop_timer): the caller may free and
-// re-allocate buffers after those, so cached allocation ranges are only trusted within one such epoch.
+// Device allocations seen so far ([base, base+size) from hipMemGetAddressRange), one cache per calling thread.
+// Callers issue hundreds of invokes per layer on the same few allocations, and one driver query per operand
+// per invoke would dominate the host time (~1 us each). The epoch is bumped at the explicit synchronisation
+// points (xsmm_hip_synchronize, perf_stop_timer): the caller may free and re-allocate buffers after those, so
+// cached ranges are only trusted within one epoch (and never in synchronous mode, see stage_in).
 std::atomic<uint64_t> g_devmem_epoch{1};
 
 struct DeviceRanges {
