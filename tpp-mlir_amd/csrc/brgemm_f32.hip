@@ -37,7 +37,7 @@ namespace tpp {
 #define TPP_ABLATE 0
 #endif
 #ifndef TPP_NACC
-#define TPP_NACC 2
+#define TPP_NACC 1 // accumulator chains per wave: 1 measured +0.9 % on C2 over 2 (and it is the oracle's summation order: one chain)
 #endif
 constexpr int ABL_NO_GLOAD = 1, ABL_NO_SWRITE = 2, ABL_NO_BARRIER = 4, ABL_NO_FRAG = 8, ABL_STAMP = 32;
 
