@@ -264,25 +264,28 @@ static inline bool aligned(const void *p, size_t a) { return (((uintptr_t)p) & (
 // read with 16-byte row pieces into LDS (row pitch 64+PAD elements), then every lane gathers
 // VEC elements of one input column (VEC small LDS reads) and stores them as 16 contiguous bytes
 // of an output row; consecutive lanes cover one contiguous output row segment.
-template <typename T>
+template <typename T, int TS>
 __global__ __launch_bounds__(256) void transpose_vec_kernel(int64_t m, int64_t n, int64_t ldi, int64_t ldo,
                                                             const T *__restrict__ in, T *__restrict__ out) {
-  constexpr int VEC = 16 / sizeof(T), TPR = 64 / VEC, RPP = 256 / TPR; // threads per row, rows per pass
-  constexpr int PITCH = 64 + (sizeof(T) == 4 ? 1 : 2);
-  __shared__ T tile[64 * PITCH];
-  const int64_t tiles_n = n / 64;
-  const int64_t i0 = (blockIdx.x / tiles_n) * 64, j0 = (blockIdx.x % tiles_n) * 64;
+  // TS x TS tile; TS = 64 (f32) or 128 (bf16, when the shape allows): every row piece is then 256 bytes on both
+  // global sides (bf16 with 64-wide tiles moved 128-byte pieces 32 KiB apart: 4.3 TB/s at 16384^2)
+  constexpr int VEC = 16 / sizeof(T), TPR = TS / VEC, RPP = 256 / TPR; // threads per row, rows per pass
+  constexpr int PITCH = TS + (sizeof(T) == 4 ? 1 : 2);
+  __shared__ T tile[TS * PITCH];
+  // (a G x G super-block tile order was measured for DRAM page / TLB locality at 16384^2: no effect)
+  const int64_t tiles_n = n / TS;
+  const int64_t i0 = (blockIdx.x / tiles_n) * TS, j0 = (blockIdx.x % tiles_n) * TS;
   const int t = threadIdx.x;
 #pragma unroll
-  for (int r = t / TPR; r < 64; r += RPP) {
+  for (int r = t / TPR; r < TS; r += RPP) {
     const Pack<T, VEC> v = *(const Pack<T, VEC> *)(in + (i0 + r) * ldi + j0 + (t % TPR) * VEC);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) tile[r * PITCH + (t % TPR) * VEC + e] = v.v[e];
   }
   __syncthreads();
-  // output row = input column c (64 of them), VEC consecutive output columns = input rows r0..r0+VEC-1
+  // output row = input column c (TS of them), VEC consecutive output columns = input rows r0..r0+VEC-1
 #pragma unroll
-  for (int q = t; q < 64 * TPR; q += 256) {
+  for (int q = t; q < TS * TPR; q += 256) {
     const int c = q / TPR, r0 = (q % TPR) * VEC; // TPR consecutive lanes = one contiguous output row segment
     Pack<T, VEC> v;
 #pragma unroll
@@ -302,8 +305,12 @@ static hipError_t launch_unary_t(const UnaryDesc &d, const void *in, float scala
   else if (d.flags & UF_COL) bc = BC_COL;
   if (op == (int)U_TRANSPOSE) {
     const int64_t tiles = ((d.m + 63) / 64) * ((d.n + 63) / 64);
-    if (d.m % 64 == 0 && d.n % 64 == 0 && d.ldi % V == 0 && d.ldo % V == 0 && aligned(in, 16) && aligned(out, 16))
-      hipLaunchKernelGGL((transpose_vec_kernel<T>), dim3((unsigned)tiles), dim3(256), 0, s, d.m, d.n, d.ldi, d.ldo,
+    const bool vec_ok = d.ldi % V == 0 && d.ldo % V == 0 && aligned(in, 16) && aligned(out, 16);
+    if (vec_ok && sizeof(T) == 2 && d.m % 128 == 0 && d.n % 128 == 0)
+      hipLaunchKernelGGL((transpose_vec_kernel<T, 128>), dim3((unsigned)((d.m / 128) * (d.n / 128))), dim3(256), 0, s, d.m, d.n,
+                         d.ldi, d.ldo, (const T *)in, (T *)out);
+    else if (vec_ok && d.m % 64 == 0 && d.n % 64 == 0)
+      hipLaunchKernelGGL((transpose_vec_kernel<T, 64>), dim3((unsigned)tiles), dim3(256), 0, s, d.m, d.n, d.ldi, d.ldo,
                          (const T *)in, (T *)out);
     else
       hipLaunchKernelGGL((transpose_kernel<T>), dim3((unsigned)tiles), dim3(256), 0, s, d.m, d.n, d.ldi, d.ldo,
