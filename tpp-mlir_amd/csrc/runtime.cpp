@@ -553,7 +553,10 @@ struct Scheduler {
   }
   ~Scheduler() {
     stop.store(true);
-    if (worker.joinable()) worker.join();
+    if (!worker.joinable()) return;
+    // a fatal error on the scheduler thread itself exits the process from that thread: never join yourself
+    if (worker.get_id() == std::this_thread::get_id()) worker.detach();
+    else worker.join();
   }
   void push(const QEntry &e) {
     const uint64_t pos = tail.fetch_add(1, std::memory_order_acq_rel);
