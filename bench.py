@@ -11,15 +11,22 @@ Step = one pass of the hot path over one batch of synthetic input:
     1024->1024->1024->1024 bf16 bs=4096 (bias+relu fused), tile rows sharded across the
     ranks with ONE RCCL all-gather of the output (strong scaling).
 Timing: inputs resident in HBM, W warm-up steps, then exactly K steps between
-barrier+synchronize pairs, max over ranks. FLOPs are the reference's BENCH_TOTAL_FLOPS
+barrier+synchronize pairs, max over ranks. The host waits for the last step by polling the closing HIP
+event and then calls torch.cuda.synchronize() (which returns at once): a blocking device wait adds tens
+of microseconds of wake-up latency, which is 10 % of a 20-step run of an 18 us kernel. FLOPs are the reference's BENCH_TOTAL_FLOPS
 arithmetic (tools/mlir-gen/MLIRGen.cpp:313-334): 2*m*n*k*br for the BRGEMM.
 Launch: python bench.py --gpus 1 | python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N
 """
 import argparse
+import glob
 import importlib
 import json
 import os
+import re
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -45,13 +52,18 @@ def parse():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the collectives even with one rank (exercises the N>1 code path)")
     ap.add_argument("--init", choices=["reference", "uniform"], default="reference",
-                    help="reference: tpp-run's normal init stream (what the reference benchmarks run on); "
-                         "uniform: U[-1,1) (sign cancellation, highest switching power)")
+                    help="input stream `value` is quoted on. reference: tpp-run's normal init stream (what the reference "
+                         "benchmarks run on); uniform: U[-1,1) (sign cancellation, highest switching power). The OTHER "
+                         "stream is always measured too and reported as roofline_uniform / roofline_reference")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="do not run the rocprofv3 PMC passes for roofline.traffic (use when bench.py itself runs under a profiler)")
     return ap.parse_args()
 
 
 def timed(fn, steps, sync, barrier):
-    """exactly `steps` calls of fn between barrier+sync pairs; returns (wall seconds, device seconds)"""
+    """exactly `steps` calls of fn between barrier+sync pairs; returns (wall seconds, device seconds).
+    The wall clock stops after the closing torch.cuda.synchronize(); before it the host polls the closing
+    event so that the synchronize finds an idle device instead of going to sleep on it."""
     import torch
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
@@ -61,9 +73,11 @@ def timed(fn, steps, sync, barrier):
     for _ in range(steps):
         fn()
     e1.record()
+    while not e1.query():
+        pass
     sync()
-    barrier()
     wall = time.perf_counter() - t0
+    barrier()
     return wall, e0.elapsed_time(e1) * 1e-3
 
 
@@ -117,17 +131,11 @@ def graph_of(fn, warm=3):
         return None
 
 
-def pmc_traffic(kernel_substr):
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/*_pmc_hbm.txt, one counter per run). FETCH_SIZE / WRITE_SIZE are KiB; on gfx950
-    FETCH_SIZE reports half of a 16 B/lane streaming read (MI355X_MICROARCH.md, HBM) -> doubled."""
-    import glob
-    import re
+def committed_traffic(kernel_substr):
+    """fallback: HBM-side bytes per launch from the newest committed rocprofv3 PMC summary (profiles/*_pmc_hbm.txt)"""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.txt")))
-    if not files:
-        return None
     fetch = write = None
-    for line in open(files[-1]):
+    for line in (open(files[-1]) if files else []):
         if kernel_substr in line:
             m = re.search(r"mean\s+([0-9.]+)", line)
             if m and "FETCH_SIZE" in line:
@@ -135,25 +143,108 @@ def pmc_traffic(kernel_substr):
             if m and "WRITE_SIZE" in line:
                 write = float(m.group(1))
     if fetch is None or write is None:
+        return None, None
+    return (2.0 * fetch + write) * 1024.0, os.path.basename(files[-1])
+
+
+def live_traffic(kernel_substr, init):
+    """HBM-side bytes per launch of the C2 kernel, measured NOW: two rocprofv3 passes (one counter each, as
+    MI355X_MICROARCH.md prescribes: FETCH_SIZE takes 3 of the 4 TCC slots, WRITE_SIZE 2) over tools/c2_probe,
+    the native twin of the timed step. Units KiB; on gfx950 FETCH_SIZE counts half of a 16 B/lane streaming
+    read (same guide, HBM section) -> doubled. Returns (bytes, detail) or (None, reason)."""
+    probe = os.path.join(ROOT, "tools", "c2_probe")
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not (os.path.exists(probe) and os.path.exists(rocprof)):
+        return None, "tools/c2_probe or rocprofv3 missing"
+    vals = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="tpp_pmc_", dir="/tmp")
+        try:
+            r = subprocess.run([rocprof, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "c2", "--",
+                                probe, "--iters", "40", "--init", init], cwd="/tmp", env=env, capture_output=True,
+                               text=True, timeout=240)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                return None, "rocprofv3 --pmc %s produced no counter file (rc %d)" % (counter, r.returncode)
+            import csv
+            v = [float(row["Counter_Value"]) for row in csv.DictReader(open(files[0]))
+                 if kernel_substr in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter]
+            if not v:
+                return None, "no %s rows for %s" % (counter, kernel_substr)
+            vals[counter] = sum(v) / len(v)
+        except Exception as ex:  # a profiler problem must not cost the bench line
+            return None, "rocprofv3 --pmc %s failed: %s" % (counter, ex)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, {
+        "FETCH_SIZE_KiB_raw": round(vals["FETCH_SIZE"], 1), "WRITE_SIZE_KiB": round(vals["WRITE_SIZE"], 1),
+        "correction": "FETCH_SIZE x 2 (gfx950 counts 64 B per 128 B request)"}
+
+
+def per_launch_figures(init):
+    """tools/c2_probe: every launch timed on its own (launch + device synchronisation), mean +- population
+    stdev - the timing style of the reference's stand-alone GPU baseline (tools/bench-ref/GPU/cuda/MatmulRef.cpp:56-63,
+    tools/bench-ref/include/Bench.h:66-77) - next to the loop mean of tpp-run's definition"""
+    probe = os.path.join(ROOT, "tools", "c2_probe")
+    if not os.path.exists(probe):
         return None
-    return (2.0 * fetch + write) * 1024.0
+    try:
+        r = subprocess.run([probe, "--iters", "300", "--init", init], capture_output=True, text=True, timeout=120)
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as ex:
+        return {"error": str(ex)}
+
+
+def parity_figures(got, A, B, C0, m, n, k, br):
+    """HIP result of one C2 invoke against the oracle on the same inputs. max_abs / max|ref| is the north-star
+    figure (<= 1e-5); max_rel is element-wise, |gpu - ref| / (|ref| + floor) with the a-priori f32 dot-product
+    floor K * eps * sum_k |a_ik| |b_kj| (any summation order obeys it) - SURVEY.md 8(d)'s second criterion"""
+    from oracle import pyoracle as orc
+    ref = C0.copy()
+    orc.fused_brgemm_omp(F32, m, n, k, 1024, 1024, 1024, k, k * 1024, 4, 0, 0, A, B, ref, None, br)
+    mag = np.zeros_like(ref)
+    orc.fused_brgemm_omp(F32, m, n, k, 1024, 1024, 1024, k, k * 1024, 4, 0, 0, np.abs(A), np.abs(B), mag, None, br)
+    d = np.abs(got.astype(np.float64) - ref.astype(np.float64))
+    K = k * br
+    floor = K * 2.0 ** -24 * mag.astype(np.float64)
+    rel = d / (np.abs(ref.astype(np.float64)) + floor)
+    return {"max_abs": float(d.max()), "max_ref": float(np.abs(ref).max()),
+            "max_abs_over_max_ref": float(d.max() / max(1.0, np.abs(ref).max())),
+            "max_rel": float(rel.max()), "frac_within_1e-5_rel": float((d <= 1e-5 * np.abs(ref)).mean()),
+            "criterion": "max_abs <= 1e-5*max(1,max|ref|); element-wise |d| <= 1e-5*|ref| + K*eps*sum|a||b| (max_rel = |d|/(|ref|+floor))",
+            "pass": bool(d.max() <= 1e-5 * max(1.0, float(np.abs(ref).max())) and (d <= 1e-5 * np.abs(ref) + floor).all())}
 
 
 def cpu_baseline(seconds, A, B, C):
-    """the CPU restatement (oracle, OpenMP over row blocks of output tiles) on the same C2 inputs"""
+    """The CPU row: the reference's packed 32x32x32-tile batch-reduce call structure under OpenMP
+    (oracle/cpu_baseline.c, compiled here with -O3 -march=native) on the same C2 inputs, checked against the
+    oracle once; libxsmm itself is not in the image. The naive oracle loop and torch's CPU GEMM are context."""
     from oracle import pyoracle as orc
-    flops = 2.0 * 1024 * 1024 * 64 * 16
-    c = C.copy()
-    orc.fused_brgemm_omp(F32, 1024, 1024, 64, 1024, 1024, 1024, 64, 65536, 0, 0, 0, A, B, c, None, 16)  # warm
+    m = n = k = 1024
+    flops = 2.0 * m * n * k
+    cb = orc.CpuBaseline(native=True)
+    Ap, Bp, Cp = cb.pack(A, B, C, m, n, k)
+    cb.run(m, n, k, Ap, Bp, Cp, True, 1)  # warm + check
+    ref = C.copy()
+    orc.fused_brgemm_omp(F32, 1024, 1024, 64, 1024, 1024, 1024, 64, 65536, 4, 0, 0, A, B, ref, None, 16)
+    ok = bool(np.abs(cb.unpack_c(Cp, m, n) - ref).max() <= 1e-5 * max(1.0, float(np.abs(ref).max())))
     reps, t0 = 0, time.perf_counter()
     while True:
-        orc.fused_brgemm_omp(F32, 1024, 1024, 64, 1024, 1024, 1024, 64, 65536, 0, 0, 0, A, B, c, None, 16)
-        reps += 1
+        cb.run(m, n, k, Ap, Bp, Cp, True, 20)
+        reps += 20
         el = time.perf_counter() - t0
-        if el >= seconds or reps >= 2000:
+        if el >= seconds or reps >= 200000:
             break
-    # context: a tuned vendor CPU GEMM on the same host (torch.matmul -> MKL / oneDNN, all cores), the same product as
-    # ONE 1024 x 1024 x 1024 matmul; not the reference's libxsmm (not in the image), not the checker
+    tiled = flops * reps / el / 1e9
+    # context 1: the naive oracle loop (the checker) on the same inputs
+    c = C.copy()
+    n_o, t1 = 0, time.perf_counter()
+    while time.perf_counter() - t1 < 2.0:
+        orc.fused_brgemm_omp(F32, 1024, 1024, 64, 1024, 1024, 1024, 64, 65536, 4, 0, 0, A, B, c, None, 16)
+        n_o += 1
+    naive = flops * n_o / (time.perf_counter() - t1) / 1e9
+    # context 2: a tuned vendor CPU GEMM on the same host (torch.matmul -> MKL / oneDNN, all cores)
     vendor = None
     try:
         import torch
@@ -168,10 +259,16 @@ def cpu_baseline(seconds, A, B, C):
         vendor = {"torch_cpu_matmul_gflops": round(flops * n_v / (time.perf_counter() - t1) / 1e9, 1), "torch_threads": torch.get_num_threads()}
     except Exception:
         pass
-    return {"value": round(flops * reps / el / 1e9, 2), "unit": "GFLOP/s", "cores": orc.num_threads(),
-            "kind": "port", "vendor_cpu_gemm": vendor,
-            "sample": "%d full passes of the same BRGEMM 1024^3 br=16 (%.1f s) by oracle/xsmm_oracle.c "
-                      "(OpenMP over 32-row output blocks; libxsmm itself is not in the image)" % (reps, el)}
+    cpu_model = ""
+    try:
+        cpu_model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        pass
+    return {"value": round(tiled, 2), "unit": "GFLOP/s", "cores": cb.threads(), "kind": "port", "cpu": cpu_model,
+            "build": cb.flags, "matches_oracle": ok,
+            "naive_oracle_loop_gflops": round(naive, 2), "vendor_cpu_gemm": vendor,
+            "sample": "%d full passes of the same BRGEMM 1024^3 (%.1f s) as 32x32 tile invokes with br=32 over packed "
+                      "32x32x32 blocks, OpenMP over the 32x32 tile grid (oracle/cpu_baseline.c; libxsmm itself is not in the image)" % (reps, el)}
 
 
 def main():
@@ -210,43 +307,57 @@ def main():
     # ------------------------------------------------------------ C2: fp32 BRGEMM 1024^3, br = 16
     m = n = 1024
     k, br = 64, 16
-    if args.init == "reference":
-        # the reference harness' inputs: tpp-run --seed 123 --init-type normal (benchmarks/harness/
-        # controller.py:149-154): N(0, 0.2) clamped to [0, 1], ONE stream over the arguments in order
-        from oracle import pyoracle as orc  # input generation only (restated TensorInit stream)
-        gen = orc.TensorInit("normal", 123 + rank)
-        hA, hB, hC = gen.fill(m * 1024), gen.fill(1024 * n), gen.fill(m * n)
-    else:
+    from oracle import pyoracle as orc  # input generation (restated TensorInit stream) and the parity check
+
+    def inputs(kind):
+        if kind == "reference":
+            # the reference harness' inputs: tpp-run --seed 123 --init-type normal (benchmarks/harness/
+            # controller.py:149-154): N(0, 0.2) clamped to [0, 1], ONE stream over the arguments in order
+            gen = orc.TensorInit("normal", 123 + rank)
+            return gen.fill(m * 1024), gen.fill(1024 * n), gen.fill(m * n)
         rng = np.random.default_rng(1234 + rank)
-        hA = rng.uniform(-1, 1, m * 1024).astype(np.float32)
-        hB = rng.uniform(-1, 1, 1024 * n).astype(np.float32)
-        hC = rng.uniform(-1, 1, m * n).astype(np.float32)
-    dA, dB, dC = (torch.from_numpy(x).cuda() for x in (hA, hB, hC))
+        return tuple(rng.uniform(-1, 1, cnt).astype(np.float32) for cnt in (m * 1024, 1024 * n, m * n))
+
     h = rt.brgemm_dispatch(F32, m, n, k, 1024, 1024, 1024, 64, 65536, pkg.GemmFlags.BETA_0)
     flops = 2.0 * m * n * k * br
-
-    def step():
-        rt.brgemm(F32, h, dA, 0, dB, 0, dC, 0, br)
-
-    spin_up(step, sync)
-    warm(step, W, sync)
-    wall, devs = timed(step, K, sync, barrier)
+    runs = {}
     mode = "invoke-loop"
-    replay = graph_of(step) if args.graph else None
-    if replay is not None:
-        for _ in range(W):
-            replay()
-        sync()
-        wall_g, devs_g = timed(replay, K, sync, barrier)
-        if wall_g < wall:
-            wall, devs, mode = wall_g, devs_g, "hipGraph-replay"
-    t = torch.tensor([wall, devs], dtype=torch.float64, device="cuda")
-    if use_dist:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    wall, devs = float(t[0]), float(t[1])
+    other = "uniform" if args.init == "reference" else "reference"
+    for kind in (other, args.init):  # the stream `value` is quoted on runs last, right after its own warm-up
+        hA, hB, hC = inputs(kind)
+        dA, dB, dC = (torch.from_numpy(x).cuda() for x in (hA, hB, hC))
+
+        def step():
+            rt.brgemm(F32, h, dA, 0, dB, 0, dC, 0, br)
+
+        spin_up(step, sync)
+        warm(step, W, sync)
+        wall, devs = timed(step, K, sync, barrier)
+        if kind == args.init and args.graph:
+            replay = graph_of(step)
+            if replay is not None:
+                for _ in range(W):
+                    replay()
+                sync()
+                wall_g, devs_g = timed(replay, K, sync, barrier)
+                if wall_g < wall:
+                    wall, devs, mode = wall_g, devs_g, "hipGraph-replay"
+        t = torch.tensor([wall, devs], dtype=torch.float64, device="cuda")
+        if use_dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        runs[kind] = {"wall": float(t[0]), "devs": float(t[1]),
+                      "parity": parity_figures(dC.cpu().numpy(), hA, hB, hC, m, n, k, br) if rank == 0 and world == 1 else None}
+    wall, devs = runs[args.init]["wall"], runs[args.init]["devs"]
     value = world * flops * K / wall / 1e9
     kernel_s = devs / K
     achieved_tf = flops / kernel_s / 1e12
+    inputs_text = {"reference": "tpp-run normal init, seed 123 (N(0,0.2) clamped to [0,1])", "uniform": "uniform [-1,1)"}
+
+    def roofline_of(kind):
+        ks = runs[kind]["devs"] / K
+        return {"bound": "mfma", "achieved": round(flops / ks / 1e12, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(flops / ks / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), "kernel_us": round(ks * 1e6, 3),
+                "inputs": inputs_text[kind], "value_gflops_wall": round(world * flops * K / runs[kind]["wall"] / 1e9, 1)}
 
     # ------------------------------------------------------------ C4: bf16 3-layer MLP, row-sharded + all-gather
     mlp = None
@@ -404,9 +515,22 @@ def main():
                     others.append({"workload": "mlir-gen mlp 3x1024 bs=256 bias+relu (fp32 unless noted), " + label + " (tools/tpp_replay)",
                                    "value": float(mm.group(2)), "unit": "GFLOP/s", "us_per_step": float(mm.group(1))})
 
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args.cpu_seconds, hA, hB, hC)
+    cpu = per_launch = None
+    traffic, traffic_source, traffic_detail = None, None, None
+    if rank == 0 and world == 1:
+        kname = "brgemm_f32"
+        if not args.no_pmc:
+            traffic, traffic_detail = live_traffic(kname, args.init)
+            traffic_source = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/c2_probe in this run"
+        if traffic is None:
+            why = traffic_detail
+            traffic, src = committed_traffic(kname)
+            traffic_source = "committed profile %s (%s)" % (src, why if why else "--no-pmc") if traffic is not None else None
+            traffic_detail = None
+        per_launch = per_launch_figures(args.init)
+        if not args.no_cpu_baseline:
+            hA, hB, hC = inputs(args.init)
+            cpu = cpu_baseline(args.cpu_seconds, hA, hB, hC)
 
     # RCCL writes its version banner to the C stdout buffer: shut the process group down and flush C
     # stdio first, so that the JSON line is the LAST thing on stdout
@@ -416,6 +540,12 @@ def main():
     import ctypes
     ctypes.CDLL(None).fflush(None)
     if rank == 0:
+        roof = roofline_of(args.init)
+        roof.update({"traffic": traffic, "traffic_unit": "bytes/launch (HBM side, PMC)", "traffic_source": traffic_source,
+                     "traffic_detail": traffic_detail, "algorithmic_bytes": 3 * 4 * 1024 * 1024,
+                     "traffic_floor_8_private_L2": 8 * (1 + 2) * 1024 * 1024 + 4 * 1024 * 1024,
+                     "note": "achieved = 2*m*n*k*br / (HIP-event time of the K timed launches / K) on the launch stream; "
+                             "traffic_floor = 8 XCDs x (1/4 of A + 1/2 of B) read + C written: every private L2 fetches its own panels"})
         line = {
             "metric": "GFLOP/s on BRGEMM 1024^3 fp32 br=16 (xsmm_brgemm_invoke)", "value": round(value, 1),
             "unit": "GFLOP/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -424,14 +554,11 @@ def main():
             "config": {"workload": "BRGEMM 1024x1024x1024 fp32, batch-reduce=16 (m=n=1024 k=64 lda=ldb=ldc=1024 "
                                    "stride_a=64 stride_b=65536 BETA_0), one independent problem per GPU",
                        "launch": mode, "kernel": rt.kernel_name(h), "flops_per_step_per_gpu": flops,
-                       "inputs": "tpp-run normal init, seed 123 (N(0,0.2) clamped to [0,1])" if args.init == "reference"
-                       else "uniform [-1,1)"},
-            "roofline": {"bound": "mfma", "achieved": round(achieved_tf, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved_tf / PEAK_F32_MFMA_TFLOPS, 4),
-                         "traffic": pmc_traffic("brgemm_f32_fast<2, 2, 1"), "traffic_unit": "bytes/launch (HBM side, PMC)",
-                         "algorithmic_bytes": 3 * 4 * 1024 * 1024,
-                         "kernel_us": round(kernel_s * 1e6, 3),
-                         "note": "achieved = 2*m*n*k*br / (HIP-event time of the K timed launches / K) on the launch stream"},
+                       "inputs": inputs_text[args.init]},
+            "roofline": roof,
+            "roofline_" + other: roofline_of(other),
+            "parity": {args.init: runs[args.init]["parity"], other: runs[other]["parity"]},
+            "per_launch": per_launch,
             "cpu_baseline": cpu,
         }
         if mlp is not None:

@@ -25,7 +25,59 @@ def build(force=False):
     stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "liboracle.so"])
+    cb = os.path.join(_HERE, "libcpu_baseline.so")
+    src = os.path.join(_HERE, "cpu_baseline.c")
+    if force or not os.path.exists(cb) or os.path.getmtime(src) > os.path.getmtime(cb):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libcpu_baseline.so"])
     return so
+
+
+class CpuBaseline:
+    """oracle/cpu_baseline.c: the reference's packed 32x32x32-tile batch-reduce call structure under OpenMP.
+    native=True compiles it for THIS host (-O3 -march=native) first and falls back to the portable build."""
+
+    def __init__(self, native=True):
+        self.flags = "-O3 -march=x86-64-v3 -fopenmp (portable build)"
+        path = os.path.join(_HERE, "libcpu_baseline.so")
+        if native:
+            nat = os.path.join(_HERE, "_cpu_native.so")
+            try:
+                subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-fopenmp", "-shared",
+                                       os.path.join(_HERE, "cpu_baseline.c"), "-o", nat],
+                                      stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                path, self.flags = nat, "-O3 -march=native -fopenmp (compiled on this host)"
+            except Exception:
+                pass
+        if not os.path.exists(path):
+            build()
+        L = ctypes.CDLL(path)
+        for f in ("cpu_pack_blocks", "cpu_unpack_blocks", "cpu_pack_b"):
+            getattr(L, f).argtypes = [VP, I64, I64, I64, VP]
+            getattr(L, f).restype = None
+        L.cpu_brgemm_tiled_f32.argtypes = [I64, I64, I64, VP, VP, VP, ctypes.c_int, I64]
+        L.cpu_brgemm_tiled_f32.restype = ctypes.c_int
+        L.cpu_baseline_threads.restype = ctypes.c_int
+        self.L = L
+
+    def threads(self):
+        return self.L.cpu_baseline_threads()
+
+    def pack(self, A, B, C, m, n, k):
+        """row-major A [m][k], B [k][n], C [m][n] -> the packed block buffers the tile loop runs on"""
+        Ap, Bp, Cp = np.empty(m * k, np.float32), np.empty(k * n, np.float32), np.empty(m * n, np.float32)
+        self.L.cpu_pack_blocks(_p(A), m, k, k, _p(Ap))
+        self.L.cpu_pack_b(_p(B), k, n, n, _p(Bp))
+        self.L.cpu_pack_blocks(_p(C), m, n, n, _p(Cp))
+        return Ap, Bp, Cp
+
+    def unpack_c(self, Cp, m, n):
+        C = np.empty(m * n, np.float32)
+        self.L.cpu_unpack_blocks(_p(Cp), m, n, n, _p(C))
+        return C
+
+    def run(self, m, n, k, Ap, Bp, Cp, beta0, reps=1):
+        rc = self.L.cpu_brgemm_tiled_f32(m, n, k, _p(Ap), _p(Bp), _p(Cp), 1 if beta0 else 0, reps)
+        assert rc == 0
 
 
 def lib():

@@ -6,7 +6,9 @@ CPU oracle, on a real MI355X:
     including ragged sizes (3, 5, 13, 33 ...), empty batches and overlapping batches;
   * the BASELINE.json configurations at full size (rows sampled where the oracle
     would be slow: output rows are independent) and size-independent properties.
-Bars: f32 max|gpu - ref| <= 1e-5 * max(1, max|ref|) (north_star); bf16 results within
+Bars: f32 max|gpu - ref| <= 1e-5 * max(1, max|ref|) (north_star) AND, element-wise,
+|gpu - ref| <= 1e-5 * |ref| + K * eps * (|C| + sum_k |a||b| + |bias|) (the relative bar
+with the a-priori f32 dot-product floor - the two sides sum in different orders); bf16 results within
 one bf16 ulp of the oracle's (reference convention fpcmp -r 0.01 is far looser);
 identity / zero / transpose / VNNI-2 pack bit-exact.
 """
@@ -54,13 +56,24 @@ def as_f32(a):
     return a if a.dtype == np.float32 else orc.bf16_to_f32(a)
 
 
-def check_close(got, ref, dt, what):
+REL_STATS = {"max_rel": 0.0, "cases": 0}  # element-wise figure over the whole session (printed at the end)
+
+
+def check_close(got, ref, dt, what, mag=None, K=0):
+    """mag: |C| + sum |a||b| + |bias| per element (f32 only): enables the element-wise criterion"""
     g, r = as_f32(got).astype(np.float64), as_f32(ref).astype(np.float64)
     assert np.isfinite(g).all(), what + ": non-finite values"
     diff = np.abs(g - r)
     if dt == F32:
         tol = 1e-5 * max(1.0, float(np.abs(r).max()) if r.size else 1.0)
         bad = diff > tol
+        if mag is not None and r.size:
+            floor = (K + 2) * 2.0 ** -24 * np.asarray(mag, dtype=np.float64)
+            bad_rel = diff > 1e-5 * np.abs(r) + floor
+            REL_STATS["max_rel"] = max(REL_STATS["max_rel"], float((diff / (np.abs(r) + floor + 1e-300)).max()))
+            REL_STATS["cases"] += 1
+            assert not bad_rel.any(), "%s: %d/%d elements outside the element-wise bar, worst |d| %g at |ref| %g" % (
+                what, int(bad_rel.sum()), bad_rel.size, float(diff[bad_rel].max()), float(np.abs(r)[bad_rel][0]))
     else:
         # one bf16 ulp of the reference value (a rounding flip: 2^-7 relative covers it) plus the
         # f32-accumulation floor of the f32 bar: where products cancel, |ref| is far below the
@@ -69,6 +82,12 @@ def check_close(got, ref, dt, what):
         bad = diff > tol
     assert not bad.any(), "%s: %d/%d mismatches, max abs diff %g (max |ref| %g)" % (
         what, int(bad.sum()), bad.size, float(diff.max()), float(np.abs(r).max()))
+
+
+def test_zz_report_elementwise_figure():
+    """runs last in this file: the session's worst element-wise figure |d| / (|ref| + K eps sum|a||b|) over all f32 GEMM cases"""
+    print("\n[parity] f32 element-wise: max |gpu-ref| / (|ref| + floor) = %.3g over %d cases (bar: 1e-5 relative + floor)" % (
+        REL_STATS["max_rel"], REL_STATS["cases"]))
 
 
 # ---------------------------------------------------------------- golden fixtures
@@ -107,6 +126,12 @@ def gemm_case(rt, dt, m, n, k, br, lda=None, ldb=None, ldc=None, sa=None, sb=Non
         else:
             orc.brgemm(dt, rr, n, k, lda, ldb, ldc, sa, sb, flags, A, offs[0] + r0 * lda, B, offs[1], Cref,
                        offs[2] + r0 * ldc, br)
+    Cmag = None
+    if dt == F32 and m * n * k * max(br, 1) <= 2 ** 28:  # |C| + sum |a||b| + |bias| for the element-wise bar
+        Cmag = np.abs(C)
+        for (r0, rr) in (row_blocks or [(0, m)]):
+            orc.fused_brgemm(dt, rr, n, k, lda, ldb, ldc, sa, sb, flags, 0, 0, 4 if bias else 0, 1 if bias else 0,
+                             np.abs(A), offs[0] + r0 * lda, np.abs(B), offs[1], Cmag, offs[2] + r0 * ldc, np.abs(D), offs[3], br)
     if force is not None:
         rt.force_variant(force)
     try:
@@ -137,9 +162,10 @@ def gemm_case(rt, dt, m, n, k, br, lda=None, ldb=None, ldc=None, sa=None, sb=Non
     if row_blocks:
         sel = np.concatenate([np.arange(offs[2] + r * ldc, offs[2] + r * ldc + n)
                               for (r0, rr) in row_blocks for r in range(r0, r0 + rr)])
-        check_close(got[sel], Cref[sel], dt, what)
+        check_close(got[sel], Cref[sel], dt, what, None if Cmag is None else Cmag[sel], k * br)
     else:
-        check_close(got, Cref, dt, what)
+        win = np.concatenate([np.arange(offs[2] + i * ldc, offs[2] + i * ldc + n) for i in range(m)]) if m and n else np.arange(0)
+        check_close(got[win], Cref[win], dt, what, None if Cmag is None else Cmag[win], k * br)
     # bytes outside the m x n window (ldc padding, guard elements) must be untouched
     mask = np.ones(C.size, dtype=bool)
     for i in range(m):
@@ -171,10 +197,24 @@ def test_brgemm_f32_fast_variants(rt, case):
     assert "fast" in name, name
 
 
-@pytest.mark.parametrize("variant,m,n", [(0, 128, 128), (1, 128, 96), (2, 96, 96), (3, 256, 128)])
+@pytest.mark.parametrize("variant,m,n", [(0, 128, 128), (1, 128, 96), (2, 96, 96), (3, 256, 128), (4, 128, 128),
+                                         (5, 128, 128), (6, 128, 192), (7, 128, 96)])
 def test_brgemm_f32_forced_tile_variants(rt, variant, m, n):
     gemm_case(rt, F32, m, n, 64, 4, sa=64, lda=256, sb=64 * n, beta0=False, bias=True, relu=True,
               seed=variant, force=variant)
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("k,br", [(64, 0), (64, 1), (64, 2), (64, 3), (64, 4), (64, 5), (64, 7), (128, 3), (192, 2), (64, 16)])
+def test_brgemm_f32_chunk_stream_lengths(rt, variant, k, br):
+    """every ring position of the uniform chunk loops (1 .. 16 chunks, chunk streams that wrap inside a batch
+    element), for every fast f32 tile family incl. the loader-wave kernels, both accumulator starts"""
+    m, n = (256, 128) if variant == 3 else (128, 128)
+    for beta0 in (True, False):
+        name = gemm_case(rt, F32, m, n, k, br, lda=k * max(br, 1) + 8, ldb=n + 4, ldc=n + 4, sa=k, sb=k * (n + 4),
+                         beta0=beta0, bias=not beta0, relu=beta0, seed=variant * 100 + k + br, force=variant,
+                         offs=(4, 8, 4, 1))
+        assert "fast" in name, name
 
 
 RAGGED = [(3, 3, 4, 2), (5, 13, 10, 3), (33, 65, 70, 2), (6, 6, 6, 2), (1, 1, 1, 1), (10, 10, 10, 1),

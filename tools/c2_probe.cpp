@@ -1,0 +1,115 @@
+// c2_probe - BASELINE config C2 (fp32 BRGEMM 1024^3, batch-reduce 16) through the C-ABI, natively:
+//   * the per-launch timing figure of the reference's stand-alone GPU baseline (tools/bench-ref/GPU/cuda/
+//     MatmulRef.cpp:56-63 + tools/bench-ref/include/Bench.h:66-77: one warm-up, then every launch timed
+//     on its own with a device synchronisation after it, mean +- population stdev), next to the loop mean of
+//     tpp-run's timing definition (lib/TPP/Runner/TppRunnerWrapper.cpp:115-130);
+//   * a small target for `rocprofv3 --pmc ...` passes (bench.py measures roofline.traffic with it: a
+//     python process under the profiler would spend its time importing torch).
+// Prints ONE JSON line on stdout. Inputs: uniform [-1, 1) (--init uniform) or the reference harness'
+// normal init N(0, 0.2) clamped to [0, 1] (--init reference), generated here with <random>.
+//   c2_probe [--iters N] [--init reference|uniform] [--variant V]
+#include "../include/tpp_xsmm_abi.h"
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <string>
+#include <vector>
+
+#define CHECK(x)                                                                   \
+  do {                                                                             \
+    hipError_t e = (x);                                                            \
+    if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1); } \
+  } while (0)
+
+int main(int argc, char **argv) {
+  int iters = 200, variant = -1;
+  std::string init = "uniform";
+  for (int i = 1; i < argc; ++i) {
+    std::string a = argv[i];
+    if (a == "--iters" && i + 1 < argc) iters = atoi(argv[++i]);
+    else if (a == "--init" && i + 1 < argc) init = argv[++i];
+    else if (a == "--variant" && i + 1 < argc) variant = atoi(argv[++i]);
+    else { fprintf(stderr, "unknown flag %s\n", a.c_str()); return 2; }
+  }
+  if (xsmm_hip_device_count() < 1) { fprintf(stderr, "c2_probe: no HIP device (there is no CPU fallback)\n"); return 1; }
+  const int64_t m = 1024, n = 1024, k = 64, br = 16;
+  const size_t elems = 1024 * 1024;
+  std::vector<float> hA(elems), hB(elems), hC(elems);
+  std::default_random_engine eng(123);
+  if (init == "reference") { // TensorInitFloat.cpp:54-95 "normal": one stream over the arguments in order
+    std::normal_distribution<float> d(0.0f, 0.2f);
+    auto draw = [&]() { float v = d(eng); return v < 0.0f ? 0.0f : v > 1.0f ? 1.0f : v; };
+    for (auto &v : hA) v = draw();
+    for (auto &v : hB) v = draw();
+    for (auto &v : hC) v = draw();
+  } else {
+    std::uniform_real_distribution<float> d(-1.0f, 1.0f);
+    for (auto &v : hA) v = d(eng);
+    for (auto &v : hB) v = d(eng);
+    for (auto &v : hC) v = d(eng);
+  }
+  float *A, *B, *C;
+  CHECK(hipMalloc((void **)&A, elems * 4));
+  CHECK(hipMalloc((void **)&B, elems * 4));
+  CHECK(hipMalloc((void **)&C, elems * 4));
+  CHECK(hipMemcpy(A, hA.data(), elems * 4, hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(B, hB.data(), elems * 4, hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(C, hC.data(), elems * 4, hipMemcpyHostToDevice));
+  xsmm_hip_set_async(1);
+  if (variant >= 0) xsmm_hip_force_variant(variant);
+  const int64_t h = xsmm_brgemm_dispatch(1, m, n, k, 1024, 1024, 1024, 64, 65536, XSMM_GEMM_FLAG_BETA_0);
+  xsmm_hip_force_variant(-1);
+  auto step = [&]() { xsmm_brgemm_invoke(1, h, A, 0, B, 0, C, 0, br); };
+  const double flops = 2.0 * m * n * k * br;
+
+  // clocks up: ~60 ms of load before anything is timed
+  const auto t_up = std::chrono::steady_clock::now();
+  while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_up).count() < 0.06) {
+    for (int i = 0; i < 200; ++i) step();
+    CHECK(hipDeviceSynchronize());
+  }
+  // (a) loop mean: one timer around N back-to-back launches (tpp-run's definition), device time by events
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  CHECK(hipEventRecord(e0, nullptr));
+  for (int i = 0; i < iters; ++i) step();
+  CHECK(hipEventRecord(e1, nullptr));
+  CHECK(hipEventSynchronize(e1));
+  float ms = 0;
+  CHECK(hipEventElapsedTime(&ms, e0, e1));
+  const double loop_us = ms * 1e3 / iters;
+  // (b) per launch: one warm-up, then launch + device synchronisation each, mean +- population stdev
+  step();
+  CHECK(hipDeviceSynchronize());
+  std::vector<double> dev_us(iters), wall_us(iters);
+  for (int i = 0; i < iters; ++i) {
+    const auto w0 = std::chrono::steady_clock::now();
+    CHECK(hipEventRecord(e0, nullptr));
+    step();
+    CHECK(hipEventRecord(e1, nullptr));
+    CHECK(hipDeviceSynchronize());
+    wall_us[i] = std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count() * 1e6;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    dev_us[i] = ms * 1e3;
+  }
+  auto stats = [&](const std::vector<double> &v, double &mean, double &sd) {
+    mean = 0;
+    for (double x : v) mean += x;
+    mean /= v.size();
+    sd = 0;
+    for (double x : v) sd += (x - mean) * (x - mean);
+    sd = std::sqrt(sd / v.size());
+  };
+  double dm, ds, wm, ws;
+  stats(dev_us, dm, ds);
+  stats(wall_us, wm, ws);
+  printf("{\"kernel\": \"%s\", \"init\": \"%s\", \"iters\": %d, \"loop_mean_us\": %.3f, \"loop_tflops\": %.2f, "
+         "\"per_launch_device_us\": {\"mean\": %.3f, \"stdev\": %.3f}, \"per_launch_wall_us\": {\"mean\": %.3f, \"stdev\": %.3f}, "
+         "\"per_launch_device_tflops\": %.2f}\n",
+         xsmm_hip_kernel_name(h), init.c_str(), iters, loop_us, flops / loop_us * 1e-6, dm, ds, wm, ws, flops / dm * 1e-6);
+  return 0;
+}

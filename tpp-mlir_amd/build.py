@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO_NAME = "libtpp_xsmm_runner_utils.so"
 SO_PATH = os.path.join(HERE, SO_NAME)
-SOURCES = ["runtime.cpp", "brgemm_f32.hip", "brgemm_bf16.hip", "brgemm_bf16_dma256.hip", "brgemm_bf16_small.hip", "eltwise.hip"]
+SOURCES = ["runtime.cpp", "brgemm_f32.hip", "brgemm_f32_lw.hip", "brgemm_bf16.hip", "brgemm_bf16_dma256.hip", "brgemm_bf16_small.hip", "eltwise.hip"]
 HEADERS = ["xsmm_desc.h", "gemm_common.h", os.path.join("..", "..", "include", "tpp_xsmm_abi.h")]
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
@@ -63,22 +63,25 @@ def build(force=False, verbose=False):
 
 
 def build_tools(verbose=False):
-    """tools/tpp_replay: the native stand-in for tpp-run's timing loop on this path (links the .so)"""
+    """native harness tools that link the .so: tools/tpp_replay (the stand-in for tpp-run's timing loop on
+    this path) and tools/c2_probe (per-launch timing of C2 + the target of bench.py's rocprofv3 PMC passes)"""
     root = os.path.dirname(HERE)
-    src = os.path.join(root, "tools", "tpp_replay.cpp")
-    out = os.path.join(root, "tools", "tpp_replay")
-    if not os.path.exists(src):
-        return None
-    if os.path.exists(out) and os.path.getmtime(out) > max(os.path.getmtime(src), os.path.getmtime(SO_PATH)):
-        return out
-    cmd = [hipcc(), "-O2", "-std=c++17", "-fopenmp", src, "-o", out, "-L", HERE, "-ltpp_xsmm_runner_utils",
-           "-Wl,-rpath,$ORIGIN/../tpp-mlir_amd", "-Wl,-rpath,/opt/rocm/lib/llvm/lib"]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError("building tpp_replay failed:\n" + r.stderr)
-    return out
+    outs = []
+    for name, extra in (("tpp_replay", ["-fopenmp"]), ("c2_probe", [])):
+        src = os.path.join(root, "tools", name + ".cpp")
+        out = os.path.join(root, "tools", name)
+        if not os.path.exists(src):
+            continue
+        if not (os.path.exists(out) and os.path.getmtime(out) > max(os.path.getmtime(src), os.path.getmtime(SO_PATH))):
+            cmd = [hipcc(), "-O2", "-std=c++17"] + extra + [src, "-o", out, "-L", HERE, "-ltpp_xsmm_runner_utils",
+                   "-Wl,-rpath,$ORIGIN/../tpp-mlir_amd", "-Wl,-rpath,/opt/rocm/lib/llvm/lib"]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("building %s failed:\n%s" % (name, r.stderr))
+        outs.append(out)
+    return outs
 
 
 if __name__ == "__main__":

@@ -1,0 +1,261 @@
+// brgemm_f32_lw.hip - f32 batch-reduce GEMM on v_mfma_f32_32x32x2_f32 with LOADER WAVES.
+//
+// Same arithmetic and LDS images as brgemm_f32_fast (brgemm_f32.hip: one workgroup per output tile,
+// each MFMA wave one 32x32 accumulator = one k-ordered f32 fma chain per element, panels HBM -> LDS by
+// LDS-DMA, A swizzled through the source address). What differs is WHO issues the DMA: measured on the
+// 64x64 tile (profiles/r01_f32_c2_timeline_cycles.txt) a chunk costs 2302 cycles against 2048 of pure
+// MFMA issue, and ~200 of the difference is the eight `buffer_load ... lds` instructions each MFMA wave
+// issues per chunk: a wave is in-order, an LDS-DMA instruction takes 25-60 cycles to be accepted by
+// the vector-memory path, and every such cycle delays the next MFMA of the SAME wave. A different wave on
+// the same SIMD issues its VMEM instruction in parallel with that MFMA. So:
+//   * WM*WN*WK MFMA waves: ds_read fragments + MFMA + ONE raw s_barrier per chunk. No vector memory
+//     instruction in the loop at all.
+//   * 2 loader waves (wave NMW streams A, wave NMW+1 streams B): all LDS-DMA of the workgroup, three
+//     chunks ahead through a 4-slot ring; they wait for their own DMA (counted vmcnt) and meet the MFMA
+//     waves at the per-chunk barrier, which publishes chunk t+1 and retires the slot of chunk t-1.
+//   * one loop body per ring slot (slot offsets are immediates) and NO specialised tail bodies: the loop
+//     is uniform, the end of the chunk stream only switches off a barrier (the first version's tail
+//     variants each ran once per launch: instruction-cache cold misses in a 16-chunk kernel).
+#include "gemm_common.h"
+#include "xsmm_desc.h"
+#include <mutex>
+#include <type_traits>
+
+namespace tpp {
+
+constexpr int LW_BK = 64;   // k per chunk
+constexpr int LW_NSLOT = 4; // LDS ring slots
+
+typedef __attribute__((address_space(3))) void lds_void_lw;
+
+template <int WM, int WN, int WK>
+__global__ __launch_bounds__(64 * (WM * WN * WK + 2)) void brgemm_f32_lw(GemmArgs p) {
+  constexpr int NMW = WM * WN * WK; // MFMA waves
+  constexpr int BM = 32 * WM, BN = 32 * WN;
+  constexpr int A_STAGE = BM * LW_BK, B_STAGE = LW_BK * BN, SLOT = A_STAGE + B_STAGE; // floats
+  constexpr int NA = BM / 4;       // DMA instructions (1 KiB each) per chunk of A: 4 rows x 64 k
+  constexpr int RPI = 256 / BN;    // B rows per DMA instruction
+  constexpr int NB = LW_BK / RPI;  // DMA instructions per chunk of B
+  constexpr int KB_PER_WAVE = 8 / WK, KB_HALF = KB_PER_WAVE / 2;
+  static_assert(KB_HALF >= 1 && NA <= 31 && NB <= 31, "tile outside the schedule's limits (vmcnt is 6 bits)");
+  extern __shared__ __attribute__((aligned(16))) float smem_lw[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // XCD-blocked (8, bn, bm) or plain (1, tiles_n, tiles_m) grid: see brgemm_f32.hip
+  const int tm = (int)(blockIdx.x >> 1) * p.tiles_m + (int)blockIdx.z;
+  const int tn = (int)(blockIdx.x & 1) * p.tiles_n + (int)blockIdx.y;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const float *__restrict__ A = (const float *)p.A;
+  const float *__restrict__ B = (const float *)p.B;
+  float *__restrict__ C = (float *)p.C;
+  const int kchunks = p.k / LW_BK;
+  const int T = p.br * kchunks;
+
+  if (wave >= NMW) {
+    // ---- loader waves --------------------------------------------------------------------
+    const bool isA = wave == NMW;
+    // per-lane source offsets, constant for the whole kernel. A instruction v covers rows 4v .. 4v+3
+    // (lane -> row 4v + lane/16, 16-byte piece lane%16, XOR-ed with row&15 = 4(v&3) + lane/16: the
+    // fragment read applies the same XOR); the 16-row group v>>2 goes into the scalar offset.
+    unsigned voA[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = 4 * j + (lane >> 4);
+      voA[j] = (unsigned)((r * (int)p.lda + 4 * ((lane & 15) ^ r)) * 4);
+    }
+    const unsigned voB = (unsigned)(((lane / (BN / 4)) * (int)p.ldb + 4 * (lane % (BN / 4))) * 4);
+    const unsigned stepA = (unsigned)(16 * (int)p.lda * 4), stepB = (unsigned)(RPI * (int)p.ldb * 4);
+    const float *g = isA ? A + (int64_t)m0 * p.lda : B + n0; // panel base of the chunk being fetched
+    int kc = 0;
+    const int64_t d_in = isA ? (int64_t)LW_BK : (int64_t)LW_BK * p.ldb;
+    const int64_t d_wrap = (isA ? p.stride_a : p.stride_b) - (int64_t)(kchunks - 1) * d_in;
+    auto issue = [&](int slot) __attribute__((always_inline)) {
+      float *base = smem_lw + slot * SLOT + (isA ? 0 : A_STAGE);
+      const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)g, 0, 0x7fffffff, 0x00020000);
+      if (isA) {
+#pragma unroll
+        for (int v = 0; v < NA; ++v)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_lw *)(base + v * 256), 16, voA[v & 3], (v >> 2) * stepA, 0, 0);
+      } else {
+#pragma unroll
+        for (int v = 0; v < NB; ++v)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_lw *)(base + v * 256), 16, voB, v * stepB, 0, 0);
+      }
+      if (++kc == kchunks) {
+        kc = 0;
+        g += d_wrap;
+      } else {
+        g += d_in;
+      }
+    };
+    // s_waitcnt vmcnt(n chunks of this wave's DMA may still be in flight)
+    auto wait_left = [&](int chunks) __attribute__((always_inline)) {
+      if (chunks == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (isA) {
+        if (chunks == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NA) : "memory");
+      } else {
+        if (chunks == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NB) : "memory");
+      }
+    };
+    if (T > 0) issue(0);
+    if (T > 1) issue(1);
+    if (T > 2) issue(2);
+    wait_left(T > 2 ? 2 : T > 1 ? 1 : 0);
+    __builtin_amdgcn_s_barrier(); // chunk 0 published
+    for (int t = 0; t + 1 < T; ++t) {
+      wait_left(t + 2 < T ? 1 : 0); // chunk t+1 has landed (chunk t+2 may still fly)
+      __builtin_amdgcn_s_barrier();  // = the MFMA waves' mid-chunk barrier of chunk t
+      if (t + 3 < T) issue((t + 3) & (LW_NSLOT - 1)); // the slot of chunk t-1: every MFMA wave is past it
+    }
+    return; // ended waves do not take part in later barriers
+  }
+
+  // ---- MFMA waves --------------------------------------------------------------------------
+  const int wk = wave / (WM * WN), wmn = wave % (WM * WN), wm = wmn / WN, wn = wmn % WN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int ccol = n0 + wn * 32 + li;
+  const __amdgpu_buffer_rsrc_t rsrcC =
+      __builtin_amdgcn_make_buffer_rsrc((void *)(C + (int64_t)m0 * p.ldc + n0), 0, 0x7fffffff, 0x00020000);
+  const unsigned voffC = (unsigned)(((wm * 32 + 4 * lh) * (int)p.ldc + wn * 32 + li) * 4);
+  const unsigned ldcb = (unsigned)((int)p.ldc * 4);
+  // the accumulator chain of K group 0 starts from C (beta = 1), as in the reference; the bias is fetched
+  // here so that its latency is not exposed in the epilogue
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  float bias = 0.0f;
+  if (wk == 0) {
+    if (p.ep & EP_BIAS) bias = ((const float *)p.D)[ccol];
+    if (!(p.ep & EP_BETA0)) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        acc[r] = __builtin_bit_cast(
+            float, __builtin_amdgcn_raw_buffer_load_b32(rsrcC, voffC, (unsigned)((r & 3) + 8 * (r >> 2)) * ldcb, 0));
+    }
+  }
+
+  // MFMA fragments of one k-block (8 k): 4 A values (one ds_read_b128) and 4 B values per lane;
+  // double-buffered so block q+1 is read while block q multiplies (brgemm_f32.hip has the layout notes)
+  f32x4 fa[2];
+  float fb[2][4];
+  const int a_off = (wm * 32 + li) * LW_BK, b_off = wn * 32 + li;
+  auto frag_load = [&](int buf, int slot, int kb) __attribute__((always_inline)) {
+    const float *as = smem_lw + slot * SLOT + a_off;
+    const float *bs = smem_lw + slot * SLOT + A_STAGE + b_off;
+    fa[buf] = *(const f32x4 *)(as + (((2 * kb + lh) ^ (li & 15)) << 2));
+#pragma unroll
+    for (int s = 0; s < 4; ++s) fb[buf][s] = bs[(8 * kb + 4 * lh + s) * BN];
+  };
+  const int kbw = wk * KB_PER_WAVE;
+  auto chunk = [&](auto slot_c, bool has_next) __attribute__((always_inline)) {
+    constexpr int S = decltype(slot_c)::value, NS = (S + 1) & (LW_NSLOT - 1);
+#pragma unroll
+    for (int q = 0; q < KB_PER_WAVE; ++q) {
+      const int cur = q & 1, nxt = cur ^ 1;
+      if (q + 1 < KB_PER_WAVE) frag_load(nxt, S, kbw + q + 1);
+      else frag_load(nxt, NS, kbw); // first block of chunk t+1 (published by this chunk's barrier; unused after the last chunk)
+      __builtin_amdgcn_sched_barrier(0); // the reads of step q+1 stay above the MFMAs of step q
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][s], fb[cur][s], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (q == KB_HALF - 1 && has_next) {
+        __builtin_amdgcn_s_barrier(); // chunk t+1 published by the loaders; the slot of chunk t-1 retired
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // the prefetched fragments of chunk t+1 are dead on the loop's exit path: without this the compiler sinks
+    // their reads into the next chunk's head, where the first MFMA then waits for them (the wait this
+    // implies sits behind the last step's four MFMAs: the reads are long back)
+    constexpr int PF = KB_PER_WAVE & 1;
+    asm volatile("" : "+v"(fa[PF]), "+v"(fb[PF][0]), "+v"(fb[PF][1]), "+v"(fb[PF][2]), "+v"(fb[PF][3]));
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>;
+  using S3 = std::integral_constant<int, 3>;
+
+  __builtin_amdgcn_s_barrier(); // chunk 0 published
+  __builtin_amdgcn_sched_barrier(0);
+  if (T > 0) {
+    frag_load(0, 0, kbw);
+    for (int t = 0;;) {
+      chunk(S0{}, t + 1 < T);
+      if (++t == T) break;
+      chunk(S1{}, t + 1 < T);
+      if (++t == T) break;
+      chunk(S2{}, t + 1 < T);
+      if (++t == T) break;
+      chunk(S3{}, t + 1 < T);
+      if (++t == T) break;
+    }
+  }
+
+  if constexpr (WK > 1) {
+    // combine the K groups through LDS: group g > 0 parks its 32x32 partial, group 0 adds
+    __syncthreads();
+    float *red = smem_lw; // (WK-1) * WM*WN * 1024 floats, fits in the ring
+    if (wk > 0) {
+      float *dst = red + ((wk - 1) * (WM * WN) + wmn) * 1024 + lane;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[r * 64] = acc[r];
+    }
+    __syncthreads();
+    if (wk > 0) return;
+#pragma unroll
+    for (int g = 1; g < WK; ++g) {
+      const float *src = red + ((g - 1) * (WM * WN) + wmn) * 1024 + lane;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] += src[r * 64];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float v = acc[r] + bias;
+    if (p.ep & EP_RELU) v = v > 0.0f ? v : 0.0f;
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrcC, voffC,
+                                          (unsigned)((r & 3) + 8 * (r >> 2)) * ldcb, 0);
+  }
+}
+
+template <int WM, int WN, int WK> static hipError_t launch_lw_t(const GemmArgs &a, hipStream_t s) {
+  constexpr int BM = 32 * WM, BN = 32 * WN, NT = 64 * (WM * WN * WK + 2);
+  constexpr size_t lds = (size_t)LW_NSLOT * (BM * LW_BK + LW_BK * BN) * sizeof(float);
+  static std::once_flag once[16]; // the attribute is per device
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  hipError_t err = hipSuccess;
+  std::call_once(once[dev & 15], [&] {
+    err = hipFuncSetAttribute((const void *)brgemm_f32_lw<WM, WN, WK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  });
+  if (err != hipSuccess) return err;
+  GemmArgs args = a;
+  const int tiles_m = a.m / BM, tiles_n = a.n / BN;
+  dim3 grid;
+  if ((tiles_m & 3) == 0 && (tiles_n & 1) == 0 && tiles_m / 4 <= 65535 && tiles_n / 2 <= 65535) {
+    args.tiles_m = tiles_m / 4; // XCD-blocked: 4 (M) x 2 (N) XCD blocks of tiles_m/4 x tiles_n/2 tiles
+    args.tiles_n = tiles_n / 2;
+    grid = dim3(8, args.tiles_n, args.tiles_m);
+  } else {
+    args.tiles_m = args.tiles_n = 0;
+    if (tiles_m > 65535 || tiles_n > 65535) return hipErrorInvalidValue;
+    grid = dim3(1, tiles_n, tiles_m);
+  }
+  hipLaunchKernelGGL((brgemm_f32_lw<WM, WN, WK>), grid, dim3(NT), lds, s, args);
+  return hipGetLastError();
+}
+
+// tile: 0 = 64x64 (4 MFMA waves), 1 = 64x64 with K split over 2 wave groups (8 MFMA waves, two per
+// SIMD), 2 = 64x32 with K split over 2 (4 MFMA waves)
+hipError_t launch_f32_lw(int tile, const GemmArgs &a, hipStream_t s) {
+  switch (tile) {
+  case 0: return launch_lw_t<2, 2, 1>(a, s);
+  case 1: return launch_lw_t<2, 2, 2>(a, s);
+  case 2: return launch_lw_t<2, 1, 2>(a, s);
+  default: return hipErrorInvalidValue;
+  }
+}
+
+} // namespace tpp
