@@ -152,6 +152,15 @@ TPP_XSMM_EXPORT void xsmm_hip_flush(void);
 TPP_XSMM_EXPORT void xsmm_hip_set_stream(void *hip_stream);
 TPP_XSMM_EXPORT void *xsmm_hip_get_stream(void);
 TPP_XSMM_EXPORT void xsmm_hip_synchronize(void);
+/* Host residents: the ABI has no allocation hook, so the runtime never caches a mirror of a host buffer
+ * behind the caller's back. A harness that knows a host buffer is long-lived (weights, the operands of a
+ * timing loop: lib/TPP/Runner/MLIRBench.cpp:207-246 allocates them once) can declare it: the buffer is
+ * uploaded once, and invokes whose operands lie inside it run on the device copy without any upload
+ * (operands the kernel writes are still copied back, so the host view stays current). _update re-uploads
+ * after the host changed the buffer; _release drops the copy. Return 0, or -1 (unknown / overlapping range). */
+TPP_XSMM_EXPORT int xsmm_hip_host_resident(const void *ptr, int64_t bytes);
+TPP_XSMM_EXPORT int xsmm_hip_host_update(const void *ptr);
+TPP_XSMM_EXPORT int xsmm_hip_host_release(const void *ptr);
 /* Number of visible HIP devices (0 on a CPU-only host; never exits). */
 TPP_XSMM_EXPORT int xsmm_hip_device_count(void);
 /* Name of the HIP kernel variant a GEMM-like handle selected, for profiles. */

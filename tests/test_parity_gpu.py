@@ -198,13 +198,13 @@ def test_brgemm_f32_fast_variants(rt, case):
 
 
 @pytest.mark.parametrize("variant,m,n", [(0, 128, 128), (1, 128, 96), (2, 96, 96), (3, 256, 128), (4, 128, 128),
-                                         (5, 128, 128), (6, 128, 192), (7, 128, 96)])
+                                         (5, 128, 128), (6, 128, 192), (7, 128, 96), (9, 96, 96)])
 def test_brgemm_f32_forced_tile_variants(rt, variant, m, n):
     gemm_case(rt, F32, m, n, 64, 4, sa=64, lda=256, sb=64 * n, beta0=False, bias=True, relu=True,
               seed=variant, force=variant)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 9])
 @pytest.mark.parametrize("k,br", [(64, 0), (64, 1), (64, 2), (64, 3), (64, 4), (64, 5), (64, 7), (128, 3), (192, 2), (64, 16)])
 def test_brgemm_f32_chunk_stream_lengths(rt, variant, k, br):
     """every ring position of the uniform chunk loops (1 .. 16 chunks, chunk streams that wrap inside a batch
@@ -776,6 +776,101 @@ def test_concurrent_invokes_on_disjoint_tiles(rt):
     for t in ths:
         t.join()
     check_close(C, ref, F32, "concurrent tiles")
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("op", ["gemm_beta1", "gemm_beta0_fused", "unary_relu", "binary_add_inplace", "transpose"])
+def test_concurrent_host_invokes_on_adjacent_tiles_of_a_flat_buffer(rt, dt, op):
+    """HOST pointers, 8 threads, 32x32 tiles of ONE flat row-major 256 x 1024 output (ld = 1024 > n): the rows of
+    neighbouring tiles interleave in memory, so a mirror that copied back the bounding span of a tile would
+    overwrite what another thread has just written (the reference's OpenMP callers on host memrefs,
+    pass-convert-mlp-to-parallel-tile.mlir:80-88 - XsmmRunnerUtils.cpp:288-306 is synchronous and re-entrant).
+    Every tile is checked against the oracle, several rounds so that interleavings vary."""
+    LD, TM, TN, T = 1024, 8, 32, 32
+    rng = np.random.default_rng(sum(map(ord, op)) + dt)
+    tiles = [(i, j) for i in range(TM) for j in range(TN)]
+    for rnd in range(3):
+        A = rand(rng, TM * T * LD, dt)
+        B = rand(rng, LD * LD, dt) if not op.startswith("gemm") or dt == F32 else rand(rng, LD * LD, dt)
+        bias = rand(rng, LD, dt)
+        C = rand(rng, TM * T * LD, dt)
+        ref = C.copy()
+        vn = VB if dt == BF16 else 0
+        if op == "gemm_beta1":      # C tile (i, j) += A[i rows, 64 k] * B[64 k, j cols]
+            h = rt.brgemm_dispatch(dt, T, T, 32, LD, LD, LD, 32, 32 * LD, vn)
+            call = lambda i, j, c: rt.brgemm(dt, h, A, i * T * LD, B, (2 if vn else 1) * j * T, c, i * T * LD + j * T, 2)  # noqa: E731
+            orc_call = lambda i, j: orc.brgemm(dt, T, T, 32, LD, LD, LD, 32, 32 * LD, vn, A, i * T * LD, B, (2 if vn else 1) * j * T, ref, i * T * LD + j * T, 2)  # noqa: E731
+        elif op == "gemm_beta0_fused":
+            h = rt.fused_brgemm_dispatch(dt, T, T, 32, LD, LD, LD, 32, 32 * LD, 4 | vn, 0, 5, 4, 1)
+            call = lambda i, j, c: rt.fused_brgemm(dt, h, A, i * T * LD, B, (2 if vn else 1) * j * T, c, i * T * LD + j * T, bias, j * T, 2)  # noqa: E731
+            orc_call = lambda i, j: orc.fused_brgemm(dt, T, T, 32, LD, LD, LD, 32, 32 * LD, 4 | vn, 0, 5, 4, 1, A, i * T * LD, B, (2 if vn else 1) * j * T, ref, i * T * LD + j * T, bias, j * T, 2)  # noqa: E731
+        elif op == "unary_relu":    # out tile = relu(in tile), both strided
+            h = rt.unary_dispatch(5, dt, T, T, LD, LD, 0)
+            call = lambda i, j, c: rt.unary(dt, h, A, i * T * LD + j * T, c, i * T * LD + j * T)  # noqa: E731
+            orc_call = lambda i, j: orc.unary(5, dt, T, T, LD, LD, 0, A, i * T * LD + j * T, ref, i * T * LD + j * T)  # noqa: E731
+        elif op == "binary_add_inplace":  # out tile = out tile + bias row (out == lhs, strided)
+            h = rt.binary_dispatch(1, dt, T, T, LD, T, LD, 8)
+            call = lambda i, j, c: rt.binary(dt, h, c, i * T * LD + j * T, bias, j * T, c, i * T * LD + j * T)  # noqa: E731
+            orc_call = lambda i, j: orc.binary(1, dt, T, T, LD, T, LD, 8, ref, i * T * LD + j * T, bias, j * T, ref, i * T * LD + j * T)  # noqa: E731
+        else:                       # out tile (j, i) of the transposed grid <- in tile (i, j); out is 1024 x 256 seen as ld 1024 tiles
+            h = rt.unary_dispatch(29, dt, T, T, LD, LD, 0)
+            call = lambda i, j, c: rt.unary(dt, h, A, i * T * LD + j * T, c, (j % TM) * T * LD + (i + TM * (j // TM)) * T)  # noqa: E731
+            orc_call = lambda i, j: orc.unary(29, dt, T, T, LD, LD, 0, A, i * T * LD + j * T, ref, (j % TM) * T * LD + (i + TM * (j // TM)) * T)  # noqa: E731
+        for (i, j) in tiles:
+            orc_call(i, j)
+        errors = []
+
+        def worker(chunk):
+            try:
+                for (i, j) in chunk:
+                    call(i, j, C)
+            except Exception as ex:  # noqa: BLE001
+                errors.append(repr(ex))
+        order = list(tiles)
+        rng.shuffle(order)
+        ths = [threading.Thread(target=worker, args=(order[w::8],)) for w in range(8)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        assert not errors, errors
+        if op in ("unary_relu", "transpose"):
+            assert np.array_equal(C, ref), "%s dt%d round %d: %d elements differ" % (op, dt, rnd, int((C != ref).sum()))
+        else:
+            check_close(C, ref, dt, "%s dt%d round %d" % (op, dt, rnd))
+
+
+def test_host_resident_operands(rt):
+    """xsmm_hip_host_resident: declared host buffers are uploaded once; invokes on them (and on sub-ranges)
+    use the device copy, results written into a resident buffer are still visible on the host on return,
+    host_update re-uploads, host_release returns to per-call mirroring"""
+    rng = np.random.default_rng(3)
+    m = n = 128
+    A, B = rand(rng, m * 256, F32), rand(rng, 256 * n, F32)
+    C = np.zeros(m * n, np.float32)
+    h = rt.brgemm_dispatch(F32, m, n, 64, 256, n, n, 64, 64 * n, 4)
+    ref = C.copy()
+    orc.brgemm(F32, m, n, 64, 256, n, n, 64, 64 * n, 4, A, 0, B, 0, ref, 0, 4)
+    assert rt.host_resident(A) == 0 and rt.host_resident(B) == 0 and rt.host_resident(C) == 0
+    assert rt.host_resident(A) == -1  # overlapping declaration
+    try:
+        rt.brgemm(F32, h, A, 0, B, 0, C, 0, 4)
+        check_close(C, ref, F32, "resident operands")
+        A2 = A.copy()
+        A[:] = 0.0  # host change NOT announced: the device copy still holds the old values
+        rt.brgemm(F32, h, A, 0, B, 0, C, 0, 4)
+        check_close(C, ref, F32, "resident operands, stale host bytes ignored until host_update")
+        assert rt.host_update(A) == 0
+        rt.brgemm(F32, h, A, 0, B, 0, C, 0, 4)
+        assert not C.any(), "after host_update the zeros must be used"
+        A[:] = A2
+        assert rt.host_update(A) == 0
+    finally:
+        for x in (A, B, C):
+            assert rt.host_release(x) == 0
+    C[:] = 0
+    rt.brgemm(F32, h, A, 0, B, 0, C, 0, 4)
+    check_close(C, ref, F32, "after release")
 
 
 def test_c5_pack_prologue_then_vnni_brgemm_full_size(rt):

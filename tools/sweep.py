@@ -60,6 +60,17 @@ def bf16_case(m, n, k, br, tag="", force=None):
         m, n, k, br, rt.kernel_name(h), t * 1e6, fl / t / 1e12, fl / t / 25e12, tag), flush=True)
 
 
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "f32lw":
+    # loader-wave f32 kernels (5 64x64, 6 64x64+K2, 7 64x32+K2, 9 32x32+K4) against the round-1 kernels (0, 1, 2, 3, 4)
+    for (m, n, k, br, tag) in ((1024, 1024, 64, 16, "C2"), (512, 1024, 64, 16, "C3 shape"), (256, 1024, 64, 16, "bs=256 layer"),
+                               (2048, 2048, 64, 16, "2048^2 K=1024"), (4096, 4096, 64, 16, "4096^2 K=1024"),
+                               (4096, 1024, 64, 16, "4096x1024 K=1024"), (1024, 1024, 64, 128, "C2 K=8192")):
+        for v in (None, 0, 5, 6, 4, 3, 1, 7, 2, 9):
+            if v == 3 and m % 128:
+                continue
+            f32_case(m, n, k, br, force=v, tag=tag + (" forced v%d" % v if v is not None else " (default pick)"))
+    sys.exit(0)
+
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "bf16":
     bf16_case(4096, 1024, 64, 16, tag="C4 layer")
     bf16_case(2048, 2048, 128, 16, tag="C5")

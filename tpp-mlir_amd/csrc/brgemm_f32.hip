@@ -31,9 +31,15 @@
 
 namespace tpp {
 
+// Timing-only ablation switches for kernel work (tools/ablate.sh builds side libraries
+// with -DTPP_ABLATE=mask; the shipped library is always built with 0 = full kernel).
+#ifndef TPP_ABLATE
+#define TPP_ABLATE 0
+#endif
 #ifndef TPP_NACC
 #define TPP_NACC 1 // accumulator chains per wave: 1 measured +0.9 % on C2 over 2 (and it is the oracle's summation order: one chain)
 #endif
+constexpr int ABL_NO_GLOAD = 1, ABL_NO_SWRITE = 2, ABL_NO_BARRIER = 4, ABL_NO_FRAG = 8, ABL_STAMP = 32;
 
 constexpr int BK = 64;     // k columns per chunk
 constexpr int NSTAGE = 3;  // LDS ring slots
@@ -44,10 +50,9 @@ typedef __attribute__((address_space(3))) void lds_void_f;
 // One LDS-DMA instruction: 64 lanes x 16 bytes from (panel base, per-lane offset) to 1 KiB of the
 // dynamic LDS at byte offset lds_off. A plain function on purpose: called from the kernel TEMPLATE with
 // template-dependent operands, the builtin made hipcc drop the kernels' host stubs without a diagnostic.
-// nrec = 0 switches the instruction off (every lane out of range: no memory access).
-static __device__ __forceinline__ void lds_dma_16B(const void *panel, unsigned lds_off, unsigned voff, unsigned nrec) {
+static __device__ __forceinline__ void lds_dma_16B(const void *panel, unsigned lds_off, unsigned voff) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds_f32[];
-  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)panel, 0, (int)nrec, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)panel, 0, 0x7fffffff, 0x00020000);
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_f *)(dyn_lds_f32 + lds_off), 16, voff, 0, 0, 0);
 }
 
@@ -79,6 +84,10 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void brgemm_f32_fast(GemmArgs p,
   float *As = smem;
   float *Bs = smem + NSTAGE * A_STAGE;
 
+  unsigned long long stamp[5] = {0, 0, 0, 0, 0};
+  unsigned long long step_stamp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long pro_stamp[4] = {0, 0, 0, 0};
+  if (TPP_ABLATE & ABL_STAMP) { stamp[0] = __builtin_readcyclecounter(); stamp[4] = wall_clock64(); }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wk = wave / (WM * WN), wmn = wave % (WM * WN), wm = wmn / WN, wn = wmn % WN;
@@ -145,18 +154,16 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void brgemm_f32_fast(GemmArgs p,
       gB += dB_in;
     }
   };
-  // nrec: 0x7fffffff, or 0 past the end of the chunk stream (the instruction then touches no memory and
-  // delivers zeros into a register set / ring slot nobody reads any more): the chunk loop below is uniform
-  auto gload_piece = [&](int set, int u, unsigned nrec) __attribute__((always_inline)) {
+  auto gload_piece = [&](int set, int u) __attribute__((always_inline)) {
     // descriptor built from wave-uniform scalars right at the load (kept in SGPRs)
     const __amdgpu_buffer_rsrc_t r =
-        __builtin_amdgcn_make_buffer_rsrc((void *)(u < LA ? gA : gB), 0, (int)nrec, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((void *)(u < LA ? gA : gB), 0, 0x7fffffff, 0x00020000);
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff[u], 0, 0);
     rs[set][u] = __builtin_bit_cast(f32x4, v);
   };
-  auto dma_piece = [&](int stage, int u, unsigned nrec) __attribute__((always_inline)) {
-    if (u < LA) lds_dma_16B(gA, (unsigned)((stage * A_STAGE + (wave * LA + u) * 256) * 4), voff[u], nrec);
-    else lds_dma_16B(gB, (unsigned)((NSTAGE * A_STAGE + stage * B_STAGE + (wave * LB + (u - LA)) * 256) * 4), voff[u], nrec);
+  auto dma_piece = [&](int stage, int u) __attribute__((always_inline)) {
+    if (u < LA) lds_dma_16B(gA, (unsigned)((stage * A_STAGE + (wave * LA + u) * 256) * 4), voff[u]);
+    else lds_dma_16B(gB, (unsigned)((NSTAGE * A_STAGE + stage * B_STAGE + (wave * LB + (u - LA)) * 256) * 4), voff[u]);
   };
   auto swrite_piece = [&](int stage, int u) __attribute__((always_inline)) {
     float *as = As + stage * A_STAGE, *bs = Bs + stage * B_STAGE;
@@ -182,22 +189,24 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void brgemm_f32_fast(GemmArgs p,
   };
 
   const int kbw = wk * KB_PER_WAVE;
-  // One chunk = KB_PER_WAVE k-block steps of 4 MFMAs, ring slot STAGE known at compile time (every LDS
-  // address is base VGPR + immediate). Register set s holds the chunk that goes to ring slot s
-  // (NSET == NSTAGE). The body is the SAME for every chunk of the stream (three instances, one per ring
-  // slot - the first version's specialised tail bodies each ran once per launch, from a cold
-  // instruction cache): register-staged panels write set STAGE+1 (chunk t+1) to slot STAGE+1 during the
-  // first half of the steps, ONE barrier publishes it, and the second half issues the loads of the chunk
-  // AHEAD of this one (DMA: chunk t+2 straight into the slot chunk t-1 has left). Past the end of the
-  // stream the loads are switched off through the descriptor (nrec = 0) and what the rest of the body
-  // moves around is never read. The last step prefetches the first fragments of chunk t+1.
-  auto chunk = [&](auto stage_c, unsigned nrec) __attribute__((always_inline)) {
+  // One chunk = KB_PER_WAVE k-block steps of 4 MFMAs, ring slot STAGE known at compile
+  // time (every LDS address is base VGPR + immediate). Register set s holds the chunk
+  // that goes to ring slot s (NSET == NSTAGE). HAS_NEXT: chunk t+1 exists: set STAGE+1
+  // is written to slot STAGE+1 during the first half of the steps, then ONE barrier
+  // publishes it. HAS_LOAD: chunk t+1+NSET exists: its global loads refill the set just
+  // written, during the second half - they have NSET-0.5 chunks of MFMAs to land. The
+  // last step prefetches the first fragments of chunk t+1.
+  auto chunk = [&](auto stage_c, auto has_next, auto has_load) __attribute__((always_inline)) {
     constexpr int STAGE = decltype(stage_c)::value, NSTG = (STAGE + 1) % NSTAGE;
+    constexpr bool HAS_NEXT = decltype(has_next)::value, HAS_LOAD = decltype(has_load)::value;
 #pragma unroll
     for (int q = 0; q < KB_PER_WAVE; ++q) {
       const int cur = q & 1, nxt = cur ^ 1;
-      if (q + 1 < KB_PER_WAVE) frag_load(nxt, STAGE, kbw + q + 1);
-      else frag_load(nxt, NSTG, kbw);
+      if ((TPP_ABLATE & ABL_STAMP) && STAGE == 0 && HAS_LOAD) step_stamp[q] = __builtin_readcyclecounter();
+      if (!(TPP_ABLATE & ABL_NO_FRAG)) {
+        if (q + 1 < KB_PER_WAVE) frag_load(nxt, STAGE, kbw + q + 1);
+        else if (HAS_NEXT) frag_load(nxt, NSTG, kbw);
+      }
       // pin the issue order: the fragment reads of step q+1 stay ABOVE the MFMAs of
       // step q, and each piece of staging work sits in the shadow of one MFMA (the
       // wave is in-order: it idles at the next MFMA until the matrix pipe frees up).
@@ -205,52 +214,65 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void brgemm_f32_fast(GemmArgs p,
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         acc[s % NACC] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][s], fb[cur][s], acc[s % NACC], 0, 0, 0);
-        if (!DMA && q == 0 && s == 0) gadvance(); // panel base of the next chunk to load: scalar work in the shadow of the MFMA above
-#pragma unroll
-        for (int u = 0; u < NP; ++u) {
-          if (!DMA && (u * WSLOTS) / NP == q * 4 + s) swrite_piece(NSTG, u);
-          if ((u * 4 * (KB_PER_WAVE - KB_HALF)) / NP == (q - KB_HALF) * 4 + s) {
-            if (DMA) dma_piece((STAGE + 2) % NSTAGE, u, nrec); // chunk t+2 into the slot chunk t-1 has left (after the barrier)
-            else gload_piece(NSTG, u, nrec);
+        if (!DMA && HAS_LOAD && !(TPP_ABLATE & ABL_NO_GLOAD) && q == 0 && s == 0) {
+          // panel base of the next chunk to load: scalar work in the shadow of the MFMA above
+          if (++kc == kchunks) {
+            kc = 0;
+            gA += dA_wrap;
+            gB += dB_wrap;
+          } else {
+            gA += BK;
+            gB += dB_in;
           }
         }
-        if (DMA && q == KB_PER_WAVE - 1 && s == 3) gadvance(); // panel base of the chunk after the one just requested
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+          if (!DMA && HAS_NEXT && !(TPP_ABLATE & ABL_NO_SWRITE) && (u * WSLOTS) / NP == q * 4 + s) swrite_piece(NSTG, u);
+          if (HAS_LOAD && !(TPP_ABLATE & ABL_NO_GLOAD) && (u * 4 * (KB_PER_WAVE - KB_HALF)) / NP == (q - KB_HALF) * 4 + s) {
+            if (DMA) dma_piece((STAGE + 2) % NSTAGE, u); // chunk t+2 into the slot chunk t-1 has left (after the barrier)
+            else gload_piece(NSTG, u);
+          }
+        }
+        if (DMA && HAS_LOAD && !(TPP_ABLATE & ABL_NO_GLOAD) && q == KB_PER_WAVE - 1 && s == 3) {
+          if (++kc == kchunks) { // panel base of the chunk after the one just requested
+            kc = 0;
+            gA += dA_wrap;
+            gB += dB_wrap;
+          } else {
+            gA += BK;
+            gB += dB_in;
+          }
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (q == KB_HALF - 1) {
+      if (q == KB_HALF - 1 && !(TPP_ABLATE & ABL_NO_BARRIER)) {
         // DMA: this wave's pieces of chunk t+1 have landed in the LDS (the fence of __syncthreads
         // does not wait for LDS-DMA), then everybody's
-        if (DMA) {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          __builtin_amdgcn_s_barrier(); // raw: no ds_write to fence, and the fragment reads in flight need no drain
-          __builtin_amdgcn_sched_barrier(0);
-        } else {
-          __syncthreads();
-        }
+        if (DMA && HAS_NEXT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
       }
     }
-    // the prefetched fragments of chunk t+1 are dead on the loop's exit path: without this the compiler sinks
-    // their reads into the next chunk's head, where the first MFMA then waits for them
-    constexpr int PF = KB_PER_WAVE & 1;
-    asm volatile("" : "+v"(fa[PF]), "+v"(fb[PF][0]), "+v"(fb[PF][1]), "+v"(fb[PF][2]), "+v"(fb[PF][3]));
+    if ((TPP_ABLATE & ABL_STAMP) && STAGE == 0 && HAS_LOAD) step_stamp[8] = __builtin_readcyclecounter();
   };
+  using yes = std::integral_constant<bool, true>;
+  using no = std::integral_constant<bool, false>;
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
   using S2 = std::integral_constant<int, 2>;
   static_assert(NSET == NSTAGE && NSTAGE == 3, "the chunk schedule below is written for 3 slots / 3 sets");
-  constexpr unsigned ON = 0x7fffffffu;
 
   // prologue: chunk 0 -> set 0 -> slot 0; chunks 1, 2, 3 -> sets 1, 2, 0 (in flight)
   if (T > 0) { // first thing the kernel does: get chunk 0 moving
+    if (TPP_ABLATE & ABL_STAMP) pro_stamp[0] = __builtin_readcyclecounter();
 #pragma unroll
     for (int u = 0; u < NP; ++u) {
-      if (DMA) dma_piece(0, u, ON);
-      else gload_piece(0, u, ON);
+      if (DMA) dma_piece(0, u);
+      else gload_piece(0, u);
     }
-    if (DMA) { // chunk 1 right behind it; afterwards the panel base points at chunk 2
+    if (DMA && T > 1) { // chunk 1 right behind it; afterwards the panel base points at chunk 2
       gadvance();
 #pragma unroll
-      for (int u = 0; u < NP; ++u) dma_piece(1, u, T > 1 ? ON : 0u);
+      for (int u = 0; u < NP; ++u) dma_piece(1, u);
       gadvance();
     }
   }
@@ -269,8 +291,6 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void brgemm_f32_fast(GemmArgs p,
       __builtin_amdgcn_make_buffer_rsrc((void *)(C + (int64_t)m0 * p.ldc + n0), 0, 0x7fffffff, 0x00020000);
   const unsigned voffC = (unsigned)(((wm * 32 + 4 * lh) * (int)p.ldc + wn * 32 + li) * 4);
   const unsigned ldcb = (unsigned)((int)p.ldc * 4);
-  // bias: fetched here, used in the epilogue (its latency hides under the whole K loop)
-  const float bias = ((p.ep & EP_BIAS) && wk == 0) ? ((const float *)p.D)[ccol] : 0.0f;
   if (!(p.ep & EP_BETA0) && wk == 0) {
 #pragma unroll
     for (int r = 0; r < 16; ++r)
@@ -282,38 +302,50 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void brgemm_f32_fast(GemmArgs p,
 #pragma unroll
     for (int c = 1; c <= NSET; ++c) {
       if (c == NSET) { // set 0 is reused for chunk NSET: chunk 0 must be in LDS first
+        if (TPP_ABLATE & ABL_STAMP) pro_stamp[1] = __builtin_readcyclecounter();
 #pragma unroll
         for (int u = 0; u < NP; ++u) swrite_piece(0, u);
+        if (TPP_ABLATE & ABL_STAMP) pro_stamp[2] = __builtin_readcyclecounter();
       }
-      gadvance();
+      if (c < T) {
+        gadvance();
 #pragma unroll
-      for (int u = 0; u < NP; ++u) gload_piece(c % NSET, u, c < T ? ON : 0u);
+        for (int u = 0; u < NP; ++u) gload_piece(c % NSET, u);
+      }
     }
   }
-  if (DMA) {
-    // chunk 0 has landed (in-order return: at most the NP pieces of chunk 1 - or, behind them, bias / C
-    // loads - are still in flight), then everybody's: a raw barrier, there are no ds_write to fence
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-  } else {
-    __syncthreads();
-  }
-  constexpr int AHEAD = DMA ? 2 : NSET + 1; // chunk t + AHEAD is the one fetched during chunk t
-  if (T > 0) {
-    frag_load(0, 0, kbw);
-    for (int t = 0;;) { // ring slots 0, 1, 2, 0, ...
-      chunk(S0{}, t + AHEAD < T ? ON : 0u);
-      if (++t == T) break;
-      chunk(S1{}, t + AHEAD < T ? ON : 0u);
-      if (++t == T) break;
-      chunk(S2{}, t + AHEAD < T ? ON : 0u);
-      if (++t == T) break;
-    }
-  }
-  // switched-off DMA instructions still count as outstanding LDS writes: retire them before the ring is reused / the wave ends
   if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (TPP_ABLATE & ABL_STAMP) pro_stamp[3] = __builtin_readcyclecounter();
+  if (T > 0) frag_load(0, 0, kbw);
+  if (TPP_ABLATE & ABL_STAMP) stamp[1] = __builtin_readcyclecounter();
+  int t = 0;
+  constexpr int AHEAD = DMA ? 2 : NSET + 1; // chunk t + AHEAD is the one fetched during chunk t
+  for (; t + 2 + AHEAD < T; t += 3) { // steady state: three chunks per trip, ring slots 0, 1, 2
+    chunk(S0{}, yes{}, yes{});
+    chunk(S1{}, yes{}, yes{});
+    chunk(S2{}, yes{}, yes{});
+  }
+  auto tail = [&](auto stage_c) __attribute__((always_inline)) { // last chunks: same bodies minus what no longer exists
+    const int left = T - t;
+    if (left > AHEAD) chunk(stage_c, yes{}, yes{});
+    else if (left >= 2) chunk(stage_c, yes{}, no{});
+    else chunk(stage_c, no{}, no{});
+    ++t;
+  };
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    if (t < T) tail(S0{});
+    if (t < T) tail(S1{});
+    if (t < T) tail(S2{});
+  }
 
+  if (TPP_ABLATE & ABL_STAMP) stamp[2] = __builtin_readcyclecounter();
+  if (TPP_ABLATE & (ABL_NO_SWRITE | ABL_NO_FRAG)) { // keep ablated producers alive
+#pragma unroll
+    for (int u = 0; u < LA + LB; ++u) asm volatile("" ::"v"(rs[0][u]), "v"(rs[DMA ? 0 : 1][u]), "v"(rs[DMA ? 0 : 2][u]));
+    asm volatile("" ::"v"(fa[0]), "v"(fa[1]));
+  }
 #pragma unroll
   for (int a = 1; a < NACC; ++a)
 #pragma unroll
@@ -338,12 +370,26 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void brgemm_f32_fast(GemmArgs p,
     }
   }
 
+  const float bias = (p.ep & EP_BIAS) ? ((const float *)p.D)[ccol] : 0.0f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     float v = acc[0][r] + bias;
     if (p.ep & EP_RELU) v = v > 0.0f ? v : 0.0f;
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrcC, voffC,
                                           (unsigned)((r & 3) + 8 * (r >> 2)) * ldcb, 0);
+  }
+  if ((TPP_ABLATE & ABL_STAMP) && p.D && !(p.ep & EP_BIAS) && tid == 0) {
+    stamp[3] = __builtin_readcyclecounter();
+    const size_t lin = blockIdx.x + gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z);
+    const size_t nblk = (size_t)gridDim.x * gridDim.y * gridDim.z;
+    unsigned long long *dbg = (unsigned long long *)p.D + lin * 8;
+    for (int e = 0; e < 5; ++e) dbg[e] = stamp[e];
+    dbg[5] = wall_clock64();
+    unsigned long long *dbg2 = (unsigned long long *)p.D + nblk * 8 + lin * 16;
+    for (int e = 0; e < 9; ++e) dbg2[e] = step_stamp[e];
+    for (int e = 0; e < 4; ++e) dbg2[9 + e] = pro_stamp[e];
+    dbg[6] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); // HW_REG_XCC_ID
+    dbg[7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_REG_HW_ID
   }
 }
 
@@ -521,6 +567,7 @@ enum GemmVariant : int {
   V_F32_LW_64x64K2 = 6,   // 8 MFMA waves 2x2x2 + 2 loader waves
   V_F32_LW_64x32K2 = 7,   // 4 MFMA waves 2x1x2 + 2 loader waves
   V_GENERIC = 8,     // chosen per invoke when the fast preconditions fail
+  V_F32_LW_32x32K4 = 9,   // 4 MFMA waves 1x1x4 + 2 loader waves
   V_BF16_FAST = 16,  // brgemm_bf16.hip: 64x64 register-staged
   V_BF16_DMA128 = 17, // brgemm_bf16.hip: 128x128, LDS-DMA + loader waves
   V_BF16_DMA256 = 18, // brgemm_bf16_dma256.hip: 256x256, LDS-DMA
@@ -659,6 +706,9 @@ static int pick_f32_variant(const GemmDesc &d) {
   if (d.lda >= (1 << 22) || d.ldb >= (1 << 22) || d.ldc >= (1 << 22)) return V_GENERIC; // 32-bit lane offsets
   const int64_t m = d.m, n = d.n;
   auto tiles = [&](int bm, int bn) { return (m % bm == 0 && n % bn == 0) ? (m / bm) * (n / bn) : 0; };
+  // 64-row tiles run on the loader-wave kernels (brgemm_f32_lw.hip). Measured on C2 (256 tiles of 64x64, uniform
+  // [-1, 1) inputs, profiles/r02_f32_variants.txt): 64x64 with the K chunks split over two wave groups (two MFMA
+  // waves per SIMD cover each other's barrier stalls) 18.3 us, one group 18.7 us, the round-1 kernel 19.7-20.4 us.
   // Outputs with at least one 64x64 tile per CU: 64x64 or 128x64 tiles, whichever needs less time over its rounds
   // of workgroups (one per CU at a time). A 128x64 round takes ~1.85x a 64x64 round (measured, K = 1024: 32.7 vs
   // 17.6 us), so 128x64 wins at 1280-2048 x 1024 (one round instead of two) and for large outputs (0.93x), and
@@ -666,12 +716,12 @@ static int pick_f32_variant(const GemmDesc &d) {
   if (tiles(64, 64) >= g_num_cus) {
     const int64_t r64 = (tiles(64, 64) + g_num_cus - 1) / g_num_cus, r128 = (tiles(128, 64) + g_num_cus - 1) / g_num_cus;
     if (tiles(128, 64) > 0 && 1.85 * (double)r128 < (double)r64) return V_F32_128x64;
-    return V_F32_64x64;
+    return V_F32_LW_64x64K2;
   }
-  if (tiles(64, 32) >= g_num_cus) return V_F32_64x32K2;
+  if (tiles(64, 32) >= g_num_cus) return V_F32_LW_64x32K2;
   if (tiles(32, 32) > 0 && tiles(32, 32) >= tiles(64, 64) * 2 && tiles(64, 32) < g_num_cus) return V_F32_32x32K4;
-  if (tiles(64, 64) > 0) return V_F32_64x64;
-  if (tiles(64, 32) > 0) return V_F32_64x32K2;
+  if (tiles(64, 64) > 0) return V_F32_LW_64x64K2;
+  if (tiles(64, 32) > 0) return V_F32_LW_64x32K2;
   if (tiles(32, 32) > 0) return V_F32_32x32K4;
   return V_GENERIC;
 }
@@ -686,6 +736,7 @@ static const char *variant_name(int v) {
   case V_F32_LW_64x64: return "brgemm_f32_fast_lw<64x64,k1>";
   case V_F32_LW_64x64K2: return "brgemm_f32_fast_lw<64x64,k2>";
   case V_F32_LW_64x32K2: return "brgemm_f32_fast_lw<64x32,k2>";
+  case V_F32_LW_32x32K4: return "brgemm_f32_fast_lw<32x32,k4>";
   case V_BF16_FAST: return "brgemm_bf16_fast<64x64>";
   case V_BF16_DMA128: return "brgemm_bf16_dma<128x128>";
   case V_BF16_DMA256: return "brgemm_bf16_dma<256x256>";
@@ -713,6 +764,7 @@ bool plan_gemm(GemmDesc &d, int forced_variant) {
     // honour the forced tile only if the shape divides it
     const int bm[] = {64, 64, 32, 128, 64, 64, 64, 64}, bn[] = {64, 32, 32, 64, 64, 64, 64, 32};
     if (forced_variant <= 7 && d.m % bm[forced_variant] == 0 && d.n % bn[forced_variant] == 0) v = forced_variant;
+    if (forced_variant == V_F32_LW_32x32K4 && d.m % 32 == 0 && d.n % 32 == 0) v = forced_variant;
     if (forced_variant == V_GENERIC) v = V_GENERIC;
   } else if (forced_variant == V_GENERIC) {
     v = V_GENERIC;
@@ -752,6 +804,7 @@ hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C,
   case V_F32_LW_64x64:
   case V_F32_LW_64x64K2:
   case V_F32_LW_64x32K2: return launch_f32_lw(v - V_F32_LW_64x64, a, stream);
+  case V_F32_LW_32x32K4: return launch_f32_lw(3, a, stream);
   case V_BF16_FAST:
   case V_BF16_DMA128:
   case V_BF16_DMA256: return launch_gemm_bf16_fast(v - V_BF16_FAST, a, stream);

@@ -248,12 +248,13 @@ template <int WM, int WN, int WK> static hipError_t launch_lw_t(const GemmArgs &
 }
 
 // tile: 0 = 64x64 (4 MFMA waves), 1 = 64x64 with K split over 2 wave groups (8 MFMA waves, two per
-// SIMD), 2 = 64x32 with K split over 2 (4 MFMA waves)
+// SIMD), 2 = 64x32 with K split over 2 (4 MFMA waves), 3 = 32x32 with K split over 4 (4 MFMA waves)
 hipError_t launch_f32_lw(int tile, const GemmArgs &a, hipStream_t s) {
   switch (tile) {
   case 0: return launch_lw_t<2, 2, 1>(a, s);
   case 1: return launch_lw_t<2, 2, 2>(a, s);
   case 2: return launch_lw_t<2, 1, 2>(a, s);
+  case 3: return launch_lw_t<1, 1, 4>(a, s);
   default: return hipErrorInvalidValue;
   }
 }

@@ -79,6 +79,9 @@ _SIGNATURES = {
     "xsmm_hip_flush": (None, []),
     "xsmm_hip_get_stream": (VP, []),
     "xsmm_hip_synchronize": (None, []),
+    "xsmm_hip_host_resident": (ctypes.c_int, [VP, I64]),
+    "xsmm_hip_host_update": (ctypes.c_int, [VP]),
+    "xsmm_hip_host_release": (ctypes.c_int, [VP]),
     "xsmm_hip_device_count": (ctypes.c_int, []),
     "xsmm_hip_kernel_name": (ctypes.c_char_p, [I64]),
     "xsmm_hip_force_variant": (None, [ctypes.c_int]),
@@ -200,6 +203,16 @@ class XsmmRuntime:
 
     def synchronize(self):
         self.lib.xsmm_hip_synchronize()
+
+    def host_resident(self, buf, nbytes=None):
+        """declare a long-lived host buffer (numpy array): uploaded once, used from its device copy afterwards"""
+        return self.lib.xsmm_hip_host_resident(_addr(buf), int(nbytes if nbytes is not None else buf.nbytes))
+
+    def host_update(self, buf):
+        return self.lib.xsmm_hip_host_update(_addr(buf))
+
+    def host_release(self, buf):
+        return self.lib.xsmm_hip_host_release(_addr(buf))
 
     def device_count(self):
         return self.lib.xsmm_hip_device_count()
