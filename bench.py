@@ -11,9 +11,8 @@ Step = one pass of the hot path over one batch of synthetic input:
     1024->1024->1024->1024 bf16 bs=4096 (bias+relu fused), tile rows sharded across the
     ranks with ONE RCCL all-gather of the output (strong scaling).
 Timing: inputs resident in HBM, W warm-up steps, then exactly K steps between
-barrier+synchronize pairs, max over ranks. The host waits for the last step by polling the closing HIP
-event and then calls torch.cuda.synchronize() (which returns at once): a blocking device wait adds tens
-of microseconds of wake-up latency, which is 10 % of a 20-step run of an 18 us kernel. FLOPs are the reference's BENCH_TOTAL_FLOPS
+barrier+synchronize pairs, max over ranks (nothing but the K invokes inside the wall-clock region); the
+HIP-event pair for the kernel-side time brackets an immediate repeat of the same K steps (see timed()). FLOPs are the reference's BENCH_TOTAL_FLOPS
 arithmetic (tools/mlir-gen/MLIRGen.cpp:313-334): 2*m*n*k*br for the BRGEMM.
 Launch: python bench.py --gpus 1 | python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N
 """
@@ -62,22 +61,28 @@ def parse():
 
 def timed(fn, steps, sync, barrier):
     """exactly `steps` calls of fn between barrier+sync pairs; returns (wall seconds, device seconds).
-    The wall clock stops after the closing torch.cuda.synchronize(); before it the host polls the closing
-    event so that the synchronize finds an idle device instead of going to sleep on it."""
+    Two passes over the same `steps` launches, back to back:
+      wall   - perf_counter around [sync, steps x fn, sync]: nothing else in the region. (A HIP event pair
+               around 20 launches costs ~30 us here - two marker packets, ~8 + 6 us of host time to record
+               them, and a slow first synchronize after an event query; profiles/r02_timing_anatomy.txt -
+               which is 8 % of a 20-step run of an 18 us kernel.)
+      device - torch.cuda.Event pair on the launch stream around a repeat of the same region: the
+               kernel-side time the roofline figure is computed from."""
     import torch
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
     sync()
     t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    sync()
+    wall = time.perf_counter() - t0
+    barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(steps):
         fn()
     e1.record()
-    while not e1.query():
-        pass
     sync()
-    wall = time.perf_counter() - t0
-    barrier()
     return wall, e0.elapsed_time(e1) * 1e-3
 
 
@@ -197,23 +202,28 @@ def per_launch_figures(init):
 
 
 def parity_figures(got, A, B, C0, m, n, k, br):
-    """HIP result of one C2 invoke against the oracle on the same inputs. max_abs / max|ref| is the north-star
-    figure (<= 1e-5); max_rel is element-wise, |gpu - ref| / (|ref| + floor) with the a-priori f32 dot-product
-    floor K * eps * sum_k |a_ik| |b_kj| (any summation order obeys it) - SURVEY.md 8(d)'s second criterion"""
+    """HIP result of one C2 invoke against the oracle on the same inputs.
+    normwise = max|d| / max(1, max|ref|) is the north-star figure (<= 1e-5). Element-wise (SURVEY.md 8d's second
+    criterion): |d| <= 1e-5 |ref| + K eps sum_k |a_ik||b_kj| - the relative bar plus the a-priori f32 dot-product
+    floor (the two sides sum in different orders; where the products cancel, |ref| is far below the summands);
+    elementwise_bar_used is the worst |d| / (that bound), <= 1 passes. max_rel is the plain relative error over the
+    elements that are not cancelled (|ref| >= 1 % of max|ref|)."""
     from oracle import pyoracle as orc
     ref = C0.copy()
     orc.fused_brgemm_omp(F32, m, n, k, 1024, 1024, 1024, k, k * 1024, 4, 0, 0, A, B, ref, None, br)
     mag = np.zeros_like(ref)
     orc.fused_brgemm_omp(F32, m, n, k, 1024, 1024, 1024, k, k * 1024, 4, 0, 0, np.abs(A), np.abs(B), mag, None, br)
-    d = np.abs(got.astype(np.float64) - ref.astype(np.float64))
-    K = k * br
-    floor = K * 2.0 ** -24 * mag.astype(np.float64)
-    rel = d / (np.abs(ref.astype(np.float64)) + floor)
-    return {"max_abs": float(d.max()), "max_ref": float(np.abs(ref).max()),
-            "max_abs_over_max_ref": float(d.max() / max(1.0, np.abs(ref).max())),
-            "max_rel": float(rel.max()), "frac_within_1e-5_rel": float((d <= 1e-5 * np.abs(ref)).mean()),
-            "criterion": "max_abs <= 1e-5*max(1,max|ref|); element-wise |d| <= 1e-5*|ref| + K*eps*sum|a||b| (max_rel = |d|/(|ref|+floor))",
-            "pass": bool(d.max() <= 1e-5 * max(1.0, float(np.abs(ref).max())) and (d <= 1e-5 * np.abs(ref) + floor).all())}
+    r = ref.astype(np.float64)
+    d = np.abs(got.astype(np.float64) - r)
+    floor = (k * br) * 2.0 ** -24 * mag.astype(np.float64)
+    big = np.abs(r) >= 1e-2 * np.abs(r).max()
+    normwise = float(d.max() / max(1.0, np.abs(r).max()))
+    used = float((d / (1e-5 * np.abs(r) + floor)).max())
+    return {"max_abs": float(d.max()), "max_ref": float(np.abs(r).max()), "normwise": normwise,
+            "max_rel": float((d[big] / np.abs(r[big])).max()), "elementwise_bar_used": used,
+            "frac_within_1e-5_rel": float((d <= 1e-5 * np.abs(r)).mean()),
+            "criterion": "normwise <= 1e-5 and |d| <= 1e-5*|ref| + K*eps*sum|a||b| element-wise (elementwise_bar_used <= 1)",
+            "pass": bool(normwise <= 1e-5 and used <= 1.0)}
 
 
 def cpu_baseline(seconds, A, B, C):

@@ -719,10 +719,10 @@ static int pick_f32_variant(const GemmDesc &d) {
     return V_F32_LW_64x64K2;
   }
   if (tiles(64, 32) >= g_num_cus) return V_F32_LW_64x32K2;
-  if (tiles(32, 32) > 0 && tiles(32, 32) >= tiles(64, 64) * 2 && tiles(64, 32) < g_num_cus) return V_F32_32x32K4;
+  if (tiles(32, 32) > 0 && tiles(32, 32) >= tiles(64, 64) * 2 && tiles(64, 32) < g_num_cus) return V_F32_LW_32x32K4;
   if (tiles(64, 64) > 0) return V_F32_LW_64x64K2;
   if (tiles(64, 32) > 0) return V_F32_LW_64x32K2;
-  if (tiles(32, 32) > 0) return V_F32_32x32K4;
+  if (tiles(32, 32) > 0) return V_F32_LW_32x32K4;
   return V_GENERIC;
 }
 
