@@ -58,8 +58,8 @@ enum {
   XSMM_GEMM_FLAG_NONE = 0, XSMM_GEMM_FLAG_BETA_0 = 4,
   XSMM_GEMM_FLAG_NO_RESET_TILECONFIG = 64, XSMM_GEMM_FLAG_NO_SETUP_TILECONFIG = 128,
   XSMM_GEMM_WIRE_VNNI_B = 2048, /* row-major B operand is [K/2][N][2] */
-  XSMM_GEMM_WIRE_VNNI_A = 4096, /* row-major A operand is VNNI (unsupported: exit(-1)) */
-  XSMM_GEMM_FLAG_VNNI_C = 8192  /* unsupported: exit(-1) */
+  XSMM_GEMM_WIRE_VNNI_A = 4096, /* row-major A operand is [M][K/2][2] = plain row-major bytes (VNNIUtils.cpp:75-77) */
+  XSMM_GEMM_FLAG_VNNI_C = 8192  /* C stored / read as VNNI-2 [M/2][N][2], ldc = pair-row stride / 2 (generic kernel) */
 };
 
 /* ---- dispatch: build (or look up) a kernel descriptor, return opaque handle ----

@@ -39,7 +39,7 @@ enum { U_IDENTITY = 1, U_ZERO = 2, U_RELU = 5, U_VNNI2 = 28, U_TRANSPOSE = 29 };
 enum { UF_ROW = 2, UF_COL = 4, UF_SCALAR = 8 };
 enum { B_ADD = 1, B_MUL = 2, B_SUB = 3, B_DIV = 4 };
 enum { BF_ROW0 = 1, BF_ROW1 = 2, BF_COL0 = 4, BF_COL1 = 8, BF_SC0 = 16, BF_SC1 = 32 };
-enum { G_BETA0 = 4, G_VNNI_B_WIRE = 2048 };
+enum { G_BETA0 = 4, G_VNNI_B_WIRE = 2048, G_VNNI_A_WIRE = 4096, G_VNNI_C = 8192 };
 
 /* ---- bf16 <-> f32, round-to-nearest-even (xsmm-ternary-bf16.mlir:15-18 pins the
  * tie 257 -> 256; TensorInitFloat.h:63-67 uses rmNearestTiesToEven for inputs) -- */
@@ -71,8 +71,20 @@ static inline int64_t b_index(int64_t kk, int64_t j, int64_t ldb, int vnni) {
   return vnni ? (kk / 2) * (2 * ldb) + j * 2 + (kk % 2) : kk * ldb + j;
 }
 
+/* C element (i, j): row-major, or - wire flag VNNI_C = 8192 - "post-packed" VNNI-2 [m/2][n][2]: the rows pair up
+ * exactly as the k rows of a VNNI-2 B operand do, so that an output can feed the next contraction as its B
+ * without a pack pass; ldc is the pair-row stride / 2 like ldb. UNPINNED in the reference tree: no lowering at
+ * this revision produces vnni_c (the flag exists in XsmmEnum.td:72-84, the verifier checks rank 3 + an even
+ * innermost dimension, XsmmVerify.cpp:91-95), no test holds numbers for it; the layout follows the flag's
+ * description in libxsmm's typedefs ("post packed formats VNNI ... indicates C") applied to the row-major view. */
+static inline int64_t c_index(int64_t i, int64_t j, int64_t ldc, int vnni_c) {
+  return vnni_c ? (i / 2) * (2 * ldc) + j * 2 + (i % 2) : i * ldc + j;
+}
+
 /*
  * C[m x n] = unary(binary(beta*C + sum_b A_b B_b, D)).
+ * Wire flag 4096 (dialect vnni_a): the A operand is [m][k/2][2] (VNNIUtils.cpp:75-77 "matrix A -
+ * [...][K/vnniFactor][vnniFactor]"), which IS row-major [m][k] byte for byte - the flag changes nothing here.
  * Summation per element is a k-ordered f32 fma chain over (batch, k): the same
  * shape of chain libxsmm's FMA microkernels and gfx950's f32 MFMA produce.
  * binary_kind/unary_kind 0 = none. Only ADD with BCAST_COL_IN_0 and RELU reach
@@ -85,7 +97,9 @@ int oracle_fused_brgemm(int64_t dt, int64_t m, int64_t n, int64_t k, int64_t lda
                         const void *B, void *C, const void *D, int64_t br) {
   if (dt != F32 && dt != BF16) return -1;
   const int vnni = (gemm_flags & G_VNNI_B_WIRE) != 0;
-  if (vnni && dt != BF16) return -1;
+  const int vnni_c = (gemm_flags & G_VNNI_C) != 0;
+  if ((gemm_flags & (G_VNNI_B_WIRE | G_VNNI_A_WIRE | G_VNNI_C)) && dt != BF16) return -1;
+  if (vnni_c && (m & 1)) return -1;
   if (binary_kind != 0 && !(binary_kind == B_ADD && binary_flags == BF_COL0)) return -1;
   if (unary_kind != 0 && unary_kind != U_RELU) return -1;
   (void)unary_flags;
@@ -93,7 +107,7 @@ int oracle_fused_brgemm(int64_t dt, int64_t m, int64_t n, int64_t k, int64_t lda
   float *brow = (float *)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
   for (int64_t i = 0; i < m; ++i) {
     for (int64_t j = 0; j < n; ++j)
-      acc[j] = (gemm_flags & G_BETA0) ? 0.0f : ld(C, i * ldc + j, (int)dt);
+      acc[j] = (gemm_flags & G_BETA0) ? 0.0f : ld(C, c_index(i, j, ldc, vnni_c), (int)dt);
     for (int64_t b = 0; b < br; ++b) {
       for (int64_t kk = 0; kk < k; ++kk) {
         const float a = ld(A, b * stride_a + i * lda + kk, (int)dt);
@@ -111,7 +125,7 @@ int oracle_fused_brgemm(int64_t dt, int64_t m, int64_t n, int64_t k, int64_t lda
       float t = acc[j];
       if (binary_kind == B_ADD) t += ld(D, j, (int)dt);
       if (unary_kind == U_RELU) t = t > 0.0f ? t : 0.0f;
-      st(C, i * ldc + j, (int)dt, t);
+      st(C, c_index(i, j, ldc, vnni_c), (int)dt, t);
     }
   }
   free(acc);

@@ -64,6 +64,22 @@ def check_numbers(text, prefix="CHECK", after=None, count=None):
     return vals
 
 
+def check_fill(text, prefix="CHECK"):
+    """the single value a test asserts for every element: all numbers on its `// <prefix>[-COUNT-n | -SAME]: ( ... )`
+    lines (they must all agree), or - tests that compare against a constant buffer - the `%outVal` constant of
+    check.expect_almost_eq"""
+    vals = []
+    for line in text.splitlines():
+        m = re.match(r"\s*//\s*%s(?:-COUNT-\d+|-SAME)?:\s*(\(.*)$" % re.escape(prefix), line)
+        if m:
+            vals += [float(x) for x in re.findall(NUM, m.group(1))]
+    if not vals and "check.expect_almost_eq" in text:
+        m = re.search(r"%outVal\s*=\s*arith\.constant\s+(" + NUM + r")\s*:", text)
+        vals = [float(m.group(1))]
+    assert vals and all(v == vals[0] for v in vals), (prefix, vals[:8])
+    return vals[0]
+
+
 def buf(dt, data=None, size=None, const=None):
     if data is not None:
         return {"dtype": dt, "data": [float(x) for x in data]}
@@ -126,34 +142,34 @@ def main():
         "buffers": {"A": buf(F32, size=2 * 32 * 16, const=1), "B": buf(F32, size=2 * 16 * 64, const=1),
                     "C": buf(F32, size=64 * 32, const=1)},
         "calls": [brgemm_call([F32, 32, 64, 16, 16, 64, 64, 512, 1024, 0], ["A", 0], ["B", 0], ["C", 0], 2)],
-        "expect": [expect("C", 32, 64, 64, fill=33, tol="exact")]})
+        "expect": [expect("C", 32, 64, 64, fill=check_fill(read(T + "xsmm-brgemm.mlir")), tol="exact")]})
     dump("xsmm_ternary", {
         "source": [T + "xsmm-ternary.mlir:5-16"],
         "buffers": {"A": buf(F32, size=24, const=1), "B": buf(F32, size=24, const=1), "C": buf(F32, size=9, const=1)},
         "calls": [brgemm_call([F32, 3, 3, 4, 4, 3, 3, 12, 12, 0], ["A", 0], ["B", 0], ["C", 0], 2)],
-        "expect": [expect("C", 3, 3, 3, fill=9, tol="exact")]})
+        "expect": [expect("C", 3, 3, 3, fill=check_fill(read(T + "xsmm-ternary.mlir")), tol="exact")]})
     # fused: wire tuple (gemm_flags, unary_flags, unary_kind, binary_flags, binary_kind) = (0,0,5,4,1)
     dump("xsmm_quarternary", {
         "source": [T + "xsmm-quarternary.mlir:4-15"],
         "buffers": {"A": buf(F32, size=64 * 16, const=1), "B": buf(F32, size=64 * 16, const=1),
                     "C": buf(F32, size=16, const=1), "D": buf(F32, size=4, const=1)},
         "calls": [fused_call([F32, 4, 4, 4, 4, 4, 4, 8, 8, 0, 0, 5, 4, 1], ["A", 0], ["B", 0], ["C", 0], ["D", 0], 16)],
-        "expect": [expect("C", 4, 4, 4, fill=66, tol="exact")]})
+        "expect": [expect("C", 4, 4, 4, fill=check_fill(read(T + "xsmm-quarternary.mlir")), tol="exact")]})
     dump("xsmm_unary_relu", {
         "source": [T + "xsmm-unary.mlir:5-13"],
         "buffers": {"X": buf(F32, size=9, const=1)},
         "calls": [unary_call([5, F32, 3, 3, 3, 3, 0], ["X", 0], ["X", 0])],
-        "expect": [expect("X", 3, 3, 3, fill=1, tol="exact")]})
+        "expect": [expect("X", 3, 3, 3, fill=check_fill(read(T + "xsmm-unary.mlir")), tol="exact")]})
     dump("xsmm_zero", {
         "source": [T + "xsmm-zero.mlir:5-16"],
         "buffers": {"X": buf(F32, size=9, const=5)},
         "calls": [unary_call([2, F32, 3, 3, 3, 3, 0], ["X", 0], ["X", 0])],
-        "expect": [expect("X", 3, 3, 3, fill=0, tol="exact")]})
+        "expect": [expect("X", 3, 3, 3, fill=check_fill(read(T + "xsmm-zero.mlir")), tol="exact")]})
     dump("xsmm_binary_add", {
         "source": [T + "xsmm-binary.mlir:5-17"],
         "buffers": {"L": buf(F32, size=9, const=1), "R": buf(F32, size=9, const=1), "O": buf(F32, size=9, const=1)},
         "calls": [binary_call([1, F32, 3, 3, 3, 3, 3, 0], ["L", 0], ["R", 0], ["O", 0])],
-        "expect": [expect("O", 3, 3, 3, fill=2, tol="exact")]})
+        "expect": [expect("O", 3, 3, 3, fill=check_fill(read(T + "xsmm-binary.mlir")), tol="exact")]})
 
     # ---- literal matrices -------------------------------------------------------
     t = read(T + "xsmm-mul.mlir")
@@ -309,14 +325,15 @@ def main():
                     "bias": buf(F32, size=10, const=1)},
         "calls": [gemm_call([F32, 10, 10, 10, 10, 10, 10, 0], ["A", 0], ["W", 0], ["C", 0]),
                   fused_call([F32, 10, 10, 10, 10, 10, 10, 0, 0, 0, 0, 0, 4, 1], ["A", 0], ["W", 0], ["C2", 0], ["bias", 0], 1)],
-        "expect": [expect("C", 10, 10, 10, fill=11, tol="exact"), expect("C2", 10, 10, 10, fill=12, tol="exact")]})
+        "expect": [expect("C", 10, 10, 10, fill=check_fill(read(T + "mlir-gen.mlir"), "GEN-MATMUL"), tol="exact"),
+                   expect("C2", 10, 10, 10, fill=check_fill(read(T + "mlir-gen.mlir"), "GEN-FC"), tol="exact")]})
     dump("mlp_fp32_1layer_512", {
         "source": [T + "mlp-fp32-1layer-512.mlir (CHECK 257)"],
         "buffers": {"A": buf(F32, size=128 * 256, const=1), "W": buf(F32, size=256 * 512, const=1),
                     "C": buf(F32, size=128 * 512, const=0), "bias": buf(F32, size=512, const=1)},
         "calls": [fused_call([F32, 128, 512, 32, 256, 512, 512, 32, 32 * 512, 4, 0, 5, 4, 1],
                              ["A", 0], ["W", 0], ["C", 0], ["bias", 0], 8)],
-        "expect": [expect("C", 128, 512, 512, fill=257, tol="exact")]})
+        "expect": [expect("C", 128, 512, 512, fill=check_fill(read(T + "mlp-fp32-1layer-512.mlir")), tol="exact")]})
 
     # ---- BASELINE config 1 ("plumbing"): the call script the default pipeline produces for
     # `mlir-gen --kernel=args --float-type=f32 --batch=256 --layers=256,256`:
@@ -356,39 +373,39 @@ def main():
         "source": [TB + "xsmm-brgemm-bf16.mlir:5-20"],
         "buffers": {"A": buf(BF16, size=72, const=1), "B": buf(BF16, size=72, const=3), "C": buf(BF16, size=36, const=1)},
         "calls": [brgemm_call([BF16, 6, 6, 6, 6, 6, 6, 36, 36, VB], ["A", 0], ["B", 0], ["C", 0], 2)],
-        "expect": [expect("C", 6, 6, 6, fill=37, tol="exact")]})
+        "expect": [expect("C", 6, 6, 6, fill=check_fill(read(TB + "xsmm-brgemm-bf16.mlir")), tol="exact")]})
     dump("xsmm_gemm_bf16", {
         "source": [TB + "xsmm-gemm-bf16.mlir:5-17"],
         "buffers": {"A": buf(BF16, size=36, const=1), "B": buf(BF16, size=36, const=3), "C": buf(BF16, size=36, const=1)},
         "calls": [gemm_call([BF16, 6, 6, 6, 6, 6, 6, VB], ["A", 0], ["B", 0], ["C", 0])],
-        "expect": [expect("C", 6, 6, 6, fill=19, tol="exact")]})
+        "expect": [expect("C", 6, 6, 6, fill=check_fill(read(TB + "xsmm-gemm-bf16.mlir")), tol="exact")]})
     dump("xsmm_quarternary_bf16", {
         "source": [TB + "xsmm-quarternary-bf16.mlir:4-14"],
         "buffers": {"A": buf(BF16, size=1024, const=1), "B": buf(BF16, size=1024, const=1),
                     "C": buf(BF16, size=16, const=1), "D": buf(BF16, size=4, const=1)},
         "calls": [fused_call([BF16, 4, 4, 4, 4, 4, 4, 8, 8, VB, 0, 5, 4, 1], ["A", 0], ["B", 0], ["C", 0], ["D", 0], 16)],
-        "expect": [expect("C", 4, 4, 4, fill=66, tol="exact")]})
+        "expect": [expect("C", 4, 4, 4, fill=check_fill(read(TB + "xsmm-quarternary-bf16.mlir")), tol="exact")]})
     # 64*4 + 1 = 257 is a bf16 tie between 256 and 258 -> pins round-to-nearest-EVEN
     dump("xsmm_ternary_bf16", {
         "source": [TB + "xsmm-ternary-bf16.mlir:5-18"],
         "buffers": {"A": buf(BF16, size=1024, const=1), "B": buf(BF16, size=1024, const=1), "C": buf(BF16, size=16, const=1)},
         "calls": [brgemm_call([BF16, 4, 4, 4, 4, 4, 4, 8, 8, VB], ["A", 0], ["B", 0], ["C", 0], 64)],
-        "expect": [expect("C", 4, 4, 4, fill=256, tol="exact")]})
+        "expect": [expect("C", 4, 4, 4, fill=check_fill(read(TB + "xsmm-ternary-bf16.mlir")), tol="exact")]})
     dump("xsmm_unary_relu_bf16", {
         "source": [TB + "xsmm-unary-bf16.mlir:5-14"],
         "buffers": {"X": buf(BF16, size=9, const=1)},
         "calls": [unary_call([5, BF16, 3, 3, 3, 3, 0], ["X", 0], ["X", 0])],
-        "expect": [expect("X", 3, 3, 3, fill=1, tol="exact")]})
+        "expect": [expect("X", 3, 3, 3, fill=check_fill(read(TB + "xsmm-unary-bf16.mlir")), tol="exact")]})
     dump("xsmm_binary_add_bf16", {
         "source": [TB + "xsmm-binary-bf16.mlir:5-18"],
         "buffers": {"L": buf(BF16, size=9, const=1), "R": buf(BF16, size=9, const=1), "O": buf(BF16, size=9, const=1)},
         "calls": [binary_call([1, BF16, 3, 3, 3, 3, 3, 0], ["L", 0], ["R", 0], ["O", 0])],
-        "expect": [expect("O", 3, 3, 3, fill=2, tol="exact")]})
+        "expect": [expect("O", 3, 3, 3, fill=check_fill(read(TB + "xsmm-binary-bf16.mlir")), tol="exact")]})
     dump("xsmm_zero_bf16", {
         "source": [TB + "xsmm-zero-bf16.mlir:5-17"],
         "buffers": {"X": buf(BF16, size=9, const=5)},
         "calls": [unary_call([2, BF16, 3, 3, 3, 3, 0], ["X", 0], ["X", 0])],
-        "expect": [expect("X", 3, 3, 3, fill=0, tol="exact")]})
+        "expect": [expect("X", 3, 3, 3, fill=check_fill(read(TB + "xsmm-zero-bf16.mlir")), tol="exact")]})
     # vnni-packing: 16x16 -> [8][16][2]; CHECK pins the first pairs (1,17),(2,18),(3,19);
     # the full expected image is the definition out[i/2][j][i%2] = in[i][j] applied to
     # the literal input (VNNIUtils.cpp:75-77), all values exactly representable in bf16.
@@ -411,7 +428,126 @@ def main():
                     "bias": buf(BF16, size=16, const=1)},
         "calls": [gemm_call([BF16, 16, 16, 16, 16, 16, 16, VB], ["A", 0], ["W", 0], ["C", 0]),
                   fused_call([BF16, 16, 16, 16, 16, 16, 16, 0, 0, VB, 0, 0, 4, 1], ["A", 0], ["W", 0], ["C2", 0], ["bias", 0], 1)],
-        "expect": [expect("C", 16, 16, 16, fill=17, tol="exact"), expect("C2", 16, 16, 16, fill=18, tol="exact")]})
+        "expect": [expect("C", 16, 16, 16, fill=check_fill(read(TB + "mlir-gen-bf16.mlir"), "GEN-MATMUL-BF16"), tol="exact"),
+                   expect("C2", 16, 16, 16, fill=check_fill(read(TB + "mlir-gen-bf16.mlir"), "GEN-FC-BF16"), tol="exact")]})
+
+    # ---- round 2: the remaining replayable tests ------------------------------------------------
+    # xsmm-strided-brgemm3: dims (b,i,h,k,j); A[(b,i),(h,k)] 4x8 as [2,2,2,4], B[(b,j),(h,k)] 16x8 as [2,8,2,4],
+    # C[(b,h),(j,i)] 4x16 as [2,2,8,2]. Per (b, h): ONE transpose dispatch (IR-COUNT-1 xsmm_unary_dispatch) turns
+    # A[b, :, h, :] (2x4, ldi 8) into a 4x2 tile (the gemm's B operand), then the pinned gemm dispatch
+    # (1, 8, 2, 4, 8, 2, 2, 4) = f32 m=8 n=2 k=4 lda=8 ldb=2 ldc=2 beta_0 takes B[b, :, h, :] (8x4, lda 8) as ITS A.
+    t = read(T + "xsmm-strided-brgemm3.mlir")
+    lits = dense_literals(t)  # A (4x8), B (16x8); C is a splat
+    assert len(lits[0]) == 32 and len(lits[1]) == 128, [len(x) for x in lits]
+    calls, bufs = [], {"A": buf(F32, data=lits[0]), "B": buf(F32, data=lits[1]), "C": buf(F32, size=64, const=0)}
+    for b in range(2):
+        for h in range(2):
+            tname = "T%d_%d" % (b, h)
+            bufs[tname] = buf(F32, size=8, const=0)
+            calls.append(unary_call([29, F32, 2, 4, 8, 2, 0], ["A", b * 16 + h * 4], [tname, 0]))
+            calls.append(gemm_call([F32, 8, 2, 4, 8, 2, 2, 4], ["B", b * 64 + h * 4], [tname, 0], ["C", (b * 2 + h) * 16]))
+    dump("xsmm_strided_brgemm3", {
+        "source": [T + "xsmm-strided-brgemm3.mlir:7-57 (gemm dispatch tuple :35, transpose dispatch :33-34, CHECK :54-57)"],
+        "buffers": bufs, "calls": calls,
+        "expect": [expect("C", 4, 16, 16, values=check_numbers(t, count=64))]})
+
+    # broadcast-transpose (--vector-to-XSMM, seed 123): arg0 (8), arg1 (4x8), arg2 (8x4) from ONE normal stream;
+    # arg1 = broadcast of arg0 along rows (identity, bcast_col), arg2 = transpose(arg1); printed: arg2, 8 rows of 4.
+    t = read(T + "broadcast-transpose.mlir")
+    gen = orc.TensorInit("normal", 123)
+    a0, a1, a2 = gen.fill(8), gen.fill(32), gen.fill(32)
+    dump("broadcast_transpose_seed123", {
+        "source": [T + "broadcast-transpose.mlir:1-40 (BROADCASTTRANSPOSE lines)",
+                   "lib/TPP/Conversion/ConvertVectorToXsmm/ConvertVectorToXsmm.cpp:46-61 (identity bcast / transpose unary calls)"],
+        "buffers": {"V": buf(F32, data=a0), "M": buf(F32, data=a1), "O": buf(F32, data=a2)},
+        "calls": [unary_call([1, F32, 4, 8, 8, 8, 4], ["V", 0], ["M", 0]),
+                  unary_call([29, F32, 4, 8, 8, 4, 0], ["M", 0], ["O", 0])],
+        "expect": [expect("O", 8, 4, 4, values=check_numbers(t, prefix="BROADCASTTRANSPOSE", count=32))]})
+
+    # tpp-run-xsmm-path: linalg add with outs == second input: binary add, out ALIASES rhs (2x2; 1 + 2 = 3)
+    t = read(T + "tpp-run-xsmm-path.mlir")
+    dump("tpp_run_xsmm_path", {
+        "source": [T + "tpp-run-xsmm-path.mlir:7-40 (IR: xsmm_binary_dispatch / invoke; outs(%arg1) aliases the rhs)"],
+        "buffers": {"L": buf(F32, size=4, const=1), "R": buf(F32, size=4, const=2)},
+        "calls": [binary_call([1, F32, 2, 2, 2, 2, 2, 0], ["L", 0], ["R", 0], ["R", 0])],
+        "expect": [expect("R", 2, 2, 2, fill=check_fill(t), tol="exact")]})
+
+    # vnni-packing-chain: tensor.pack (outer_dims_perm [1,0], 16x16 tiles) as per-block identity copies
+    # (LowerPacksAndUnpacks.cpp:45-49) into [2][2][16][16], then the VNNI-2 pack of every block (IR: xsmm_unary_invoke)
+    # into [2][2][8][16][2]; expected image = the test's %G literal, threshold 0.
+    t = read(TB + "vnni-packing-chain.mlir")
+    lits = dense_literals(t)
+    assert len(lits[0]) == 1024 and len(lits[1]) == 1024
+    calls = []
+    for cb in range(2):       # outer_dims_perm = [1, 0]: block (cb, rb) <- rows 16 rb .., columns 16 cb ..
+        for rb in range(2):
+            blk = (cb * 2 + rb) * 256
+            calls.append(unary_call([1, BF16, 16, 16, 32, 16, 0], ["X", rb * 16 * 32 + cb * 16], ["P", blk]))
+            calls.append(unary_call([28, BF16, 16, 16, 16, 16, 0], ["P", blk], ["G", blk]))
+    dump("vnni_packing_chain", {
+        "source": [TB + "vnni-packing-chain.mlir:7-60 (check.expect_almost_eq against %G, threshold 0.0)"],
+        "buffers": {"X": buf(BF16, data=lits[0]), "P": buf(BF16, size=1024, const=0), "G": buf(BF16, size=1024, const=0)},
+        "calls": calls,
+        "expect": [expect("G", 32, 32, 32, values=lits[1], tol="exact")]})
+
+    # conv-to-matmul: conv_2d_nhwc_hwcf rewritten to one matmul per output row and filter tap
+    # (RewriteConvsToMatmulOrBrgemm.cpp; IR: linalg.matmul x3): A = image rows [Q x C] with row stride
+    # conv_stride * C, B = filter tap [C x K], C = output row [Q x K], accumulating (beta = 1). Inputs are the
+    # test's generate_1D_source broadcasts: image value = channel index, filter value = output channel index,
+    # output initialised with the output channel index.
+    t = read(T + "conv-to-matmul.mlir")
+    outs = re.split(r"vector\.print", t)
+    conv_cases = [("conv_unit_no_stride", 4, 4, 3, 8, 1, 1, 1, 0), ("conv_3x3_no_stride", 5, 5, 3, 8, 3, 3, 1, 1),
+                  ("conv_3x3_stride2", 5, 5, 3, 8, 3, 3, 2, 2)]
+    for name, H, W, Ci, K, R, S, st, idx in conv_cases:
+        P, Q = (H - R) // st + 1, (W - S) // st + 1
+        img = [float(c) for _ in range(H * W) for c in range(Ci)]
+        flt = [float(f) for _ in range(R * S * Ci) for f in range(K)]
+        out0 = [float(f) for _ in range(P * Q) for f in range(K)]
+        want = [float(x) for x in re.findall(NUM, "".join(l.split(":", 1)[1] for l in outs[idx].splitlines()
+                                                           if re.match(r"\s*//\s*CHECK(-SAME)?:", l)))]
+        assert len(want) == P * Q * K, (name, len(want))
+        calls = []
+        for p_ in range(P):
+            for r in range(R):
+                for s_ in range(S):
+                    calls.append(gemm_call([F32, Q, K, Ci, st * Ci, K, K, 0], ["I", ((p_ * st + r) * W + s_) * Ci],
+                                           ["F", (r * S + s_) * Ci * K], ["O", p_ * Q * K]))
+        dump(name, {
+            "source": [T + "conv-to-matmul.mlir (function @%s, CHECK block %d)" % (name if idx else "conv_unit_no_stride", idx + 1),
+                       "lib/TPP/Transforms/RewriteConvsToMatmulOrBrgemm.cpp (matmul per output row and filter tap)"],
+            "buffers": {"I": buf(F32, data=img), "F": buf(F32, data=flt), "O": buf(F32, data=out0)},
+            "calls": calls,
+            "expect": [expect("O", P * Q, K, K, values=want, tol="exact")]})
+
+    # ---- ABI wire order: the argument tuples FileCheck pins in test/Conversion/XsmmToFunc/xsmm-to-func.mlir ----
+    # (symbol, positional i64 arguments the compiler emits). Asserted against tpp-mlir_amd/runtime.py's argtypes
+    # and the parameter order of include/tpp_xsmm_abi.h by tests/test_abi_symbols.py; the dispatch tuples are
+    # dispatched through the ABI on the GPU box (every one of them must be accepted).
+    t = read("test/Conversion/XsmmToFunc/xsmm-to-func.mlir")
+    wire = []
+    for block in t.split("// -----"):
+        consts = {m.group(1): int(m.group(2)) for m in re.finditer(r"%\[\[(\w+):\.\+\]\] = arith\.constant (-?\d+) : i64", block)}
+        # the dialect-level op the tuple was lowered from (kind, dims, flag names, data type)
+        om = re.search(r"xsmm\.(\w+)\.dispatch\s+(\w+\s+)?\[([\d,\s]+)\]\s*(\[[\w,\s]+\])?(.*?)data_type\s*=\s*(\w+)", block, re.S)
+        for m in re.finditer(r"call @(xsmm_\w+_dispatch)\((.*?)\)\s*$", block, re.M):
+            names = re.findall(r"%\[\[(\w+)\]\]", m.group(2))
+            if names and all(nm in consts for nm in names) and om:
+                flags = {k: [f.strip() for f in v.split(",")] for k, v in re.findall(r"(\w*flags)\s*=\s*\(([^)]*)\)", om.group(5))}
+                wire.append({"symbol": m.group(1), "args": [consts[nm] for nm in names],
+                             "op": {"family": om.group(1), "kind": (om.group(2) or "").strip() or None,
+                                    "dims": [int(x) for x in om.group(3).split(",")],
+                                    "fused": [x.strip() for x in om.group(4).strip("[]").split(",")] if om.group(4) else None,
+                                    "flags": flags, "data_type": om.group(6)}})
+    invokes = [{"symbol": "xsmm_brgemm_invoke", "pattern": ["dtype", "handle", "ptr", "off", "ptr", "off", "ptr", "off", "batch"], "line": 144},
+               {"symbol": "xsmm_unary_invoke", "pattern": ["dtype", "handle", "ptr", "off", "ptr", "off"], "line": 165},
+               {"symbol": "xsmm_gemm_invoke", "pattern": ["dtype", "handle", "ptr", "off", "ptr", "off", "ptr", "off"], "line": 190}]
+    assert len(wire) >= 12, len(wire)
+    with open(os.path.join(HERE, "xsmm_to_func_wire.json"), "w") as f:
+        json.dump({"source": ["test/Conversion/XsmmToFunc/xsmm-to-func.mlir (CHECK: call @xsmm_*_dispatch lines; invoke lines 144, 165, 190, 224)"],
+                   "dispatch": wire, "invoke": invokes}, f)
+        f.write("\n")
+    print("wrote tests/golden/xsmm_to_func_wire.json (%d dispatch tuples)" % len(wire))
 
     # ---- FLOP arithmetic of mlir-gen (BENCH_TOTAL_FLOPS), MLIRGen.cpp:313-334 --------
     flops = {"source": ["test/Integration/mlir-gen-flops.mlir:93-112", "tools/mlir-gen/MLIRGen.cpp:313-334"],

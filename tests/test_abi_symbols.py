@@ -75,6 +75,66 @@ def test_dispatch_is_idempotent_and_distinct(rt):
     assert rt.binary_dispatch(1, 1, 3, 3, 3, 3, 3, 0) != u
 
 
+def header_params():
+    """symbol -> parameter names, in order, from include/tpp_xsmm_abi.h"""
+    with open(os.path.join(ROOT, "include", "tpp_xsmm_abi.h")) as f:
+        text = f.read()
+    out = {}
+    for m in re.finditer(r"TPP_XSMM_EXPORT\s+[\w\s\*]+?\b(\w+)\s*\(([^;]*?)\)\s*;", text, re.S):
+        out[m.group(1)] = [p.split()[-1].lstrip("*") for p in m.group(2).split(",") if p.strip() and p.strip() != "void"]
+    return out
+
+
+def test_wire_order_matches_the_reference_filecheck_lines():
+    """tests/golden/xsmm_to_func_wire.json = the argument tuples test/Conversion/XsmmToFunc/xsmm-to-func.mlir pins with
+    FileCheck, next to the dialect-level op each one was lowered from. Rebuilding every tuple from the op's fields
+    through the parameter NAMES of include/tpp_xsmm_abi.h must reproduce it - which pins the header's parameter order,
+    the enum wire values (incl. the vnni_a <-> vnni_b exchange, ConvertXsmmToFunc.cpp:251-265) and runtime.py's arity."""
+    import json
+    from importlib import import_module
+    rtmod = import_module("tpp-mlir_amd.runtime")
+    with open(os.path.join(ROOT, "tests", "golden", "xsmm_to_func_wire.json")) as f:
+        wire = json.load(f)
+    params = header_params()
+    dtype = {"f32": 1, "bf16": 2}
+    unary_kind = {"identity": 1, "zero": 2, "relu": 5, "vnni_2": 28, "transpose": 29, "none": 0}
+    binary_kind = {"add": 1, "mul": 2, "sub": 3, "div": 4, "none": 0}
+    gemm_flag = {"none": 0, "beta_0": 4, "vnni_a": 4096, "vnni_b": 2048, "vnni_c": 8192}   # wire values
+    unary_flag = {"none": 0, "bcast_row": 2, "bcast_col": 4, "bcast_scalar": 8}
+    binary_flag = {"none": 0, "bcast_row_in0": 1, "bcast_row_in1": 2, "bcast_col_in0": 4, "bcast_col_in1": 8,
+                   "bcast_scalar_in0": 16, "bcast_scalar_in1": 32}
+    ored = lambda table, names: sum(table[n] for n in names)  # noqa: E731
+    seen = set()
+    for w in wire["dispatch"]:
+        op, sym = w["op"], w["symbol"]
+        v = {"dtype": dtype[op["data_type"]]}
+        fam = op["family"]
+        if fam in ("gemm", "brgemm", "fused_brgemm"):
+            names = ["m", "n", "k", "lda", "ldb", "ldc", "stride_a", "stride_b"][:len(op["dims"])]
+            v.update(dict(zip(names, op["dims"])))
+            v["flags"] = v["gemm_flags"] = ored(gemm_flag, op["flags"]["flags"])
+            if fam == "fused_brgemm":
+                v["binary_kind"], v["unary_kind"] = binary_kind[op["fused"][0]], unary_kind[op["fused"][1]]
+                v["unary_flags"] = ored(unary_flag, op["flags"]["unary_flags"])
+                v["binary_flags"] = ored(binary_flag, op["flags"]["binary_flags"])
+        elif fam == "unary":
+            v.update(dict(zip(["m", "n", "ldi", "ldo"], op["dims"])))
+            v["unary_kind"], v["flags"] = unary_kind[op["kind"]], ored(unary_flag, op["flags"]["flags"])
+        else:
+            v.update(dict(zip(["m", "n", "ldi_lhs", "ldi_rhs", "ldo"], op["dims"])))
+            v["binary_kind"], v["flags"] = binary_kind[op["kind"]], ored(binary_flag, op["flags"]["flags"])
+        assert [v[p] for p in params[sym]] == w["args"], (sym, params[sym], w)
+        assert len(rtmod._SIGNATURES[sym][1]) == len(w["args"]), sym
+        seen.add(sym)
+    assert seen == {"xsmm_gemm_dispatch", "xsmm_brgemm_dispatch", "xsmm_fused_brgemm_dispatch", "xsmm_unary_dispatch",
+                    "xsmm_binary_dispatch"}
+    for inv in wire["invoke"]:  # invoke: dtype, handle, then (pointer, element offset) per memref operand [, batch]
+        want = {"dtype": "int64_t", "handle": "int64_t", "off": "int64_t", "batch": "int64_t", "ptr": "void"}
+        ctype = {"int64_t": rtmod.I64, "void": rtmod.VP}
+        assert [ctype[want[p]] for p in inv["pattern"]] == rtmod._SIGNATURES[inv["symbol"]][1], inv
+        assert len(params[inv["symbol"]]) == len(inv["pattern"])
+
+
 def test_variant_selection(rt):
     assert "64x64" in rt.kernel_name(rt.brgemm_dispatch(1, 1024, 1024, 64, 1024, 1024, 1024, 64, 65536, 0))
     assert "64x32" in rt.kernel_name(rt.fused_brgemm_dispatch(1, 512, 1024, 64, 1024, 1024, 1024, 64, 65536,
@@ -87,7 +147,10 @@ BAD_CALLS = {
     "bad_dtype": "rt.brgemm_dispatch(7, 4, 4, 4, 4, 4, 4, 16, 16, 0)",
     "lda_lt_k": "rt.gemm_dispatch(1, 4, 4, 8, 4, 4, 4, 0)",          # XsmmOps.cpp:335-340
     "vnni_f32": "rt.brgemm_dispatch(1, 4, 4, 4, 4, 4, 4, 16, 16, 2048)",  # XsmmOps.cpp:292-298
-    "vnni_a": "rt.brgemm_dispatch(2, 4, 4, 4, 4, 4, 4, 16, 16, 4096)",
+    "vnni_a_f32": "rt.brgemm_dispatch(1, 4, 4, 4, 4, 4, 4, 16, 16, 4096)",
+    "vnni_odd_k": "rt.gemm_dispatch(2, 1, 2, 3, 4, 5, 6, 6144)",        # xsmm-to-func.mlir:62 tuple: k = 3 cannot be VNNI-2 packed
+    "vnni_c_odd_m": "rt.gemm_dispatch(2, 3, 4, 4, 4, 4, 4, 8192)",
+    "unknown_gemm_flag": "rt.gemm_dispatch(1, 4, 4, 4, 4, 4, 4, 1)",
     "fused_mul": "rt.fused_brgemm_dispatch(1, 4, 4, 4, 4, 4, 4, 16, 16, 0, 0, 5, 4, 2)",
     "fused_bcast_row": "rt.fused_brgemm_dispatch(1, 4, 4, 4, 4, 4, 4, 16, 16, 0, 0, 5, 1, 1)",
     "unary_kind": "rt.unary_dispatch(17, 1, 4, 4, 4, 4, 0)",

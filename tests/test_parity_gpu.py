@@ -378,6 +378,79 @@ def test_brgemm_ragged_tiles_vector_loads(rt, dt, shape):
         assert "grouped" in name, name
 
 
+@pytest.mark.parametrize("shape", [(6, 6, 6, 2), (32, 32, 32, 4), (64, 48, 64, 3), (10, 7, 4, 1), (128, 256, 64, 2)],
+                         ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("mode", ["device", "host"])
+def test_brgemm_vnni_a_and_vnni_c_operands(rt, shape, mode):
+    """wire flags 4096 (dialect vnni_a: A is [m][k/2][2] = row-major bytes) and 8192 (vnni_c: C stored and, with
+    beta = 1, read as VNNI-2 [m/2][n][2]); XsmmEnum.td:72-84, dispatch tuples of xsmm-to-func.mlir:62,80,98.
+    Oracle semantics are unpinned in the reference tree (see oracle/xsmm_oracle.c c_index)."""
+    m, n, k, br = shape
+    rng = np.random.default_rng(sum(shape))
+    lda, ldb, ldc = k + 2, n + 1, n + 3
+    A, B = rand(rng, br * m * lda + 8, BF16), rand(rng, br * (k // 2) * 2 * ldb + 2 * ldb + 8, BF16)
+    D = rand(rng, n + 8, BF16)
+    for flags, fused in ((VB | 4096, False), (VB | 8192 | 4, True), (VB | 4096 | 8192, False), (VB | 4096 | 8192 | 4, True)):
+        C = rand(rng, m * ldc + 2 * ldc + 8, BF16)
+        ref = C.copy()
+        if fused:
+            orc.fused_brgemm(BF16, m, n, k, lda, ldb, ldc, m * lda, k * ldb, flags, 0, 5, 4, 1, A, 2, B, 2, ref, 3, D, 1, br)
+            h = rt.fused_brgemm_dispatch(BF16, m, n, k, lda, ldb, ldc, m * lda, k * ldb, flags, 0, 5, 4, 1)
+        else:
+            orc.brgemm(BF16, m, n, k, lda, ldb, ldc, m * lda, k * ldb, flags, A, 2, B, 2, ref, 3, br)
+            h = rt.brgemm_dispatch(BF16, m, n, k, lda, ldb, ldc, m * lda, k * ldb, flags)
+        if mode == "device":
+            dA, dB, dC, dD = dev(A), dev(B), dev(C), dev(D)
+            if fused:
+                rt.fused_brgemm(BF16, h, dA, 2, dB, 2, dC, 3, dD, 1, br)
+            else:
+                rt.brgemm(BF16, h, dA, 2, dB, 2, dC, 3, br)
+            got = host(dC, C)
+        else:
+            got = C.copy()
+            if fused:
+                rt.fused_brgemm(BF16, h, A, 2, B, 2, got, 3, D, 1, br)
+            else:
+                rt.brgemm(BF16, h, A, 2, B, 2, got, 3, br)
+        check_close(got, ref, BF16, "vnni flags %d [%s]" % (flags, rt.kernel_name(h)))
+        ii, jj = np.meshgrid(np.arange(m), np.arange(n), indexing="ij")
+        foot = 3 + ((ii // 2) * (2 * ldc) + 2 * jj + ii % 2 if flags & 8192 else ii * ldc + jj)
+        outside = np.ones(C.size, dtype=bool)
+        outside[foot.reshape(-1)] = False
+        assert np.array_equal(got[outside], C[outside]), "wrote outside the output footprint (flags %d)" % flags
+        assert np.array_equal(ref[outside], C[outside])
+
+
+def test_conv_as_gemm_invokes_strided_rows(rt):
+    """conv2d NHWC x HWCF as the reference rewrites it (RewriteConvsToMatmulOrBrgemm.cpp: one matmul per output row
+    and filter tap, A = image rows [Q x C] with row stride conv_stride * C, B = filter tap [C x K], C = output row
+    [Q x K], accumulating) - the lda > k, overlapping-window operand pattern - through the ABI on device buffers,
+    against a direct numpy convolution (independent of the oracle) and against the oracle's replay of the same calls"""
+    rng = np.random.default_rng(8)
+    for (H, W, Cin, K, R, S, st) in ((5, 5, 3, 8, 3, 3, 2), (9, 9, 16, 32, 3, 3, 1), (12, 10, 8, 64, 1, 1, 1), (17, 17, 4, 12, 5, 3, 2)):
+        P, Q = (H - R) // st + 1, (W - S) // st + 1
+        img = rng.uniform(-1, 1, H * W * Cin).astype(np.float32)
+        flt = rng.uniform(-1, 1, R * S * Cin * K).astype(np.float32)
+        out0 = rng.uniform(-1, 1, P * Q * K).astype(np.float32)
+        want = out0.reshape(P, Q, K).astype(np.float64).copy()
+        im, fl = img.reshape(H, W, Cin).astype(np.float64), flt.reshape(R, S, Cin, K).astype(np.float64)
+        for p_ in range(P):
+            for q in range(Q):
+                want[p_, q] += np.einsum("rsc,rsck->k", im[p_ * st:p_ * st + R, q * st:q * st + S], fl)
+        h = rt.gemm_dispatch(F32, Q, K, Cin, st * Cin, K, K, 0)
+        dimg, dflt, dout = dev(img), dev(flt), dev(out0)
+        ref = out0.copy()
+        for p_ in range(P):
+            for r in range(R):
+                for s_ in range(S):
+                    oa, ob, oc = ((p_ * st + r) * W + s_) * Cin, (r * S + s_) * Cin * K, p_ * Q * K
+                    rt.gemm(F32, h, dimg, oa, dflt, ob, dout, oc)
+                    orc.gemm(F32, Q, K, Cin, st * Cin, K, K, 0, img, oa, flt, ob, ref, oc)
+        got = host(dout, out0)
+        check_close(got, ref, F32, "conv %s as gemm invokes [%s]" % ((H, W, Cin, K, R, S, st), rt.kernel_name(h)))
+        assert np.abs(got.reshape(P, Q, K) - want).max() <= 1e-4 * max(1.0, np.abs(want).max())
+
+
 def test_brgemm_bf16_flat_b_generic(rt):
     gemm_case(rt, BF16, 48, 40, 24, 3, vnni=False, seed=3, bias=True)
 

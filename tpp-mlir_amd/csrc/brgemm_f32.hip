@@ -548,10 +548,13 @@ __global__ __launch_bounds__(256) void brgemm_grouped(GemmArgs p, const WorkItem
     const int row = m0 + 4 * lh + (r & 3) + 8 * (r >> 2);
     if (row < p.m && col < p.n) {
       float v = acc[r];
-      if (!(p.ep & EP_BETA0)) v += Elem<T>::load((g_cvoid *)gC, (int64_t)row * p.ldc + col);
+      // C element (row, col): row-major, or VNNI-2 [m/2][n][2] (wire flag 8192, see the oracle's c_index)
+      const int64_t ci = (p.ep & EP_VNNI_C) ? (int64_t)(row >> 1) * (2 * p.ldc) + 2 * (int64_t)col + (row & 1)
+                                            : (int64_t)row * p.ldc + col;
+      if (!(p.ep & EP_BETA0)) v += Elem<T>::load((g_cvoid *)gC, ci);
       v += bias;
       if (p.ep & EP_RELU) v = v > 0.0f ? v : 0.0f;
-      Elem<T>::store(gC, (int64_t)row * p.ldc + col, v);
+      Elem<T>::store(gC, ci, v);
     }
   }
 }
@@ -668,7 +671,7 @@ hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_i
   a.A = a.B = a.D = nullptr; a.C = nullptr;
   a.lda = d.lda; a.ldb = d.ldb; a.ldc = d.ldc; a.stride_a = d.stride_a; a.stride_b = d.stride_b;
   a.m = (int)d.m; a.n = (int)d.n; a.k = (int)d.k; a.br = 0;
-  a.ep = (d.beta0 ? EP_BETA0 : 0) | (d.bias ? EP_BIAS : 0) | (d.relu ? EP_RELU : 0);
+  a.ep = (d.beta0 ? EP_BETA0 : 0) | (d.bias ? EP_BIAS : 0) | (d.relu ? EP_RELU : 0) | (d.vnni_c ? EP_VNNI_C : 0);
   a.tiles_m = a.tiles_n = 0;
   const bool tiles_ok = vec_ok && d.n % 4 == 0 && d.k % GK == 0; // 16-byte pieces; ragged m / n edges are predicated
   const bool vec = tiles_ok && d.dtype == DT_F32 && !d.vnni_b && !((d.lda | d.ldb | d.stride_a | d.stride_b) & 3);
@@ -747,6 +750,7 @@ static const char *variant_name(int v) {
 
 bool plan_gemm(GemmDesc &d, int forced_variant) {
   int v = V_GENERIC;
+  if (d.vnni_c) forced_variant = V_GENERIC; // VNNI-2 C store: the generic kernel's epilogue only
   if (d.dtype == DT_F32 && !d.vnni_b) v = pick_f32_variant(d);
   else if (d.dtype == DT_BF16 && bf16_fast_eligible(d)) {
     v = V_BF16_FAST + pick_bf16_tile(d);
@@ -782,7 +786,7 @@ hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C,
   a.A = A; a.B = B; a.C = C; a.D = D;
   a.lda = d.lda; a.ldb = d.ldb; a.ldc = d.ldc; a.stride_a = d.stride_a; a.stride_b = d.stride_b;
   a.m = (int)d.m; a.n = (int)d.n; a.k = (int)d.k; a.br = (int)(br < 0 ? 0 : br);
-  a.ep = (d.beta0 ? EP_BETA0 : 0) | (d.bias ? EP_BIAS : 0) | (d.relu ? EP_RELU : 0);
+  a.ep = (d.beta0 ? EP_BETA0 : 0) | (d.bias ? EP_BIAS : 0) | (d.relu ? EP_RELU : 0) | (d.vnni_c ? EP_VNNI_C : 0);
   a.tiles_m = a.tiles_n = 0;
   int v = d.variant;
   const bool aligned16 = ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0;

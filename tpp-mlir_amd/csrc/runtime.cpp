@@ -346,13 +346,18 @@ int64_t gemm_dispatch_common(const char *who, int has_batch, int fused, int64_t 
     die("%s: failed to generate func: expect lda >= k, ldb >= n, ldc >= n (M: %ld N: %ld K: %ld lda: %ld ldb: %ld ldc: %ld)",
         who, (long)m, (long)n, (long)k, (long)lda, (long)ldb, (long)ldc);
   const int64_t known = XSMM_GEMM_FLAG_BETA_0 | XSMM_GEMM_FLAG_NO_RESET_TILECONFIG |
-                        XSMM_GEMM_FLAG_NO_SETUP_TILECONFIG | XSMM_GEMM_WIRE_VNNI_B;
-  if (flags & ~known)
-    die("%s: unsupported gemm flags %ld (VNNI_A / VNNI_C operands and unknown bits are not implemented)", who,
-        (long)flags);
+                        XSMM_GEMM_FLAG_NO_SETUP_TILECONFIG | XSMM_GEMM_WIRE_VNNI_B | XSMM_GEMM_WIRE_VNNI_A |
+                        XSMM_GEMM_FLAG_VNNI_C;
+  if (flags & ~known) die("%s: unsupported gemm flags %ld", who, (long)flags);
   const bool vnni_b = (flags & XSMM_GEMM_WIRE_VNNI_B) != 0;
-  if (vnni_b && dtype != DT_BF16) die("%s: VNNI flags require bf16 (XsmmOps.cpp:292-298)", who);
+  // wire 4096 = dialect vnni_a: A is [m][k/2][2] (VNNIUtils.cpp:75-77), byte-identical to row-major [m][k]: accepted,
+  // nothing to do. wire 8192 = vnni_c: C is stored (and, without BETA_0, read) as VNNI-2 [m/2][n][2].
+  const bool vnni_c = (flags & XSMM_GEMM_FLAG_VNNI_C) != 0;
+  if ((flags & (XSMM_GEMM_WIRE_VNNI_B | XSMM_GEMM_WIRE_VNNI_A | XSMM_GEMM_FLAG_VNNI_C)) && dtype != DT_BF16)
+    die("%s: VNNI flags require bf16 (XsmmOps.cpp:292-298)", who);
   if (vnni_b && (k & 1)) die("%s: VNNI-2 B operand needs an even k, got %ld", who, (long)k);
+  if ((flags & XSMM_GEMM_WIRE_VNNI_A) && (k & 1)) die("%s: VNNI-2 A operand needs an even k, got %ld", who, (long)k);
+  if (vnni_c && (m & 1)) die("%s: VNNI-2 C operand needs an even m, got %ld", who, (long)m);
   if (fused) {
     if (unary_flags != 0) die("%s: unsupported unary flags %ld on a fused brgemm", who, (long)unary_flags);
     if (unary_kind != XSMM_UNARY_NONE && unary_kind != XSMM_UNARY_RELU)
@@ -366,7 +371,7 @@ int64_t gemm_dispatch_common(const char *who, int has_batch, int fused, int64_t 
     }
   }
   std::vector<int64_t> key = {KIND_GEMM, has_batch, fused, dtype, m, n, k, lda, ldb, ldc, stride_a, stride_b,
-                              flags & (XSMM_GEMM_FLAG_BETA_0 | XSMM_GEMM_WIRE_VNNI_B), unary_kind, binary_kind,
+                              flags & (XSMM_GEMM_FLAG_BETA_0 | XSMM_GEMM_WIRE_VNNI_B | XSMM_GEMM_FLAG_VNNI_C), unary_kind, binary_kind,
                               cfg().forced_variant.load()};
   void *h = intern(key, [&]() {
     GemmDesc *d = new GemmDesc();
@@ -378,6 +383,7 @@ int64_t gemm_dispatch_common(const char *who, int has_batch, int fused, int64_t 
     d->stride_a = stride_a; d->stride_b = stride_b; d->wire_flags = flags;
     d->beta0 = (flags & XSMM_GEMM_FLAG_BETA_0) != 0;
     d->vnni_b = vnni_b;
+    d->vnni_c = vnni_c;
     d->bias = fused && binary_kind == XSMM_BINARY_ADD;
     d->relu = fused && unary_kind == XSMM_UNARY_RELU;
     plan_gemm(*d, cfg().forced_variant.load());
@@ -826,9 +832,10 @@ void gemm_invoke_common(const char *who, bool want_fused, int64_t dtype, int64_t
   const size_t es = esize(dtype);
   const int64_t kk = br > 0 ? d->k : 0;
   Operand A{(char *)a + off_a * es, 0, false, nullptr}, B{(char *)b + off_b * es, 0, false, nullptr},
-      C{(char *)c + off_c * es, span(d->m, d->ldc, d->n) * es, true, nullptr},
+      C{(char *)c + off_c * es, (d->vnni_c ? span(d->m / 2, 2 * d->ldc, 2 * d->n) : span(d->m, d->ldc, d->n)) * es, true, nullptr},
       D{dptr ? (char *)dptr + off_d * es : nullptr, d->bias ? (size_t)d->n * es : 0, false, nullptr};
-  C.shape(d->m, (size_t)d->n * es, (size_t)d->ldc * es);
+  if (d->vnni_c) C.shape(d->m / 2, (size_t)2 * d->n * es, (size_t)2 * d->ldc * es);
+  else C.shape(d->m, (size_t)d->n * es, (size_t)d->ldc * es);
   if (kk > 0) {
     A.bytes = ((size_t)(br - 1) * d->stride_a + span(d->m, d->lda, d->k)) * es;
     const size_t bspan = d->vnni_b ? span((d->k + 1) / 2, 2 * d->ldb, 2 * d->n) : span(d->k, d->ldb, d->n);

@@ -20,6 +20,7 @@ struct GemmDesc {
   int64_t dtype, m, n, k, lda, ldb, ldc, stride_a, stride_b;
   int64_t wire_flags;   // as received (BETA_0 = 4, VNNI_B wire = 2048, ...)
   int beta0, vnni_b, bias, relu;
+  int vnni_c;           // C stored / read as VNNI-2 [m/2][n][2] (wire flag 8192): generic kernel only
   int variant;          // kernel variant chosen at dispatch (see gemm_variants.h), -1 = by invoke
   char name[64];        // kernel name for profiles
 };
