@@ -84,12 +84,6 @@ def check_close(got, ref, dt, what, mag=None, K=0):
         what, int(bad.sum()), bad.size, float(diff.max()), float(np.abs(r).max()))
 
 
-def test_zz_report_elementwise_figure():
-    """runs last in this file: the session's worst element-wise figure |d| / (|ref| + K eps sum|a||b|) over all f32 GEMM cases"""
-    print("\n[parity] f32 element-wise: max |gpu-ref| / (|ref| + floor) = %.3g over %d cases (bar: 1e-5 relative + floor)" % (
-        REL_STATS["max_rel"], REL_STATS["cases"]))
-
-
 # ---------------------------------------------------------------- golden fixtures
 @pytest.mark.parametrize("mode", ["host", "device"])
 @pytest.mark.parametrize("path", fr.fixtures(), ids=lambda p: os.path.basename(p)[:-5])
@@ -967,3 +961,9 @@ def test_c5_pack_prologue_then_vnni_brgemm_full_size(rt):
         # flat B: batch b covers k in [128 b, 128 b + 128): stride_b = 128 rows of the flat matrix
         orc.brgemm(BF16, rr, M, 128, M, M, M, 128, 128 * M, 4, A, r0 * M, B, 0, ref, 0, 16)
         check_close(got[r0:r0 + rr].reshape(-1), ref, BF16, "C5 rows %d..%d" % (r0, r0 + rr))
+
+
+def test_zz_report_elementwise_figure():
+    """runs last in this file: the session's worst element-wise figure |d| / (|ref| + K eps sum|a||b|) over all f32 GEMM cases"""
+    print("\n[parity] f32 element-wise: max |gpu-ref| / (|ref| + floor) = %.3g over %d cases (bar: 1e-5 relative + floor)" % (
+        REL_STATS["max_rel"], REL_STATS["cases"]))

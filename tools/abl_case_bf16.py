@@ -4,5 +4,4 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import sweep
 tag = sys.argv[1] if len(sys.argv) > 1 else ""
 sweep.bf16_case(4096, 1024, 64, 16, tag=tag + " C4 layer")
-sweep.bf16_case(4096, 4096, 64, 64, tag=tag + " 4096^3")
 sweep.bf16_case(4096, 1024, 64, 128, tag=tag + " K=8192 (256 tiles)")

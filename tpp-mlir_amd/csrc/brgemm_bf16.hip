@@ -420,7 +420,7 @@ template <int NLW>
 __global__ __launch_bounds__(256 + 64 * NLW) void brgemm_bf16_dma128(GemmArgs p) {
   constexpr bool LW = NLW > 0;
   constexpr int PPL = LW ? 32 / NLW : 0; // DMA instructions per loader wave per chunk
-  constexpr int BM = 128, BN = 128, NSLOT = 4, TM = 2, TN = 2;
+  constexpr int BM = 128, BN = 128, NSLOT = 5, TM = 2, TN = 2; // 5 x 32 KiB = all 160 KiB of LDS
   constexpr int A_SLOT = BM * BKH * 2, B_SLOT = (BKH / 2) * BN * 4, SLOT = A_SLOT + B_SLOT;
   constexpr int DMA_PER_CHUNK = 8; // per wave: 4 x 1 KiB of A + 4 x 1 KiB of B
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_d[];
@@ -511,18 +511,25 @@ __global__ __launch_bounds__(256 + 64 * NLW) void brgemm_bf16_dma128(GemmArgs p)
       }
       TPP_DMA_ADVANCE();
     };
+    // Ring of 5 slots: chunk t+4 is requested while chunk t multiplies. Measured (profiles/r02_bf16_dma128_ablation.txt):
+    // the loop waits for data, not for the LDS or the barrier - each kernel starts with cold L2s and the workgroups that
+    // share a panel run in lockstep, so every chunk is a first-touch miss (~1.4 us to the Infinity Cache / HBM) and the
+    // chunk time is that latency divided by the chunks in flight. Chunks 0 and 1 go first and chunk 0 is published as
+    // soon as it has landed; the rest of the ring fills behind the barrier.
     if (T > 0) issue(0);
     if (T > 1) issue(1);
-    if (T > 2) issue(2);
-    if (T > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPL) : "memory");
-    else if (T > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPL) : "memory");
+    if (T > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPL) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier(); // chunk 0 published
+    if (T > 2) issue(2);
+    if (T > 3) issue(3);
     for (int t = 0; t + 1 < T; ++t) {
-      if (t + 2 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPL) : "memory");
+      // chunk t+1 has landed; up to two younger chunks (t+2, t+3) may still fly
+      if (t + 3 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPL) : "memory");
+      else if (t + 2 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPL) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier(); // = the MFMA waves' mid-chunk barrier of chunk t: chunk t+1 published
-      if (t + 3 < T) issue((t + 3) & 3);
+      __builtin_amdgcn_s_barrier(); // = the MFMA waves' mid-chunk barrier of chunk t: chunk t+1 published, slot of chunk t-1 retired
+      if (t + 4 < T) issue((t + 4) % NSLOT);
     }
     return; // ended waves do not take part in later barriers
   }
@@ -583,7 +590,7 @@ __global__ __launch_bounds__(256 + 64 * NLW) void brgemm_bf16_dma128(GemmArgs p)
     for (int q = 0; q < 4; ++q) {
       if ((TPP_ABLATE & HABL_STAMP) && STEADY && S == 0) step_stamp[q] = __builtin_readcyclecounter();
       const bool reads = !(TPP_ABLATE & HABL_NO_FRAG) && (q + 2 < 4 || H1);
-      const int rbuf = q + 2 < 4 ? q + 2 : q - 2, rslot = q + 2 < 4 ? S : (S + 1) & (NSLOT - 1), rks = rbuf;
+      const int rbuf = q + 2 < 4 ? q + 2 : q - 2, rslot = q + 2 < 4 ? S : (S + 1) % NSLOT, rks = rbuf;
       if (reads && !(STEADY && TPP_BF16_SPREAD_READS)) frag_load(rbuf, rslot, rks);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -597,7 +604,7 @@ __global__ __launch_bounds__(256 + 64 * NLW) void brgemm_bf16_dma128(GemmArgs p)
             if (m < 2) frag_piece(rbuf, rslot, rks, m == 0 ? 1 : 3);
           }
           if (!LW && STEADY && q >= 2 && !(TPP_ABLATE & HABL_NO_GLOAD)) {
-            dma_piece((S + 3) & (NSLOT - 1), (q - 2) * 4 + i * TN + j); // slot of chunk t-1: every wave is past it
+            dma_piece((S + 3) % NSLOT, (q - 2) * 4 + i * TN + j); // a slot no wave reads any more (NLW = 0 keeps 3 chunks in flight)
             if (q == 3 && i == TM - 1 && j == TN - 1) TPP_DMA_ADVANCE();
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -611,7 +618,7 @@ __global__ __launch_bounds__(256 + 64 * NLW) void brgemm_bf16_dma128(GemmArgs p)
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         if (!LW && !STEADY && H3 && !(TPP_ABLATE & HABL_NO_GLOAD)) { // the last chunks: one burst
-          dma_chunk((S + 3) & (NSLOT - 1));
+          dma_chunk((S + 3) % NSLOT);
           TPP_DMA_ADVANCE();
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -643,6 +650,16 @@ __global__ __launch_bounds__(256 + 64 * NLW) void brgemm_bf16_dma128(GemmArgs p)
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  // bias: fetched here (8 bytes = 4 columns per register quad), used in the epilogue - its latency hides under the K loop
+  typedef unsigned int u32x2b __attribute__((ext_vector_type(2)));
+  u32x2b biasw[TN][4];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      biasw[j][g] = u32x2b{0u, 0u};
+      if (p.ep & EP_BIAS) biasw[j][g] = *(const u32x2b *)((const unsigned short *)p.D + n0 + wn * 64 + 32 * j + 8 * g + 4 * lh);
+    }
   if (!LW) {
     if (T > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DMA_PER_CHUNK) : "memory");
     else if (T > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_CHUNK) : "memory");
@@ -656,13 +673,14 @@ __global__ __launch_bounds__(256 + 64 * NLW) void brgemm_bf16_dma128(GemmArgs p)
   }
   if (TPP_ABLATE & HABL_STAMP) stamp[1] = __builtin_readcyclecounter();
   int t = 0;
-  for (; t + 6 < T; t += 4) { // steady state (t % 4 == 0 here: ring slots are literals)
+  for (; t + 7 < T; t += NSLOT) { // steady state (t % 5 == 0 here: ring slots are literals)
     chunk(yes{}, 0, true, true, true);
     chunk(yes{}, 1, true, true, true);
     chunk(yes{}, 2, true, true, true);
     chunk(yes{}, 3, true, true, true);
+    chunk(yes{}, 4, true, true, true);
   }
-  for (; t < T; ++t) chunk(no{}, t & (NSLOT - 1), t + 1 < T, t + 2 < T, t + 3 < T); // the last <= 6 chunks
+  for (; t < T; ++t) chunk(no{}, t % NSLOT, t + 1 < T, t + 2 < T, t + 3 < T); // the last <= 7 chunks
 
   if (TPP_ABLATE & HABL_STAMP) stamp[2] = __builtin_readcyclecounter();
   if (TPP_ABLATE & HABL_NO_FRAG) {
@@ -702,9 +720,7 @@ __global__ __launch_bounds__(256 + 64 * NLW) void brgemm_bf16_dma128(GemmArgs p)
     float bias[4][4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      u32x2d b2 = {0u, 0u};
-      if (p.ep & EP_BIAS)
-        b2 = *(const u32x2d *)((const unsigned short *)p.D + n0 + wn * 64 + 32 * j + 8 * g + 4 * lh);
+      const u32x2b b2 = biasw[j][g];
       bias[g][0] = __uint_as_float(b2[0] << 16);
       bias[g][1] = __uint_as_float(b2[0] & 0xffff0000u);
       bias[g][2] = __uint_as_float(b2[1] << 16);
@@ -759,7 +775,7 @@ __global__ __launch_bounds__(256 + 64 * NLW) void brgemm_bf16_dma128(GemmArgs p)
 }
 
 template <int LW> static hipError_t launch_bf16_dma128(const GemmArgs &a, hipStream_t s) {
-  constexpr size_t lds = 4 * 32768;
+  constexpr size_t lds = 5 * 32768;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void *)brgemm_bf16_dma128<LW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
