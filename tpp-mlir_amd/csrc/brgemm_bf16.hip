@@ -25,6 +25,8 @@ namespace tpp {
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
+// Timing-only ablation masks: SIDE builds only (tools/ablate_bf16.sh compiles this file with -DTPP_ABLATE=mask into
+// build/libabl_*.so); the shipped library is built with 0 and every `if (TPP_ABLATE & ...)` below folds away.
 #ifndef TPP_ABLATE
 #define TPP_ABLATE 0
 #endif
@@ -52,9 +54,6 @@ __global__ __launch_bounds__(64 * WM * WN) void brgemm_bf16_fast(GemmArgs p, con
   unsigned char *As = smem_h;
   unsigned char *Bs = smem_h + NSTAGE_H * A_STAGE;
 
-  unsigned long long stamp[6] = {0, 0, 0, 0, 0, 0};
-  unsigned long long step_stamp[5] = {0, 0, 0, 0, 0};
-  if (TPP_ABLATE & HABL_STAMP) { stamp[0] = __builtin_readcyclecounter(); stamp[4] = wall_clock64(); }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int li = lane & 31, lh = lane >> 5;
@@ -156,7 +155,6 @@ __global__ __launch_bounds__(64 * WM * WN) void brgemm_bf16_fast(GemmArgs p, con
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int cur = q & 1, nxt = cur ^ 1;
-      if ((TPP_ABLATE & HABL_STAMP) && STAGE == 0 && HAS_LOAD) step_stamp[q] = __builtin_readcyclecounter();
       if (!(TPP_ABLATE & HABL_NO_FRAG)) {
         if (q + 1 < 4) frag_load(nxt, STAGE, q + 1);
         else if (HAS_NEXT) frag_load(nxt, NSTG, 0);
@@ -189,7 +187,6 @@ __global__ __launch_bounds__(64 * WM * WN) void brgemm_bf16_fast(GemmArgs p, con
         }
       if (q == 1 && !(TPP_ABLATE & HABL_NO_BARRIER)) __syncthreads();
     }
-    if ((TPP_ABLATE & HABL_STAMP) && STAGE == 0 && HAS_LOAD) step_stamp[4] = __builtin_readcyclecounter();
   };
   using yes = std::integral_constant<bool, true>;
   using no = std::integral_constant<bool, false>;
@@ -252,7 +249,6 @@ __global__ __launch_bounds__(64 * WM * WN) void brgemm_bf16_fast(GemmArgs p, con
   }
   __syncthreads();
   if (T > 0) frag_load(0, 0, 0);
-  if (TPP_ABLATE & HABL_STAMP) stamp[1] = __builtin_readcyclecounter();
   int t = 0;
   for (; t + 2 + NSET_H + 1 < T; t += 3) {
     chunk(S0{}, yes{}, yes{});
@@ -273,8 +269,7 @@ __global__ __launch_bounds__(64 * WM * WN) void brgemm_bf16_fast(GemmArgs p, con
     if (t < T) tail(S2{});
   }
 
-  if (TPP_ABLATE & HABL_STAMP) stamp[2] = __builtin_readcyclecounter();
-  if (TPP_ABLATE & ~HABL_STAMP) {
+  if (TPP_ABLATE) {
 #pragma unroll
     for (int st = 0; st < NSET_H; ++st) {
 #pragma unroll
@@ -337,29 +332,15 @@ __global__ __launch_bounds__(64 * WM * WN) void brgemm_bf16_fast(GemmArgs p, con
       }
     }
   }
-  if ((TPP_ABLATE & HABL_STAMP) && p.D && !(p.ep & EP_BIAS) && tid == 0) {
-    stamp[3] = __builtin_readcyclecounter();
-    const size_t lin = blockIdx.x + gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z);
-    unsigned long long *dbg = (unsigned long long *)p.D + lin * 8;
-    for (int e = 0; e < 5; ++e) dbg[e] = stamp[e];
-    dbg[5] = wall_clock64();
-    const size_t nblk = (size_t)gridDim.x * gridDim.y * gridDim.z;
-    unsigned long long *dbg2 = (unsigned long long *)p.D + nblk * 8 + lin * 8;
-    for (int e = 0; e < 5; ++e) dbg2[e] = step_stamp[e];
-  }
 }
 
 template <int WM, int WN, int TM, int TN>
 static hipError_t launch_bf16(const GemmArgs &a, hipStream_t s) {
   constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN, NT = 64 * WM * WN;
   constexpr size_t lds = (size_t)NSTAGE_H * (BM * BKH * 2 + 8 * (BN + 1) * 16);
-  static bool attr_set = false;
   auto kern = brgemm_bf16_fast<WM, WN, TM, TN>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> lds_set{0};
+  if (hipError_t e = ensure_dynamic_lds((const void *)kern, (int)lds, lds_set); e != hipSuccess) return e;
   GemmArgs args = a;
   const int tiles_m = a.m / BM, tiles_n = a.n / BN;
   dim3 grid;
@@ -379,13 +360,9 @@ static hipError_t launch_bf16(const GemmArgs &a, hipStream_t s) {
 // grouped launch of the 64x64 bf16 tile: one workgroup per (item, 64x64 tile of the item)
 hipError_t launch_bf16_grouped64(const GemmArgs &a, const WorkItem *items, int n_items, hipStream_t s) {
   constexpr size_t lds = (size_t)NSTAGE_H * (64 * BKH * 2 + 8 * (64 + 1) * 16);
-  static bool attr_set = false;
   auto kern = brgemm_bf16_fast<2, 2, 1, 1>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> lds_set{0};
+  if (hipError_t e = ensure_dynamic_lds((const void *)kern, (int)lds, lds_set); e != hipSuccess) return e;
   GemmArgs args = a;
   args.tiles_m = args.tiles_n = 0;
   hipLaunchKernelGGL(kern, dim3((unsigned)n_items, a.n / 64, a.m / 64), dim3(256), lds, s, args, items);
@@ -425,9 +402,6 @@ __global__ __launch_bounds__(256 + 64 * NLW) void brgemm_bf16_dma128(GemmArgs p)
   constexpr int DMA_PER_CHUNK = 8; // per wave: 4 x 1 KiB of A + 4 x 1 KiB of B
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_d[];
 
-  unsigned long long stamp[6] = {0, 0, 0, 0, 0, 0};
-  unsigned long long step_stamp[5] = {0, 0, 0, 0, 0};
-  if (TPP_ABLATE & HABL_STAMP) { stamp[0] = __builtin_readcyclecounter(); stamp[4] = wall_clock64(); }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -588,7 +562,6 @@ __global__ __launch_bounds__(256 + 64 * NLW) void brgemm_bf16_dma128(GemmArgs p)
     const bool H1 = STEADY || h1, H2 = STEADY || h2, H3 = STEADY || h3;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      if ((TPP_ABLATE & HABL_STAMP) && STEADY && S == 0) step_stamp[q] = __builtin_readcyclecounter();
       const bool reads = !(TPP_ABLATE & HABL_NO_FRAG) && (q + 2 < 4 || H1);
       const int rbuf = q + 2 < 4 ? q + 2 : q - 2, rslot = q + 2 < 4 ? S : (S + 1) % NSLOT, rks = rbuf;
       if (reads && !(STEADY && TPP_BF16_SPREAD_READS)) frag_load(rbuf, rslot, rks);
@@ -624,7 +597,6 @@ __global__ __launch_bounds__(256 + 64 * NLW) void brgemm_bf16_dma128(GemmArgs p)
         }
       }
     }
-    if ((TPP_ABLATE & HABL_STAMP) && STEADY && S == 0) step_stamp[4] = __builtin_readcyclecounter();
   };
   using yes = std::integral_constant<bool, true>;
   using no = std::integral_constant<bool, false>;
@@ -671,7 +643,6 @@ __global__ __launch_bounds__(256 + 64 * NLW) void brgemm_bf16_dma128(GemmArgs p)
     frag_load(0, 0, 0);
     frag_load(1, 0, 1);
   }
-  if (TPP_ABLATE & HABL_STAMP) stamp[1] = __builtin_readcyclecounter();
   int t = 0;
   for (; t + 7 < T; t += NSLOT) { // steady state (t % 5 == 0 here: ring slots are literals)
     chunk(yes{}, 0, true, true, true);
@@ -682,7 +653,6 @@ __global__ __launch_bounds__(256 + 64 * NLW) void brgemm_bf16_dma128(GemmArgs p)
   }
   for (; t < T; ++t) chunk(no{}, t % NSLOT, t + 1 < T, t + 2 < T, t + 3 < T); // the last <= 7 chunks
 
-  if (TPP_ABLATE & HABL_STAMP) stamp[2] = __builtin_readcyclecounter();
   if (TPP_ABLATE & HABL_NO_FRAG) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(af[0][i]), "v"(af[1][i]), "v"(af[2][i]), "v"(af[3][i]));
@@ -762,26 +732,12 @@ __global__ __launch_bounds__(256 + 64 * NLW) void brgemm_bf16_dma128(GemmArgs p)
     __builtin_amdgcn_raw_buffer_store_b128(v, rsrcC, (unsigned)(lane >> 3) * ldcb + (unsigned)(ch * 16),
                                            (unsigned)(it * 8) * ldcb, 0);
   }
-  if ((TPP_ABLATE & HABL_STAMP) && p.D && !(p.ep & EP_BIAS) && tid == 0) {
-    stamp[3] = __builtin_readcyclecounter();
-    const size_t lin = blockIdx.x + gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z);
-    const size_t nblk = (size_t)gridDim.x * gridDim.y * gridDim.z;
-    unsigned long long *dbg = (unsigned long long *)p.D + lin * 8;
-    for (int e = 0; e < 5; ++e) dbg[e] = stamp[e];
-    dbg[5] = wall_clock64();
-    unsigned long long *dbg2 = (unsigned long long *)p.D + nblk * 8 + lin * 8;
-    for (int e = 0; e < 5; ++e) dbg2[e] = step_stamp[e];
-  }
 }
 
 template <int LW> static hipError_t launch_bf16_dma128(const GemmArgs &a, hipStream_t s) {
   constexpr size_t lds = 5 * 32768;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)brgemm_bf16_dma128<LW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> lds_set{0};
+  if (hipError_t e = ensure_dynamic_lds((const void *)brgemm_bf16_dma128<LW>, (int)lds, lds_set); e != hipSuccess) return e;
   GemmArgs args = a;
   const int tiles_m = a.m / 128, tiles_n = a.n / 128;
   dim3 grid;
@@ -818,8 +774,7 @@ hipError_t launch_bf16_dma256(const GemmArgs &a, hipStream_t s); // brgemm_bf16_
 //    to 256 tiles while the 64 x 64 family jumps from 9.1 to 12.8 us past one tile per CU (tools/mid_probe.py);
 //  * 64 x 64 below that, so that more CUs have work.
 int pick_bf16_tile(const GemmDesc &d) {
-  static const int64_t t256_min = getenv("TPP_HIP_BF16_T256MIN") ? atoll(getenv("TPP_HIP_BF16_T256MIN")) : 240;
-  static const int64_t t128_min = getenv("TPP_HIP_BF16_T128MIN") ? atoll(getenv("TPP_HIP_BF16_T128MIN")) : 65;
+  constexpr int64_t t256_min = 240, t128_min = 65; // crossovers measured in profiles/r01_sweep_shapes.txt
   const int64_t t256 = (d.m % 256 == 0 && d.n % 256 == 0) ? (d.m / 256) * (d.n / 256) : 0;
   const int64_t t128 = (d.m % 128 == 0 && d.n % 128 == 0) ? (d.m / 128) * (d.n / 128) : 0;
   auto fill = [](int64_t t) { return (double)t / (double)(((t + 255) / 256) * 256); }; // CU occupancy over the rounds
@@ -829,12 +784,13 @@ int pick_bf16_tile(const GemmDesc &d) {
 }
 
 hipError_t launch_gemm_bf16_fast(int tile, const GemmArgs &a, hipStream_t s) {
-  static const int legacy = getenv("TPP_HIP_BF16_LEGACY") ? atoi(getenv("TPP_HIP_BF16_LEGACY")) : 0;
   if (tile == 2) return launch_bf16_dma256(a, s);
-  // TPP_HIP_BF16_LEGACY: A/B measurement knob - 2 = no loader waves, 4 = four loader waves (default two;
-  // measured equal: the loop is not bound by the DMA issue rate of a wave)
-  if (tile == 1)
-    return legacy == 2 ? launch_bf16_dma128<0>(a, s) : legacy == 4 ? launch_bf16_dma128<4>(a, s) : launch_bf16_dma128<2>(a, s);
+  // two loader waves; none / four were measured equal (profiles/r02_bf16_dma128_ablation.txt: the loop is bound by the
+  // fill path, not by the DMA issue rate of a wave). -DTPP_BF16_NLW=0|4 builds those variants for A/B runs.
+#ifndef TPP_BF16_NLW
+#define TPP_BF16_NLW 2
+#endif
+  if (tile == 1) return launch_bf16_dma128<TPP_BF16_NLW>(a, s);
   return launch_bf16<2, 2, 1, 1>(a, s);
 }
 

@@ -32,9 +32,6 @@ namespace tpp {
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void lds_void_t;
 
-#ifndef TPP_STAMP256
-#define TPP_STAMP256 0 // 1: workgroup timeline stamps into the D operand (tools/stamp_bf16_256.py)
-#endif
 #ifndef TPP_ABLATE256
 #define TPP_ABLATE256 0 // timing experiments (results are wrong): 1 no DMA in the loop, 2 no fragment reads, 4 no barrier
 #endif
@@ -46,8 +43,6 @@ __global__ __launch_bounds__(256) void brgemm_bf16_dma256(GemmArgs p) {
   static_assert(SLOT == 32768, "ring slot");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_x[];
 
-  unsigned long long stamp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  if (TPP_STAMP256) { stamp[0] = __builtin_readcyclecounter(); stamp[4] = wall_clock64(); }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -141,7 +136,6 @@ __global__ __launch_bounds__(256) void brgemm_bf16_dma256(GemmArgs p) {
   auto chunk = [&](auto steady_c, int slot, bool h1, bool h2, bool h3) __attribute__((always_inline)) {
     constexpr bool STEADY = decltype(steady_c)::value;
     // ---- K step 0 (fragments in set 0); set 1 <- K step 1 of this chunk, one read per MFMA
-    if (TPP_STAMP256 && STEADY && slot == 0) stamp[6] = __builtin_readcyclecounter();
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -150,7 +144,6 @@ __global__ __launch_bounds__(256) void brgemm_bf16_dma256(GemmArgs p) {
         if (i * TN + j < 12) frag_piece(1, slot, 1, i * TN + j);
         __builtin_amdgcn_sched_barrier(0);
       }
-    if (TPP_STAMP256 && STEADY && slot == 0) stamp[7] = __builtin_readcyclecounter();
     const bool next = STEADY || h1;
     if (next) {
       // chunk t+1: this wave's DMA has landed (chunk t+2's may still fly), then everybody's
@@ -168,7 +161,6 @@ __global__ __launch_bounds__(256) void brgemm_bf16_dma256(GemmArgs p) {
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if (TPP_STAMP256 && STEADY && slot == 0) stamp[8] = __builtin_readcyclecounter();
     // ---- K step 1 (set 1); set 0 <- K step 0 of chunk t+1; the DMA of chunk t+3 rides along, into
     // the slot chunk t-1 has left
 #pragma unroll
@@ -183,7 +175,6 @@ __global__ __launch_bounds__(256) void brgemm_bf16_dma256(GemmArgs p) {
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-    if (TPP_STAMP256 && STEADY && slot == 0) stamp[9] = __builtin_readcyclecounter();
   };
   using yes = std::integral_constant<bool, true>;
   using no = std::integral_constant<bool, false>;
@@ -218,7 +209,6 @@ __global__ __launch_bounds__(256) void brgemm_bf16_dma256(GemmArgs p) {
         asm volatile("" : "+v"(af[q][i]), "+v"(bw[q][i]));
       }
   }
-  if (TPP_STAMP256) stamp[1] = __builtin_readcyclecounter();
   int t = 0;
   for (; t + 6 < T; t += 4) { // steady state: ring slots are compile-time constants (t % 4 == 0 here)
     chunk(yes{}, 0, true, true, true);
@@ -227,7 +217,6 @@ __global__ __launch_bounds__(256) void brgemm_bf16_dma256(GemmArgs p) {
     chunk(yes{}, 3, true, true, true);
   }
   for (; t < T; ++t) chunk(no{}, t & (NSLOT - 1), t + 1 < T, t + 2 < T, t + 3 < T); // <= 6 chunks
-  if (TPP_STAMP256) stamp[2] = __builtin_readcyclecounter();
 
   // ---- epilogue ------------------------------------------------------------------------
   // lane (li, lh) owns row 32*i + li of wave-tile row block i and, in registers 4g..4g+3 of
@@ -308,23 +297,12 @@ __global__ __launch_bounds__(256) void brgemm_bf16_dma256(GemmArgs p) {
                                              (unsigned)(ih * 64 + it * 4) * ldcb, 0);
     }
   }
-  if (TPP_STAMP256 && p.D && !(p.ep & EP_BIAS) && tid == 0) {
-    stamp[3] = __builtin_readcyclecounter();
-    stamp[5] = wall_clock64();
-    const size_t lin = blockIdx.x + gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z);
-    unsigned long long *dbg = (unsigned long long *)p.D + lin * 16;
-    for (int e = 0; e < 10; ++e) dbg[e] = stamp[e];
-  }
 }
 
 hipError_t launch_bf16_dma256(const GemmArgs &a, hipStream_t s) {
   constexpr size_t lds = 4 * 32768;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)brgemm_bf16_dma256, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> lds_set{0};
+  if (hipError_t e = ensure_dynamic_lds((const void *)brgemm_bf16_dma256, (int)lds, lds_set); e != hipSuccess) return e;
   GemmArgs args = a;
   const int tiles_m = a.m / 256, tiles_n = a.n / 256;
   dim3 grid;

@@ -581,13 +581,8 @@ template <int WM, int WN, int WK, int NACC, bool DMA>
 static hipError_t launch_fast_t(const GemmArgs &a, hipStream_t s) {
   constexpr int BM = 32 * WM, BN = 32 * WN, NT = 64 * WM * WN * WK;
   constexpr size_t lds = (size_t)NSTAGE * (BM * BK + BK * BN) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)brgemm_f32_fast<WM, WN, WK, NACC, DMA>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> lds_set{0};
+  if (hipError_t e = ensure_dynamic_lds((const void *)brgemm_f32_fast<WM, WN, WK, NACC, DMA>, (int)lds, lds_set); e != hipSuccess) return e;
   GemmArgs args = a;
   const int tiles_m = a.m / BM, tiles_n = a.n / BN;
   dim3 grid;
@@ -609,13 +604,8 @@ template <int WM, int WN, int WK, int NACC, bool DMA>
 static hipError_t launch_fast_grouped_t(const GemmArgs &a, const WorkItem *items, int n_items, hipStream_t s) {
   constexpr int BM = 32 * WM, BN = 32 * WN, NT = 64 * WM * WN * WK;
   constexpr size_t lds = (size_t)NSTAGE * (BM * BK + BK * BN) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)brgemm_f32_fast<WM, WN, WK, NACC, DMA>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> lds_set{0};
+  if (hipError_t e = ensure_dynamic_lds((const void *)brgemm_f32_fast<WM, WN, WK, NACC, DMA>, (int)lds, lds_set); e != hipSuccess) return e;
   GemmArgs args = a;
   args.tiles_m = args.tiles_n = 0;
   hipLaunchKernelGGL((brgemm_f32_fast<WM, WN, WK, NACC, DMA>), dim3((unsigned)n_items, a.n / BN, a.m / BM), dim3(NT), lds, s, args,
@@ -623,11 +613,9 @@ static hipError_t launch_fast_grouped_t(const GemmArgs &a, const WorkItem *items
   return hipGetLastError();
 }
 
-// DMA_DEFAULT: which panel path the tile uses unless TPP_HIP_F32_DMA=0|1 overrides it (A/B measurements)
-template <int WM, int WN, int WK, int NACC, bool DMA_DEFAULT>
+template <int WM, int WN, int WK, int NACC, bool DMA>
 static hipError_t launch_fast(const GemmArgs &a, hipStream_t s) {
-  static const bool use_dma = getenv("TPP_HIP_F32_DMA") ? atoi(getenv("TPP_HIP_F32_DMA")) != 0 : DMA_DEFAULT;
-  return use_dma ? launch_fast_t<WM, WN, WK, NACC, true>(a, s) : launch_fast_t<WM, WN, WK, NACC, false>(a, s);
+  return launch_fast_t<WM, WN, WK, NACC, DMA>(a, s);
 }
 
 hipError_t launch_gemm_bf16_fast(int tile, const GemmArgs &a, hipStream_t s); // brgemm_bf16.hip
@@ -638,13 +626,9 @@ bool bf16_fast_eligible(const GemmDesc &d);
 template <typename T, bool VNNI, bool VEC>
 static hipError_t launch_grouped_t(const GemmArgs &a, const WorkItem *items, int n_items, hipStream_t s) {
   constexpr size_t lds = 4 * 2 * 2 * 32 * GK * sizeof(float); // 64 KiB: 4 waves x 2 buffers x (A + B)
-  static bool attr_set = false;
   auto kern = brgemm_grouped<T, VNNI, VEC>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> lds_set{0};
+  if (hipError_t e = ensure_dynamic_lds((const void *)kern, (int)lds, lds_set); e != hipSuccess) return e;
   GemmArgs args = a;
   args.tiles_m = (a.m + 31) / 32;
   args.tiles_n = (a.n + 31) / 32;
@@ -655,7 +639,7 @@ static hipError_t launch_grouped_t(const GemmArgs &a, const WorkItem *items, int
   return hipGetLastError();
 }
 
-static int g_num_cus = 256;
+#define g_num_cus device_cu_count() /* compute units of the current device (gemm_common.h) */
 
 hipError_t launch_bf16_grouped64(const GemmArgs &a, const WorkItem *items, int n_items, hipStream_t s); // brgemm_bf16.hip
 hipError_t launch_bf16_small32(const GemmArgs &a, const WorkItem *items, int n_items, hipStream_t s); // brgemm_bf16_small.hip

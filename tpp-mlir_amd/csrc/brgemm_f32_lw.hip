@@ -18,7 +18,6 @@
 //     variants each ran once per launch: instruction-cache cold misses in a 16-chunk kernel).
 #include "gemm_common.h"
 #include "xsmm_desc.h"
-#include <mutex>
 #include <type_traits>
 
 namespace tpp {
@@ -223,14 +222,8 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + 2)) void brgemm_f32_lw(GemmArg
 template <int WM, int WN, int WK> static hipError_t launch_lw_t(const GemmArgs &a, hipStream_t s) {
   constexpr int BM = 32 * WM, BN = 32 * WN, NT = 64 * (WM * WN * WK + 2);
   constexpr size_t lds = (size_t)LW_NSLOT * (BM * LW_BK + LW_BK * BN) * sizeof(float);
-  static std::once_flag once[16]; // the attribute is per device
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-  hipError_t err = hipSuccess;
-  std::call_once(once[dev & 15], [&] {
-    err = hipFuncSetAttribute((const void *)brgemm_f32_lw<WM, WN, WK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  });
-  if (err != hipSuccess) return err;
+  static std::atomic<unsigned long long> lds_set{0};
+  if (hipError_t e = ensure_dynamic_lds((const void *)brgemm_f32_lw<WM, WN, WK>, (int)lds, lds_set); e != hipSuccess) return e;
   GemmArgs args = a;
   const int tiles_m = a.m / BM, tiles_n = a.n / BN;
   dim3 grid;

@@ -15,6 +15,8 @@
 
 namespace tpp {
 
+typedef unsigned int u32x4_e __attribute__((ext_vector_type(4)));
+
 enum : int64_t { U_IDENTITY = 1, U_ZERO = 2, U_RELU = 5, U_VNNI2 = 28, U_TRANSPOSE = 29 };
 enum : int64_t { UF_ROW = 2, UF_COL = 4, UF_SCALAR = 8 };
 enum : int64_t { B_ADD = 1, B_MUL = 2, B_SUB = 3, B_DIV = 4 };
@@ -152,6 +154,31 @@ __global__ __launch_bounds__(256) void vnni2_kernel(int64_t m, int64_t n, int64_
       }
     }
   }
+}
+
+// Row-pair variant of the 16-byte path for matrices whose row pairs fit the grid's y dimension (every shape the
+// reference packs: weights of a layer): blockIdx.y = row pair, 256 lanes x 8 columns per block along x. No
+// grid-stride loop and no 64-bit division - at the C5 size (2048^2 bf16, 16 MiB moved in ~3 us) the kernel is a
+// single wave of blocks and the address arithmetic of the generic loop was a measurable part of it.
+__global__ __launch_bounds__(256) void vnni2_rows_kernel(int n8, int64_t ldi, int64_t ldo,
+                                                         const unsigned short *__restrict__ in,
+                                                         unsigned short *__restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x; // 8-column piece
+  if (c >= n8) return;
+  const int64_t r = blockIdx.y;
+  const u32x4_e e = *(const u32x4_e *)(in + (2 * r) * ldi + 8 * (int64_t)c);
+  const u32x4_e o = *(const u32x4_e *)(in + (2 * r + 1) * ldi + 8 * (int64_t)c);
+  u32x4_e w0, w1; // dword q of the output = (even row element q, odd row element q)
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    w0[2 * q] = (e[q] & 0xffffu) | (o[q] << 16);
+    w0[2 * q + 1] = (e[q] >> 16) | (o[q] & 0xffff0000u);
+    w1[2 * q] = (e[q + 2] & 0xffffu) | (o[q + 2] << 16);
+    w1[2 * q + 1] = (e[q + 2] >> 16) | (o[q + 2] & 0xffff0000u);
+  }
+  u32x4_e *dst = (u32x4_e *)(out + r * (2 * ldo) + 16 * (int64_t)c);
+  dst[0] = w0;
+  dst[1] = w1;
 }
 
 // ---- grouped variants (tile queue): ONE block per queued invoke of one small-tile descriptor ----
@@ -334,7 +361,10 @@ hipError_t launch_unary(const UnaryDesc &d, const void *in, float scalar, bool u
   if (d.m <= 0 || d.n <= 0) return hipSuccess;
   if (d.op == U_VNNI2) {
     const bool vec = d.n % 8 == 0 && d.ldi % 8 == 0 && (2 * d.ldo) % 8 == 0 && aligned(in, 16) && aligned(out, 16);
-    if (vec)
+    if (vec && d.m / 2 <= 65535 && d.n / 8 < (1 << 30))
+      hipLaunchKernelGGL(vnni2_rows_kernel, dim3((unsigned)((d.n / 8 + 255) / 256), (unsigned)(d.m / 2)), dim3(256), 0, s,
+                         (int)(d.n / 8), d.ldi, d.ldo, (const unsigned short *)in, (unsigned short *)out);
+    else if (vec)
       hipLaunchKernelGGL((vnni2_kernel<8>), dim3(grid_for((d.m / 2) * (d.n / 8))), dim3(256), 0, s, d.m, d.n, d.ldi,
                          d.ldo, (const unsigned short *)in, (unsigned short *)out);
     else

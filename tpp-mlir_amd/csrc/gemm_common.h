@@ -63,4 +63,33 @@ template <> struct Elem<unsigned short> {
   }
 };
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute: set it once per (call site, device). `done` is
+// the call site's own bit mask of devices (bit = device id mod 64), updated atomically - concurrent first callers
+// may both set the attribute (harmless), nobody skips it.
+} // namespace tpp
+#include <atomic>
+namespace tpp {
+static inline hipError_t ensure_dynamic_lds(const void *kernel, int bytes, std::atomic<unsigned long long> &done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+  return e;
+}
+// compute units of the current device (queried once per process; tile heuristics use it)
+static inline int device_cu_count() {
+  static std::atomic<int> cus{0};
+  int v = cus.load(std::memory_order_relaxed);
+  if (v > 0) return v;
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) v = n;
+  else {
+    (void)hipGetLastError(); // no device visible (dispatch on a CPU-only host still plans for an MI355X)
+    v = 256;
+  }
+  cus.store(v, std::memory_order_relaxed);
+  return v;
+}
 } // namespace tpp

@@ -13,6 +13,7 @@
 #include "../../include/tpp_xsmm_abi.h"
 #include "xsmm_desc.h"
 
+#include <dlfcn.h>
 #include <sched.h>
 #include <algorithm>
 #include <atomic>
@@ -53,10 +54,10 @@ struct Config {
   std::atomic<hipStream_t> stream{nullptr};
   std::atomic<int> forced_variant{-1};
   std::atomic<int> tile_queue{0};
-  bool trace = false;
+  int trace = 0; // TPP_HIP_TRACE: 1 = one stderr line per dispatch + a roctx range per invoke, 2 = also one stderr line per invoke
   Config() {
     if (const char *e = getenv("TPP_HIP_ASYNC")) async = atoi(e) != 0;
-    if (const char *e = getenv("TPP_HIP_TRACE")) trace = atoi(e) != 0;
+    if (const char *e = getenv("TPP_HIP_TRACE")) trace = atoi(e);
     if (const char *e = getenv("TPP_HIP_VARIANT")) forced_variant = atoi(e);
     if (const char *e = getenv("TPP_HIP_TILE_QUEUE")) tile_queue = atoi(e) != 0;
   }
@@ -65,6 +66,41 @@ Config &cfg() {
   static Config c;
   return c;
 }
+
+// ---- tracing: with TPP_HIP_TRACE >= 1 every invoke runs inside a roctx range named after its
+// dispatch tuple and kernel, so `rocprofv3 --marker-trace --kernel-trace` timelines show which xsmm call a kernel
+// belongs to. libroctx64 is looked up at run time (profiling tool, not a link dependency of the product).
+struct Roctx {
+  int (*push)(const char *) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    if (cfg().trace < 1) return;
+    // rocprofv3 (rocprofiler-sdk) traces the SDK's roctx library; the classic libroctx64 serves older tools
+    void *h = nullptr;
+    for (const char *name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "/opt/rocm/lib/librocprofiler-sdk-roctx.so",
+                             "libroctx64.so", "libroctx64.so.4", "/opt/rocm/lib/libroctx64.so"})
+      if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h) return;
+    push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
+    pop = (int (*)())dlsym(h, "roctxRangePop");
+    if (!push || !pop) push = nullptr, pop = nullptr;
+  }
+};
+Roctx &roctx() {
+  static Roctx r;
+  return r;
+}
+struct TraceRange {
+  bool on = false;
+  TraceRange(const char *who, const char *what) {
+    if (cfg().trace < 1) return;
+    if (cfg().trace >= 2) fprintf(stderr, "[tpp-xsmm-hip] %s %s\n", who, what);
+    if (roctx().push) on = roctx().push(what) >= 0;
+  }
+  ~TraceRange() {
+    if (on) roctx().pop();
+  }
+};
 
 // ---- handle registry: hash-cons descriptors by their dispatch tuple -----------------
 std::mutex g_mu;
@@ -387,6 +423,8 @@ int64_t gemm_dispatch_common(const char *who, int has_batch, int fused, int64_t 
     d->bias = fused && binary_kind == XSMM_BINARY_ADD;
     d->relu = fused && unary_kind == XSMM_UNARY_RELU;
     plan_gemm(*d, cfg().forced_variant.load());
+    snprintf(d->trace, sizeof(d->trace), "%s[%ld,%ld,%ld,%ld,%ld,%ld,%ld,%ld] dt%ld flags%ld %s", fused ? "fused_brgemm" : has_batch ? "brgemm" : "gemm",
+             (long)m, (long)n, (long)k, (long)lda, (long)ldb, (long)ldc, (long)stride_a, (long)stride_b, (long)dtype, (long)flags, d->name);
     if (cfg().trace)
       fprintf(stderr, "[tpp-xsmm-hip] %s dtype %ld m %ld n %ld k %ld lda %ld ldb %ld ldc %ld sa %ld sb %ld flags %ld -> %s\n",
               who, (long)dtype, (long)m, (long)n, (long)k, (long)lda, (long)ldb, (long)ldc, (long)stride_a,
@@ -534,7 +572,12 @@ struct TileQueue {
   bool vec_ok = true, out_ok = true;
   int n = 0;
   Footprint reads, writes;
-  WorkItem *pinned[SLOTS] = {nullptr, nullptr, nullptr, nullptr}; // host-pinned, read by the kernel over PCIe once per workgroup
+  // Work lists live in host-pinned (device-mapped) memory and every workgroup reads its 40-byte item over PCIe, once,
+  // at its head. Moving the list to HBM with one hipMemcpyAsync in front of each grouped launch was built and
+  // measured (profiles/r02_tile_queue_device_lists.txt): the copy costs 15-20 us of host time per flush on this
+  // runtime - the reference's headline pattern (3 flushes per iteration) went from 47 to 103 us - while the PCIe
+  // read is ~1 us of latency that all workgroups pay in parallel.
+  WorkItem *pinned[SLOTS] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t done[SLOTS];
   bool used[SLOTS] = {false, false, false, false};
   int slot = 0;
@@ -551,8 +594,7 @@ struct TileQueue {
   }
   void flush() {
     if (n == 0) return;
-    static const bool dry = getenv("TPP_HIP_QUEUE_DRYRUN") != nullptr; // host-cost measurements: enqueue, never launch
-    if (!dry) {
+    {
       if (kind == KIND_GEMM) HIP_OK(launch_gemm_grouped(*(const GemmDesc *)desc, pinned[slot], n, vec_ok, out_ok, stream));
       else if (kind == KIND_UNARY) HIP_OK(launch_unary_grouped(*(const UnaryDesc *)desc, pinned[slot], n, stream));
       else HIP_OK(launch_binary_grouped(*(const BinaryDesc *)desc, pinned[slot], n, stream));
@@ -628,28 +670,52 @@ struct Scheduler {
   int device = 0;
   TileQueue q;
 
+  // The worker exists only while there is traffic: after ~2 s without an entry it leaves (a library that was used
+  // once must not keep a thread napping for the rest of the process), and the next push starts a new one. The
+  // hand-over is a Dekker pair on (running, tail): the worker clears `running` BEFORE it re-reads the tail, a
+  // producer bumps the tail BEFORE it reads `running` - at least one of them sees the other.
+  alignas(64) std::atomic<bool> running{false}; // read by every producer on every push: its own cache line, written twice in a worker's life
+  alignas(64) std::mutex life_mu;
+  uint64_t saved_head = 0; // next ticket to process, handed from one worker to the next (the live value is a local of run())
+
   Scheduler() {
     ring = new Slot[N];
     for (uint64_t i = 0; i < N; ++i) ring[i].seq.store(i, std::memory_order_relaxed);
     if (hipGetDevice(&device) != hipSuccess) device = 0;
-    worker = std::thread([this] { run(); });
   }
   ~Scheduler() {
     stop.store(true);
-    if (!worker.joinable()) return;
+    std::thread w;
+    {
+      std::lock_guard<std::mutex> lk(life_mu);
+      w = std::move(worker);
+    }
+    if (!w.joinable()) return;
     // a fatal error on the scheduler thread itself exits the process from that thread: never join yourself
-    if (worker.get_id() == std::this_thread::get_id()) worker.detach();
-    else worker.join();
+    if (w.get_id() == std::this_thread::get_id()) w.detach();
+    else w.join(); // outside life_mu: a worker on its way out takes that lock
+  }
+  void ensure_worker() {
+    if (running.load(std::memory_order_seq_cst)) return;
+    std::lock_guard<std::mutex> lk(life_mu);
+    if (running.load(std::memory_order_relaxed) || stop.load()) return;
+    if (worker.joinable()) worker.join(); // the previous worker has left (it cleared `running` on its way out)
+    running.store(true, std::memory_order_seq_cst);
+    worker = std::thread([this] { run(); });
   }
   void push(const QEntry &e) {
-    const uint64_t pos = tail.fetch_add(1, std::memory_order_acq_rel);
+    const uint64_t pos = tail.fetch_add(1, std::memory_order_seq_cst);
     Slot &s = ring[pos & MASK];
     for (unsigned spins = 0; s.seq.load(std::memory_order_acquire) != pos; ++spins) { // ring full: wait for the scheduler
       if (spins < 2000) __builtin_ia32_pause();
-      else sched_yield();
+      else {
+        ensure_worker();
+        sched_yield();
+      }
     }
     s.e = e;
     s.seq.store(pos + 1, std::memory_order_release);
+    ensure_worker();
   }
   // everything pushed before this call has been launched on return
   void drain() {
@@ -671,8 +737,8 @@ struct Scheduler {
     // (taskset / numactl / cgroup limits are respected; only later per-thread pinning is undone).
     if (g_have_process_mask) (void)sched_setaffinity(0, sizeof(g_process_mask), &g_process_mask);
     (void)hipSetDevice(device);
-    uint64_t head = 0;
     unsigned idle = 0;
+    uint64_t head = saved_head; // (written under life_mu by the previous worker, read after the join in ensure_worker)
     for (;;) {
       Slot &s = ring[head & MASK];
       if (s.seq.load(std::memory_order_acquire) == head + 1) {
@@ -694,7 +760,16 @@ struct Scheduler {
         else { // nothing for a long while: stop burning a core (a caller that arrives now waits one nap)
           timespec ts{0, idle < 40000 ? 50000 : 1000000}; // 50 us naps, then 1 ms naps
           nanosleep(&ts, nullptr);
-          if (idle > 1000000) idle = 40000;
+          if (idle > 42000) { // ~2 s of 1 ms naps: leave, unless a producer has taken a ticket meanwhile
+            std::lock_guard<std::mutex> lk(life_mu); // ensure_worker() joins this thread under the same lock: decide inside it
+            running.store(false, std::memory_order_seq_cst);
+            if (tail.load(std::memory_order_seq_cst) == head) {
+              saved_head = head;
+              return;
+            }
+            running.store(true, std::memory_order_seq_cst);
+            idle = 0;
+          }
         }
       }
     }
@@ -780,7 +855,7 @@ bool enqueue_item(int kind, const void *desc, const WorkItem &item, const Operan
       if (iq.owner != me) {
         if (iq.owner != 0 && ++iq.foreign > 4) { // several threads are queueing concurrently: hand over to the scheduler
           iq.q.flush();
-          (void)sched(); // start it
+          (void)sched(); // create it (its worker thread starts with the first entry)
           iq.scheduled.store(true, std::memory_order_release);
         }
         iq.owner = me;
@@ -829,6 +904,7 @@ void gemm_invoke_common(const char *who, bool want_fused, int64_t dtype, int64_t
   if (want_fused != (d->fused != 0)) die("%s: handle dispatched for a different gemm flavour", who);
   if (br < 0) die("%s: negative batch count %ld", who, (long)br);
   if (d->m == 0 || d->n == 0) return;
+  TraceRange trace_range(who, d->trace);
   const size_t es = esize(dtype);
   const int64_t kk = br > 0 ? d->k : 0;
   Operand A{(char *)a + off_a * es, 0, false, nullptr}, B{(char *)b + off_b * es, 0, false, nullptr},
@@ -905,7 +981,9 @@ extern "C" int64_t xsmm_unary_dispatch(int64_t kind, int64_t dtype, int64_t m, i
   }
   std::vector<int64_t> key = {KIND_UNARY, kind, dtype, m, n, ldi, ldo, flags};
   void *h = intern(key, [&]() {
-    UnaryDesc *d = new UnaryDesc{KIND_UNARY, kind, dtype, m, n, ldi, ldo, flags};
+    UnaryDesc *d = new UnaryDesc{KIND_UNARY, kind, dtype, m, n, ldi, ldo, flags, {0}};
+    snprintf(d->trace, sizeof(d->trace), "unary kind%ld [%ld,%ld,%ld,%ld] dt%ld flags%ld", (long)kind, (long)m, (long)n, (long)ldi, (long)ldo, (long)dtype, (long)flags);
+    if (cfg().trace) fprintf(stderr, "[tpp-xsmm-hip] xsmm_unary_dispatch %s\n", d->trace);
     return (void *)d;
   });
   return reinterpret_cast<int64_t>(h);
@@ -927,7 +1005,9 @@ extern "C" int64_t xsmm_binary_dispatch(int64_t kind, int64_t dtype, int64_t m, 
   if (f1 == 0 && ldi_rhs < n) die("%s: ldi rhs %ld < n %ld", who, (long)ldi_rhs, (long)n);
   std::vector<int64_t> key = {KIND_BINARY, kind, dtype, m, n, ldi_lhs, ldi_rhs, ldo, flags};
   void *h = intern(key, [&]() {
-    BinaryDesc *d = new BinaryDesc{KIND_BINARY, kind, dtype, m, n, ldi_lhs, ldi_rhs, ldo, flags};
+    BinaryDesc *d = new BinaryDesc{KIND_BINARY, kind, dtype, m, n, ldi_lhs, ldi_rhs, ldo, flags, {0}};
+    snprintf(d->trace, sizeof(d->trace), "binary kind%ld [%ld,%ld,%ld,%ld,%ld] dt%ld flags%ld", (long)kind, (long)m, (long)n, (long)ldi_lhs, (long)ldi_rhs, (long)ldo, (long)dtype, (long)flags);
+    if (cfg().trace) fprintf(stderr, "[tpp-xsmm-hip] xsmm_binary_dispatch %s\n", d->trace);
     return (void *)d;
   });
   return reinterpret_cast<int64_t>(h);
@@ -965,6 +1045,7 @@ static void unary_invoke_common(const char *who, int64_t dtype, int64_t handle, 
   const UnaryDesc *d = as_desc<UnaryDesc>(handle, KIND_UNARY, who);
   if (d->dtype != dtype) die("%s: invoke dtype %ld != dispatch dtype %ld", who, (long)dtype, (long)d->dtype);
   if (d->m == 0 || d->n == 0) return;
+  TraceRange trace_range(who, d->trace);
   const size_t es = esize(dtype);
   Operand I{nullptr, 0, false, nullptr}, O{(char *)out + off_out * es, 0, true, nullptr};
   if (use_scalar && (d->op == XSMM_UNARY_TRANSPOSE || d->op == XSMM_UNARY_VNNI2))
@@ -1020,6 +1101,7 @@ extern "C" void xsmm_binary_invoke(int64_t dtype, int64_t handle, void *lhs, int
   const BinaryDesc *d = as_desc<BinaryDesc>(handle, KIND_BINARY, who);
   if (d->dtype != dtype) die("%s: invoke dtype %ld != dispatch dtype %ld", who, (long)dtype, (long)d->dtype);
   if (d->m == 0 || d->n == 0) return;
+  TraceRange trace_range(who, d->trace);
   const size_t es = esize(dtype);
   auto in_bytes = [&](int64_t row, int64_t col, int64_t sc, int64_t ld) -> size_t {
     if (d->flags & sc) return es;

@@ -23,16 +23,19 @@ struct GemmDesc {
   int vnni_c;           // C stored / read as VNNI-2 [m/2][n][2] (wire flag 8192): generic kernel only
   int variant;          // kernel variant chosen at dispatch (see gemm_variants.h), -1 = by invoke
   char name[64];        // kernel name for profiles
+  char trace[160];      // dispatch tuple + kernel name as text (trace ranges)
 };
 
 struct UnaryDesc {
   int kind;             // KIND_UNARY
   int64_t op, dtype, m, n, ldi, ldo, flags;
+  char trace[96];       // dispatch tuple as text (trace ranges)
 };
 
 struct BinaryDesc {
   int kind;             // KIND_BINARY
   int64_t op, dtype, m, n, ldi_lhs, ldi_rhs, ldo, flags;
+  char trace[96];
 };
 
 struct AmxDesc {
