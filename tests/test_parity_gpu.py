@@ -963,6 +963,38 @@ def test_c5_pack_prologue_then_vnni_brgemm_full_size(rt):
         check_close(got[r0:r0 + rr].reshape(-1), ref, BF16, "C5 rows %d..%d" % (r0, r0 + rr))
 
 
+@pytest.mark.parametrize("dt", [F32, BF16])
+def test_softmax_tail_as_xsmm_calls(rt, dt):
+    """of mlir-gen's softmax (tools/mlir-gen/MLIRGen.cpp:560-630: exp, row sum, splat, divide) the pieces
+    that HAVE an xsmm kind at this revision are the splat of the [batch, 1] row sums (xsmm.unary identity, bcast_row,
+    ldi = 1: ConvertLinalgToXsmm broadcast handling, linalg-to-unary.mlir:148-164) and the divide (xsmm.binary div) -
+    plus the fused form div with bcast_row_in1, which needs no splat buffer; exp and the reduction have no
+    xsmm.unary kind (XsmmEnum.td:34-45) and stay loops in the reference. Checked against numpy and the oracle."""
+    rng = np.random.default_rng(21 + dt)
+    m, n = 96, 200
+    e = np.exp(rng.uniform(-2, 2, m * n)).astype(np.float32)
+    rs = e.reshape(m, n).sum(axis=1).astype(np.float32)
+    E, R = (e, rs) if dt == F32 else (orc.f32_to_bf16(e), orc.f32_to_bf16(rs))
+    zeros = np.zeros(m * n, np.float32 if dt == F32 else np.uint16)
+    dE, dR, dS, dO, dO2 = dev(E), dev(R), dev(zeros), dev(zeros), dev(zeros)
+    hs = rt.unary_dispatch(1, dt, m, n, 1, n, 2)            # identity, bcast_row: [m,1] -> [m,n]
+    hd = rt.binary_dispatch(4, dt, m, n, n, n, n, 0)        # div
+    hd2 = rt.binary_dispatch(4, dt, m, n, n, 1, n, 2)       # div, bcast_row_in1 (no splat buffer)
+    rt.unary(dt, hs, dR, 0, dS, 0)
+    rt.binary(dt, hd, dE, 0, dS, 0, dO, 0)
+    rt.binary(dt, hd2, dE, 0, dR, 0, dO2, 0)
+    S, O, O2 = zeros.copy(), zeros.copy(), zeros.copy()
+    orc.unary(1, dt, m, n, 1, n, 2, R, 0, S, 0)
+    orc.binary(4, dt, m, n, n, n, n, 0, E, 0, S, 0, O, 0)
+    orc.binary(4, dt, m, n, n, 1, n, 2, E, 0, R, 0, O2, 0)
+    assert np.array_equal(host(dS, zeros), S)
+    check_close(host(dO, zeros), O, dt, "softmax div")
+    check_close(host(dO2, zeros), O2, dt, "softmax div bcast_row_in1")
+    want = as_f32(E).reshape(m, n) / as_f32(R).reshape(m, 1)
+    got = as_f32(host(dO2, zeros)).reshape(m, n)
+    assert np.abs(got - want).max() <= (2e-7 if dt == F32 else 2.0 ** -8) * np.abs(want).max() * 4
+
+
 def test_zz_report_elementwise_figure():
     """runs last in this file: the session's worst element-wise figure |d| / (|ref| + K eps sum|a||b|) over all f32 GEMM cases"""
     print("\n[parity] f32 element-wise: max |gpu-ref| / (|ref| + floor) = %.3g over %d cases (bar: 1e-5 relative + floor)" % (
