@@ -372,11 +372,8 @@ def main():
     # ------------------------------------------------------------ C4: bf16 3-layer MLP, row-sharded + all-gather
     mlp = None
     if not args.no_mlp:
-        spec = pkg.MlpSpec()
         N = 1024
-        sh = pkg.ShardedMlp(spec, rank, world, rt)
         g = torch.Generator(device="cpu").manual_seed(7)
-        X = (torch.randn(sh.rows, N, generator=g) * 0.5).to(torch.bfloat16).cuda()
         hp = rt.unary_dispatch(pkg.UnaryKind.VNNI2, BF16, N, N, N, N, 0)
         Wv, Bs = [], []
         for _ in range(3):
@@ -385,28 +382,53 @@ def main():
             rt.unary(BF16, hp, wf, 0, wv, 0)  # C5 prologue: weights packed to VNNI-2 by the runtime's own op
             Wv.append(wv)
             Bs.append((torch.randn(N, generator=g) * 0.1).to(torch.bfloat16).cuda())
-        acts = [torch.empty(sh.rows, N, dtype=torch.bfloat16, device="cuda") for _ in range(3)]
-        full = torch.empty(spec.batch, N, dtype=torch.bfloat16, device="cuda")
-        sync()
 
-        def mlp_step():
-            out = sh.forward(X, Wv, Bs, acts)
-            if use_dist:
-                pkg.all_gather_rows(out, full, spec, world)
+        def run_mlp(batch, steps, warmup):
+            """row-sharded MLP on `batch` rows: (spec, sharded object, step seconds with the gather, without it)"""
+            spec_ = pkg.MlpSpec(batch=batch)
+            sh_ = pkg.ShardedMlp(spec_, rank, world, rt)
+            X_ = (torch.randn(max(sh_.rows, 1), N, generator=g) * 0.5).to(torch.bfloat16).cuda()
+            acts_ = [torch.empty(max(sh_.rows, 1), N, dtype=torch.bfloat16, device="cuda") for _ in range(3)]
+            full_ = torch.empty(batch, N, dtype=torch.bfloat16, device="cuda")
+            sync()
 
-        spin_up(mlp_step, sync)
-        warm(mlp_step, W, sync)
-        mwall, mdev = timed(mlp_step, K, sync, barrier)
-        tm = torch.tensor([mwall], dtype=torch.float64, device="cuda")
-        if use_dist:
-            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-        mwall = float(tm[0])
+            def compute_only():
+                sh_.forward(X_, Wv, Bs, acts_)
+
+            def with_gather():
+                out = sh_.forward(X_, Wv, Bs, acts_)
+                if use_dist:
+                    pkg.all_gather_rows(out, full_, spec_, world)
+
+            res = []
+            for fn in (compute_only, with_gather):
+                spin_up(fn, sync, 0.03)
+                warm(fn, warmup, sync)
+                w_, _ = timed(fn, steps, sync, barrier)
+                tw = torch.tensor([w_], dtype=torch.float64, device="cuda")
+                if use_dist:
+                    dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+                res.append(float(tw[0]) / steps)
+            return spec_, sh_, res[1], res[0]
+
+        spec, sh, mstep, mcompute = run_mlp(4096, K, W)
         mlp = {"workload": "3-layer MLP 1024x3 bf16 bs=4096 bias+relu, rows sharded over %d GPU(s)%s" % (
                    world, " + RCCL all-gather of the output" if use_dist else ""),
-               "value": round(spec.flops() * K / mwall / 1e9, 1), "unit": "GFLOP/s", "scaling": "strong",
-               "ms_per_step": round(mwall / K * 1e3, 5), "flops_per_step": spec.flops(),
-               "frac_of_bf16_mfma_peak": round(spec.flops() * K / mwall / 1e12 / (PEAK_BF16_MFMA_TFLOPS * world), 4),
-               "kernel": rt.kernel_name(sh.handles[0][0]) if sh.rows else ""}
+               "value": round(spec.flops() / mstep / 1e9, 1), "unit": "GFLOP/s", "scaling": "strong",
+               "ms_per_step": round(mstep * 1e3, 5), "ms_per_step_compute_only": round(mcompute * 1e3, 5),
+               "flops_per_step": spec.flops(),
+               "frac_of_bf16_mfma_peak": round(spec.flops() / mstep / 1e12 / (PEAK_BF16_MFMA_TFLOPS * world), 4),
+               "kernel": rt.kernel_name(sh.handles[0][0]) if sh.rows else "",
+               "note": "25.8 GFLOP per step: at N > 1 a rank's layer is a few microseconds of kernel behind ~4.5 us of host launch "
+                       "each, plus one collective call - launch-latency-bound, see DESIGN.md section 5"}
+        if use_dist:
+            # the same MLP at a batch where compute dominates (8 x 4096 rows): what the sharding itself scales like
+            spec_l, sh_l, lstep, lcompute = run_mlp(32768, max(20, K // 10), max(5, W // 10))
+            mlp["large_batch_variant"] = {
+                "workload": "same MLP, bs=32768, rows sharded over %d GPU(s) + RCCL all-gather of the output (64 MiB)" % world,
+                "value": round(spec_l.flops() / lstep / 1e9, 1), "unit": "GFLOP/s", "scaling": "strong",
+                "ms_per_step": round(lstep * 1e3, 5), "ms_per_step_compute_only": round(lcompute * 1e3, 5),
+                "kernel": rt.kernel_name(sh_l.handles[0][0]) if sh_l.rows else ""}
 
         # the other sharding of SURVEY.md 8(e): column blocks + an all-gather after EVERY layer; the
         # gathered [W][batch][N/W] activations feed the next layer as a batch-reduce over the rank blocks
