@@ -31,7 +31,8 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 #define TPP_ABLATE 0
 #endif
 constexpr int HABL_NO_GLOAD = 1, HABL_NO_SWRITE = 2, HABL_NO_BARRIER = 4, HABL_NO_FRAG = 8, HABL_NO_TRANSPOSE = 16, HABL_STAMP = 32,
-              HABL_NO_BFRAG = 64 /* dma128: no B fragment reads */, HABL_NO_BDMA = 128 /* dma128: the B loader wave fetches nothing */;
+              HABL_NO_BFRAG = 64 /* dma128: no B fragment reads */, HABL_NO_BDMA = 128 /* dma128: the B loader wave fetches nothing */,
+              HABL_NO_ADMA = 256 /* dma128: the A loader wave fetches nothing */, HABL_LOADERS_ONLY = 512 /* dma128: the MFMA waves leave at once */;
 
 constexpr int BKH = 64;     // k per chunk
 constexpr int NSTAGE_H = 3;
@@ -473,10 +474,12 @@ __global__ __launch_bounds__(256 + 64 * NLW) void brgemm_bf16_dma128(GemmArgs p)
     auto issue = [&](int slot) __attribute__((always_inline)) {
       unsigned char *base = smem_d + slot * SLOT + (isA ? 0 : A_SLOT) + v0 * 1024;
       if (isA) {
-        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)gA, 0, 0x7fffffff, 0x00020000);
+        if (!(TPP_ABLATE & HABL_NO_ADMA)) {
+          const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)gA, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-        for (int v = 0; v < PPL; ++v)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_t *)(base + v * 1024), 16, (v & 1) ? voA1 : voA0, (v0 + v) * stepA, 0, 0);
+          for (int v = 0; v < PPL; ++v)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_t *)(base + v * 1024), 16, (v & 1) ? voA1 : voA0, (v0 + v) * stepA, 0, 0);
+        }
       } else if (!(TPP_ABLATE & HABL_NO_BDMA)) {
         const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)gB, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
@@ -502,12 +505,13 @@ __global__ __launch_bounds__(256 + 64 * NLW) void brgemm_bf16_dma128(GemmArgs p)
       if (t + 3 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPL) : "memory");
       else if (t + 2 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPL) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier(); // = the MFMA waves' mid-chunk barrier of chunk t: chunk t+1 published, slot of chunk t-1 retired
+      if (!(TPP_ABLATE & HABL_NO_BARRIER)) __builtin_amdgcn_s_barrier(); // = the MFMA waves' mid-chunk barrier of chunk t: chunk t+1 published, slot of chunk t-1 retired
       if (t + 4 < T) issue((t + 4) % NSLOT);
     }
     return; // ended waves do not take part in later barriers
   }
 
+  if (TPP_ABLATE & HABL_LOADERS_ONLY) return; // timing only: how fast can the loader waves alone fill the ring?
   f32x16 acc[TM][TN];
   constexpr int NFB = 4; // fragment buffers: step q+2 is read while step q multiplies
   bf16x8_t af[NFB][TM];
@@ -588,7 +592,7 @@ __global__ __launch_bounds__(256 + 64 * NLW) void brgemm_bf16_dma128(GemmArgs p)
           if (H2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_CHUNK) : "memory");
           else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        __builtin_amdgcn_s_barrier();
+        if (!(TPP_ABLATE & HABL_NO_BARRIER)) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         if (!LW && !STEADY && H3 && !(TPP_ABLATE & HABL_NO_GLOAD)) { // the last chunks: one burst
           dma_chunk((S + 3) % NSLOT);
