@@ -1,0 +1,153 @@
+// driver.cpp - TEST INFRASTRUCTURE (tests/test_tsan_scheduler.py): drives the C-ABI the way the reference's
+// compiled code does - several OpenMP-style worker threads invoking tile kernels, a barrier between layers
+// (scf.parallel + omp.wsloop, pass-convert-mlp-to-parallel-tile.mlir:80-88) - against runtime.cpp built with
+// ThreadSanitizer on top of tests/tsan/fake_hip.cpp. Exit code 0 = results identical to a serial run; TSAN
+// reports (and fails the process) on any race in the ring / scheduler / mirror code.
+#include "../../include/tpp_xsmm_abi.h"
+#include <dirent.h>
+#include <pthread.h>
+#include <unistd.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+extern "C" int hipMalloc(void **, size_t); // the fake device allocator of fake_hip.cpp (hipError_t is an int-sized enum)
+extern "C" int hipFree(void *);
+
+static const int NT = 8, M = 128, N = 128, K = 128, TS = 32, KB = 32, LAYERS = 3;
+
+static int thread_count() {
+  int n = 0;
+  if (DIR *d = opendir("/proc/self/task")) {
+    while (dirent *e = readdir(d)) n += e->d_name[0] != '.';
+    closedir(d);
+  }
+  return n;
+}
+
+static float *dev_alloc(size_t n) {
+  void *p = nullptr;
+  if (hipMalloc(&p, n * sizeof(float)) != 0) abort();
+  return (float *)p;
+}
+
+static void fill(float *p, size_t n, unsigned seed, int zero_every) {
+  for (size_t i = 0; i < n; ++i) {
+    seed = seed * 1664525u + 1013904223u;
+    p[i] = (int)((seed >> 24) % (unsigned)zero_every) ? 0.0f : (float)((int)((seed >> 16) & 3) - 1);
+  }
+}
+
+// serial reference with the fake kernels' summation order: zero, += batches in order, relu
+static void serial_layer(const float *X, const float *W, float *Y) {
+  for (int i = 0; i < M; ++i)
+    for (int j = 0; j < N; ++j) {
+      float acc = 0.0f;
+      for (int kk = 0; kk < K; ++kk) acc += X[i * K + kk] * W[kk * N + j];
+      Y[i * N + j] = acc > 0.0f ? acc : 0.0f;
+    }
+}
+
+// one layer's tiles, striped over the threads; every thread dispatches its own handles (dispatch cache under fire)
+static void layer_tiles(int tid, float *X, float *W, float *Y) {
+  const int64_t hz = xsmm_unary_dispatch(XSMM_UNARY_ZERO, XSMM_DTYPE_F32, TS, TS, N, N, 0);
+  const int64_t hg = xsmm_brgemm_dispatch(XSMM_DTYPE_F32, TS, TS, KB, K, N, N, KB, (int64_t)KB * N, 0);
+  const int64_t hr = xsmm_unary_dispatch(XSMM_UNARY_RELU, XSMM_DTYPE_F32, TS, TS, N, N, 0);
+  const int tiles_n = N / TS, tiles = (M / TS) * tiles_n;
+  for (int t = tid; t < tiles; t += NT) {
+    const int i = t / tiles_n, j = t % tiles_n;
+    const int64_t oc = (int64_t)i * TS * N + j * TS;
+    xsmm_unary_invoke(XSMM_DTYPE_F32, hz, Y, oc, Y, oc);
+    xsmm_brgemm_invoke(XSMM_DTYPE_F32, hg, X, (int64_t)i * TS * K, W, j * TS, Y, oc, K / KB);
+    xsmm_unary_invoke(XSMM_DTYPE_F32, hr, Y, oc, Y, oc);
+  }
+}
+
+static int run_mlp(bool device_operands, int reps, const char *what) {
+  std::vector<float *> act(LAYERS + 1), w(LAYERS), ref(LAYERS + 1);
+  auto alloc = [&](size_t n) { return device_operands ? dev_alloc(n) : (float *)malloc(n * sizeof(float)); };
+  for (int l = 0; l <= LAYERS; ++l) {
+    act[l] = alloc((size_t)M * N);
+    ref[l] = (float *)malloc((size_t)M * N * sizeof(float));
+  }
+  for (int l = 0; l < LAYERS; ++l) {
+    w[l] = alloc((size_t)K * N);
+    fill(w[l], (size_t)K * N, 77u + l, 4);
+  }
+  fill(act[0], (size_t)M * K, 5u, 2);
+  memcpy(ref[0], act[0], (size_t)M * K * sizeof(float));
+  for (int l = 0; l < LAYERS; ++l) serial_layer(ref[l], w[l], ref[l + 1]);
+
+  int bad = 0;
+  pthread_barrier_t bar;
+  pthread_barrier_init(&bar, nullptr, NT);
+  for (int rep = 0; rep < reps; ++rep) {
+    for (int l = 1; l <= LAYERS; ++l) memset(act[l], 0xff, (size_t)M * N * sizeof(float));
+    std::vector<std::thread> th;
+    for (int tid = 0; tid < NT; ++tid)
+      th.emplace_back([&, tid] {
+        for (int l = 0; l < LAYERS; ++l) {
+          layer_tiles(tid, act[l], w[l], act[l + 1]);
+          pthread_barrier_wait(&bar); // the implicit barrier at the end of the omp.wsloop
+        }
+        if (tid == NT - 1) xsmm_hip_synchronize(); // perf_stop_timer / the end of the entry point
+      });
+    for (auto &t : th) t.join();
+    for (int l = 1; l <= LAYERS; ++l)
+      if (memcmp(act[l], ref[l], (size_t)M * N * sizeof(float))) ++bad;
+  }
+  pthread_barrier_destroy(&bar);
+  printf("%-46s reps %d: %s\n", what, reps, bad ? "MISMATCH" : "identical to the serial run");
+  for (int l = 0; l <= LAYERS; ++l) {
+    device_operands ? (void)hipFree(act[l]) : free(act[l]);
+    free(ref[l]);
+  }
+  for (int l = 0; l < LAYERS; ++l) device_operands ? (void)hipFree(w[l]) : free(w[l]);
+  return bad;
+}
+
+int main() {
+  int bad = 0;
+  // 1. synchronous mode, device operands: every invoke launches on the caller's thread
+  xsmm_hip_set_async(0);
+  xsmm_hip_set_tile_queue(0);
+  bad += run_mlp(true, 2, "sync, device operands, 8 callers");
+  // 2. host operands: each invoke mirrors its operands and copies ITS tile back (neighbours belong to other threads)
+  bad += run_mlp(false, 2, "sync, host operands (mirror), 8 callers");
+  // 3. the tile queue: inline bookkeeping for the first caller, then the ring + scheduler thread
+  xsmm_hip_set_async(1);
+  xsmm_hip_set_tile_queue(1);
+  const int threads_before = thread_count();
+  bad += run_mlp(true, 6, "tile queue, device operands, 8 callers");
+  const int threads_busy = thread_count();
+  bad += run_mlp(false, 2, "tile queue on, host operands, 8 callers");
+  // 4. the scheduler thread leaves after ~2-5 s without traffic, and the next push starts a new one
+  int waited = 0;
+  while (thread_count() >= threads_busy && threads_busy > threads_before && waited < 300) {
+    usleep(100000);
+    ++waited;
+  }
+  const int threads_idle = thread_count();
+  printf("threads: %d before the queue, %d with the scheduler, %d after %.1f s idle\n", threads_before, threads_busy,
+         threads_idle, waited * 0.1);
+  if (threads_busy != threads_before + 1 || threads_idle != threads_before) {
+    printf("scheduler thread life cycle: UNEXPECTED\n");
+    ++bad;
+  }
+  bad += run_mlp(true, 3, "tile queue after the worker restarted");
+  if (thread_count() != threads_before + 1) {
+    printf("scheduler thread did not come back\n");
+    ++bad;
+  }
+  // 5. mode switches between bursts
+  xsmm_hip_set_async(0);
+  bad += run_mlp(true, 1, "back to sync");
+  xsmm_hip_set_async(1);
+  bad += run_mlp(true, 2, "async again");
+  xsmm_hip_set_tile_queue(0);
+  bad += run_mlp(true, 1, "async, queue off");
+  printf("%s\n", bad ? "FAILED" : "OK");
+  return bad ? 1 : 0;
+}
