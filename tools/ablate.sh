@@ -9,7 +9,7 @@ rm -f $B/libabl_*.so
 for spec in $1; do
   m=${spec%%:*}; n=${spec##*:}
   ( hipcc $FLAGS -DTPP_ABLATE=$m -DTPP_NACC=$n -c $C/brgemm_f32.hip -o $B/abl_f32_${m}_$n.o &&
-    hipcc --offload-arch=gfx950 -shared -fPIC -o $B/libabl_${m}_n$n.so $B/abl_f32_${m}_$n.o $B/runtime.o $B/brgemm_bf16.o $B/brgemm_bf16_dma256.o $B/brgemm_bf16_small.o $B/eltwise.o -pthread ) &
+    hipcc --offload-arch=gfx950 -shared -fPIC -o $B/libabl_${m}_n$n.so $B/abl_f32_${m}_$n.o $B/runtime.o $B/brgemm_bf16.o $B/brgemm_f32_lw.o $B/brgemm_bf16_dma256.o $B/brgemm_bf16_small.o $B/eltwise.o -pthread ) &
 done
 wait
 ls $B/libabl_*.so

@@ -39,7 +39,7 @@ namespace tpp {
 #ifndef TPP_NACC
 #define TPP_NACC 1 // accumulator chains per wave: 1 measured +0.9 % on C2 over 2 (and it is the oracle's summation order: one chain)
 #endif
-constexpr int ABL_NO_GLOAD = 1, ABL_NO_SWRITE = 2, ABL_NO_BARRIER = 4, ABL_NO_FRAG = 8, ABL_STAMP = 32;
+constexpr int ABL_NO_GLOAD = 1, ABL_NO_SWRITE = 2, ABL_NO_BARRIER = 4, ABL_NO_FRAG = 8;
 
 constexpr int BK = 64;     // k columns per chunk
 constexpr int NSTAGE = 3;  // LDS ring slots
@@ -84,10 +84,6 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void brgemm_f32_fast(GemmArgs p,
   float *As = smem;
   float *Bs = smem + NSTAGE * A_STAGE;
 
-  unsigned long long stamp[5] = {0, 0, 0, 0, 0};
-  unsigned long long step_stamp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long pro_stamp[4] = {0, 0, 0, 0};
-  if (TPP_ABLATE & ABL_STAMP) { stamp[0] = __builtin_readcyclecounter(); stamp[4] = wall_clock64(); }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wk = wave / (WM * WN), wmn = wave % (WM * WN), wm = wmn / WN, wn = wmn % WN;
@@ -202,7 +198,6 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void brgemm_f32_fast(GemmArgs p,
 #pragma unroll
     for (int q = 0; q < KB_PER_WAVE; ++q) {
       const int cur = q & 1, nxt = cur ^ 1;
-      if ((TPP_ABLATE & ABL_STAMP) && STAGE == 0 && HAS_LOAD) step_stamp[q] = __builtin_readcyclecounter();
       if (!(TPP_ABLATE & ABL_NO_FRAG)) {
         if (q + 1 < KB_PER_WAVE) frag_load(nxt, STAGE, kbw + q + 1);
         else if (HAS_NEXT) frag_load(nxt, NSTG, kbw);
@@ -252,7 +247,6 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void brgemm_f32_fast(GemmArgs p,
         __syncthreads();
       }
     }
-    if ((TPP_ABLATE & ABL_STAMP) && STAGE == 0 && HAS_LOAD) step_stamp[8] = __builtin_readcyclecounter();
   };
   using yes = std::integral_constant<bool, true>;
   using no = std::integral_constant<bool, false>;
@@ -263,7 +257,6 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void brgemm_f32_fast(GemmArgs p,
 
   // prologue: chunk 0 -> set 0 -> slot 0; chunks 1, 2, 3 -> sets 1, 2, 0 (in flight)
   if (T > 0) { // first thing the kernel does: get chunk 0 moving
-    if (TPP_ABLATE & ABL_STAMP) pro_stamp[0] = __builtin_readcyclecounter();
 #pragma unroll
     for (int u = 0; u < NP; ++u) {
       if (DMA) dma_piece(0, u);
@@ -302,10 +295,8 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void brgemm_f32_fast(GemmArgs p,
 #pragma unroll
     for (int c = 1; c <= NSET; ++c) {
       if (c == NSET) { // set 0 is reused for chunk NSET: chunk 0 must be in LDS first
-        if (TPP_ABLATE & ABL_STAMP) pro_stamp[1] = __builtin_readcyclecounter();
 #pragma unroll
         for (int u = 0; u < NP; ++u) swrite_piece(0, u);
-        if (TPP_ABLATE & ABL_STAMP) pro_stamp[2] = __builtin_readcyclecounter();
       }
       if (c < T) {
         gadvance();
@@ -316,9 +307,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void brgemm_f32_fast(GemmArgs p,
   }
   if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (TPP_ABLATE & ABL_STAMP) pro_stamp[3] = __builtin_readcyclecounter();
   if (T > 0) frag_load(0, 0, kbw);
-  if (TPP_ABLATE & ABL_STAMP) stamp[1] = __builtin_readcyclecounter();
   int t = 0;
   constexpr int AHEAD = DMA ? 2 : NSET + 1; // chunk t + AHEAD is the one fetched during chunk t
   for (; t + 2 + AHEAD < T; t += 3) { // steady state: three chunks per trip, ring slots 0, 1, 2
@@ -340,7 +329,6 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void brgemm_f32_fast(GemmArgs p,
     if (t < T) tail(S2{});
   }
 
-  if (TPP_ABLATE & ABL_STAMP) stamp[2] = __builtin_readcyclecounter();
   if (TPP_ABLATE & (ABL_NO_SWRITE | ABL_NO_FRAG)) { // keep ablated producers alive
 #pragma unroll
     for (int u = 0; u < LA + LB; ++u) asm volatile("" ::"v"(rs[0][u]), "v"(rs[DMA ? 0 : 1][u]), "v"(rs[DMA ? 0 : 2][u]));
@@ -377,19 +365,6 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void brgemm_f32_fast(GemmArgs p,
     if (p.ep & EP_RELU) v = v > 0.0f ? v : 0.0f;
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrcC, voffC,
                                           (unsigned)((r & 3) + 8 * (r >> 2)) * ldcb, 0);
-  }
-  if ((TPP_ABLATE & ABL_STAMP) && p.D && !(p.ep & EP_BIAS) && tid == 0) {
-    stamp[3] = __builtin_readcyclecounter();
-    const size_t lin = blockIdx.x + gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z);
-    const size_t nblk = (size_t)gridDim.x * gridDim.y * gridDim.z;
-    unsigned long long *dbg = (unsigned long long *)p.D + lin * 8;
-    for (int e = 0; e < 5; ++e) dbg[e] = stamp[e];
-    dbg[5] = wall_clock64();
-    unsigned long long *dbg2 = (unsigned long long *)p.D + nblk * 8 + lin * 16;
-    for (int e = 0; e < 9; ++e) dbg2[e] = step_stamp[e];
-    for (int e = 0; e < 4; ++e) dbg2[9 + e] = pro_stamp[e];
-    dbg[6] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); // HW_REG_XCC_ID
-    dbg[7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_REG_HW_ID
   }
 }
 
