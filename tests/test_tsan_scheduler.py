@@ -4,7 +4,8 @@ g++ -fsanitize=thread against tests/tsan/fake_hip.cpp (the HIP host API and the 
 executed on the launching thread) and driven by tests/tsan/driver.cpp the way the reference's compiled code calls
 it: 8 OpenMP-style workers invoking zero / brgemm / relu tiles of a 3-layer MLP with a barrier per layer
 (pass-convert-mlp-to-parallel-tile.mlir:80-88), in sync / async / queued modes, with device and host operands
-(adjacent tiles of one host matrix on different threads), across an idle period that retires the scheduler thread.
+(adjacent tiles of one host matrix on different threads), a chain of non-commuting in-place ops handed from thread to
+thread through an atomic only, across an idle period that retires the scheduler thread.
 Pass = results identical to a serial run AND no ThreadSanitizer report."""
 import os
 import shutil
@@ -29,12 +30,16 @@ def test_runtime_layer_is_race_free_under_tsan(tmp_path):
     if b.returncode != 0 and "tsan" in b.stderr.lower():
         pytest.skip("this g++ has no ThreadSanitizer runtime")
     assert b.returncode == 0, b.stderr[-3000:]
-    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 exitcode=66")
-    for k in ("TPP_HIP_ASYNC", "TPP_HIP_TILE_QUEUE", "TPP_HIP_TRACE", "TPP_HIP_VARIANT"):
-        env.pop(k, None)
-    r = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=500)
-    out = r.stdout + r.stderr
-    assert "ThreadSanitizer" not in out, out[-6000:]
-    assert r.returncode == 0 and out.strip().endswith("OK"), out[-3000:]
-    assert "identical to the serial run" in out and "MISMATCH" not in out
-    assert "after" in out and "UNEXPECTED" not in out  # the scheduler thread left when idle and came back
+    # the scheduler's two portability switches: time stamps from the TSC or from a shared counter; the parking handshake
+    # with membarrier() on the scheduler's side or with sequentially consistent stores on the producers' side
+    for extra in ({}, {"TPP_HIP_NO_TSC": "1", "TPP_HIP_NO_MEMBARRIER": "1"}):
+        env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 exitcode=66", **extra)
+        for k in ("TPP_HIP_ASYNC", "TPP_HIP_TILE_QUEUE", "TPP_HIP_TRACE", "TPP_HIP_VARIANT"):
+            env.pop(k, None)
+        r = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=500)
+        out = r.stdout + r.stderr
+        assert "ThreadSanitizer" not in out, out[-6000:]
+        assert r.returncode == 0 and out.strip().endswith("OK"), out[-3000:]
+        assert "identical to the serial run" in out and "MISMATCH" not in out
+        assert "dependent chain" in out
+        assert "after" in out and "UNEXPECTED" not in out  # the scheduler thread left when idle and came back

@@ -6,6 +6,7 @@
 #include "../../include/tpp_xsmm_abi.h"
 #include <dirent.h>
 #include <pthread.h>
+#include <atomic>
 #include <unistd.h>
 #include <cstdio>
 #include <cstdlib>
@@ -108,8 +109,53 @@ static int run_mlp(bool device_operands, int reps, const char *what) {
   return bad;
 }
 
-int main() {
+// A chain of dependent in-place ops on ONE tile, each step issued by a different thread, handed over through an atomic
+// (release / acquire) only: x = 0; then alternately x = 2 x and x = x + 1, i.e. after 2 n steps x = 2^n - 1 ... only if the
+// scheduler takes the steps in the order the hand-overs define (the ops do not commute).
+static int run_chain(int rounds, const char *what) {
+  const int T = 16, STEPS = 40; // 20 doublings: values stay exact in f32
+  float *x = dev_alloc(T * T), *two = dev_alloc(T * T), *one = dev_alloc(T * T);
+  for (int i = 0; i < T * T; ++i) two[i] = 2.0f, one[i] = 1.0f;
+  const int64_t hz = xsmm_unary_dispatch(XSMM_UNARY_ZERO, XSMM_DTYPE_F32, T, T, T, T, 0);
+  const int64_t hm = xsmm_binary_dispatch(XSMM_BINARY_MUL, XSMM_DTYPE_F32, T, T, T, T, T, 0);
+  const int64_t ha = xsmm_binary_dispatch(XSMM_BINARY_ADD, XSMM_DTYPE_F32, T, T, T, T, T, 0);
+  std::atomic<int> turn{0};
+  std::atomic<int> bad{0};
+  std::vector<std::thread> th;
+  for (int tid = 0; tid < NT; ++tid)
+    th.emplace_back([&, tid] {
+      for (int r = 0; r < rounds; ++r)
+        for (int st = 0; st <= STEPS + 1; ++st) {
+          const int my = r * (STEPS + 2) + st;
+          if (my % NT != tid) continue;
+          while (turn.load(std::memory_order_acquire) != my) {
+          }
+          if (st == 0) xsmm_unary_invoke(XSMM_DTYPE_F32, hz, x, 0, x, 0);
+          else if (st == STEPS + 1) {
+            xsmm_hip_synchronize();
+            float want = 0.0f;
+            for (int k = 1; k <= STEPS; ++k) want = (k & 1) ? want * 2.0f : want + 1.0f;
+            for (int i = 0; i < T * T; ++i)
+              if (x[i] != want) {
+                bad.fetch_add(1);
+                break;
+              }
+          } else if (st & 1) xsmm_binary_invoke(XSMM_DTYPE_F32, hm, x, 0, two, 0, x, 0);
+          else xsmm_binary_invoke(XSMM_DTYPE_F32, ha, x, 0, one, 0, x, 0);
+          turn.store(my + 1, std::memory_order_release);
+        }
+    });
+  for (auto &t : th) t.join();
+  printf("%-46s rounds %d: %s\n", what, rounds, bad.load() ? "MISMATCH" : "identical to the serial run");
+  hipFree(x);
+  hipFree(two);
+  hipFree(one);
+  return bad.load();
+}
+
+int main(int argc, char **argv) {
   int bad = 0;
+  const int chain_rounds = argc > 1 ? atoi(argv[1]) : 200;
   // 1. synchronous mode, device operands: every invoke launches on the caller's thread
   xsmm_hip_set_async(0);
   xsmm_hip_set_tile_queue(0);
@@ -123,6 +169,7 @@ int main() {
   bad += run_mlp(true, 6, "tile queue, device operands, 8 callers");
   const int threads_busy = thread_count();
   bad += run_mlp(false, 2, "tile queue on, host operands, 8 callers");
+  bad += run_chain(chain_rounds, "tile queue, 41-step dependent chain over 8 threads");
   // 4. the scheduler thread leaves after ~2-5 s without traffic, and the next push starts a new one
   int waited = 0;
   while (thread_count() >= threads_busy && threads_busy > threads_before && waited < 300) {

@@ -73,6 +73,10 @@ hipError_t hipMemGetAddressRange(hipDeviceptr_t *base, size_t *size, hipDevicept
   *size = s;
   return hipSuccess;
 }
+hipError_t hipMemcpy(void *dst, const void *src, size_t bytes, hipMemcpyKind) {
+  memcpy(dst, src, bytes);
+  return hipSuccess;
+}
 hipError_t hipMemcpyAsync(void *dst, const void *src, size_t bytes, hipMemcpyKind, hipStream_t) {
   memcpy(dst, src, bytes);
   return hipSuccess;
@@ -90,6 +94,10 @@ hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 
 namespace tpp {
 
+// FAKE_HIP_NO_COMPUTE=1: launches return at once (host-side throughput runs of the enqueue path, e.g. tools/tpp_replay
+// built against this file; results are then meaningless)
+static const bool g_compute = getenv("FAKE_HIP_NO_COMPUTE") == nullptr;
+
 bool plan_gemm(GemmDesc &d, int) {
   d.variant = 0;
   strcpy(d.name, "fake_host_gemm");
@@ -99,6 +107,7 @@ bool plan_gemm(GemmDesc &d, int) {
 hipError_t launch_gemm(const GemmDesc &d, const void *A_, const void *B_, void *C_, const void *D_, int64_t br, hipStream_t) {
   const float *A = (const float *)A_, *B = (const float *)B_, *D = (const float *)D_;
   float *C = (float *)C_;
+  if (!g_compute) return hipSuccess;
   for (int64_t i = 0; i < d.m; ++i)
     for (int64_t j = 0; j < d.n; ++j) {
       float acc = d.beta0 ? 0.0f : C[i * d.ldc + j];
@@ -117,6 +126,7 @@ hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *it, int n, boo
 hipError_t launch_unary(const UnaryDesc &d, const void *in_, float scalar, bool use_scalar, void *out_, hipStream_t) {
   const float *in = (const float *)in_;
   float *out = (float *)out_;
+  if (!g_compute) return hipSuccess;
   for (int64_t i = 0; i < d.m; ++i)
     for (int64_t j = 0; j < d.n; ++j) {
       float v = d.op == 2 ? 0.0f : (use_scalar ? scalar : in[i * d.ldi + j]);
@@ -132,6 +142,7 @@ hipError_t launch_unary_grouped(const UnaryDesc &d, const WorkItem *it, int n, h
 hipError_t launch_binary(const BinaryDesc &d, const void *l_, const void *r_, void *out_, hipStream_t) {
   const float *l = (const float *)l_, *r = (const float *)r_;
   float *out = (float *)out_;
+  if (!g_compute) return hipSuccess;
   for (int64_t i = 0; i < d.m; ++i)
     for (int64_t j = 0; j < d.n; ++j) {
       const float a = l[i * d.ldi_lhs + j], b = r[i * d.ldi_rhs + j];

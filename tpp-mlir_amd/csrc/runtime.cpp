@@ -14,7 +14,10 @@
 #include "xsmm_desc.h"
 
 #include <dlfcn.h>
+#include <linux/membarrier.h>
 #include <sched.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -438,6 +441,102 @@ int64_t gemm_dispatch_common(const char *who, int has_batch, int fused, int64_t 
 cpu_set_t g_process_mask;
 const bool g_have_process_mask = sched_getaffinity(0, sizeof(g_process_mask), &g_process_mask) == 0;
 
+// ---- operands of one invoke, from its descriptor and the element-offset-applied pointers ----------------
+// (shared by the invoke entry points and by the scheduler thread, which receives only descriptor + pointers)
+struct QueuedOps {
+  Operand op[4];
+  int n_in;      // op[0 .. n_in) are read
+  int out;       // index of the written operand
+  bool vec_ok, out_ok;
+  QueuedOps() {} // members are filled by queued_operands (no zero-fill on the enqueue path)
+};
+__attribute__((always_inline)) inline void set_operand(Operand &o, void *ptr, size_t bytes, bool written) {
+  o.ptr = ptr;
+  o.bytes = bytes;
+  o.written = written;
+  o.dev = nullptr;
+  o.rows = o.row_bytes = o.pitch = 0;
+  o.read = true;
+  o.host = false;
+}
+__attribute__((always_inline)) inline void gemm_operands(const GemmDesc *d, void *a, void *b, void *c, void *dp, int64_t br, Operand &A, Operand &B,
+                          Operand &C, Operand &D) {
+  const size_t es = esize(d->dtype);
+  set_operand(A, a, 0, false);
+  set_operand(B, b, 0, false);
+  set_operand(C, c, (d->vnni_c ? span(d->m / 2, 2 * d->ldc, 2 * d->n) : span(d->m, d->ldc, d->n)) * es, true);
+  set_operand(D, dp, d->bias ? (size_t)d->n * es : 0, false);
+  if (d->vnni_c) C.shape(d->m / 2, (size_t)2 * d->n * es, (size_t)2 * d->ldc * es);
+  else C.shape(d->m, (size_t)d->n * es, (size_t)d->ldc * es);
+  if (br > 0 && d->k > 0) {
+    A.bytes = ((size_t)(br - 1) * d->stride_a + span(d->m, d->lda, d->k)) * es;
+    const size_t bspan = d->vnni_b ? span((d->k + 1) / 2, 2 * d->ldb, 2 * d->n) : span(d->k, d->ldb, d->n);
+    B.bytes = ((size_t)(br - 1) * d->stride_b + bspan) * es;
+  }
+}
+// in == nullptr: scalar input or a ZERO op (nothing is read)
+inline void unary_operands(const UnaryDesc *d, void *in, void *out, Operand &I, Operand &O) {
+  const size_t es = esize(d->dtype);
+  set_operand(I, nullptr, 0, false);
+  set_operand(O, out, 0, true);
+  if (d->op == XSMM_UNARY_TRANSPOSE) {
+    O.bytes = span(d->n, d->ldo, d->m) * es;
+    O.shape(d->n, (size_t)d->m * es, (size_t)d->ldo * es);
+  } else if (d->op == XSMM_UNARY_VNNI2) {
+    O.bytes = span(d->m / 2, 2 * d->ldo, 2 * d->n) * es;
+    O.shape(d->m / 2, (size_t)2 * d->n * es, (size_t)2 * d->ldo * es);
+  } else {
+    O.bytes = span(d->m, d->ldo, d->n) * es;
+    O.shape(d->m, (size_t)d->n * es, (size_t)d->ldo * es);
+  }
+  if (in && d->op != XSMM_UNARY_ZERO) {
+    I.ptr = in;
+    if (d->flags & XSMM_UNARY_FLAG_BCAST_SCALAR) I.bytes = es;
+    else if (d->flags & XSMM_UNARY_FLAG_BCAST_ROW) I.bytes = span(d->m, d->ldi, 1) * es;
+    else if (d->flags & XSMM_UNARY_FLAG_BCAST_COL) I.bytes = (size_t)d->n * es;
+    else {
+      I.bytes = span(d->m, d->ldi, d->n) * es;
+      I.shape(d->m, (size_t)d->n * es, (size_t)d->ldi * es);
+    }
+  }
+}
+inline void binary_operands(const BinaryDesc *d, void *lhs, void *rhs, void *out, Operand &L, Operand &R, Operand &O) {
+  const size_t es = esize(d->dtype);
+  auto in_bytes = [&](int64_t row, int64_t col, int64_t sc, int64_t ld) -> size_t {
+    if (d->flags & sc) return es;
+    if (d->flags & row) return span(d->m, ld, 1) * es;
+    if (d->flags & col) return (size_t)d->n * es;
+    return span(d->m, ld, d->n) * es;
+  };
+  set_operand(L, lhs, in_bytes(1, 4, 16, d->ldi_lhs), false);
+  set_operand(R, rhs, in_bytes(2, 8, 32, d->ldi_rhs), false);
+  set_operand(O, out, span(d->m, d->ldo, d->n) * es, true);
+  O.shape(d->m, (size_t)d->n * es, (size_t)d->ldo * es);
+  if (!(d->flags & (1 | 4 | 16))) L.shape(d->m, (size_t)d->n * es, (size_t)d->ldi_lhs * es);
+  if (!(d->flags & (2 | 8 | 32))) R.shape(d->m, (size_t)d->n * es, (size_t)d->ldi_rhs * es);
+}
+// the operands of a queued work item (kind from the descriptor's first field), as the queue's bookkeeping wants them
+__attribute__((always_inline)) inline void queued_operands(const void *desc, const WorkItem &w, QueuedOps &q) {
+  const int kind = *(const int *)desc;
+  if (kind == KIND_GEMM) {
+    gemm_operands((const GemmDesc *)desc, (void *)w.A, (void *)w.B, w.C, (void *)w.D, w.br, q.op[0], q.op[1], q.op[3], q.op[2]);
+    q.n_in = 3; // A, B, D read; op[3] = C written (and read when the op accumulates - a superset is harmless)
+    q.out = 3;
+    q.vec_ok = (((uintptr_t)w.A | (uintptr_t)w.B) & 15) == 0;
+    q.out_ok = (((uintptr_t)w.C) & 15) == 0 && (((uintptr_t)w.D) & 7) == 0;
+  } else if (kind == KIND_UNARY) {
+    unary_operands((const UnaryDesc *)desc, (void *)w.A, w.C, q.op[0], q.op[1]);
+    q.n_in = 1;
+    q.out = 1;
+    q.vec_ok = q.out_ok = true;
+  } else {
+    binary_operands((const BinaryDesc *)desc, (void *)w.A, (void *)w.B, w.C, q.op[0], q.op[1], q.op[2]);
+    q.n_in = 2;
+    q.out = 2;
+    q.vec_ok = q.out_ok = true;
+  }
+}
+
 // ---- tile queue -------------------------------------------------------------------
 // The compiler's native granularity is hundreds of invokes per layer on 32x32 tiles from
 // OpenMP workers; one launch per invoke would be pure launch latency on a GPU. In async
@@ -610,17 +709,14 @@ struct TileQueue {
   }
 };
 
-// What a caller hands over: one invoke with its footprints (resolved on the caller's thread) - or a fence.
+// What a caller hands over to the scheduler: descriptor + pointers of one invoke - or a fence (desc == nullptr,
+// w.C = the flag to raise). 56 bytes: with the slot's sequence word ONE cache line crosses from the caller's core
+// to the scheduler's per invoke (a 300-byte entry with the footprints resolved on the caller's side cost five, and
+// made two callers 3x slower than one); the scheduler derives the footprints itself (queued_operands).
 struct QEntry {
-  int kind = 0; // KIND_GEMM / KIND_UNARY / KIND_BINARY; 0 = fence
   const void *desc = nullptr;
   WorkItem w{};
-  Operand out{}, in[3]{};
-  uintptr_t anchor_out = 0, anchor_in[3] = {0, 0, 0};
-  int n_in = 0;
-  bool vec_ok = true, out_ok = true;
   hipStream_t stream = nullptr;
-  std::atomic<int> *fence = nullptr;
 };
 
 // appends one invoke to the group being collected, launching the group first if the invoke conflicts with it
@@ -643,44 +739,136 @@ inline void process_ops(TileQueue &q, int kind, const void *desc, const WorkItem
   for (int i = 0; i < n_in; ++i) q.reads.insert(*in[i], anchor_in[i]);
   q.writes.insert(out, anchor_out);
 }
-inline void process_entry(TileQueue &q, const QEntry &e) {
-  const Operand *in[3] = {&e.in[0], &e.in[1], &e.in[2]};
-  process_ops(q, e.kind, e.desc, e.w, e.out, e.anchor_out, in, e.anchor_in, e.n_in, e.vec_ok, e.out_ok, e.stream);
+// bookkeeping of one queued invoke: footprints from the descriptor, allocation bases ("anchors" of the 2-D planes) from
+// `devmem` - the allocation cache of the thread that runs this (every operand was seen to be device memory by the caller)
+__attribute__((always_inline)) inline void process_item(TileQueue &q, DeviceRanges &devmem, const void *desc, const WorkItem &w, hipStream_t stream) {
+  QueuedOps o;
+  queued_operands(desc, w, o);
+  const Operand *in[3] = {&o.op[0], &o.op[1], &o.op[2]};
+  uintptr_t anchor_in[3] = {0, 0, 0};
+  auto anchor = [&](const Operand &x) -> uintptr_t {
+    if (!x.rows || !x.ptr) return 0;
+    if (uintptr_t b = devmem.base_of(x.ptr)) return b;
+    (void)devmem.is_device(x.ptr); // first sight of this allocation on this thread in this epoch
+    return devmem.base_of(x.ptr);
+  };
+  for (int i = 0; i < o.n_in; ++i) anchor_in[i] = anchor(o.op[i]);
+  const Operand &out = o.op[o.out];
+  process_ops(q, *(const int *)desc, desc, w, out, anchor(out), in, anchor_in, o.n_in, o.vec_ok, o.out_ok, stream);
 }
 
 // The scheduler. The reference calls invoke from OpenMP workers (scf.parallel over the tile grid): with one
 // lock around the dependence bookkeeping eight callers took 290 us for what one caller did in 45 (lock
-// hand-offs, and interleaved callers defeat the interval merging). Callers therefore only PUSH their invoke
-// into a bounded multi-producer ring (one fetch_add + a 300-byte store); a single scheduler thread pops in
-// ticket order - a linearisation that respects every caller's program order and every happens-before
-// between callers (an OpenMP barrier orders the tickets) - does the dependence bookkeeping without any
-// lock, and launches a group whenever the next invoke conflicts with it. Callers never touch HIP on this
-// path; launches and slot waits happen on the scheduler thread, overlapped with the callers.
+// hand-offs, and interleaved callers defeat the interval merging). Callers therefore only HAND OVER their
+// invokes; a single scheduler thread does the dependence bookkeeping without any lock and launches a group
+// whenever the next invoke conflicts with it. Callers never touch HIP on this path; launches and slot waits
+// happen on the scheduler thread, overlapped with the callers.
+//
+// Hand-over = one private single-producer ring per calling thread, merged by TIME STAMP. (Round 1 used one
+// multi-producer ring with a ticket counter: on the 256-core host of the GPU box the counter's cache line
+// hopping between the callers cost 130-230 ns per invoke - two callers took 180 us for what one did in 48.)
+//   * An entry is ONE cache line: stamp, descriptor, the four operand pointers, batch count, stream; the
+//     scheduler derives the footprints itself (queued_operands). A push writes that line and nothing shared.
+//   * The stamp is the invariant TSC (`lfence; rdtsc`) when the kernel trusts it as its clock source, else a shared
+//     counter. Either way  a happens-before b  =>  stamp(a) < stamp(b), and a is visible to whoever sees b.
+//   * The scheduler keeps the non-empty rings in a min-heap on the stamp of their oldest entry and always takes
+//     the smallest. A ring it finds empty stays WARM for a while: its next slot (a line in the scheduler's cache
+//     until the producer writes it) is polled before every pop. A ring that stays empty for some thousand polls is
+//     PARKED (flag in the ring, Dekker-style re-check); the producer's next push sees the flag and announces
+//     the ring on a small wake list - the only shared write on the producer side, once per burst.
+//   * Before every pop the warm rings and the wake list are polled until a whole pass finds nothing new. So when an
+//     entry b is taken, every entry that happened before b is already consumed, or in the heap with a smaller stamp,
+//     or behind such an entry in its own ring: the processing order respects every caller's program order and
+//     every happens-before between callers (an OpenMP barrier, a join). Entries without such a relation are
+//     concurrent invokes of the caller's program, and those do not conflict in a race-free program.
+struct alignas(64) PSlot {
+  std::atomic<uint32_t> seq; // (uint32_t)(index + 1) once the entry at `index` is complete
+  int32_t br;
+  uint64_t stamp;
+  const void *desc; // nullptr: a fence, C = the std::atomic<int> to raise once everything before it is launched
+  const void *A, *B;
+  void *C;
+  const void *D;
+  hipStream_t stream;
+};
+static_assert(sizeof(PSlot) == 64, "one cache line per queued invoke");
+
+struct PQueue {
+  static constexpr uint64_t CAP = 2048, MASK = CAP - 1;
+  PSlot *ring = nullptr;
+  // producer side
+  alignas(64) uint64_t tail = 0;
+  uint64_t head_seen = 0;              // last value read from head_pub
+  std::atomic<uint64_t> tail_pub{0};   // = tail, for drain()'s "anything pending?" test
+  // consumer side
+  alignas(64) uint64_t head = 0;       // next index to consume (owned by the live scheduler thread)
+  std::atomic<uint64_t> head_pub{0};   // published every 16 entries and when the ring is parked: the producer reads it only when the ring looks full
+  std::atomic<uint64_t> clean_head{0}; // every entry below this has been LAUNCHED
+  // rarely written by either side
+  alignas(64) std::atomic<int> parked{1}; // 1: the scheduler is not watching this ring - the next push must announce it
+  std::atomic<int> owned{0};               // a caller thread holds this ring
+};
+
 struct Scheduler {
-  static constexpr uint64_t N = 8192, MASK = N - 1;
-  struct alignas(64) Slot {
-    std::atomic<uint64_t> seq;
-    QEntry e;
-  };
-  Slot *ring = nullptr;
-  alignas(64) std::atomic<uint64_t> tail{0};       // next ticket
-  alignas(64) std::atomic<uint64_t> clean_upto{0}; // every ticket below this has been launched (or was a fence)
+  static constexpr int MAXQ = 1024;
+  std::atomic<PQueue *> queues[MAXQ];
+  std::atomic<int> nq{0}; // high-water mark of allocated rings
+  std::mutex alloc_mu;
+  PQueue overflow; // more than MAXQ simultaneous caller threads: they share this ring under a mutex
+  std::mutex overflow_mu;
+  // wake list: ring indices + 1 (0 = empty cell); a ring is on it at most once, so MAXQ + 1 cells cannot overflow
+  static constexpr uint32_t WCAP = 2048;
+  alignas(64) std::atomic<uint32_t> wake_tail{0};
+  alignas(64) std::atomic<uint32_t> wake_cell[WCAP];
+  uint32_t wake_head = 0; // scheduler thread only
+
+  const bool use_tsc;
+  // Parking a ring is a Dekker pair (producer: publish entry, read `parked`; scheduler: set `parked`, re-read the slot). The
+  // producer's side runs once per invoke and a full fence there stalls it on the slot line's ownership request (the line is in the
+  // scheduler's cache from the previous lap: ~150 ns across cores, measured as 260 ns per invoke with two callers), so the
+  // fence is moved to the side that runs once per burst: the scheduler issues membarrier(PRIVATE_EXPEDITED) - a full barrier on
+  // every thread of the process - between its two steps, and the producers use plain release stores / loads. Without that
+  // system call (old kernels, seccomp) the producers fall back to sequentially consistent stores.
+  const bool asym_fence;
+  alignas(64) std::atomic<uint64_t> stamp_ctr{1};
+
   std::atomic<bool> stop{false};
   std::thread worker;
   int device = 0;
   TileQueue q;
+  DeviceRanges devmem; // the worker's allocation cache (per epoch, like the callers' own)
+  std::vector<std::pair<uint64_t, int>> heap; // (stamp of the ring's oldest entry, ring index), min on top
+  struct Warm {
+    int qi;
+    unsigned polls;
+  };
+  std::vector<Warm> warm; // rings found empty a moment ago
+  static constexpr unsigned PARK_AFTER = 4096; // polls without an entry before a warm ring is parked
 
   // The worker exists only while there is traffic: after ~2 s without an entry it leaves (a library that was used
   // once must not keep a thread napping for the rest of the process), and the next push starts a new one. The
-  // hand-over is a Dekker pair on (running, tail): the worker clears `running` BEFORE it re-reads the tail, a
-  // producer bumps the tail BEFORE it reads `running` - at least one of them sees the other.
+  // hand-over is a Dekker pair on (running, wake list): the worker clears `running` BEFORE it re-reads the wake list
+  // (every ring is parked while the worker idles, so every push goes through that list), a producer announces its
+  // ring BEFORE it reads `running` - at least one of them sees the other.
   alignas(64) std::atomic<bool> running{false}; // read by every producer on every push: its own cache line, written twice in a worker's life
   alignas(64) std::mutex life_mu;
-  uint64_t saved_head = 0; // next ticket to process, handed from one worker to the next (the live value is a local of run())
 
-  Scheduler() {
-    ring = new Slot[N];
-    for (uint64_t i = 0; i < N; ++i) ring[i].seq.store(i, std::memory_order_relaxed);
+  static bool kernel_trusts_tsc() {
+    char buf[32] = {0};
+    if (FILE *f = fopen("/sys/devices/system/clocksource/clocksource0/current_clocksource", "r")) {
+      if (!fgets(buf, sizeof(buf), f)) buf[0] = 0;
+      fclose(f);
+    }
+    return strncmp(buf, "tsc", 3) == 0;
+  }
+  static bool register_membarrier() {
+    if (getenv("TPP_HIP_NO_MEMBARRIER")) return false;
+    return syscall(__NR_membarrier, MEMBARRIER_CMD_REGISTER_PRIVATE_EXPEDITED, 0) == 0;
+  }
+  Scheduler() : use_tsc(kernel_trusts_tsc() && !getenv("TPP_HIP_NO_TSC")), asym_fence(register_membarrier()) {
+    for (auto &c : queues) c.store(nullptr, std::memory_order_relaxed);
+    for (auto &c : wake_cell) c.store(0, std::memory_order_relaxed);
+    init_ring(overflow);
     if (hipGetDevice(&device) != hipSuccess) device = 0;
   }
   ~Scheduler() {
@@ -695,6 +883,56 @@ struct Scheduler {
     if (w.get_id() == std::this_thread::get_id()) w.detach();
     else w.join(); // outside life_mu: a worker on its way out takes that lock
   }
+  static void init_ring(PQueue &Q) {
+    Q.ring = static_cast<PSlot *>(aligned_alloc(64, sizeof(PSlot) * PQueue::CAP));
+    if (!Q.ring) die("tpp-xsmm-hip: out of memory for a caller's invoke ring");
+    for (uint64_t i = 0; i < PQueue::CAP; ++i) new (&Q.ring[i].seq) std::atomic<uint32_t>(0);
+  }
+  uint64_t stamp() {
+    if (use_tsc) {
+      unsigned lo, hi;
+      asm volatile("lfence\n\trdtsc" : "=a"(lo), "=d"(hi)::"memory"); // after every earlier load (the caller's synchronisation) has completed
+      return ((uint64_t)hi << 32) | lo;
+    }
+    return stamp_ctr.fetch_add(1, std::memory_order_seq_cst);
+  }
+  PQueue *ring_at(int i) { return i == MAXQ ? &overflow : queues[i].load(std::memory_order_acquire); }
+
+  // ---- caller side -------------------------------------------------------------------------------------------
+  // the calling thread's ring: claimed on first use, handed back when the thread ends (entries still in it stay
+  // valid; the next owner continues at its tail)
+  struct Lease {
+    Scheduler *s = nullptr;
+    int idx = -1;
+    ~Lease() {
+      if (s && idx >= 0 && idx < MAXQ) s->queues[idx].load(std::memory_order_relaxed)->owned.store(0, std::memory_order_release);
+    }
+  };
+  int claim() {
+    const int n = nq.load(std::memory_order_acquire);
+    for (int i = 0; i < n; ++i) {
+      PQueue *Q = queues[i].load(std::memory_order_acquire);
+      int expect = 0;
+      if (Q && Q->owned.load(std::memory_order_relaxed) == 0 && Q->owned.compare_exchange_strong(expect, 1, std::memory_order_acq_rel)) return i;
+    }
+    std::lock_guard<std::mutex> lk(alloc_mu);
+    const int m = nq.load(std::memory_order_relaxed);
+    if (m >= MAXQ) return MAXQ; // the shared overflow ring
+    PQueue *Q = new PQueue;
+    init_ring(*Q);
+    Q->owned.store(1, std::memory_order_relaxed);
+    queues[m].store(Q, std::memory_order_release);
+    nq.store(m + 1, std::memory_order_release);
+    return m;
+  }
+  int my_ring() {
+    thread_local Lease lease;
+    if (lease.s != this) {
+      lease.s = this;
+      lease.idx = claim();
+    }
+    return lease.idx;
+  }
   void ensure_worker() {
     if (running.load(std::memory_order_seq_cst)) return;
     std::lock_guard<std::mutex> lk(life_mu);
@@ -703,34 +941,142 @@ struct Scheduler {
     running.store(true, std::memory_order_seq_cst);
     worker = std::thread([this] { run(); });
   }
-  void push(const QEntry &e) {
-    const uint64_t pos = tail.fetch_add(1, std::memory_order_seq_cst);
-    Slot &s = ring[pos & MASK];
-    for (unsigned spins = 0; s.seq.load(std::memory_order_acquire) != pos; ++spins) { // ring full: wait for the scheduler
-      if (spins < 2000) __builtin_ia32_pause();
-      else {
-        ensure_worker();
-        sched_yield();
+  void push_to(int qi, PQueue &Q, const QEntry &e) {
+    const uint64_t h = Q.tail;
+    if (h - Q.head_seen >= PQueue::CAP) {
+      // Ring full: this caller outruns the scheduler. Wait until HALF of it is free again, not for one slot: the scheduler
+      // then streams through a backlog of finished (prefetched) lines while the producer refills in a burst, instead of
+      // the two moving in lockstep with every line crossing cores just in time.
+      for (unsigned spins = 0; h - (Q.head_seen = Q.head_pub.load(std::memory_order_acquire)) > PQueue::CAP / 2; ++spins) {
+        if (spins < 2000) __builtin_ia32_pause();
+        else {
+          ensure_worker();
+          sched_yield();
+        }
       }
     }
-    s.e = e;
-    s.seq.store(pos + 1, std::memory_order_release);
+    PSlot &s = Q.ring[h & PQueue::MASK];
+    s.br = (int32_t)e.w.br;
+    s.desc = e.desc;
+    s.A = e.w.A;
+    s.B = e.w.B;
+    s.C = e.w.C;
+    s.D = e.w.D;
+    s.stream = e.stream;
+    s.stamp = stamp();
+    s.seq.store((uint32_t)(h + 1), asym_fence ? std::memory_order_release : std::memory_order_seq_cst); // Dekker with `parked`, see asym_fence
+    Q.tail = h + 1;
+    Q.tail_pub.store(h + 1, std::memory_order_relaxed);
+    if (Q.parked.load(std::memory_order_seq_cst) && Q.parked.exchange(0, std::memory_order_seq_cst)) {
+      const uint32_t pos = wake_tail.fetch_add(1, std::memory_order_seq_cst);
+      std::atomic<uint32_t> &cell = wake_cell[pos % WCAP];
+      while (cell.load(std::memory_order_acquire) != 0) __builtin_ia32_pause(); // (a lap behind: cannot happen with <= MAXQ + 1 rings)
+      cell.store((uint32_t)qi + 1, std::memory_order_seq_cst);
+    }
     ensure_worker();
   }
-  // everything pushed before this call has been launched on return
+  void push(const QEntry &e) {
+    if (e.w.br > 0x7fffffff) die("tpp-xsmm-hip: batch count %ld is too large for the tile queue", (long)e.w.br);
+    const int qi = my_ring();
+    if (qi == MAXQ) {
+      std::lock_guard<std::mutex> lk(overflow_mu);
+      push_to(qi, overflow, e);
+    } else {
+      push_to(qi, *queues[qi].load(std::memory_order_relaxed), e);
+    }
+  }
+  // everything pushed before this call (by this thread, or by another with a happens-before to this call) has been
+  // launched on return
   void drain() {
-    const uint64_t t = tail.load(std::memory_order_acquire);
-    if (clean_upto.load(std::memory_order_acquire) >= t) return;
+    bool pending = false;
+    const int n = nq.load(std::memory_order_acquire);
+    for (int i = 0; i <= n && !pending; ++i) {
+      PQueue *Q = i == n ? &overflow : queues[i].load(std::memory_order_acquire);
+      pending = Q && Q->clean_head.load(std::memory_order_acquire) < Q->tail_pub.load(std::memory_order_acquire);
+    }
+    if (!pending) return;
     std::atomic<int> flag{0};
     QEntry f;
-    f.fence = &flag;
+    f.w.C = &flag; // desc == nullptr: a fence
     push(f);
     for (unsigned spins = 0; !flag.load(std::memory_order_acquire); ++spins) {
       if (spins < 4000) __builtin_ia32_pause();
       else sched_yield();
     }
   }
-  void process(const QEntry &e) { process_entry(q, e); }
+
+  // ---- scheduler thread -----------------------------------------------------------------------------------------
+  static bool later(const std::pair<uint64_t, int> &a, const std::pair<uint64_t, int> &b) { return a.first > b.first; }
+  bool take_if_ready(int qi, PQueue &Q) { // the ring's next slot: into the heap with it if it is complete
+    PSlot &s = Q.ring[Q.head & PQueue::MASK];
+    if (s.seq.load(std::memory_order_acquire) != (uint32_t)(Q.head + 1)) return false;
+    heap.emplace_back(s.stamp, qi);
+    std::push_heap(heap.begin(), heap.end(), later);
+    return true;
+  }
+  void examine(int qi, PQueue &Q) { // after a pop / a wake-up: heap or warm list
+    if (!take_if_ready(qi, Q)) warm.push_back(Warm{qi, 0});
+  }
+  bool park(int qi, PQueue &Q) { // true: an entry slipped in and is in the heap now
+    PSlot &s = Q.ring[Q.head & PQueue::MASK];
+    Q.head_pub.store(Q.head, std::memory_order_release);
+    Q.parked.store(1, std::memory_order_seq_cst);
+    if (asym_fence && syscall(__NR_membarrier, MEMBARRIER_CMD_PRIVATE_EXPEDITED, 0) != 0) die("tpp-xsmm-hip: membarrier failed");
+    if (s.seq.load(std::memory_order_seq_cst) == (uint32_t)(Q.head + 1) && Q.parked.exchange(0, std::memory_order_seq_cst)) {
+      // an entry arrived while the ring was being parked and its producer has not taken the flag: it is ours again
+      // (if the producer took the flag, the ring comes back through the wake list)
+      heap.emplace_back(s.stamp, qi);
+      std::push_heap(heap.begin(), heap.end(), later);
+      return true;
+    }
+    return false;
+  }
+  bool drain_wake_list() {
+    bool any = false;
+    for (;;) {
+      std::atomic<uint32_t> &cell = wake_cell[wake_head % WCAP];
+      const uint32_t v = cell.load(std::memory_order_seq_cst);
+      if (!v) return any;
+      cell.store(0, std::memory_order_release);
+      ++wake_head;
+      any = true;
+      examine((int)v - 1, *ring_at((int)v - 1));
+    }
+  }
+  // one pass over the warm rings; true if an entry turned up. count: this pass counts towards parking
+  bool poll_warm(bool count) {
+    bool any = false;
+    for (size_t i = 0; i < warm.size();) {
+      PQueue &Q = *ring_at(warm[i].qi);
+      if (take_if_ready(warm[i].qi, Q)) {
+        any = true;
+      } else if (count && ++warm[i].polls > PARK_AFTER) {
+        any = park(warm[i].qi, Q) || any;
+      } else {
+        ++i;
+        continue;
+      }
+      warm[i] = warm.back();
+      warm.pop_back();
+    }
+    return any;
+  }
+  // everything that happened before any entry now in the heap is consumed, in the heap, or behind a heap entry of its ring
+  void collect() {
+    bool any = drain_wake_list();
+    any = poll_warm(true) || any;
+    while (any) { // an entry turned up: whatever happened before IT was published earlier - look again
+      any = drain_wake_list();
+      any = poll_warm(false) || any;
+    }
+  }
+  void mark_clean() { // everything consumed so far has been launched
+    const int n = nq.load(std::memory_order_acquire);
+    for (int i = 0; i <= n; ++i) {
+      PQueue *Q = i == n ? &overflow : queues[i].load(std::memory_order_acquire);
+      if (Q) Q->clean_head.store(Q->head, std::memory_order_release);
+    }
+  }
   void run() {
     // the creating thread may be pinned (OMP_PROC_BIND pins each worker to one core): inheriting that mask would
     // put the scheduler on the caller's own core. Use the mask the PROCESS had when the library was loaded
@@ -738,38 +1084,47 @@ struct Scheduler {
     if (g_have_process_mask) (void)sched_setaffinity(0, sizeof(g_process_mask), &g_process_mask);
     (void)hipSetDevice(device);
     unsigned idle = 0;
-    uint64_t head = saved_head; // (written under life_mu by the previous worker, read after the join in ensure_worker)
     for (;;) {
-      Slot &s = ring[head & MASK];
-      if (s.seq.load(std::memory_order_acquire) == head + 1) {
-        const QEntry e = s.e;
-        s.seq.store(head + N, std::memory_order_release); // the slot is free for the next lap
-        ++head;
+      collect();
+      if (!heap.empty()) {
+        std::pop_heap(heap.begin(), heap.end(), later);
+        const int qi = heap.back().second;
+        heap.pop_back();
+        PQueue &Q = *ring_at(qi);
+        const PSlot &s = Q.ring[Q.head & PQueue::MASK];
+        QEntry e;
+        e.desc = s.desc;
+        e.w = WorkItem{s.A, s.B, s.C, s.D, s.br};
+        e.stream = s.stream;
+        __builtin_prefetch(&Q.ring[(Q.head + 4) & PQueue::MASK]);
+        __builtin_prefetch(&Q.ring[(Q.head + 8) & PQueue::MASK]);
+        ++Q.head;
+        if ((Q.head & 15) == 0) Q.head_pub.store(Q.head, std::memory_order_release);
+        examine(qi, Q);
         idle = 0;
-        if (e.kind == 0) {
+        if (!e.desc) {
           q.flush();
-          clean_upto.store(head, std::memory_order_release);
-          e.fence->store(1, std::memory_order_release);
+          mark_clean();
+          ((std::atomic<int> *)e.w.C)->store(1, std::memory_order_release);
         } else {
-          process(e);
+          devmem.refresh();
+          process_item(q, devmem, e.desc, e.w, e.stream);
         }
-      } else {
-        if (stop.load(std::memory_order_relaxed)) break;
-        if (++idle < 4000) __builtin_ia32_pause();
-        else if (idle < 20000) sched_yield();
-        else { // nothing for a long while: stop burning a core (a caller that arrives now waits one nap)
-          timespec ts{0, idle < 40000 ? 50000 : 1000000}; // 50 us naps, then 1 ms naps
-          nanosleep(&ts, nullptr);
-          if (idle > 42000) { // ~2 s of 1 ms naps: leave, unless a producer has taken a ticket meanwhile
-            std::lock_guard<std::mutex> lk(life_mu); // ensure_worker() joins this thread under the same lock: decide inside it
-            running.store(false, std::memory_order_seq_cst);
-            if (tail.load(std::memory_order_seq_cst) == head) {
-              saved_head = head;
-              return;
-            }
-            running.store(true, std::memory_order_seq_cst);
-            idle = 0;
-          }
+        continue;
+      }
+      if (stop.load(std::memory_order_relaxed)) break;
+      if (++idle < 4000) __builtin_ia32_pause();
+      else if (idle < 20000) sched_yield();
+      else { // nothing for a long while: stop burning a core (a caller that arrives now waits one nap)
+        timespec ts{0, idle < 40000 ? 50000 : 1000000}; // 50 us naps, then 1 ms naps
+        nanosleep(&ts, nullptr);
+        if (idle > 42000) { // ~2 s of 1 ms naps: leave, unless a producer has announced a ring meanwhile
+          std::lock_guard<std::mutex> lk(life_mu); // ensure_worker() joins this thread under the same lock: decide inside it
+          if (!warm.empty()) continue; // (every ring must be parked before the worker may leave)
+          running.store(false, std::memory_order_seq_cst);
+          if (!drain_wake_list()) return;
+          running.store(true, std::memory_order_seq_cst);
+          idle = 0;
         }
       }
     }
@@ -833,20 +1188,13 @@ void flush_tile_queue() {
   if (Scheduler *p = g_sched.load(std::memory_order_acquire)) p->drain();
 }
 
-// Queues one invoke of (kind, desc); true if queued (nothing launched yet), false if an operand is host
-// memory (the caller flushes and takes the mirrored path). `in` are the operands the invoke reads, `out`
-// the one it writes (also read when the op accumulates - a superset is harmless).
-bool enqueue_item(int kind, const void *desc, const WorkItem &item, const Operand *const *in, int n_in,
-                  const Operand &out, bool vec_ok, bool out_ok, hipStream_t s) {
+// Queues one invoke of `desc`; true if queued (nothing launched yet), false if an operand is host memory (the
+// caller flushes and takes the mirrored path). `ptrs` are the item's non-null operand pointers.
+bool enqueue_item(const void *desc, const WorkItem &item, const void *const *ptrs, int n_ptrs, hipStream_t s) {
   thread_local DeviceRanges devmem; // per caller: no sharing, no lock
   devmem.refresh();
-  if (!devmem.is_device(out.ptr)) return false;
-  for (int i = 0; i < n_in; ++i)
-    if (!devmem.is_device(in[i]->ptr)) return false;
-  auto anchor = [&](const Operand &o) { return o.rows ? devmem.base_of(o.ptr) : (uintptr_t)0; };
-  const uintptr_t anchor_out = anchor(out);
-  uintptr_t anchor_in[3] = {0, 0, 0};
-  for (int i = 0; i < n_in; ++i) anchor_in[i] = anchor(*in[i]);
+  for (int i = 0; i < n_ptrs; ++i)
+    if (!devmem.is_device(ptrs[i])) return false;
   InlineQueue &iq = inl();
   if (!iq.scheduled.load(std::memory_order_acquire)) {
     std::lock_guard<SpinLock> lk(iq.mu);
@@ -861,24 +1209,14 @@ bool enqueue_item(int kind, const void *desc, const WorkItem &item, const Operan
         iq.owner = me;
       }
       if (!iq.scheduled.load(std::memory_order_relaxed)) {
-        process_ops(iq.q, kind, desc, item, out, anchor_out, in, anchor_in, n_in, vec_ok, out_ok, s);
+        process_item(iq.q, devmem, desc, item, s);
         return true;
       }
     }
   }
   QEntry e;
-  e.kind = kind;
   e.desc = desc;
   e.w = item;
-  e.out = out;
-  e.anchor_out = anchor_out;
-  e.n_in = n_in;
-  for (int i = 0; i < n_in; ++i) {
-    e.in[i] = *in[i];
-    e.anchor_in[i] = anchor_in[i];
-  }
-  e.vec_ok = vec_ok;
-  e.out_ok = out_ok;
   e.stream = s;
   sched().push(e);
   return true;
@@ -888,13 +1226,10 @@ bool queue_active() {
   return cfg().tile_queue.load(std::memory_order_relaxed) && cfg().async.load(std::memory_order_relaxed);
 }
 
-bool try_enqueue(const GemmDesc *d, const Operand &A, const Operand &B, const Operand &C, const Operand &D, int64_t br,
-                 hipStream_t s) {
+bool try_enqueue(const GemmDesc *d, void *a, void *b, void *c, void *dp, int64_t br, hipStream_t s) {
   if (d->m > 64 || d->n > 64) return false; // big descriptors fill the chip on their own
-  const Operand *in[3] = {&A, &B, &D};
-  const bool vec_ok = (((uintptr_t)A.ptr | (uintptr_t)B.ptr) & 15) == 0;
-  const bool out_ok = (((uintptr_t)C.ptr) & 15) == 0 && (((uintptr_t)D.ptr) & 7) == 0;
-  return enqueue_item(KIND_GEMM, d, WorkItem{A.ptr, B.ptr, C.ptr, D.ptr, br}, in, 3, C, vec_ok, out_ok, s);
+  const void *ptrs[4] = {a, b, c, dp};
+  return enqueue_item(d, WorkItem{a, b, c, dp, br}, ptrs, 4, s);
 }
 
 void gemm_invoke_common(const char *who, bool want_fused, int64_t dtype, int64_t handle, void *a, int64_t off_a,
@@ -906,23 +1241,16 @@ void gemm_invoke_common(const char *who, bool want_fused, int64_t dtype, int64_t
   if (d->m == 0 || d->n == 0) return;
   TraceRange trace_range(who, d->trace);
   const size_t es = esize(dtype);
-  const int64_t kk = br > 0 ? d->k : 0;
-  Operand A{(char *)a + off_a * es, 0, false, nullptr}, B{(char *)b + off_b * es, 0, false, nullptr},
-      C{(char *)c + off_c * es, (d->vnni_c ? span(d->m / 2, 2 * d->ldc, 2 * d->n) : span(d->m, d->ldc, d->n)) * es, true, nullptr},
-      D{dptr ? (char *)dptr + off_d * es : nullptr, d->bias ? (size_t)d->n * es : 0, false, nullptr};
-  if (d->vnni_c) C.shape(d->m / 2, (size_t)2 * d->n * es, (size_t)2 * d->ldc * es);
-  else C.shape(d->m, (size_t)d->n * es, (size_t)d->ldc * es);
-  if (kk > 0) {
-    A.bytes = ((size_t)(br - 1) * d->stride_a + span(d->m, d->lda, d->k)) * es;
-    const size_t bspan = d->vnni_b ? span((d->k + 1) / 2, 2 * d->ldb, 2 * d->n) : span(d->k, d->ldb, d->n);
-    B.bytes = ((size_t)(br - 1) * d->stride_b + bspan) * es;
-  }
+  void *pa = (char *)a + off_a * es, *pb = (char *)b + off_b * es, *pc = (char *)c + off_c * es;
+  void *pd = dptr ? (char *)dptr + off_d * es : nullptr;
   if (d->bias && !dptr) die("%s: fused bias operand is null", who);
   hipStream_t s = cfg().stream.load(std::memory_order_relaxed);
   if (cfg().tile_queue.load(std::memory_order_relaxed)) {
-    if (cfg().async.load(std::memory_order_relaxed) && try_enqueue(d, A, B, C, D, br, s)) return;
+    if (cfg().async.load(std::memory_order_relaxed) && try_enqueue(d, pa, pb, pc, pd, br, s)) return;
     flush_tile_queue();
   }
+  Operand A, B, C, D;
+  gemm_operands(d, pa, pb, pc, pd, br, A, B, C, D);
   C.read = !d->beta0; // pure output under BETA_0: never uploaded
   std::vector<Operand *> ops = {&A, &B, &C, &D};
   stage_in(ops, s);
@@ -1047,38 +1375,20 @@ static void unary_invoke_common(const char *who, int64_t dtype, int64_t handle, 
   if (d->m == 0 || d->n == 0) return;
   TraceRange trace_range(who, d->trace);
   const size_t es = esize(dtype);
-  Operand I{nullptr, 0, false, nullptr}, O{(char *)out + off_out * es, 0, true, nullptr};
   if (use_scalar && (d->op == XSMM_UNARY_TRANSPOSE || d->op == XSMM_UNARY_VNNI2))
     die("%s: scalar input is meaningless for op %ld", who, (long)d->op);
-  if (d->op == XSMM_UNARY_TRANSPOSE) {
-    O.bytes = span(d->n, d->ldo, d->m) * es;
-    O.shape(d->n, (size_t)d->m * es, (size_t)d->ldo * es);
-  } else if (d->op == XSMM_UNARY_VNNI2) {
-    O.bytes = span(d->m / 2, 2 * d->ldo, 2 * d->n) * es;
-    O.shape(d->m / 2, (size_t)2 * d->n * es, (size_t)2 * d->ldo * es);
-  } else {
-    O.bytes = span(d->m, d->ldo, d->n) * es;
-    O.shape(d->m, (size_t)d->n * es, (size_t)d->ldo * es);
-  }
-  if (!use_scalar && d->op != XSMM_UNARY_ZERO) {
-    I.ptr = (char *)in + off_in * es;
-    if (d->flags & XSMM_UNARY_FLAG_BCAST_SCALAR) I.bytes = es;
-    else if (d->flags & XSMM_UNARY_FLAG_BCAST_ROW) I.bytes = span(d->m, d->ldi, 1) * es;
-    else if (d->flags & XSMM_UNARY_FLAG_BCAST_COL) I.bytes = (size_t)d->n * es;
-    else {
-      I.bytes = span(d->m, d->ldi, d->n) * es;
-      I.shape(d->m, (size_t)d->n * es, (size_t)d->ldi * es);
-    }
-  }
+  void *pi = use_scalar || d->op == XSMM_UNARY_ZERO ? nullptr : (char *)in + off_in * es, *po = (char *)out + off_out * es;
   hipStream_t s = cfg().stream.load(std::memory_order_relaxed);
   if (cfg().tile_queue.load(std::memory_order_relaxed)) {
     // small tiles of tensor.pack / unpack lowering and bias broadcasts: queued like the GEMM tiles
     if (queue_active() && !use_scalar && d->m <= 64 && d->n <= 64) {
-      const Operand *in[1] = {&I};
-      if (enqueue_item(KIND_UNARY, d, WorkItem{I.ptr, nullptr, O.ptr, nullptr, 0}, in, 1, O, true, true, s)) return;
+      const void *ptrs[2] = {pi, po};
+      if (enqueue_item(d, WorkItem{pi, nullptr, po, nullptr, 0}, ptrs, 2, s)) return;
     }
     flush_tile_queue();
   }
+  Operand I, O;
+  unary_operands(d, pi, po, I, O);
   O.read = false; // an in-place input is uploaded through I
   std::vector<Operand *> ops = {&I, &O};
   stage_in(ops, s);
@@ -1103,26 +1413,17 @@ extern "C" void xsmm_binary_invoke(int64_t dtype, int64_t handle, void *lhs, int
   if (d->m == 0 || d->n == 0) return;
   TraceRange trace_range(who, d->trace);
   const size_t es = esize(dtype);
-  auto in_bytes = [&](int64_t row, int64_t col, int64_t sc, int64_t ld) -> size_t {
-    if (d->flags & sc) return es;
-    if (d->flags & row) return span(d->m, ld, 1) * es;
-    if (d->flags & col) return (size_t)d->n * es;
-    return span(d->m, ld, d->n) * es;
-  };
-  Operand L{(char *)lhs + off_lhs * es, in_bytes(1, 4, 16, d->ldi_lhs), false, nullptr},
-      R{(char *)rhs + off_rhs * es, in_bytes(2, 8, 32, d->ldi_rhs), false, nullptr},
-      O{(char *)out + off_out * es, span(d->m, d->ldo, d->n) * es, true, nullptr};
-  O.shape(d->m, (size_t)d->n * es, (size_t)d->ldo * es);
-  if (!(d->flags & (1 | 4 | 16))) L.shape(d->m, (size_t)d->n * es, (size_t)d->ldi_lhs * es);
-  if (!(d->flags & (2 | 8 | 32))) R.shape(d->m, (size_t)d->n * es, (size_t)d->ldi_rhs * es);
+  void *pl = (char *)lhs + off_lhs * es, *pr = (char *)rhs + off_rhs * es, *po = (char *)out + off_out * es;
   hipStream_t s = cfg().stream.load(std::memory_order_relaxed);
   if (cfg().tile_queue.load(std::memory_order_relaxed)) {
     if (queue_active() && d->m <= 64 && d->n <= 64) {
-      const Operand *in[2] = {&L, &R};
-      if (enqueue_item(KIND_BINARY, d, WorkItem{L.ptr, R.ptr, O.ptr, nullptr, 0}, in, 2, O, true, true, s)) return;
+      const void *ptrs[3] = {pl, pr, po};
+      if (enqueue_item(d, WorkItem{pl, pr, po, nullptr, 0}, ptrs, 3, s)) return;
     }
     flush_tile_queue();
   }
+  Operand L, R, O;
+  binary_operands(d, pl, pr, po, L, R, O);
   O.read = false; // out == lhs / rhs is uploaded through that operand
   std::vector<Operand *> ops = {&L, &R, &O};
   stage_in(ops, s);
