@@ -335,3 +335,98 @@ def test_packed_layers_bf16_64_tiles(rtq, nblk):
                 rt.fused_brgemm(BF16, h, dX, i * KB * tm * tk, dW, j * KB * tk * tn, dC, (i * NB + j) * tm * tn, db, j * tn, KB)
         rt.synchronize()
         close(host(dC, C0), ref, BF16)
+
+
+def _tile_program(rng, n_ops, nbuf, ntile):
+    """a random program of 32x32 f32 tile ops over `nbuf` buffers of `ntile` tiles: (op, src buffer, src tile, second
+    source, dst buffer, dst tile); ops: copy, relu, add, mul-accumulate (gemm with beta = 1)"""
+    prog = []
+    for _ in range(n_ops):
+        op = int(rng.integers(0, 4))
+        prog.append((op, int(rng.integers(0, nbuf)), int(rng.integers(0, ntile)), int(rng.integers(0, nbuf)),
+                     int(rng.integers(0, ntile)), int(rng.integers(0, nbuf)), int(rng.integers(0, ntile))))
+    return prog
+
+
+def _run_program(prog, bufs, do):
+    for (op, sb, st, s2b, s2t, db, dt_) in prog:
+        if op == 3 and db in (sb, s2b):
+            op = 2  # a gemm must not write a buffer it reads; the eltwise ops may work in place (whole tiles)
+        do(op, bufs[sb], st * 1024, bufs[s2b], s2t * 1024, bufs[db], dt_ * 1024)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_trace_cache_replays_and_diverges(rtq, seed):
+    """The trace cache replays a group of invokes it has collected before without the footprint bookkeeping. A program of
+    dependent tile ops (long independent runs + random dependences) is run 4 times (groups get recorded, then replayed),
+    then mutated at a few places - a pointer, an op, an insertion, a deletion - and run again, several times over:
+    every run must equal the oracle's replay of the same sequence in program order."""
+    rt = rtq
+    rng = np.random.default_rng(100 + seed)
+    nbuf, ntile = 4, 96
+    init = [(rng.uniform(-1, 1, ntile * 1024) * 0.1).astype(np.float32) for _ in range(nbuf)]  # 32-term products contract
+    ref = [b.copy() for b in init]
+    dbuf = [dev(b) for b in init]
+    copy = rt.unary_dispatch(1, F32, 32, 32, 32, 32, 0)
+    relu = rt.unary_dispatch(5, F32, 32, 32, 32, 32, 0)
+    add = rt.binary_dispatch(1, F32, 32, 32, 32, 32, 32, 0)
+    gemm = rt.brgemm_dispatch(F32, 32, 32, 32, 32, 32, 32, 1024, 1024, 0)
+
+    def on_gpu(op, s, so, s2, s2o, d, do_):
+        if op == 0:
+            rt.unary(F32, copy, s, so, d, do_)
+        elif op == 1:
+            rt.unary(F32, relu, s, so, d, do_)
+        elif op == 2:
+            rt.binary(F32, add, s, so, s2, s2o, d, do_)
+        else:
+            rt.brgemm(F32, gemm, s, so, s2, s2o, d, do_, 1)
+
+    def on_oracle(op, s, so, s2, s2o, d, do_):
+        if op == 0:
+            orc.unary(1, F32, 32, 32, 32, 32, 0, s, so, d, do_)
+        elif op == 1:
+            orc.unary(5, F32, 32, 32, 32, 32, 0, s, so, d, do_)
+        elif op == 2:
+            orc.binary(1, F32, 32, 32, 32, 32, 32, 0, s, so, s2, s2o, d, do_)
+        else:
+            orc.brgemm(F32, 32, 32, 32, 32, 32, 32, 1024, 1024, 0, s, so, s2, s2o, d, do_, 1)
+
+    # long runs of one op over consecutive tiles (what compiled layers look like), glued by random single ops
+    prog = []
+    for run in range(10):
+        op = int(rng.integers(0, 4))
+        sb, s2b, db = (int(x) for x in rng.permutation(nbuf)[:3])
+        n = int(rng.integers(20, 60))
+        t0 = int(rng.integers(0, ntile - n))
+        prog += [(op, sb, t0 + i, s2b, (t0 + 2 * i) % ntile, db, t0 + i) for i in range(n)]
+        prog += _tile_program(rng, int(rng.integers(0, 3)), nbuf, ntile)
+    for generation in range(4):
+        for rep in range(4):
+            _run_program(prog, dbuf, on_gpu)
+            _run_program(prog, ref, on_oracle)
+            if rep == 2:
+                rt.synchronize()  # an external flush point in the middle of the repetitions
+        rt.synchronize()
+        for b in range(nbuf):
+            got = host(dbuf[b], init[b])
+            # values grow through the accumulating gemms: compare with the oracle's own result, relative
+            assert np.allclose(got, ref[b], rtol=2e-5, atol=1e-6), (generation, b, float(np.abs(got - ref[b]).max()))
+            ref[b][:] = got  # continue from the device state (rounding differences must not accumulate into the bar)
+        # mutate: change a pointer, change an op, insert, delete
+        prog = list(prog)
+        for _ in range(3):
+            i = int(rng.integers(0, len(prog)))
+            o = list(prog[i])
+            o[int(rng.integers(1, 7))] = int(rng.integers(0, nbuf if rng.integers(0, 2) else 4))
+            o[2], o[4], o[6] = o[2] % ntile, o[4] % ntile, o[6] % ntile
+            o[1], o[3], o[5] = o[1] % nbuf, o[3] % nbuf, o[5] % nbuf
+            prog[i] = tuple(o)
+        prog.insert(int(rng.integers(0, len(prog))), _tile_program(rng, 1, nbuf, ntile)[0])
+        del prog[int(rng.integers(0, len(prog)))]
+        # keep magnitudes bounded for the next generation
+        for b in range(nbuf):
+            fresh = (rng.uniform(-1, 1, ntile * 1024) * 0.1).astype(np.float32)
+            ref[b][:] = fresh
+            dbuf[b].copy_(dev(fresh))
+        rt.synchronize()

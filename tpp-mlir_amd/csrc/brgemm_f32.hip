@@ -394,9 +394,9 @@ __global__ __launch_bounds__(256) void brgemm_grouped(GemmArgs p, const WorkItem
   g_cvoid *gA = (g_cvoid *)it.A, *gB = (g_cvoid *)it.B, *gD = (g_cvoid *)it.D; // global, not flat, accesses
   g_void *gC = (g_void *)it.C;
   typedef __attribute__((address_space(1))) const u32x4 g_cu32x4;
-  typedef __attribute__((address_space(1))) const f32x4 g_cf32x4;
+
   typedef __attribute__((address_space(1))) const unsigned short g_cu16;
-  typedef __attribute__((address_space(1))) const float g_cf32;
+
   const int tm = blockIdx.x / p.tiles_n, tn = blockIdx.x % p.tiles_n;
   const int m0 = tm * 32, n0 = tn * 32;
   const int kchunks = (p.k + GK - 1) / GK;
@@ -409,10 +409,43 @@ __global__ __launch_bounds__(256) void brgemm_grouped(GemmArgs p, const WorkItem
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 
   // staging registers: A tile rows [m0, m0+32) x k [kk0, kk0+32); B tile k x n
-  f32x4 ra[4], rb[4]; // 32 x 32 floats = 256 pieces of 16 B per panel, 4 per lane
-  auto gload = [&](int c) __attribute__((always_inline)) {
+  // two staging register sets: 32 x 32 floats = 256 pieces of 16 B per panel, 4 per lane and panel
+  f32x4 rs[2][2][4];
+  // f32 with 16-byte loads (the compiler-native packed 32x32x32 tiles): per-lane byte offsets inside a chunk, fixed for the kernel.
+  // Rows / 4-column pieces beyond a ragged edge (m not a multiple of 32, n only of 4, e.g. --tiles=64,48,64) are loaded from
+  // a CLAMPED address and left as they are: an output element depends on its own A row and B column only, and the
+  // epilogue stores nothing beyond the edge.
+  unsigned voffA[4] = {0, 0, 0, 0}, voffB[4] = {0, 0, 0, 0};
+  if constexpr (VEC && sizeof(T) == 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int q = lane + 64 * u, row = q >> 3, c4 = q & 7; // 32 rows x 8 pieces of 4 floats
+      const int a_row = m0 + row < p.m ? m0 + row : p.m - 1, b_col = n0 + 4 * c4 < p.n ? n0 + 4 * c4 : 0;
+      voffA[u] = (unsigned)((a_row * (int)p.lda + 4 * c4) * 4);
+      voffB[u] = (unsigned)((row * (int)p.ldb + b_col) * 4);
+    }
+  }
+  // live = false: the chunk does not exist. The f32 16-byte path then still ISSUES its loads, switched off through the buffer
+  // descriptor (num_records = 0, no memory traffic): a branch around a load makes hipcc wait with vmcnt(0) at the next use of
+  // ANY staged register, which would serialise the two chunks kept in flight.
+  auto gload = [&](int c, int set, bool live) __attribute__((always_inline)) {
+    f32x4(&ra)[4] = rs[set][0];
+    f32x4(&rb)[4] = rs[set][1];
     const int b = c / kchunks, kk0 = (c - b * kchunks) * GK;
     const int64_t abase = (int64_t)b * p.stride_a, bbase = (int64_t)b * p.stride_b;
+    if constexpr (VEC && sizeof(T) == 4) {
+      const int nrec = __builtin_amdgcn_readfirstlane(live ? 0x7fffffff : 0);
+      const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void *)((const float *)it.A + abase + kk0), 0, nrec, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rB =
+          __builtin_amdgcn_make_buffer_rsrc((void *)((const float *)it.B + bbase + (int64_t)kk0 * p.ldb), 0, nrec, 0x00020000);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        ra[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, voffA[u], 0, 0));
+        rb[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rB, voffB[u], 0, 0));
+      }
+      return;
+    }
+    if (!live) return;
     if constexpr (VEC && sizeof(T) == 2) {
       // bf16, VNNI-2 B, 16-byte loads (8 elements), widened to f32 on the way into the staging registers:
       // A piece (row, 8 k) -> two register quads; B piece (pair-row p, 4 columns x 2 k) -> quad of row 2p
@@ -420,14 +453,10 @@ __global__ __launch_bounds__(256) void brgemm_grouped(GemmArgs p, const WorkItem
 #pragma unroll
       for (int v = 0; v < 2; ++v) {
         const int q = lane + 64 * v;
-        // ragged tiles (m not a multiple of 32, n a multiple of 4 only, e.g. --tiles=64,48,64): rows / column
-        // pieces beyond the edge are zero-filled, the epilogue stores nothing there
-        u32x4 a8 = {0u, 0u, 0u, 0u}, b8 = {0u, 0u, 0u, 0u};
-        if (m0 + (q >> 2) < p.m)
-          a8 = *(g_cu32x4 *)((g_cu16 *)gA + abase + (int64_t)(m0 + (q >> 2)) * p.lda + kk0 + 8 * (q & 3));
-        if (n0 + 4 * (q & 7) < p.n)
-          b8 = *(g_cu32x4 *)((g_cu16 *)gB + bbase + (int64_t)((kk0 >> 1) + (q >> 3)) * (2 * p.ldb) +
-                                2 * (n0 + 4 * (q & 7)));
+        // ragged edges: clamped addresses, see above
+        const int a_row = m0 + (q >> 2) < p.m ? m0 + (q >> 2) : p.m - 1, b_col = n0 + 4 * (q & 7) < p.n ? n0 + 4 * (q & 7) : 0;
+        const u32x4 a8 = *(g_cu32x4 *)((g_cu16 *)gA + abase + (int64_t)a_row * p.lda + kk0 + 8 * (q & 3));
+        const u32x4 b8 = *(g_cu32x4 *)((g_cu16 *)gB + bbase + (int64_t)((kk0 >> 1) + (q >> 3)) * (2 * p.ldb) + 2 * b_col);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           ra[2 * v + (e >> 1)][2 * (e & 1)] = __uint_as_float(a8[e] << 16);
@@ -441,12 +470,7 @@ __global__ __launch_bounds__(256) void brgemm_grouped(GemmArgs p, const WorkItem
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int q = lane + 64 * u, row = q >> 3, c4 = q & 7; // 32 rows x 8 pieces of 4 floats
-      if (VEC) { // rows / 4-column pieces beyond a ragged edge are zero-filled
-        ra[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        rb[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        if (m0 + row < p.m) ra[u] = *(g_cf32x4 *)((g_cf32 *)gA + abase + (int64_t)(m0 + row) * p.lda + kk0 + 4 * c4);
-        if (n0 + 4 * c4 < p.n) rb[u] = *(g_cf32x4 *)((g_cf32 *)gB + bbase + (int64_t)(kk0 + row) * p.ldb + n0 + 4 * c4);
-      } else {
+      { // element-wise loads: any shape, stride and alignment
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int gr = m0 + row, gk = kk0 + 4 * c4 + e;
@@ -463,46 +487,73 @@ __global__ __launch_bounds__(256) void brgemm_grouped(GemmArgs p, const WorkItem
       }
     }
   };
-  auto swrite = [&](int buf) __attribute__((always_inline)) {
+  // piece u (one A quad + one B quad per lane) of staging set `set` into LDS buffer `buf`
+  auto swrite_piece = [&](int buf, int set, int u) __attribute__((always_inline)) {
+    f32x4(&ra)[4] = rs[set][0];
+    f32x4(&rb)[4] = rs[set][1];
     float *as = wl + buf * (2 * 32 * GK), *bs = as + 32 * GK;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      int row, c4, krow, c4b;
-      if constexpr (VEC && sizeof(T) == 2) { // where gload put quad u (see there)
-        const int q = lane + 64 * (u >> 1);
-        row = q >> 2, c4 = 2 * (q & 3) + (u & 1);
-        krow = 2 * (q >> 3) + (u & 1), c4b = q & 7;
-      } else {
-        const int q = lane + 64 * u;
-        row = krow = q >> 3, c4 = c4b = q & 7;
-      }
-      *(f32x4 *)(as + row * GK + ((c4 ^ ((row >> 1) & 7)) << 2)) = ra[u]; // 128-byte rows: XOR on (row>>1)
-      *(f32x4 *)(bs + krow * 32 + 4 * c4b) = rb[u];
+    int row, c4, krow, c4b;
+    if constexpr (VEC && sizeof(T) == 2) { // where gload put quad u (see there)
+      const int q = lane + 64 * (u >> 1);
+      row = q >> 2, c4 = 2 * (q & 3) + (u & 1);
+      krow = 2 * (q >> 3) + (u & 1), c4b = q & 7;
+    } else {
+      const int q = lane + 64 * u;
+      row = krow = q >> 3, c4 = c4b = q & 7;
     }
+    *(f32x4 *)(as + row * GK + ((c4 ^ ((row >> 1) & 7)) << 2)) = ra[u]; // 128-byte rows: XOR on (row>>1)
+    *(f32x4 *)(bs + krow * 32 + 4 * c4b) = rb[u];
   };
-  auto compute = [&](int buf) __attribute__((always_inline)) {
+  auto swrite = [&](int buf, int set) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) swrite_piece(buf, set, u);
+  };
+  // The 16 MFMAs of the chunk in LDS buffer `buf`, software-pipelined: the fragments of k-block kb + 1 are read while the four
+  // MFMAs of k-block kb run, and (stage) the staging set `set` = the NEXT chunk of this wave goes into the other LDS buffer one
+  // piece per k-block - a wave is alone on its SIMD here, so whatever is not overlapped inside the wave is idle matrix-core time
+  // (before: 2300 cycles per chunk for 1024 cycles of MFMA).
+  auto compute = [&](int buf, bool stage, int set) __attribute__((always_inline)) {
     const float *as = wl + buf * (2 * 32 * GK) + li * GK, *bs = wl + buf * (2 * 32 * GK) + 32 * GK + li;
+    f32x4 a4[2];
+    float b4[2][4];
+    auto frag = [&](int kb, int to) __attribute__((always_inline)) {
+      a4[to] = *(const f32x4 *)(as + (((2 * kb + lh) ^ ((li >> 1) & 7)) << 2));
+#pragma unroll
+      for (int s = 0; s < 4; ++s) b4[to][s] = bs[(8 * kb + 4 * lh + s) * 32];
+    };
+    frag(0, 0);
 #pragma unroll
     for (int kb = 0; kb < GK / 8; ++kb) {
-      const f32x4 a4 = *(const f32x4 *)(as + (((2 * kb + lh) ^ ((li >> 1) & 7)) << 2));
+      if (kb + 1 < GK / 8) frag(kb + 1, (kb + 1) & 1);
+      if (stage) swrite_piece(buf ^ 1, set, kb);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s = 0; s < 4; ++s)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s], bs[(8 * kb + 4 * lh + s) * 32], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[kb & 1][s], b4[kb & 1][s], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
-  // wave-private pipeline: loads of the next chunk fly while the current one multiplies
-  int c = wave, buf = 0;
-  if (c < nchunk) {
-    gload(c);
-    swrite(0);
+  // wave-private pipeline, TWO chunks of loads in flight: while chunk c multiplies out of LDS buffer i & 1, chunk c + 4 sits in
+  // (or is on its way to) register set (i + 1) & 1 and the loads of chunk c + 8 are issued into set i & 1. With one chunk in
+  // flight a wave waited out most of an L2 round trip per chunk (0.5 us of MFMA against 0.6-0.8 us of latency): the tile-queue
+  // launches of the reference's 32x32x32 pattern took 12.7 us per 256 tiles against 7.4 us for the whole-layer kernel.
+  // The loop runs whole PAIRS of chunks (one per staging set / LDS buffer) with ONE exit and no branch inside: loads of chunks
+  // that do not exist are switched off (f32 16-byte path) and staging them moves zeros / stale registers into an LDS
+  // buffer nobody computes from. (With an exit per chunk hipcc keeps the accumulator in two register sets and moves it -
+  // 16 v_accvgpr_read + 16 v_accvgpr_write behind every chunk's last MFMA; a branch around loads defeats the counted waits.)
+  const int mine = nchunk > wave ? (nchunk - wave + 3) >> 2 : 0; // chunks of this wave: wave, wave + 4, ...
+  int c = wave;
+  gload(c, 0, mine > 0);
+  gload(c + 4, 1, mine > 1);
+  if (mine > 0) swrite(0, 0);
+  for (int i = 0; i + 1 < mine; i += 2) {
+    gload(c + 8, 0, i + 2 < mine);
+    compute(0, true, 1);
+    gload(c + 12, 1, i + 3 < mine);
+    compute(1, true, 0);
+    c += 8;
   }
-  for (; c < nchunk; c += 4) {
-    const bool more = c + 4 < nchunk;
-    if (more) gload(c + 4);
-    compute(buf);
-    if (more) swrite(buf ^ 1);
-    buf ^= 1;
-  }
+  if (mine & 1) compute(0, false, 0);
   // combine the four waves' partial sums (waves 1..3 park theirs), then wave 0 finishes
   __syncthreads();
   float *red = smem_g;

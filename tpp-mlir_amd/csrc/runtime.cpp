@@ -664,8 +664,44 @@ struct Footprint {
   }
 };
 
+// One queued invoke as the trace cache remembers it.
+struct TraceItem {
+  const void *desc = nullptr;
+  WorkItem w{};
+  hipStream_t stream = nullptr;
+  bool same(const void *d, const WorkItem &x, hipStream_t s) const {
+    return desc == d && w.A == x.A && w.B == x.B && w.C == x.C && w.D == x.D && w.br == x.br && stream == s;
+  }
+};
+// A group as it was once collected: its invokes in order and the invoke that ended it by conflicting with it.
+struct Segment {
+  std::vector<TraceItem> items;
+  TraceItem next;
+  bool has_next = false;
+  bool vec_ok = true, out_ok = true;
+  uint64_t last_use = 0;
+};
+
 struct TileQueue {
   static constexpr int CAP = 4096, SLOTS = 4;
+  // TRACE CACHE. Compiled code repeats itself: the same handles on the same pointers in the same order, iteration after
+  // iteration (the timing loop of tpp-run, every layer of a model). Whether a group of queued invokes is conflict-free,
+  // and whether the next invoke conflicts with it, is a pure function of that sequence of (descriptor, pointers, batch)
+  // - the footprints follow from them - so a group that was collected once with full bookkeeping is REPLAYED the next
+  // time its first invoke shows up on an empty queue: each following invoke is compared with the recorded one (seven
+  // words) and appended to the work list, nothing else; the recorded terminator launches the group. The first invoke
+  // that differs rebuilds the footprints of the replayed prefix and drops back to the full bookkeeping (and records the
+  // new sequence). Replaying a recorded flush is always safe (a flush never is unsafe), skipping checks is safe because
+  // the same sequence was proven conflict-free. Callers whose interleaving changes from run to run (several OpenMP
+  // callers in stamp order) mismatch often: after a mismatch the cache is left alone for a growing number of groups.
+  static constexpr size_t NSEG = 8, MIN_SEG = 16;
+  std::vector<Segment> segs;
+  int replay = -1;        // index of the segment being replayed
+  size_t rpos = 0;        // next item of it
+  Segment rec;            // the group being recorded (full bookkeeping path)
+  bool rec_open = false;
+  uint64_t use_clock = 0;
+  unsigned backoff = 0, backoff_next = 8; // groups to collect without consulting the cache / after the next mismatch
   int kind = 0;               // KIND_GEMM / KIND_UNARY / KIND_BINARY of the queued invokes
   const void *desc = nullptr; // their (single) descriptor
   bool vec_ok = true, out_ok = true;
@@ -691,7 +727,36 @@ struct TileQueue {
       used[slot] = false;
     }
   }
-  void flush() {
+  void store_recording(const TraceItem *next) {
+    if (rec_open && rec.items.size() >= MIN_SEG) {
+      rec.has_next = next != nullptr;
+      if (next) rec.next = *next;
+      rec.vec_ok = vec_ok;
+      rec.out_ok = out_ok;
+      rec.last_use = ++use_clock;
+      size_t at = segs.size();
+      for (size_t i = 0; i < segs.size(); ++i)
+        if (segs[i].items[0].same(rec.items[0].desc, rec.items[0].w, rec.items[0].stream)) at = i; // same start: the newer sequence wins
+      if (at == segs.size() && segs.size() >= NSEG) {
+        at = 0;
+        for (size_t i = 1; i < segs.size(); ++i)
+          if (segs[i].last_use < segs[at].last_use) at = i;
+      }
+      if (at == segs.size()) segs.emplace_back();
+      std::swap(segs[at], rec);
+    }
+    rec.items.clear();
+    rec_open = false;
+  }
+  int find_segment(const void *d, const WorkItem &w, hipStream_t s) {
+    for (size_t i = 0; i < segs.size(); ++i)
+      if (segs[i].items[0].same(d, w, s)) return (int)i;
+    return -1;
+  }
+  // next: the invoke whose conflict ends this group (nullptr: an external flush point)
+  void flush(const TraceItem *next = nullptr) {
+    store_recording(next);
+    replay = -1;
     if (n == 0) return;
     {
       if (kind == KIND_GEMM) HIP_OK(launch_gemm_grouped(*(const GemmDesc *)desc, pinned[slot], n, vec_ok, out_ok, stream));
@@ -719,25 +784,55 @@ struct QEntry {
   hipStream_t stream = nullptr;
 };
 
-// appends one invoke to the group being collected, launching the group first if the invoke conflicts with it
-inline void process_ops(TileQueue &q, int kind, const void *desc, const WorkItem &w, const Operand &out, uintptr_t anchor_out,
-                        const Operand *const *in, const uintptr_t *anchor_in, int n_in, bool vec_ok, bool out_ok,
-                        hipStream_t stream) {
-  bool conflict = q.n > 0 && (q.kind != kind || q.desc != desc || q.stream != stream || q.n >= TileQueue::CAP);
-  if (!conflict && q.n > 0) {
-    conflict = q.writes.overlaps(out, anchor_out) || q.reads.overlaps(out, anchor_out);
-    for (int i = 0; i < n_in && !conflict; ++i) conflict = q.writes.overlaps(*in[i], anchor_in[i]);
-  }
-  if (conflict) q.flush();
+// does the invoke conflict with the group being collected (another handle / stream, capacity, a data dependence)?
+inline bool conflicts_with_group(const TileQueue &q, int kind, const void *desc, const Operand &out, uintptr_t anchor_out,
+                                 const Operand *const *in, const uintptr_t *anchor_in, int n_in, hipStream_t stream) {
+  if (q.n == 0) return false;
+  if (q.kind != kind || q.desc != desc || q.stream != stream || q.n >= TileQueue::CAP) return true;
+  if (q.writes.overlaps(out, anchor_out) || q.reads.overlaps(out, anchor_out)) return true;
+  for (int i = 0; i < n_in; ++i)
+    if (q.writes.overlaps(*in[i], anchor_in[i])) return true;
+  return false;
+}
+// appends one invoke to the group being collected (full bookkeeping; the group is recorded for the trace cache)
+inline void append_to_group(TileQueue &q, int kind, const void *desc, const WorkItem &w, const Operand &out, uintptr_t anchor_out,
+                            const Operand *const *in, const uintptr_t *anchor_in, int n_in, bool vec_ok, bool out_ok,
+                            hipStream_t stream) {
   q.ensure_slot();
   q.kind = kind;
   q.desc = desc;
   q.stream = stream;
   q.vec_ok = q.vec_ok && vec_ok;
   q.out_ok = q.out_ok && out_ok;
+  if (q.n == 0) { // a new group: record it
+    q.rec.items.clear();
+    q.rec_open = true;
+  }
+  if (q.rec_open) q.rec.items.push_back(TraceItem{desc, w, stream});
   q.pinned[q.slot][q.n++] = w;
   for (int i = 0; i < n_in; ++i) q.reads.insert(*in[i], anchor_in[i]);
   q.writes.insert(out, anchor_out);
+}
+// the first invoke of a group on an empty queue: replay the recorded group that starts with it, if there is one
+inline bool try_start_replay(TileQueue &q, const void *desc, const WorkItem &w, hipStream_t stream) {
+  if (q.backoff > 0) {
+    --q.backoff;
+    return false;
+  }
+  const int idx = q.find_segment(desc, w, stream);
+  if (idx < 0) return false;
+  Segment &S = q.segs[idx];
+  q.ensure_slot();
+  q.kind = *(const int *)desc;
+  q.desc = desc;
+  q.stream = stream;
+  q.vec_ok = S.vec_ok;
+  q.out_ok = S.out_ok;
+  q.pinned[q.slot][q.n++] = w;
+  q.replay = idx;
+  q.rpos = 1;
+  S.last_use = ++q.use_clock;
+  return true;
 }
 // bookkeeping of one queued invoke: footprints from the descriptor, allocation bases ("anchors" of the 2-D planes) from
 // `devmem` - the allocation cache of the thread that runs this (every operand was seen to be device memory by the caller)
@@ -754,7 +849,59 @@ __attribute__((always_inline)) inline void process_item(TileQueue &q, DeviceRang
   };
   for (int i = 0; i < o.n_in; ++i) anchor_in[i] = anchor(o.op[i]);
   const Operand &out = o.op[o.out];
-  process_ops(q, *(const int *)desc, desc, w, out, anchor(out), in, anchor_in, o.n_in, o.vec_ok, o.out_ok, stream);
+  const uintptr_t anchor_out = anchor(out);
+  const int kind = *(const int *)desc;
+  if (conflicts_with_group(q, kind, desc, out, anchor_out, in, anchor_in, o.n_in, stream)) {
+    const TraceItem term{desc, w, stream};
+    q.flush(&term);
+    if (try_start_replay(q, desc, w, stream)) return; // the group this invoke starts has been collected before
+  }
+  append_to_group(q, kind, desc, w, out, anchor_out, in, anchor_in, o.n_in, o.vec_ok, o.out_ok, stream);
+}
+
+// footprints of the first k items of segment S into the (empty) read / write sets: a replay is being abandoned
+inline void rebuild_footprints(TileQueue &q, DeviceRanges &devmem, const Segment &S, size_t k) {
+  for (size_t i = 0; i < k; ++i) {
+    QueuedOps o;
+    queued_operands(S.items[i].desc, S.items[i].w, o);
+    for (int j = 0; j <= o.out; ++j) {
+      const Operand &x = o.op[j];
+      uintptr_t a = 0;
+      if (x.rows && x.ptr && !(a = devmem.base_of(x.ptr))) {
+        (void)devmem.is_device(x.ptr);
+        a = devmem.base_of(x.ptr);
+      }
+      if (j == o.out) q.writes.insert(x, a);
+      else q.reads.insert(x, a);
+    }
+  }
+}
+// One queued invoke: replayed from the trace cache if it continues a recorded group, else the full bookkeeping.
+inline void submit_item(TileQueue &q, DeviceRanges &devmem, const void *desc, const WorkItem &w, hipStream_t stream) {
+  if (q.replay >= 0) {
+    Segment &S = q.segs[q.replay];
+    if (q.rpos < S.items.size()) {
+      if (S.items[q.rpos].same(desc, w, stream)) {
+        q.pinned[q.slot][q.n++] = w;
+        ++q.rpos;
+        return;
+      }
+    } else if (S.has_next && S.next.same(desc, w, stream)) {
+      q.flush(); // as recorded: this invoke conflicts with the group (replay ends, the queue is empty)
+      q.backoff_next = 8; // a whole group replayed: the caller is repeating itself
+    }
+    if (q.replay >= 0) { // the caller left the recorded sequence: make the bookkeeping catch up, record the new one
+      const int idx = q.replay;
+      q.replay = -1;
+      rebuild_footprints(q, devmem, q.segs[idx], q.rpos);
+      q.rec.items.assign(q.segs[idx].items.begin(), q.segs[idx].items.begin() + q.rpos);
+      q.rec_open = true;
+      q.backoff = q.backoff_next;
+      if (q.backoff_next < 4096) q.backoff_next *= 2;
+    }
+  }
+  if (q.n == 0 && try_start_replay(q, desc, w, stream)) return;
+  process_item(q, devmem, desc, w, stream);
 }
 
 // The scheduler. The reference calls invoke from OpenMP workers (scf.parallel over the tile grid): with one
@@ -1108,7 +1255,7 @@ struct Scheduler {
           ((std::atomic<int> *)e.w.C)->store(1, std::memory_order_release);
         } else {
           devmem.refresh();
-          process_item(q, devmem, e.desc, e.w, e.stream);
+          submit_item(q, devmem, e.desc, e.w, e.stream);
         }
         continue;
       }
@@ -1209,7 +1356,7 @@ bool enqueue_item(const void *desc, const WorkItem &item, const void *const *ptr
         iq.owner = me;
       }
       if (!iq.scheduled.load(std::memory_order_relaxed)) {
-        process_item(iq.q, devmem, desc, item, s);
+        submit_item(iq.q, devmem, desc, item, s);
         return true;
       }
     }
