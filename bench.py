@@ -536,6 +536,7 @@ def main():
             import re
             import subprocess
             for label, extra in (("tile queue, tiles 32,32,32", ["--tiles", "32", "--queue", "1", "-n", "200"]),
+                                 ("tile queue, tiles 32,32,32, 2 OpenMP callers", ["--tiles", "32", "--queue", "1", "-n", "200", "--threads", "2"]),
                                  ("tile queue, tiles 64,64,64", ["--tiles", "64", "--queue", "1", "-n", "200"]),
                                  ("tile queue, tiles 32,32,32, bf16 + VNNI-2 W", ["--tiles", "32", "--queue", "1", "-n", "200", "--bf16"]),
                                  ("tile queue, tiles 64,64,64, bf16 + VNNI-2 W", ["--tiles", "64", "--queue", "1", "-n", "200", "--bf16"]),

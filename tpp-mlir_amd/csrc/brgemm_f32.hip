@@ -646,6 +646,7 @@ static hipError_t launch_fast(const GemmArgs &a, hipStream_t s) {
 
 hipError_t launch_gemm_bf16_fast(int tile, const GemmArgs &a, hipStream_t s); // brgemm_bf16.hip
 hipError_t launch_f32_lw(int tile, const GemmArgs &a, hipStream_t s);         // brgemm_f32_lw.hip
+hipError_t launch_f32_lw_grouped(int tile, const GemmArgs &a, const WorkItem *items, int n_items, hipStream_t s);
 int pick_bf16_tile(const GemmDesc &d);
 bool bf16_fast_eligible(const GemmDesc &d);
 
@@ -692,9 +693,16 @@ hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_i
     const int64_t t64 = (d.m % 64 == 0 && d.n % 64 == 0) ? (int64_t)n_items * (d.m / 64) * (d.n / 64) : 0;
     const int64_t t6432 = (d.m % 64 == 0) ? (int64_t)n_items * (d.m / 64) * (d.n / 32) : 0;
     if (n_items <= 65535 * 32) { // grid.x carries the item index
+      // the loader-wave kernels (brgemm_f32_lw.hip) in grouped mode; TPP_GROUPED_FAST builds the round-1 register-staged family for A/B runs
+#ifdef TPP_GROUPED_FAST
       if (t64 >= g_num_cus) return launch_fast_grouped_t<2, 2, 1, TPP_NACC, true>(a, items, n_items, stream);
       if (t6432 >= g_num_cus) return launch_fast_grouped_t<2, 1, 2, TPP_NACC, true>(a, items, n_items, stream);
       return launch_fast_grouped_t<1, 1, 4, TPP_NACC, false>(a, items, n_items, stream);
+#else
+      if (t64 >= g_num_cus) return launch_f32_lw_grouped(t64 >= 2 * g_num_cus ? 0 : 1, a, items, n_items, stream);
+      if (t6432 >= g_num_cus) return launch_f32_lw_grouped(2, a, items, n_items, stream);
+      return launch_f32_lw_grouped(3, a, items, n_items, stream);
+#endif
     }
   }
   // bf16 + VNNI-2 B with 16-byte loads: 8-element A pieces, pair-rows of B 16-byte aligned

@@ -28,7 +28,7 @@ constexpr int LW_NSLOT = 4; // LDS ring slots
 typedef __attribute__((address_space(3))) void lds_void_lw;
 
 template <int WM, int WN, int WK>
-__global__ __launch_bounds__(64 * (WM * WN * WK + 2)) void brgemm_f32_lw(GemmArgs p) {
+__global__ __launch_bounds__(64 * (WM * WN * WK + 2)) void brgemm_f32_lw(GemmArgs p, const WorkItem *__restrict__ items) {
   constexpr int NMW = WM * WN * WK; // MFMA waves
   constexpr int BM = 32 * WM, BN = 32 * WN;
   constexpr int A_STAGE = BM * LW_BK, B_STAGE = LW_BK * BN, SLOT = A_STAGE + B_STAGE; // floats
@@ -41,15 +41,18 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + 2)) void brgemm_f32_lw(GemmArg
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // XCD-blocked (8, bn, bm) or plain (1, tiles_n, tiles_m) grid: see brgemm_f32.hip
-  const int tm = (int)(blockIdx.x >> 1) * p.tiles_m + (int)blockIdx.z;
-  const int tn = (int)(blockIdx.x & 1) * p.tiles_n + (int)blockIdx.y;
+  // XCD-blocked (8, bn, bm) or plain (1, tiles_n, tiles_m) grid: see brgemm_f32.hip. items != nullptr: grouped mode (tile
+  // queue), grid (items, tiles_n, tiles_m): workgroup = one tile of one queued invoke, operands and batch count from its item
+  WorkItem it{p.A, p.B, p.C, p.D, (int64_t)p.br};
+  if (items) it = items[blockIdx.x];
+  const int tm = items ? (int)blockIdx.z : (int)(blockIdx.x >> 1) * p.tiles_m + (int)blockIdx.z;
+  const int tn = items ? (int)blockIdx.y : (int)(blockIdx.x & 1) * p.tiles_n + (int)blockIdx.y;
   const int m0 = tm * BM, n0 = tn * BN;
-  const float *__restrict__ A = (const float *)p.A;
-  const float *__restrict__ B = (const float *)p.B;
-  float *__restrict__ C = (float *)p.C;
+  const float *__restrict__ A = (const float *)it.A;
+  const float *__restrict__ B = (const float *)it.B;
+  float *__restrict__ C = (float *)it.C;
   const int kchunks = p.k / LW_BK;
-  const int T = p.br * kchunks;
+  const int T = (int)it.br * kchunks;
 
   if (wave >= NMW) {
     // ---- loader waves --------------------------------------------------------------------
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + 2)) void brgemm_f32_lw(GemmArg
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
   float bias = 0.0f;
   if (wk == 0) {
-    if (p.ep & EP_BIAS) bias = ((const float *)p.D)[ccol];
+    if (p.ep & EP_BIAS) bias = ((const float *)it.D)[ccol];
     if (!(p.ep & EP_BETA0)) {
 #pragma unroll
       for (int r = 0; r < 16; ++r)
@@ -236,8 +239,32 @@ template <int WM, int WN, int WK> static hipError_t launch_lw_t(const GemmArgs &
     if (tiles_m > 65535 || tiles_n > 65535) return hipErrorInvalidValue;
     grid = dim3(1, tiles_n, tiles_m);
   }
-  hipLaunchKernelGGL((brgemm_f32_lw<WM, WN, WK>), grid, dim3(NT), lds, s, args);
+  hipLaunchKernelGGL((brgemm_f32_lw<WM, WN, WK>), grid, dim3(NT), lds, s, args, (const WorkItem *)nullptr);
   return hipGetLastError();
+}
+
+// grouped launch (tile queue): one workgroup per (item, tile of the item); m, n multiples of the tile, k of 64
+template <int WM, int WN, int WK>
+static hipError_t launch_lw_grouped_t(const GemmArgs &a, const WorkItem *items, int n_items, hipStream_t s) {
+  constexpr int BM = 32 * WM, BN = 32 * WN, NT = 64 * (WM * WN * WK + 2);
+  constexpr size_t lds = (size_t)LW_NSLOT * (BM * LW_BK + LW_BK * BN) * sizeof(float);
+  static std::atomic<unsigned long long> lds_set{0};
+  if (hipError_t e = ensure_dynamic_lds((const void *)brgemm_f32_lw<WM, WN, WK>, (int)lds, lds_set); e != hipSuccess) return e;
+  GemmArgs args = a;
+  args.tiles_m = args.tiles_n = 0;
+  hipLaunchKernelGGL((brgemm_f32_lw<WM, WN, WK>), dim3((unsigned)n_items, a.n / BN, a.m / BM), dim3(NT), lds, s, args, items);
+  return hipGetLastError();
+}
+
+// tile as in launch_f32_lw
+hipError_t launch_f32_lw_grouped(int tile, const GemmArgs &a, const WorkItem *items, int n_items, hipStream_t s) {
+  switch (tile) {
+  case 0: return launch_lw_grouped_t<2, 2, 1>(a, items, n_items, s);
+  case 1: return launch_lw_grouped_t<2, 2, 2>(a, items, n_items, s);
+  case 2: return launch_lw_grouped_t<2, 1, 2>(a, items, n_items, s);
+  case 3: return launch_lw_grouped_t<1, 1, 4>(a, items, n_items, s);
+  default: return hipErrorInvalidValue;
+  }
 }
 
 // tile: 0 = 64x64 (4 MFMA waves), 1 = 64x64 with K split over 2 wave groups (8 MFMA waves, two per
