@@ -430,3 +430,73 @@ def test_trace_cache_replays_and_diverges(rtq, seed):
             ref[b][:] = fresh
             dbuf[b].copy_(dev(fresh))
         rt.synchronize()
+
+
+def test_trace_cache_with_several_callers(rtq):
+    """Four caller threads run a 3-layer chain of 32x32 tile GEMMs (a barrier after every layer, as the OpenMP loops of the
+    compiled code do) eight times over: the scheduler sees the same groups in a different interleaving every time and
+    replays them by membership. Then the weights pointer of one layer changes (same shapes, another buffer) and two
+    tiles are skipped: the replay must notice. Every run against the oracle."""
+    rt = rtq
+    rng = np.random.default_rng(77)
+    MB, NB, KB = 4, 8, 8  # activations [MB][KB] blocks of 32x32, weights [NB][KB] blocks (NB == KB: layers chain)
+    X = (rng.uniform(-1, 1, MB * KB * 1024) * 0.3).astype(np.float32)
+    Ws = [(rng.uniform(-1, 1, NB * KB * 1024) * 0.2).astype(np.float32) for _ in range(4)]
+    h = rt.brgemm_dispatch(F32, 32, 32, 32, 32, 32, 32, 1024, 1024, 4)
+    dX, dW = dev(X), [dev(w) for w in Ws]
+    acts = [dev(np.zeros(MB * NB * 1024, np.float32)) for _ in range(3)]
+    nthr = 4
+    barrier = threading.Barrier(nthr)
+    errors = []
+
+    def run(weights, skip):
+        def worker(tid):
+            try:
+                src = dX
+                for layer in range(3):
+                    for t in range(tid, MB * NB, nthr):
+                        if (layer, t) in skip:
+                            continue
+                        i, j = divmod(t, NB)
+                        rt.brgemm(F32, h, src, i * KB * 1024, weights[layer], j * KB * 1024, acts[layer], t * 1024, KB)
+                    barrier.wait()
+                    src = acts[layer]
+            except Exception as ex:  # noqa: BLE001
+                errors.append(repr(ex))
+                barrier.abort()
+        ths = [threading.Thread(target=worker, args=(w,)) for w in range(nthr)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+
+    def oracle(weights, skip, prev):
+        src, outs = X, []
+        for layer in range(3):
+            out = prev[layer].copy()
+            for t in range(MB * NB):
+                if (layer, t) in skip:
+                    continue
+                i, j = divmod(t, NB)
+                orc.brgemm(F32, 32, 32, 32, 32, 32, 32, 1024, 1024, 4, src, i * KB * 1024, weights[layer], j * KB * 1024, out, t * 1024, KB)
+            outs.append(out)
+            src = out
+        return outs
+
+    prev = [np.zeros(MB * NB * 1024, np.float32) for _ in range(3)]
+    for rep in range(8):
+        run(dW[:3], set())
+    rt.synchronize()
+    assert not errors, errors
+    ref = oracle(Ws[:3], set(), prev)
+    for layer in range(3):
+        close(host(acts[layer], X), ref[layer], F32)
+    # diverge: layer 1 reads other weights, two tiles are not computed (they keep their old values)
+    skip = {(0, 5), (2, 17)}
+    for rep in range(3):
+        run([dW[0], dW[3], dW[2]], skip)
+    rt.synchronize()
+    assert not errors, errors
+    ref2 = oracle([Ws[0], Ws[3], Ws[2]], skip, ref)
+    for layer in range(3):
+        close(host(acts[layer], X), ref2[layer], F32)

@@ -673,13 +673,46 @@ struct TraceItem {
     return desc == d && w.A == x.A && w.B == x.B && w.C == x.C && w.D == x.D && w.br == x.br && stream == s;
   }
 };
-// A group as it was once collected: its invokes in order and the invoke that ended it by conflicting with it.
+// A group as it was once collected: its invokes (in the order of that collection, and as a hash set) and the invokes that have
+// been seen to end it by conflicting with it.
 struct Segment {
   std::vector<TraceItem> items;
-  TraceItem next;
-  bool has_next = false;
+  std::vector<TraceItem> terminators;
+  std::vector<uint32_t> seen; // round in which items[i] was last replayed (an invoke may join a group once)
+  std::vector<int32_t> table; // open addressing over items, -1 = empty
+  uint32_t round = 0;
   bool vec_ok = true, out_ok = true;
   uint64_t last_use = 0;
+  static size_t hash(const WorkItem &w) {
+    uint64_t h = (uint64_t)(uintptr_t)w.C * 0x9E3779B97F4A7C15ull;
+    h ^= ((uint64_t)(uintptr_t)w.A >> 4) * 0xC2B2AE3D27D4EB4Full;
+    h ^= ((uint64_t)(uintptr_t)w.B >> 4) * 0x165667B19E3779F9ull;
+    return (size_t)(h ^ (h >> 29));
+  }
+  void build() {
+    size_t cap = 16;
+    while (cap < 2 * items.size()) cap *= 2;
+    table.assign(cap, -1);
+    for (size_t i = 0; i < items.size(); ++i) {
+      size_t at = hash(items[i].w) & (cap - 1);
+      while (table[at] >= 0) at = (at + 1) & (cap - 1);
+      table[at] = (int32_t)i;
+    }
+    seen.assign(items.size(), 0);
+    round = 0;
+  }
+  int index_of(const void *d, const WorkItem &w, hipStream_t st) const {
+    if (table.empty()) return -1;
+    const size_t mask = table.size() - 1;
+    for (size_t at = hash(w) & mask; table[at] >= 0; at = (at + 1) & mask)
+      if (items[table[at]].same(d, w, st)) return table[at];
+    return -1;
+  }
+  bool is_terminator(const void *d, const WorkItem &w, hipStream_t st) const {
+    for (const TraceItem &t : terminators)
+      if (t.same(d, w, st)) return true;
+    return false;
+  }
 };
 
 struct TileQueue {
@@ -688,16 +721,21 @@ struct TileQueue {
   // iteration (the timing loop of tpp-run, every layer of a model). Whether a group of queued invokes is conflict-free,
   // and whether the next invoke conflicts with it, is a pure function of that sequence of (descriptor, pointers, batch)
   // - the footprints follow from them - so a group that was collected once with full bookkeeping is REPLAYED the next
-  // time its first invoke shows up on an empty queue: each following invoke is compared with the recorded one (seven
-  // words) and appended to the work list, nothing else; the recorded terminator launches the group. The first invoke
-  // that differs rebuilds the footprints of the replayed prefix and drops back to the full bookkeeping (and records the
-  // new sequence). Replaying a recorded flush is always safe (a flush never is unsafe), skipping checks is safe because
-  // the same sequence was proven conflict-free. Callers whose interleaving changes from run to run (several OpenMP
-  // callers in stamp order) mismatch often: after a mismatch the cache is left alone for a growing number of groups.
+  // time one of its invokes shows up on an empty queue: each following invoke that is a MEMBER of the recorded group
+  // (compared with the next recorded one first, else looked up in the group's hash set) and has not joined in this
+  // round is appended to the work list, nothing else; an invoke that has been seen to end the group launches it.
+  // Membership, not order: a group is conflict-free iff its invokes are pairwise so, in any order and for any subset -
+  // which is what several OpenMP callers produce, whose interleaving changes from iteration to iteration. Any other
+  // invoke rebuilds the footprints of what has been queued and drops back to the full bookkeeping: if it conflicts, it
+  // is remembered as one more terminator of the group; if it joins, the new group is recorded, and the cache is left
+  // alone for a growing number of groups. Replaying a flush is always safe, skipping the checks is safe because the
+  // same set was proven conflict-free.
   static constexpr size_t NSEG = 8, MIN_SEG = 16;
   std::vector<Segment> segs;
   int replay = -1;        // index of the segment being replayed
-  size_t rpos = 0;        // next item of it
+  size_t rpos = 0;        // the item expected next (a hint: the one after the last match)
+  int learn = -1;         // a replay of this segment was just abandoned: if the invoke that did it conflicts, it is a terminator
+  size_t learn_n = 0;     // ... provided the group still has this many invokes
   Segment rec;            // the group being recorded (full bookkeeping path)
   bool rec_open = false;
   uint64_t use_clock = 0;
@@ -728,15 +766,20 @@ struct TileQueue {
     }
   }
   void store_recording(const TraceItem *next) {
-    if (rec_open && rec.items.size() >= MIN_SEG) {
-      rec.has_next = next != nullptr;
-      if (next) rec.next = *next;
+    if (learn >= 0 && next && rec_open && rec.items.size() == learn_n) {
+      // the group is exactly what was replayed from segs[learn] and `next` conflicts with it: one more way that group ends
+      Segment &S = segs[learn];
+      if (S.terminators.size() < 64 && !S.is_terminator(next->desc, next->w, next->stream)) S.terminators.push_back(*next);
+    } else if (rec_open && rec.items.size() >= MIN_SEG) {
+      rec.terminators.clear();
+      if (next) rec.terminators.push_back(*next);
       rec.vec_ok = vec_ok;
       rec.out_ok = out_ok;
       rec.last_use = ++use_clock;
+      rec.build();
       size_t at = segs.size();
       for (size_t i = 0; i < segs.size(); ++i)
-        if (segs[i].items[0].same(rec.items[0].desc, rec.items[0].w, rec.items[0].stream)) at = i; // same start: the newer sequence wins
+        if (segs[i].index_of(rec.items[0].desc, rec.items[0].w, rec.items[0].stream) >= 0) at = i; // overlapping group: the newer one wins
       if (at == segs.size() && segs.size() >= NSEG) {
         at = 0;
         for (size_t i = 1; i < segs.size(); ++i)
@@ -745,13 +788,21 @@ struct TileQueue {
       if (at == segs.size()) segs.emplace_back();
       std::swap(segs[at], rec);
     }
+    learn = -1;
     rec.items.clear();
     rec_open = false;
   }
-  int find_segment(const void *d, const WorkItem &w, hipStream_t s) {
-    for (size_t i = 0; i < segs.size(); ++i)
-      if (segs[i].items[0].same(d, w, s)) return (int)i;
-    return -1;
+  // the most recently used recorded group that contains the invoke; its index in *item
+  int find_segment(const void *d, const WorkItem &w, hipStream_t s, int *item) {
+    int best = -1;
+    for (size_t i = 0; i < segs.size(); ++i) {
+      const int idx = segs[i].index_of(d, w, s);
+      if (idx >= 0 && (best < 0 || segs[i].last_use > segs[best].last_use)) {
+        best = (int)i;
+        *item = idx;
+      }
+    }
+    return best;
   }
   // next: the invoke whose conflict ends this group (nullptr: an external flush point)
   void flush(const TraceItem *next = nullptr) {
@@ -809,19 +860,30 @@ inline void append_to_group(TileQueue &q, int kind, const void *desc, const Work
     q.rec_open = true;
   }
   if (q.rec_open) q.rec.items.push_back(TraceItem{desc, w, stream});
+  if (q.learn >= 0) { // the invoke that ended a replay joined the group: the caller has left the recorded pattern
+    q.learn = -1;
+    q.backoff = q.backoff_next;
+    if (q.backoff_next < 4096) q.backoff_next *= 2;
+  }
   q.pinned[q.slot][q.n++] = w;
   for (int i = 0; i < n_in; ++i) q.reads.insert(*in[i], anchor_in[i]);
   q.writes.insert(out, anchor_out);
 }
-// the first invoke of a group on an empty queue: replay the recorded group that starts with it, if there is one
+// the first invoke of a group on an empty queue: replay the recorded group it belongs to, if there is one
 inline bool try_start_replay(TileQueue &q, const void *desc, const WorkItem &w, hipStream_t stream) {
   if (q.backoff > 0) {
     --q.backoff;
     return false;
   }
-  const int idx = q.find_segment(desc, w, stream);
+  int item = 0;
+  const int idx = q.find_segment(desc, w, stream, &item);
   if (idx < 0) return false;
   Segment &S = q.segs[idx];
+  if (++S.round == 0) { // (wrapped: forget the marks)
+    std::fill(S.seen.begin(), S.seen.end(), 0u);
+    S.round = 1;
+  }
+  S.seen[item] = S.round;
   q.ensure_slot();
   q.kind = *(const int *)desc;
   q.desc = desc;
@@ -830,7 +892,7 @@ inline bool try_start_replay(TileQueue &q, const void *desc, const WorkItem &w, 
   q.out_ok = S.out_ok;
   q.pinned[q.slot][q.n++] = w;
   q.replay = idx;
-  q.rpos = 1;
+  q.rpos = (size_t)item + 1;
   S.last_use = ++q.use_clock;
   return true;
 }
@@ -859,11 +921,11 @@ __attribute__((always_inline)) inline void process_item(TileQueue &q, DeviceRang
   append_to_group(q, kind, desc, w, out, anchor_out, in, anchor_in, o.n_in, o.vec_ok, o.out_ok, stream);
 }
 
-// footprints of the first k items of segment S into the (empty) read / write sets: a replay is being abandoned
-inline void rebuild_footprints(TileQueue &q, DeviceRanges &devmem, const Segment &S, size_t k) {
-  for (size_t i = 0; i < k; ++i) {
+// footprints of the queued invokes into the (empty) read / write sets: a replay is being abandoned
+inline void rebuild_footprints(TileQueue &q, DeviceRanges &devmem) {
+  for (int i = 0; i < q.n; ++i) {
     QueuedOps o;
-    queued_operands(S.items[i].desc, S.items[i].w, o);
+    queued_operands(q.desc, q.pinned[q.slot][i], o);
     for (int j = 0; j <= o.out; ++j) {
       const Operand &x = o.op[j];
       uintptr_t a = 0;
@@ -876,28 +938,30 @@ inline void rebuild_footprints(TileQueue &q, DeviceRanges &devmem, const Segment
     }
   }
 }
-// One queued invoke: replayed from the trace cache if it continues a recorded group, else the full bookkeeping.
+// One queued invoke: replayed from the trace cache if it belongs to the recorded group being replayed, else the full bookkeeping.
 inline void submit_item(TileQueue &q, DeviceRanges &devmem, const void *desc, const WorkItem &w, hipStream_t stream) {
   if (q.replay >= 0) {
     Segment &S = q.segs[q.replay];
-    if (q.rpos < S.items.size()) {
-      if (S.items[q.rpos].same(desc, w, stream)) {
-        q.pinned[q.slot][q.n++] = w;
-        ++q.rpos;
-        return;
-      }
-    } else if (S.has_next && S.next.same(desc, w, stream)) {
-      q.flush(); // as recorded: this invoke conflicts with the group (replay ends, the queue is empty)
-      q.backoff_next = 8; // a whole group replayed: the caller is repeating itself
+    int idx = -1;
+    if (q.rpos < S.items.size() && S.items[q.rpos].same(desc, w, stream)) idx = (int)q.rpos;
+    else idx = S.index_of(desc, w, stream);
+    if (idx >= 0 && S.seen[idx] != S.round) {
+      S.seen[idx] = S.round;
+      q.pinned[q.slot][q.n++] = w;
+      q.rpos = (size_t)idx + 1;
+      return;
     }
-    if (q.replay >= 0) { // the caller left the recorded sequence: make the bookkeeping catch up, record the new one
-      const int idx = q.replay;
+    if (idx < 0 && S.is_terminator(desc, w, stream)) {
+      q.flush();          // as seen before: this invoke conflicts with the group (replay ends, the queue is empty)
+      q.backoff_next = 8; // a whole group replayed: the caller is repeating itself
+    } else { // neither a member nor a known terminator: make the bookkeeping catch up with what has been queued
+      q.learn = q.replay;
+      q.learn_n = (size_t)q.n;
       q.replay = -1;
-      rebuild_footprints(q, devmem, q.segs[idx], q.rpos);
-      q.rec.items.assign(q.segs[idx].items.begin(), q.segs[idx].items.begin() + q.rpos);
+      rebuild_footprints(q, devmem);
+      q.rec.items.clear();
+      for (int i = 0; i < q.n; ++i) q.rec.items.push_back(TraceItem{q.desc, q.pinned[q.slot][i], q.stream});
       q.rec_open = true;
-      q.backoff = q.backoff_next;
-      if (q.backoff_next < 4096) q.backoff_next *= 2;
     }
   }
   if (q.n == 0 && try_start_replay(q, desc, w, stream)) return;
