@@ -52,6 +52,14 @@ namespace {
     if (e_ != hipSuccess) die("tpp-xsmm-hip: %s failed: %s (no CPU fallback exists)", #expr, hipGetErrorString(e_)); \
   } while (0)
 
+inline void cpu_relax() {
+#if defined(__x86_64__)
+  __builtin_ia32_pause();
+#else
+  asm volatile("" ::: "memory");
+#endif
+}
+
 struct Config {
   std::atomic<int> async{0};
   std::atomic<hipStream_t> stream{nullptr};
@@ -1100,11 +1108,13 @@ struct Scheduler {
     for (uint64_t i = 0; i < PQueue::CAP; ++i) new (&Q.ring[i].seq) std::atomic<uint32_t>(0);
   }
   uint64_t stamp() {
+#if defined(__x86_64__)
     if (use_tsc) {
       unsigned lo, hi;
       asm volatile("lfence\n\trdtsc" : "=a"(lo), "=d"(hi)::"memory"); // after every earlier load (the caller's synchronisation) has completed
       return ((uint64_t)hi << 32) | lo;
     }
+#endif
     return stamp_ctr.fetch_add(1, std::memory_order_seq_cst);
   }
   PQueue *ring_at(int i) { return i == MAXQ ? &overflow : queues[i].load(std::memory_order_acquire); }
@@ -1159,7 +1169,7 @@ struct Scheduler {
       // then streams through a backlog of finished (prefetched) lines while the producer refills in a burst, instead of
       // the two moving in lockstep with every line crossing cores just in time.
       for (unsigned spins = 0; h - (Q.head_seen = Q.head_pub.load(std::memory_order_acquire)) > PQueue::CAP / 2; ++spins) {
-        if (spins < 2000) __builtin_ia32_pause();
+        if (spins < 2000) cpu_relax();
         else {
           ensure_worker();
           sched_yield();
@@ -1181,7 +1191,7 @@ struct Scheduler {
     if (Q.parked.load(std::memory_order_seq_cst) && Q.parked.exchange(0, std::memory_order_seq_cst)) {
       const uint32_t pos = wake_tail.fetch_add(1, std::memory_order_seq_cst);
       std::atomic<uint32_t> &cell = wake_cell[pos % WCAP];
-      while (cell.load(std::memory_order_acquire) != 0) __builtin_ia32_pause(); // (a lap behind: cannot happen with <= MAXQ + 1 rings)
+      while (cell.load(std::memory_order_acquire) != 0) cpu_relax(); // (a lap behind: cannot happen with <= MAXQ + 1 rings)
       cell.store((uint32_t)qi + 1, std::memory_order_seq_cst);
     }
     ensure_worker();
@@ -1211,7 +1221,7 @@ struct Scheduler {
     f.w.C = &flag; // desc == nullptr: a fence
     push(f);
     for (unsigned spins = 0; !flag.load(std::memory_order_acquire); ++spins) {
-      if (spins < 4000) __builtin_ia32_pause();
+      if (spins < 4000) cpu_relax();
       else sched_yield();
     }
   }
@@ -1324,7 +1334,7 @@ struct Scheduler {
         continue;
       }
       if (stop.load(std::memory_order_relaxed)) break;
-      if (++idle < 4000) __builtin_ia32_pause();
+      if (++idle < 4000) cpu_relax();
       else if (idle < 20000) sched_yield();
       else { // nothing for a long while: stop burning a core (a caller that arrives now waits one nap)
         timespec ts{0, idle < 40000 ? 50000 : 1000000}; // 50 us naps, then 1 ms naps
@@ -1364,7 +1374,7 @@ struct SpinLock {
   std::atomic_flag f = ATOMIC_FLAG_INIT;
   void lock() {
     for (unsigned spins = 0; f.test_and_set(std::memory_order_acquire); ++spins) {
-      if (spins < 2000) __builtin_ia32_pause();
+      if (spins < 2000) cpu_relax();
       else sched_yield();
     }
   }
