@@ -27,7 +27,7 @@ constexpr int LW_NSLOT = 4; // LDS ring slots
 
 typedef __attribute__((address_space(3))) void lds_void_lw;
 
-template <int WM, int WN, int WK>
+template <int WM, int WN, int WK, bool GROUPED>
 __global__ __launch_bounds__(64 * (WM * WN * WK + 2)) void brgemm_f32_lw(GemmArgs p, const WorkItem *__restrict__ items) {
   constexpr int NMW = WM * WN * WK; // MFMA waves
   constexpr int BM = 32 * WM, BN = 32 * WN;
@@ -41,12 +41,13 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + 2)) void brgemm_f32_lw(GemmArg
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // XCD-blocked (8, bn, bm) or plain (1, tiles_n, tiles_m) grid: see brgemm_f32.hip. items != nullptr: grouped mode (tile
-  // queue), grid (items, tiles_n, tiles_m): workgroup = one tile of one queued invoke, operands and batch count from its item
+  // XCD-blocked (8, bn, bm) or plain (1, tiles_n, tiles_m) grid: see brgemm_f32.hip. GROUPED (tile queue): grid (items,
+  // tiles_n, tiles_m), workgroup = one tile of one queued invoke, operands and batch count from its item. A template
+  // parameter, not a run-time test: the plain kernel is the headline kernel and must not carry a second mode (measured: 0.6 %).
   WorkItem it{p.A, p.B, p.C, p.D, (int64_t)p.br};
-  if (items) it = items[blockIdx.x];
-  const int tm = items ? (int)blockIdx.z : (int)(blockIdx.x >> 1) * p.tiles_m + (int)blockIdx.z;
-  const int tn = items ? (int)blockIdx.y : (int)(blockIdx.x & 1) * p.tiles_n + (int)blockIdx.y;
+  if constexpr (GROUPED) it = items[blockIdx.x];
+  const int tm = GROUPED ? (int)blockIdx.z : (int)(blockIdx.x >> 1) * p.tiles_m + (int)blockIdx.z;
+  const int tn = GROUPED ? (int)blockIdx.y : (int)(blockIdx.x & 1) * p.tiles_n + (int)blockIdx.y;
   const int m0 = tm * BM, n0 = tn * BN;
   const float *__restrict__ A = (const float *)it.A;
   const float *__restrict__ B = (const float *)it.B;
@@ -226,7 +227,7 @@ template <int WM, int WN, int WK> static hipError_t launch_lw_t(const GemmArgs &
   constexpr int BM = 32 * WM, BN = 32 * WN, NT = 64 * (WM * WN * WK + 2);
   constexpr size_t lds = (size_t)LW_NSLOT * (BM * LW_BK + LW_BK * BN) * sizeof(float);
   static std::atomic<unsigned long long> lds_set{0};
-  if (hipError_t e = ensure_dynamic_lds((const void *)brgemm_f32_lw<WM, WN, WK>, (int)lds, lds_set); e != hipSuccess) return e;
+  if (hipError_t e = ensure_dynamic_lds((const void *)brgemm_f32_lw<WM, WN, WK, false>, (int)lds, lds_set); e != hipSuccess) return e;
   GemmArgs args = a;
   const int tiles_m = a.m / BM, tiles_n = a.n / BN;
   dim3 grid;
@@ -239,7 +240,7 @@ template <int WM, int WN, int WK> static hipError_t launch_lw_t(const GemmArgs &
     if (tiles_m > 65535 || tiles_n > 65535) return hipErrorInvalidValue;
     grid = dim3(1, tiles_n, tiles_m);
   }
-  hipLaunchKernelGGL((brgemm_f32_lw<WM, WN, WK>), grid, dim3(NT), lds, s, args, (const WorkItem *)nullptr);
+  hipLaunchKernelGGL((brgemm_f32_lw<WM, WN, WK, false>), grid, dim3(NT), lds, s, args, (const WorkItem *)nullptr);
   return hipGetLastError();
 }
 
@@ -249,10 +250,10 @@ static hipError_t launch_lw_grouped_t(const GemmArgs &a, const WorkItem *items, 
   constexpr int BM = 32 * WM, BN = 32 * WN, NT = 64 * (WM * WN * WK + 2);
   constexpr size_t lds = (size_t)LW_NSLOT * (BM * LW_BK + LW_BK * BN) * sizeof(float);
   static std::atomic<unsigned long long> lds_set{0};
-  if (hipError_t e = ensure_dynamic_lds((const void *)brgemm_f32_lw<WM, WN, WK>, (int)lds, lds_set); e != hipSuccess) return e;
+  if (hipError_t e = ensure_dynamic_lds((const void *)brgemm_f32_lw<WM, WN, WK, true>, (int)lds, lds_set); e != hipSuccess) return e;
   GemmArgs args = a;
   args.tiles_m = args.tiles_n = 0;
-  hipLaunchKernelGGL((brgemm_f32_lw<WM, WN, WK>), dim3((unsigned)n_items, a.n / BN, a.m / BM), dim3(NT), lds, s, args, items);
+  hipLaunchKernelGGL((brgemm_f32_lw<WM, WN, WK, true>), dim3((unsigned)n_items, a.n / BN, a.m / BM), dim3(NT), lds, s, args, items);
   return hipGetLastError();
 }
 
