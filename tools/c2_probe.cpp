@@ -25,17 +25,19 @@
   } while (0)
 
 int main(int argc, char **argv) {
-  int iters = 200, variant = -1;
+  int iters = 200, variant = -1, br_arg = 16;
   std::string init = "uniform";
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
     if (a == "--iters" && i + 1 < argc) iters = atoi(argv[++i]);
     else if (a == "--init" && i + 1 < argc) init = argv[++i];
     else if (a == "--variant" && i + 1 < argc) variant = atoi(argv[++i]);
+    else if (a == "--br" && i + 1 < argc) br_arg = atoi(argv[++i]); // 0..16 batch elements (kernel-time anatomy: fixed cost vs per chunk)
     else { fprintf(stderr, "unknown flag %s\n", a.c_str()); return 2; }
   }
   if (xsmm_hip_device_count() < 1) { fprintf(stderr, "c2_probe: no HIP device (there is no CPU fallback)\n"); return 1; }
-  const int64_t m = 1024, n = 1024, k = 64, br = 16;
+  if (br_arg < 0 || br_arg > 16) { fprintf(stderr, "--br must be 0..16\n"); return 2; }
+  const int64_t m = 1024, n = 1024, k = 64, br = br_arg;
   const size_t elems = 1024 * 1024;
   std::vector<float> hA(elems), hB(elems), hC(elems);
   std::default_random_engine eng(123);
