@@ -137,7 +137,13 @@ TPP_XSMM_EXPORT double perf_stop_timer(int64_t start);
 /* 0 (default): every invoke returns after its kernel completed (reference
  * semantics). 1: invokes only enqueue on the runtime's stream; call
  * xsmm_hip_synchronize() or perf_stop_timer() to drain. Returns previous mode.
- * Also settable with env TPP_HIP_ASYNC=1. */
+ * Also settable with env TPP_HIP_ASYNC=1.
+ * BUFFER LIFETIME in async mode: operands may be freed / re-allocated only after
+ * xsmm_hip_synchronize(), perf_stop_timer() or xsmm_hip_set_async(0) returned -
+ * those calls launch whatever the tile queue still holds, drain the stream and
+ * forget the device allocation ranges the runtime has cached since the last such
+ * call. Synchronising the device some other way (hipDeviceSynchronize,
+ * torch.cuda.synchronize) leaves queued invokes unlaunched and the cache in place. */
 TPP_XSMM_EXPORT int xsmm_hip_set_async(int enable);
 /* Tile queue (async mode only, device pointers only): invokes of ONE small-tile handle - GEMM
  * family, unary or binary, m, n <= 64: the compiler's native 32x32x32 call pattern and its per-block
