@@ -404,7 +404,13 @@ __global__ __launch_bounds__(256 + 64 * NLW) void brgemm_bf16_dma128(GemmArgs p)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_d[];
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifndef TPP_BF16_LOADERS_FIRST
+#define TPP_BF16_LOADERS_FIRST 1
+#endif
+  // the loader waves are the FIRST hardware waves of the workgroup (waves start in order: the first chunks are requested before
+  // the MFMA waves have been launched); `wave` is the role index: MFMA waves 0-3, loaders 4 .. 4 + NLW - 1
+  const int hw_wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = (LW && TPP_BF16_LOADERS_FIRST) ? (hw_wave < NLW ? 4 + hw_wave : hw_wave - NLW) : hw_wave;
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
   const int tm = (int)(blockIdx.x >> 1) * p.tiles_m + (int)blockIdx.z;

@@ -40,7 +40,13 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + 2)) void brgemm_f32_lw(GemmArg
   extern __shared__ __attribute__((aligned(16))) float smem_lw[];
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifndef TPP_LW_LOADERS_FIRST
+#define TPP_LW_LOADERS_FIRST 1
+#endif
+  // the two loader waves are the FIRST two hardware waves of the workgroup (waves start in order: the panels' first
+  // chunks are requested before the MFMA waves have been launched); `wave` is the role index: MFMA waves 0 .. NMW-1, loaders NMW, NMW+1
+  const int hw_wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = TPP_LW_LOADERS_FIRST ? (hw_wave < 2 ? NMW + hw_wave : hw_wave - 2) : hw_wave;
   // XCD-blocked (8, bn, bm) or plain (1, tiles_n, tiles_m) grid: see brgemm_f32.hip. GROUPED (tile queue): grid (items,
   // tiles_n, tiles_m), workgroup = one tile of one queued invoke, operands and batch count from its item. A template
   // parameter, not a run-time test: the plain kernel is the headline kernel and must not carry a second mode (measured: 0.6 %).
