@@ -393,9 +393,7 @@ __global__ __launch_bounds__(256) void brgemm_grouped(GemmArgs p, const WorkItem
   const WorkItem it = items ? items[blockIdx.y] : WorkItem{p.A, p.B, p.C, p.D, (int64_t)p.br};
   g_cvoid *gA = (g_cvoid *)it.A, *gB = (g_cvoid *)it.B, *gD = (g_cvoid *)it.D; // global, not flat, accesses
   g_void *gC = (g_void *)it.C;
-  typedef __attribute__((address_space(1))) const u32x4 g_cu32x4;
 
-  typedef __attribute__((address_space(1))) const unsigned short g_cu16;
 
   const int tm = blockIdx.x / p.tiles_n, tn = blockIdx.x % p.tiles_n;
   const int m0 = tm * 32, n0 = tn * 32;
@@ -446,27 +444,6 @@ __global__ __launch_bounds__(256) void brgemm_grouped(GemmArgs p, const WorkItem
       return;
     }
     if (!live) return;
-    if constexpr (VEC && sizeof(T) == 2) {
-      // bf16, VNNI-2 B, 16-byte loads (8 elements), widened to f32 on the way into the staging registers:
-      // A piece (row, 8 k) -> two register quads; B piece (pair-row p, 4 columns x 2 k) -> quad of row 2p
-      // (elements 0, 2, 4, 6) and quad of row 2p+1 (elements 1, 3, 5, 7)
-#pragma unroll
-      for (int v = 0; v < 2; ++v) {
-        const int q = lane + 64 * v;
-        // ragged edges: clamped addresses, see above
-        const int a_row = m0 + (q >> 2) < p.m ? m0 + (q >> 2) : p.m - 1, b_col = n0 + 4 * (q & 7) < p.n ? n0 + 4 * (q & 7) : 0;
-        const u32x4 a8 = *(g_cu32x4 *)((g_cu16 *)gA + abase + (int64_t)a_row * p.lda + kk0 + 8 * (q & 3));
-        const u32x4 b8 = *(g_cu32x4 *)((g_cu16 *)gB + bbase + (int64_t)((kk0 >> 1) + (q >> 3)) * (2 * p.ldb) + 2 * b_col);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          ra[2 * v + (e >> 1)][2 * (e & 1)] = __uint_as_float(a8[e] << 16);
-          ra[2 * v + (e >> 1)][2 * (e & 1) + 1] = __uint_as_float(a8[e] & 0xffff0000u);
-          rb[2 * v][e] = __uint_as_float(b8[e] << 16);            // k even, column 4c + e
-          rb[2 * v + 1][e] = __uint_as_float(b8[e] & 0xffff0000u); // k odd
-        }
-      }
-      return;
-    }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int q = lane + 64 * u, row = q >> 3, c4 = q & 7; // 32 rows x 8 pieces of 4 floats
@@ -492,15 +469,8 @@ __global__ __launch_bounds__(256) void brgemm_grouped(GemmArgs p, const WorkItem
     f32x4(&ra)[4] = rs[set][0];
     f32x4(&rb)[4] = rs[set][1];
     float *as = wl + buf * (2 * 32 * GK), *bs = as + 32 * GK;
-    int row, c4, krow, c4b;
-    if constexpr (VEC && sizeof(T) == 2) { // where gload put quad u (see there)
-      const int q = lane + 64 * (u >> 1);
-      row = q >> 2, c4 = 2 * (q & 3) + (u & 1);
-      krow = 2 * (q >> 3) + (u & 1), c4b = q & 7;
-    } else {
-      const int q = lane + 64 * u;
-      row = krow = q >> 3, c4 = c4b = q & 7;
-    }
+    const int q = lane + 64 * u;
+    const int row = q >> 3, krow = row, c4 = q & 7, c4b = c4;
     *(f32x4 *)(as + row * GK + ((c4 ^ ((row >> 1) & 7)) << 2)) = ra[u]; // 128-byte rows: XOR on (row>>1)
     *(f32x4 *)(bs + krow * 32 + 4 * c4b) = rb[u];
   };
@@ -543,17 +513,86 @@ __global__ __launch_bounds__(256) void brgemm_grouped(GemmArgs p, const WorkItem
   // 16 v_accvgpr_read + 16 v_accvgpr_write behind every chunk's last MFMA; a branch around loads defeats the counted waits.)
   const int mine = nchunk > wave ? (nchunk - wave + 3) >> 2 : 0; // chunks of this wave: wave, wave + 4, ...
   int c = wave;
-  gload(c, 0, mine > 0);
-  gload(c + 4, 1, mine > 1);
-  if (mine > 0) swrite(0, 0);
-  for (int i = 0; i + 1 < mine; i += 2) {
-    gload(c + 8, 0, i + 2 < mine);
-    compute(0, true, 1);
-    gload(c + 12, 1, i + 3 < mine);
-    compute(1, true, 0);
-    c += 8;
+  if constexpr (sizeof(T) == 2 && VNNI && VEC) {
+    // bf16 + VNNI-2 B with 16-byte loads (ragged bf16 tiles, e.g. mlir-gen --tiles=64,48,64 --vnni=2): the panels stay bf16 in
+    // LDS and the chunk is TWO v_mfma_f32_32x32x16_bf16 (f32 accumulate, the arithmetic of the other bf16 kernels) instead of
+    // sixteen f32 MFMAs on widened operands. Same pipeline: two chunks of loads in flight, switched off past the stream's end.
+    //   A image [32 rows][32 k] bf16, row pitch 80 B (16-byte fragment reads of 16 consecutive rows hit 16 different bank quads);
+    //   B image = the 16 VNNI pair-rows x 32 columns as they are (a lane's fragment: 4 dwords one pair-row apart).
+    typedef __bf16 bf16x8_g __attribute__((ext_vector_type(8)));
+    constexpr int APITCH = 80, ABYTES = 32 * APITCH, BUFB = ABYTES + 16 * 128;
+    unsigned char *wlb = (unsigned char *)smem_g + wave * 16384;
+    unsigned vA[2], vB[2];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      const int q = lane + 64 * v;
+      const int a_row = m0 + (q >> 2) < p.m ? m0 + (q >> 2) : p.m - 1, b_col = n0 + 4 * (q & 7) < p.n ? n0 + 4 * (q & 7) : 0;
+      vA[v] = (unsigned)((a_row * (int)p.lda + 8 * (q & 3)) * 2);
+      vB[v] = (unsigned)(((q >> 3) * 2 * (int)p.ldb + 2 * b_col) * 2);
+    }
+    u32x4 sa[2][2], sb[2][2];
+    auto gload_bf = [&](int cc, int set, bool live) __attribute__((always_inline)) {
+      const int b = cc / kchunks, kk0 = (cc - b * kchunks) * GK;
+      const int nrec = __builtin_amdgcn_readfirstlane(live ? 0x7fffffff : 0);
+      const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
+          (void *)((const unsigned short *)it.A + (int64_t)b * p.stride_a + kk0), 0, nrec, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(
+          (void *)((const unsigned short *)it.B + (int64_t)b * p.stride_b + (int64_t)(kk0 >> 1) * (2 * p.ldb)), 0, nrec, 0x00020000);
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        sa[set][v] = __builtin_amdgcn_raw_buffer_load_b128(rA, vA[v], 0, 0);
+        sb[set][v] = __builtin_amdgcn_raw_buffer_load_b128(rB, vB[v], 0, 0);
+      }
+    };
+    auto swrite_bf = [&](int buf, int set, int v) __attribute__((always_inline)) {
+      const int q = lane + 64 * v;
+      unsigned char *ab = wlb + buf * BUFB;
+      *(u32x4 *)(ab + (q >> 2) * APITCH + (q & 3) * 16) = sa[set][v];
+      *(u32x4 *)(ab + ABYTES + (q >> 3) * 128 + (q & 7) * 16) = sb[set][v];
+    };
+    auto compute_bf = [&](int buf, bool stage, int set) __attribute__((always_inline)) {
+      const unsigned char *ab = wlb + buf * BUFB;
+      bf16x8_g af[2];
+      u32x4 bfr[2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        af[ks] = *(const bf16x8_g *)(ab + li * APITCH + (2 * ks + lh) * 16);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bfr[ks][t] = *(const unsigned int *)(ab + ABYTES + (8 * ks + 4 * lh + t) * 128 + li * 4);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        if (stage) swrite_bf(buf ^ 1, set, ks);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], __builtin_bit_cast(bf16x8_g, bfr[ks]), acc, 0, 0, 0);
+      }
+    };
+    gload_bf(c, 0, mine > 0);
+    gload_bf(c + 4, 1, mine > 1);
+    if (mine > 0) {
+      swrite_bf(0, 0, 0);
+      swrite_bf(0, 0, 1);
+    }
+    for (int i = 0; i + 1 < mine; i += 2) {
+      gload_bf(c + 8, 0, i + 2 < mine);
+      compute_bf(0, true, 1);
+      gload_bf(c + 12, 1, i + 3 < mine);
+      compute_bf(1, true, 0);
+      c += 8;
+    }
+    if (mine & 1) compute_bf(0, false, 0);
+  } else {
+    gload(c, 0, mine > 0);
+    gload(c + 4, 1, mine > 1);
+    if (mine > 0) swrite(0, 0);
+    for (int i = 0; i + 1 < mine; i += 2) {
+      gload(c + 8, 0, i + 2 < mine);
+      compute(0, true, 1);
+      gload(c + 12, 1, i + 3 < mine);
+      compute(1, true, 0);
+      c += 8;
+    }
+    if (mine & 1) compute(0, false, 0);
   }
-  if (mine & 1) compute(0, false, 0);
   // combine the four waves' partial sums (waves 1..3 park theirs), then wave 0 finishes
   __syncthreads();
   float *red = smem_g;
@@ -706,7 +745,8 @@ hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_i
     }
   }
   // bf16 + VNNI-2 B with 16-byte loads: 8-element A pieces, pair-rows of B 16-byte aligned
-  const bool vec16 = tiles_ok && d.dtype == DT_BF16 && d.vnni_b && !((d.lda | d.stride_a | d.stride_b) & 7) && !(d.ldb & 3);
+  const bool vec16 = tiles_ok && d.dtype == DT_BF16 && d.vnni_b && !((d.lda | d.stride_a | d.stride_b) & 7) && !(d.ldb & 3) &&
+                     d.lda < (1 << 21) && d.ldb < (1 << 21); // (32-bit lane offsets)
   // bf16 tiles of 64x64 with k a multiple of 64: the 64x64 bf16 family in grouped mode (it stores 16-byte
   // row pieces and reads the bias 8 bytes at a time: checked per item by the queue through out_ok)
   if (vec16 && out_ok && d.variant >= V_BF16_FAST && d.variant != V_BF16_SMALL32 && bf16_fast_eligible(d) &&
@@ -836,7 +876,8 @@ hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C,
   // everything else: the grouped kernel with a single, inline work item
   const bool tiles_ok = aligned16 && d.n % 4 == 0 && d.k % GK == 0; // ragged m / n edges are predicated
   const bool vec = tiles_ok && d.dtype == DT_F32 && !d.vnni_b && !((d.lda | d.ldb | d.stride_a | d.stride_b) & 3);
-  const bool vec16 = tiles_ok && d.dtype == DT_BF16 && d.vnni_b && !((d.lda | d.stride_a | d.stride_b) & 7) && !(d.ldb & 3);
+  const bool vec16 = tiles_ok && d.dtype == DT_BF16 && d.vnni_b && !((d.lda | d.stride_a | d.stride_b) & 7) && !(d.ldb & 3) &&
+                     d.lda < (1 << 21) && d.ldb < (1 << 21); // (32-bit lane offsets)
   if (d.dtype == DT_F32) return vec ? launch_grouped_t<float, false, true>(a, nullptr, 1, stream)
                                     : launch_grouped_t<float, false, false>(a, nullptr, 1, stream);
   if (d.vnni_b) return vec16 ? launch_grouped_t<unsigned short, true, true>(a, nullptr, 1, stream)
