@@ -154,6 +154,10 @@ TPP_XSMM_EXPORT int xsmm_hip_set_async(int enable);
  * TPP_HIP_TILE_QUEUE=1. */
 TPP_XSMM_EXPORT int xsmm_hip_set_tile_queue(int enable);
 TPP_XSMM_EXPORT void xsmm_hip_flush(void);
+/* counters of the tile queue since process start: out[0] grouped launches, out[1] invokes queued with the full
+ * dependence bookkeeping, out[2] invokes queued by replay of a recorded group (trace cache), out[3] groups ended by
+ * a remembered terminator, out[4] replays abandoned (the caller left the recorded group) */
+TPP_XSMM_EXPORT void xsmm_hip_tile_queue_stats(int64_t out[5]);
 /* Stream the kernels are launched on (a hipStream_t). NULL = default stream. */
 TPP_XSMM_EXPORT void xsmm_hip_set_stream(void *hip_stream);
 TPP_XSMM_EXPORT void *xsmm_hip_get_stream(void);

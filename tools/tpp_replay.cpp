@@ -186,6 +186,12 @@ int main(int argc, char **argv) {
           whole ? "whole-layer dispatch" : "packed tile invokes", (long)batch, L, queue, mean * 1e6,
           host_dt / (double)n_iter * 1e6, flops / mean / 1e9, flops,
           xsmm_hip_kernel_name(handle[0]));
+  if (queue) {
+    int64_t qs[5];
+    xsmm_hip_tile_queue_stats(qs);
+    fprintf(stderr, "tpp_replay: tile queue: %ld grouped launches, %ld invokes with full bookkeeping, %ld replayed, %ld groups ended by a known terminator, %ld replays abandoned\n",
+            (long)qs[0], (long)qs[1], (long)qs[2], (long)qs[3], (long)qs[4]);
+  }
   if (print) {
     std::vector<float> h(8);
     if (bf16) {

@@ -672,6 +672,9 @@ struct Footprint {
   }
 };
 
+// tile-queue counters (xsmm_hip_tile_queue_stats): launches, invokes queued with full bookkeeping / by replay, abandoned replays
+std::atomic<int64_t> g_q_launches{0}, g_q_checked{0}, g_q_replayed{0}, g_q_abandoned{0}, g_q_terminated{0};
+
 // One queued invoke as the trace cache remembers it.
 struct TraceItem {
   const void *desc = nullptr;
@@ -817,6 +820,7 @@ struct TileQueue {
     store_recording(next);
     replay = -1;
     if (n == 0) return;
+    g_q_launches.fetch_add(1, std::memory_order_relaxed);
     {
       if (kind == KIND_GEMM) HIP_OK(launch_gemm_grouped(*(const GemmDesc *)desc, pinned[slot], n, vec_ok, out_ok, stream));
       else if (kind == KIND_UNARY) HIP_OK(launch_unary_grouped(*(const UnaryDesc *)desc, pinned[slot], n, stream));
@@ -867,6 +871,7 @@ inline void append_to_group(TileQueue &q, int kind, const void *desc, const Work
     q.rec.items.clear();
     q.rec_open = true;
   }
+  g_q_checked.fetch_add(1, std::memory_order_relaxed);
   if (q.rec_open) q.rec.items.push_back(TraceItem{desc, w, stream});
   if (q.learn >= 0) { // the invoke that ended a replay joined the group: the caller has left the recorded pattern
     q.learn = -1;
@@ -902,6 +907,7 @@ inline bool try_start_replay(TileQueue &q, const void *desc, const WorkItem &w, 
   q.replay = idx;
   q.rpos = (size_t)item + 1;
   S.last_use = ++q.use_clock;
+  g_q_replayed.fetch_add(1, std::memory_order_relaxed);
   return true;
 }
 // bookkeeping of one queued invoke: footprints from the descriptor, allocation bases ("anchors" of the 2-D planes) from
@@ -957,12 +963,15 @@ inline void submit_item(TileQueue &q, DeviceRanges &devmem, const void *desc, co
       S.seen[idx] = S.round;
       q.pinned[q.slot][q.n++] = w;
       q.rpos = (size_t)idx + 1;
+      g_q_replayed.fetch_add(1, std::memory_order_relaxed);
       return;
     }
     if (idx < 0 && S.is_terminator(desc, w, stream)) {
+      g_q_terminated.fetch_add(1, std::memory_order_relaxed);
       q.flush();          // as seen before: this invoke conflicts with the group (replay ends, the queue is empty)
       q.backoff_next = 8; // a whole group replayed: the caller is repeating itself
     } else { // neither a member nor a known terminator: make the bookkeeping catch up with what has been queued
+      g_q_abandoned.fetch_add(1, std::memory_order_relaxed);
       q.learn = q.replay;
       q.learn_n = (size_t)q.n;
       q.replay = -1;
@@ -1691,6 +1700,13 @@ extern "C" int xsmm_hip_set_tile_queue(int enable) {
   return cfg().tile_queue.exchange(enable != 0);
 }
 extern "C" void xsmm_hip_flush(void) { flush_tile_queue(); }
+extern "C" void xsmm_hip_tile_queue_stats(int64_t out[5]) {
+  out[0] = g_q_launches.load(std::memory_order_relaxed);
+  out[1] = g_q_checked.load(std::memory_order_relaxed);
+  out[2] = g_q_replayed.load(std::memory_order_relaxed);
+  out[3] = g_q_terminated.load(std::memory_order_relaxed);
+  out[4] = g_q_abandoned.load(std::memory_order_relaxed);
+}
 extern "C" void *xsmm_hip_get_stream(void) { return (void *)cfg().stream.load(); }
 extern "C" void xsmm_hip_synchronize(void) {
   flush_tile_queue();

@@ -77,6 +77,7 @@ _SIGNATURES = {
     "xsmm_hip_set_stream": (None, [VP]),
     "xsmm_hip_set_tile_queue": (ctypes.c_int, [ctypes.c_int]),
     "xsmm_hip_flush": (None, []),
+    "xsmm_hip_tile_queue_stats": (None, [ctypes.POINTER(ctypes.c_int64)]),
     "xsmm_hip_get_stream": (VP, []),
     "xsmm_hip_synchronize": (None, []),
     "xsmm_hip_host_resident": (ctypes.c_int, [VP, I64]),
@@ -200,6 +201,12 @@ class XsmmRuntime:
 
     def flush(self):
         self.lib.xsmm_hip_flush()
+
+    def tile_queue_stats(self):
+        """(grouped launches, invokes with full bookkeeping, invokes replayed, groups ended by a known terminator, replays abandoned)"""
+        out = (ctypes.c_int64 * 5)()
+        self.lib.xsmm_hip_tile_queue_stats(out)
+        return tuple(out)
 
     def synchronize(self):
         self.lib.xsmm_hip_synchronize()
