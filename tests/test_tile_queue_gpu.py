@@ -392,6 +392,7 @@ def test_trace_cache_replays_and_diverges(rtq, seed):
         else:
             orc.brgemm(F32, 32, 32, 32, 32, 32, 32, 1024, 1024, 0, s, so, s2, s2o, d, do_, 1)
 
+    stats0 = rt.tile_queue_stats()
     # long runs of one op over consecutive tiles (what compiled layers look like), glued by random single ops
     prog = []
     for run in range(10):
@@ -430,6 +431,9 @@ def test_trace_cache_replays_and_diverges(rtq, seed):
             ref[b][:] = fresh
             dbuf[b].copy_(dev(fresh))
         rt.synchronize()
+    launches, checked, replayed, terminated, abandoned = (b - a for a, b in zip(stats0, rt.tile_queue_stats()))
+    # the cache did its work: most invokes were queued by replay, and the mutations were noticed
+    assert replayed > checked // 2 and terminated > 0 and abandoned > 0, (launches, checked, replayed, terminated, abandoned)
 
 
 def test_trace_cache_with_several_callers(rtq):
@@ -484,6 +488,7 @@ def test_trace_cache_with_several_callers(rtq):
         return outs
 
     prev = [np.zeros(MB * NB * 1024, np.float32) for _ in range(3)]
+    stats0 = rt.tile_queue_stats()
     for rep in range(8):
         run(dW[:3], set())
     rt.synchronize()
@@ -500,3 +505,5 @@ def test_trace_cache_with_several_callers(rtq):
     ref2 = oracle([Ws[0], Ws[3], Ws[2]], skip, ref)
     for layer in range(3):
         close(host(acts[layer], X), ref2[layer], F32)
+    launches, checked, replayed, terminated, abandoned = (b - a for a, b in zip(stats0, rt.tile_queue_stats()))
+    assert replayed > 0 and abandoned > 0, (launches, checked, replayed, terminated, abandoned)

@@ -741,7 +741,7 @@ struct TileQueue {
   // is remembered as one more terminator of the group; if it joins, the new group is recorded, and the cache is left
   // alone for a growing number of groups. Replaying a flush is always safe, skipping the checks is safe because the
   // same set was proven conflict-free.
-  static constexpr size_t NSEG = 8, MIN_SEG = 16;
+  static constexpr size_t NSEG = 64, MIN_SEG = 16; // recorded groups kept (a 20-layer model repeats ~20 groups per iteration)
   std::vector<Segment> segs;
   int replay = -1;        // index of the segment being replayed
   size_t rpos = 0;        // the item expected next (a hint: the one after the last match)
@@ -750,7 +750,7 @@ struct TileQueue {
   Segment rec;            // the group being recorded (full bookkeeping path)
   bool rec_open = false;
   uint64_t use_clock = 0;
-  unsigned backoff = 0, backoff_next = 8; // groups to collect without consulting the cache / after the next mismatch
+  unsigned backoff = 0, backoff_next = 2; // groups to collect without consulting the cache / after the next mismatch
   int kind = 0;               // KIND_GEMM / KIND_UNARY / KIND_BINARY of the queued invokes
   const void *desc = nullptr; // their (single) descriptor
   bool vec_ok = true, out_ok = true;
@@ -876,7 +876,7 @@ inline void append_to_group(TileQueue &q, int kind, const void *desc, const Work
   if (q.learn >= 0) { // the invoke that ended a replay joined the group: the caller has left the recorded pattern
     q.learn = -1;
     q.backoff = q.backoff_next;
-    if (q.backoff_next < 4096) q.backoff_next *= 2;
+    if (q.backoff_next < 64) q.backoff_next *= 2;
   }
   q.pinned[q.slot][q.n++] = w;
   for (int i = 0; i < n_in; ++i) q.reads.insert(*in[i], anchor_in[i]);
@@ -969,7 +969,7 @@ inline void submit_item(TileQueue &q, DeviceRanges &devmem, const void *desc, co
     if (idx < 0 && S.is_terminator(desc, w, stream)) {
       g_q_terminated.fetch_add(1, std::memory_order_relaxed);
       q.flush();          // as seen before: this invoke conflicts with the group (replay ends, the queue is empty)
-      q.backoff_next = 8; // a whole group replayed: the caller is repeating itself
+      q.backoff_next = 2; // a whole group replayed: the caller is repeating itself
     } else { // neither a member nor a known terminator: make the bookkeeping catch up with what has been queued
       g_q_abandoned.fetch_add(1, std::memory_order_relaxed);
       q.learn = q.replay;
