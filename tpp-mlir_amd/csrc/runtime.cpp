@@ -188,13 +188,16 @@ struct DeviceRanges {
       epoch = e;
     }
   }
-  mutable size_t mru = 0; // index of the last hit: operands of consecutive invokes share allocations
-  bool contains(const void *p) const {
+  // index of the last hit PER OPERAND POSITION (A, B, C, D of consecutive invokes each stay in their own allocation;
+  // one shared index would miss on every operand and fall into the scan)
+  mutable size_t mru[4] = {0, 0, 0, 0};
+  bool contains(const void *p, int pos = 0) const {
     const uintptr_t a = (uintptr_t)p;
-    if (mru < known.size() && a >= known[mru].b && a < known[mru].e) return true;
+    size_t &m = mru[pos & 3];
+    if (m < known.size() && a >= known[m].b && a < known[m].e) return true;
     for (size_t i = 0; i < known.size(); ++i)
       if (a >= known[i].b && a < known[i].e) {
-        mru = i;
+        m = i;
         return true;
       }
     return false;
@@ -205,8 +208,8 @@ struct DeviceRanges {
       if (a >= r.b && a < r.e) return r.b;
     return 0;
   }
-  bool is_device(const void *p) {
-    if (!p || contains(p)) return true;
+  bool is_device(const void *p, int pos = 0) {
+    if (!p || contains(p, pos)) return true;
     if (!is_device_ptr(p)) return false;
     hipDeviceptr_t base = nullptr;
     size_t size = 0;
@@ -674,6 +677,9 @@ struct Footprint {
 
 // tile-queue counters (xsmm_hip_tile_queue_stats): launches, invokes queued with full bookkeeping / by replay, abandoned replays
 std::atomic<int64_t> g_q_launches{0}, g_q_checked{0}, g_q_replayed{0}, g_q_abandoned{0}, g_q_terminated{0};
+// (bumped only by whoever owns the queue state at that moment - the inline queue's lock holder or the scheduler thread: a
+// plain load + store, not a locked read-modify-write on the enqueue path)
+inline void bump(std::atomic<int64_t> &c) { c.store(c.load(std::memory_order_relaxed) + 1, std::memory_order_relaxed); }
 
 // One queued invoke as the trace cache remembers it.
 struct TraceItem {
@@ -820,7 +826,7 @@ struct TileQueue {
     store_recording(next);
     replay = -1;
     if (n == 0) return;
-    g_q_launches.fetch_add(1, std::memory_order_relaxed);
+    bump(g_q_launches);
     {
       if (kind == KIND_GEMM) HIP_OK(launch_gemm_grouped(*(const GemmDesc *)desc, pinned[slot], n, vec_ok, out_ok, stream));
       else if (kind == KIND_UNARY) HIP_OK(launch_unary_grouped(*(const UnaryDesc *)desc, pinned[slot], n, stream));
@@ -871,7 +877,7 @@ inline void append_to_group(TileQueue &q, int kind, const void *desc, const Work
     q.rec.items.clear();
     q.rec_open = true;
   }
-  g_q_checked.fetch_add(1, std::memory_order_relaxed);
+  bump(g_q_checked);
   if (q.rec_open) q.rec.items.push_back(TraceItem{desc, w, stream});
   if (q.learn >= 0) { // the invoke that ended a replay joined the group: the caller has left the recorded pattern
     q.learn = -1;
@@ -907,7 +913,7 @@ inline bool try_start_replay(TileQueue &q, const void *desc, const WorkItem &w, 
   q.replay = idx;
   q.rpos = (size_t)item + 1;
   S.last_use = ++q.use_clock;
-  g_q_replayed.fetch_add(1, std::memory_order_relaxed);
+  bump(g_q_replayed);
   return true;
 }
 // bookkeeping of one queued invoke: footprints from the descriptor, allocation bases ("anchors" of the 2-D planes) from
@@ -963,15 +969,15 @@ inline void submit_item(TileQueue &q, DeviceRanges &devmem, const void *desc, co
       S.seen[idx] = S.round;
       q.pinned[q.slot][q.n++] = w;
       q.rpos = (size_t)idx + 1;
-      g_q_replayed.fetch_add(1, std::memory_order_relaxed);
+      bump(g_q_replayed);
       return;
     }
     if (idx < 0 && S.is_terminator(desc, w, stream)) {
-      g_q_terminated.fetch_add(1, std::memory_order_relaxed);
+      bump(g_q_terminated);
       q.flush();          // as seen before: this invoke conflicts with the group (replay ends, the queue is empty)
       q.backoff_next = 2; // a whole group replayed: the caller is repeating itself
     } else { // neither a member nor a known terminator: make the bookkeeping catch up with what has been queued
-      g_q_abandoned.fetch_add(1, std::memory_order_relaxed);
+      bump(g_q_abandoned);
       q.learn = q.replay;
       q.learn_n = (size_t)q.n;
       q.replay = -1;
@@ -1400,10 +1406,6 @@ InlineQueue &inl() {
   static InlineQueue i;
   return i;
 }
-inline uint64_t this_thread_tag() {
-  thread_local char tag;
-  return (uint64_t)(uintptr_t)&tag;
-}
 void flush_tile_queue() {
   if (!cfg().tile_queue.load(std::memory_order_relaxed)) return;
   InlineQueue &iq = inl();
@@ -1424,12 +1426,12 @@ bool enqueue_item(const void *desc, const WorkItem &item, const void *const *ptr
   thread_local DeviceRanges devmem; // per caller: no sharing, no lock
   devmem.refresh();
   for (int i = 0; i < n_ptrs; ++i)
-    if (!devmem.is_device(ptrs[i])) return false;
+    if (!devmem.is_device(ptrs[i], i)) return false;
   InlineQueue &iq = inl();
   if (!iq.scheduled.load(std::memory_order_acquire)) {
     std::lock_guard<SpinLock> lk(iq.mu);
     if (!iq.scheduled.load(std::memory_order_relaxed)) {
-      const uint64_t me = this_thread_tag();
+      const uint64_t me = (uint64_t)(uintptr_t)&devmem; // the address of this thread's cache identifies the thread (one TLS lookup per invoke, not two)
       if (iq.owner != me) {
         if (iq.owner != 0 && ++iq.foreign > 4) { // several threads are queueing concurrently: hand over to the scheduler
           iq.q.flush();
