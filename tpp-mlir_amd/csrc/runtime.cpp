@@ -733,7 +733,7 @@ struct Segment {
 };
 
 struct TileQueue {
-  static constexpr int CAP = 4096, SLOTS = 4;
+  static constexpr int CAP = 4096, SLOTS = 32, GROUP = 8; // work-list slots; one completion event per GROUP slots
   // TRACE CACHE. Compiled code repeats itself: the same handles on the same pointers in the same order, iteration after
   // iteration (the timing loop of tpp-run, every layer of a model). Whether a group of queued invokes is conflict-free,
   // and whether the next invoke conflicts with it, is a pure function of that sequence of (descriptor, pointers, batch)
@@ -767,20 +767,35 @@ struct TileQueue {
   // measured (profiles/r02_tile_queue_device_lists.txt): the copy costs 15-20 us of host time per flush on this
   // runtime - the reference's headline pattern (3 flushes per iteration) went from 47 to 103 us - while the PCIe
   // read is ~1 us of latency that all workgroups pay in parallel.
-  WorkItem *pinned[SLOTS] = {nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t done[SLOTS];
-  bool used[SLOTS] = {false, false, false, false};
+  // A slot is reused SLOTS flushes later, once the launch that read it has finished. One event per flush cost ~2 us of host
+  // time each (two of the 25 us of the headline bf16 pattern): the slots are used in groups of GROUP, ONE event is recorded
+  // behind the last launch of a group, and it is waited for when the group is entered again - 24 launches later.
+  WorkItem *pinned[SLOTS] = {};
+  hipEvent_t done[SLOTS / GROUP] = {};
+  bool used[SLOTS / GROUP] = {};
+  hipStream_t gstream[SLOTS / GROUP] = {}; // the stream the group's launches went to
   int slot = 0;
   hipStream_t stream = nullptr;
 
   void ensure_slot() {
-    if (!pinned[slot]) {
-      HIP_OK(hipHostMalloc((void **)&pinned[slot], sizeof(WorkItem) * CAP, hipHostMallocDefault));
-      HIP_OK(hipEventCreateWithFlags(&done[slot], hipEventDisableTiming));
-    } else if (used[slot] && n == 0) {
-      HIP_OK(hipEventSynchronize(done[slot])); // the launch that read this slot has finished
-      used[slot] = false;
+    if (n != 0) return;
+    const int g = slot / GROUP;
+    if (slot % GROUP == 0 && used[g]) {
+      HIP_OK(hipEventSynchronize(done[g])); // every launch that read a slot of this group has finished
+      used[g] = false;
     }
+    if (!pinned[slot]) HIP_OK(hipHostMalloc((void **)&pinned[slot], sizeof(WorkItem) * CAP, hipHostMallocDefault));
+  }
+  void launched() { // a grouped launch on `stream` has been issued from pinned[slot]
+    const int g = slot / GROUP;
+    if (slot % GROUP != 0 && gstream[g] != stream) HIP_OK(hipStreamSynchronize(gstream[g])); // (the caller changed streams inside a group)
+    gstream[g] = stream;
+    if (slot % GROUP == GROUP - 1) {
+      if (!done[g]) HIP_OK(hipEventCreateWithFlags(&done[g], hipEventDisableTiming));
+      HIP_OK(hipEventRecord(done[g], stream));
+      used[g] = true;
+    }
+    slot = (slot + 1) % SLOTS;
   }
   void store_recording(const TraceItem *next) {
     if (learn >= 0 && next && rec_open && rec.items.size() == learn_n) {
@@ -831,9 +846,7 @@ struct TileQueue {
       if (kind == KIND_GEMM) HIP_OK(launch_gemm_grouped(*(const GemmDesc *)desc, pinned[slot], n, vec_ok, out_ok, stream));
       else if (kind == KIND_UNARY) HIP_OK(launch_unary_grouped(*(const UnaryDesc *)desc, pinned[slot], n, stream));
       else HIP_OK(launch_binary_grouped(*(const BinaryDesc *)desc, pinned[slot], n, stream));
-      HIP_OK(hipEventRecord(done[slot], stream));
-      used[slot] = true;
-      slot = (slot + 1) % SLOTS;
+      launched();
     }
     n = 0;
     desc = nullptr;
