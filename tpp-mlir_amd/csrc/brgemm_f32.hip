@@ -593,26 +593,24 @@ __global__ __launch_bounds__(256) void brgemm_grouped(GemmArgs p, const WorkItem
     }
     if (mine & 1) compute(0, false, 0);
   }
-  // combine the four waves' partial sums (waves 1..3 park theirs), then wave 0 finishes
+  // combine the four waves' partial sums: every wave parks all of its 16 accumulator registers, then wave w finishes the four
+  // registers 4w .. 4w+3 (rows 8w + 4 lh + 0..3 of the tile): a quarter of the reads and stores per wave (one wave doing all of
+  // it kept the other three idle for the whole tail). Summation order as before: wave 0 + wave 1 + wave 2 + wave 3, (+ C), + bias.
   __syncthreads();
   float *red = smem_g;
-  if (wave > 0) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red[(wave - 1) * 1024 + r * 64 + lane] = acc[r];
-  }
+  for (int r = 0; r < 16; ++r) red[wave * 1024 + r * 64 + lane] = acc[r];
   __syncthreads();
-  if (wave > 0) return;
-#pragma unroll
-  for (int g = 0; g < 3; ++g)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] += red[g * 1024 + r * 64 + lane];
   const int col = n0 + li;
   const float bias = ((p.ep & EP_BIAS) && col < p.n) ? Elem<T>::load(gD, col) : 0.0f;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = m0 + 4 * lh + (r & 3) + 8 * (r >> 2);
+  for (int j = 0; j < 4; ++j) {
+    const int r = 4 * wave + j;
+    const int row = m0 + 4 * lh + j + 8 * wave;
+    float v = red[r * 64 + lane];
+#pragma unroll
+    for (int g = 1; g < 4; ++g) v += red[g * 1024 + r * 64 + lane];
     if (row < p.m && col < p.n) {
-      float v = acc[r];
       // C element (row, col): row-major, or VNNI-2 [m/2][n][2] (wire flag 8192, see the oracle's c_index)
       const int64_t ci = (p.ep & EP_VNNI_C) ? (int64_t)(row >> 1) * (2 * p.ldc) + 2 * (int64_t)col + (row & 1)
                                             : (int64_t)row * p.ldc + col;
