@@ -136,8 +136,8 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + 2)) void brgemm_f32_lw(GemmArg
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
   float bias = 0.0f;
+  if (p.ep & EP_BIAS) bias = ((const float *)it.D)[ccol]; // (every K group: the groups share the epilogue)
   if (wk == 0) {
-    if (p.ep & EP_BIAS) bias = ((const float *)it.D)[ccol];
     if (!(p.ep & EP_BETA0)) {
 #pragma unroll
       for (int r = 0; r < 16; ++r)
@@ -203,22 +203,30 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + 2)) void brgemm_f32_lw(GemmArg
   }
 
   if constexpr (WK > 1) {
-    // combine the K groups through LDS: group g > 0 parks its 32x32 partial, group 0 adds
+    // combine the K groups through LDS: EVERY group parks its 32x32 partial, then group g finishes the accumulator registers
+    // [g * 16 / WK, (g + 1) * 16 / WK) of its tile - sum in group order (group 0 carries C when beta = 1), bias, relu, store.
+    // (With group 0 finishing alone the other groups' waves idled through 16 LDS reads + 16 stores per lane.)
     __syncthreads();
-    float *red = smem_lw; // (WK-1) * WM*WN * 1024 floats, fits in the ring
-    if (wk > 0) {
-      float *dst = red + ((wk - 1) * (WM * WN) + wmn) * 1024 + lane;
+    float *red = smem_lw; // WK * WM*WN * 1024 floats, fits in the ring
+    {
+      float *dst = red + (wk * (WM * WN) + wmn) * 1024 + lane;
 #pragma unroll
       for (int r = 0; r < 16; ++r) dst[r * 64] = acc[r];
     }
     __syncthreads();
-    if (wk > 0) return;
+    constexpr int RPG = 16 / WK;
 #pragma unroll
-    for (int g = 1; g < WK; ++g) {
-      const float *src = red + ((g - 1) * (WM * WN) + wmn) * 1024 + lane;
+    for (int j = 0; j < RPG; ++j) {
+      const int r = wk * RPG + j;
+      float v = red[wmn * 1024 + r * 64 + lane];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] += src[r * 64];
+      for (int g = 1; g < WK; ++g) v += red[(g * (WM * WN) + wmn) * 1024 + r * 64 + lane];
+      v += bias;
+      if (p.ep & EP_RELU) v = v > 0.0f ? v : 0.0f;
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrcC, voffC,
+                                            (unsigned)((r & 3) + 8 * (r >> 2)) * ldcb, 0);
     }
+    return;
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
