@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void brgemm_bf16_small32(GemmArgs p, const Wor
     const WorkItem it = items[blockIdx.x];
     p.A = it.A; p.B = it.B; p.C = it.C; p.D = it.D; p.br = (int)it.br;
   }
-  __shared__ float red[3 * 16 * 64];
+  __shared__ float red[4 * 16 * 64];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
@@ -99,18 +99,12 @@ __global__ __launch_bounds__(256) void brgemm_bf16_small32(GemmArgs p, const Wor
     mul_group(1, nxt);
   }
 
-  // combine the four K shares: waves 1..3 park theirs, wave 0 finishes
-  if (wave > 0) {
+  // combine the four K shares: every wave parks its 16 accumulator registers, then wave w finishes register quad w (the four
+  // columns 8w + 4lh + 0..3 of row li) - sum in wave order, (+ C), + bias, relu, one rounding, one 8-byte store. (Wave 0 doing
+  // all four quads kept the other three idle through 48 LDS reads and the loads / stores of the whole tile.)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red[(wave - 1) * 1024 + r * 64 + lane] = acc[r];
-  }
+  for (int r = 0; r < 16; ++r) red[wave * 1024 + r * 64 + lane] = acc[r];
   __syncthreads();
-  if (wave > 0) return;
-#pragma unroll
-  for (int w = 0; w < 3; ++w)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] += red[w * 1024 + r * 64 + lane];
-
   // operands were swapped (D = B^T A^T): lane (li, lh) owns row li and, in registers 4g..4g+3, columns 8g + 4lh + (0..3)
   typedef unsigned int u32x2d __attribute__((ext_vector_type(2)));
   typedef __attribute__((address_space(1))) u32x2d g_u32x2;
@@ -118,9 +112,15 @@ __global__ __launch_bounds__(256) void brgemm_bf16_small32(GemmArgs p, const Wor
   g_u16 *crow = (g_u16 *)p.C + (int64_t)(m0 + li) * p.ldc + n0 + 4 * lh;
   g_cu16 *drow = (g_cu16 *)p.D + n0 + 4 * lh;
   const bool relu = (p.ep & EP_RELU) != 0;
+  {
+    const int g = wave;
+    float v[4];
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    float v[4] = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+    for (int x = 0; x < 4; ++x) {
+      v[x] = red[(4 * g + x) * 64 + lane];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) v[x] += red[w * 1024 + (4 * g + x) * 64 + lane];
+    }
     if (!(p.ep & EP_BETA0)) {
       const u32x2d c2 = *(g_cu32x2 *)(crow + 8 * g);
       v[0] += __uint_as_float(c2[0] << 16);
