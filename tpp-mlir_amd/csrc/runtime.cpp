@@ -639,7 +639,7 @@ struct Footprint {
     if (!o.ptr || !o.bytes) return false;
     const Range b = bounding(o);
     if (flat.overlaps(b)) return true;
-    Rect r;
+    Rect r{0, 0, 0, 0};
     const bool is_rect = to_rect(o, anchor, r);
     for (const Plane &p : planes) {
       if (!p.bound.overlaps(b)) continue;
