@@ -1,5 +1,5 @@
 """ThreadSanitizer run of the C-ABI layer's host-side concurrency (no GPU needed): runtime.cpp - tile queue,
-multi-producer ring, scheduler thread and its life cycle, host-operand mirroring - is compiled UNCHANGED with
+per-caller rings merged by time stamp, trace cache, scheduler thread and its life cycle, host-operand mirroring - is compiled UNCHANGED with
 g++ -fsanitize=thread against tests/tsan/fake_hip.cpp (the HIP host API and the kernel launchers over host memory,
 executed on the launching thread) and driven by tests/tsan/driver.cpp the way the reference's compiled code calls
 it: 8 OpenMP-style workers invoking zero / brgemm / relu tiles of a 3-layer MLP with a barrier per layer
