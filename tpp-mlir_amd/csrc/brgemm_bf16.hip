@@ -30,7 +30,7 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 #ifndef TPP_ABLATE
 #define TPP_ABLATE 0
 #endif
-constexpr int HABL_NO_GLOAD = 1, HABL_NO_SWRITE = 2, HABL_NO_BARRIER = 4, HABL_NO_FRAG = 8, HABL_NO_TRANSPOSE = 16, HABL_STAMP = 32,
+constexpr int HABL_NO_GLOAD = 1, HABL_NO_SWRITE = 2, HABL_NO_BARRIER = 4, HABL_NO_FRAG = 8, HABL_NO_TRANSPOSE = 16,
               HABL_NO_BFRAG = 64 /* dma128: no B fragment reads */, HABL_NO_BDMA = 128 /* dma128: the B loader wave fetches nothing */,
               HABL_NO_ADMA = 256 /* dma128: the A loader wave fetches nothing */, HABL_LOADERS_ONLY = 512 /* dma128: the MFMA waves leave at once */;
 
