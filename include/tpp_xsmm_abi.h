@@ -151,7 +151,8 @@ TPP_XSMM_EXPORT int xsmm_hip_set_async(int enable);
  * handle / other op / data dependence on a queued output or overwrite of a queued input /
  * xsmm_hip_flush / xsmm_hip_synchronize / perf_stop_timer). Program order is preserved. Operands
  * of queued invokes must stay valid until the flush. Returns the previous setting. Also env
- * TPP_HIP_TILE_QUEUE=1. */
+ * TPP_HIP_TILE_QUEUE=1. The queue serves ONE device per process (the device current on the first
+ * queued invoke): a queued invoke from a thread whose current device differs is a fatal error. */
 TPP_XSMM_EXPORT int xsmm_hip_set_tile_queue(int enable);
 TPP_XSMM_EXPORT void xsmm_hip_flush(void);
 /* counters of the tile queue since process start: out[0] grouped launches, out[1] invokes queued with the full

@@ -266,6 +266,41 @@ def test_brgemm_huge_leading_dimensions(rt, dt, ld):
         assert "fast" not in rt.kernel_name(h) and "dma" not in rt.kernel_name(h), rt.kernel_name(h)
 
 
+@pytest.mark.parametrize("dt,m,lda", [(F32, 66000, 8192), (BF16, 1100, 1 << 20)], ids=["f32", "bf16"])
+def test_brgemm_generic_vector_path_a_beyond_2gib(rt, dt, m, lda):
+    """(m - 1) * lda * esize >= 2^31 on the generic kernel's 16-byte-load path (n a multiple of 4 only, k of 32 only):
+    the per-lane offset is relative to the TILE and the 64-bit descriptor base carries m0 * lda, so rows past 2 GiB of A
+    are addressed correctly (an absolute 32-bit row offset wrapped / read zeros there)"""
+    import torch
+    n, k, br = 40, 32, 2
+    vnni = dt == BF16
+    es = 4 if dt == F32 else 2
+    assert (m - 1) * lda * es >= 2 ** 31
+    rng = np.random.default_rng(m)
+    Ac = rand(rng, m * k * br, dt).reshape(m, k * br)  # compact copy for the oracle (lda = k * br)
+    B = rand(rng, br * k * n + 8, dt)
+    C0 = rand(rng, m * n, dt)
+    ref = C0.copy()
+    flags = (VB if vnni else 0)
+    orc.brgemm(dt, m, n, k, k * br, n, n, k, k * n, flags, Ac.reshape(-1), 0, B, 0, ref, 0, br)
+    tdt = torch.float32 if dt == F32 else torch.int16
+    dA = torch.zeros(((m - 1) * lda + k * br + 8,), dtype=tdt, device="cuda")
+    src = torch.from_numpy((Ac if dt == F32 else Ac.view(np.int16)).copy()).cuda()
+    dA.as_strided((m, k * br), (lda, 1)).copy_(src)
+    dB, dC = dev(B), dev(C0)
+    rt.force_variant(8)
+    try:
+        h = rt.brgemm_dispatch(dt, m, n, k, lda, n, n, k, k * n, flags)
+    finally:
+        rt.force_variant(-1)
+    rt.brgemm(dt, h, dA, 0, dB, 0, dC, 0, br)
+    got = host(dC, C0)
+    del dA, src
+    torch.cuda.empty_cache()
+    assert "grouped" in rt.kernel_name(h), rt.kernel_name(h)
+    check_close(got, ref, dt, "A beyond 2 GiB [%s]" % rt.kernel_name(h))
+
+
 def test_brgemm_unaligned_pointers_fall_back(rt):
     # fast shape, but A/B offsets break 16-byte alignment: the runtime must pick the generic kernel
     gemm_case(rt, F32, 64, 64, 64, 2, offs=(1, 3, 0, 0), seed=5)

@@ -418,7 +418,9 @@ __global__ __launch_bounds__(256) void brgemm_grouped(GemmArgs p, const WorkItem
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int q = lane + 64 * u, row = q >> 3, c4 = q & 7; // 32 rows x 8 pieces of 4 floats
-      const int a_row = m0 + row < p.m ? m0 + row : p.m - 1, b_col = n0 + 4 * c4 < p.n ? n0 + 4 * c4 : 0;
+      // offsets are relative to the TILE (the 64-bit descriptor base carries m0 * lda and n0): 32 rows x ld x 4 B stays below
+      // 2^31 for every ld the launcher admits (< 2^24), whatever m is - an absolute row here would wrap past 2 GiB of A
+      const int a_row = m0 + row < p.m ? row : p.m - 1 - m0, b_col = n0 + 4 * c4 < p.n ? 4 * c4 : 0;
       voffA[u] = (unsigned)((a_row * (int)p.lda + 4 * c4) * 4);
       voffB[u] = (unsigned)((row * (int)p.ldb + b_col) * 4);
     }
@@ -433,9 +435,10 @@ __global__ __launch_bounds__(256) void brgemm_grouped(GemmArgs p, const WorkItem
     const int64_t abase = (int64_t)b * p.stride_a, bbase = (int64_t)b * p.stride_b;
     if constexpr (VEC && sizeof(T) == 4) {
       const int nrec = __builtin_amdgcn_readfirstlane(live ? 0x7fffffff : 0);
-      const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void *)((const float *)it.A + abase + kk0), 0, nrec, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rA =
+          __builtin_amdgcn_make_buffer_rsrc((void *)((const float *)it.A + abase + (int64_t)m0 * p.lda + kk0), 0, nrec, 0x00020000);
       const __amdgpu_buffer_rsrc_t rB =
-          __builtin_amdgcn_make_buffer_rsrc((void *)((const float *)it.B + bbase + (int64_t)kk0 * p.ldb), 0, nrec, 0x00020000);
+          __builtin_amdgcn_make_buffer_rsrc((void *)((const float *)it.B + bbase + (int64_t)kk0 * p.ldb + n0), 0, nrec, 0x00020000);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         ra[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, voffA[u], 0, 0));
@@ -526,7 +529,8 @@ __global__ __launch_bounds__(256) void brgemm_grouped(GemmArgs p, const WorkItem
 #pragma unroll
     for (int v = 0; v < 2; ++v) {
       const int q = lane + 64 * v;
-      const int a_row = m0 + (q >> 2) < p.m ? m0 + (q >> 2) : p.m - 1, b_col = n0 + 4 * (q & 7) < p.n ? n0 + 4 * (q & 7) : 0;
+      // tile-relative (see the f32 path): the descriptor base carries m0 * lda and 2 * n0
+      const int a_row = m0 + (q >> 2) < p.m ? (q >> 2) : p.m - 1 - m0, b_col = n0 + 4 * (q & 7) < p.n ? 4 * (q & 7) : 0;
       vA[v] = (unsigned)((a_row * (int)p.lda + 8 * (q & 3)) * 2);
       vB[v] = (unsigned)(((q >> 3) * 2 * (int)p.ldb + 2 * b_col) * 2);
     }
@@ -535,9 +539,9 @@ __global__ __launch_bounds__(256) void brgemm_grouped(GemmArgs p, const WorkItem
       const int b = cc / kchunks, kk0 = (cc - b * kchunks) * GK;
       const int nrec = __builtin_amdgcn_readfirstlane(live ? 0x7fffffff : 0);
       const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
-          (void *)((const unsigned short *)it.A + (int64_t)b * p.stride_a + kk0), 0, nrec, 0x00020000);
+          (void *)((const unsigned short *)it.A + (int64_t)b * p.stride_a + (int64_t)m0 * p.lda + kk0), 0, nrec, 0x00020000);
       const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(
-          (void *)((const unsigned short *)it.B + (int64_t)b * p.stride_b + (int64_t)(kk0 >> 1) * (2 * p.ldb)), 0, nrec, 0x00020000);
+          (void *)((const unsigned short *)it.B + (int64_t)b * p.stride_b + (int64_t)(kk0 >> 1) * (2 * p.ldb) + 2 * (int64_t)n0), 0, nrec, 0x00020000);
 #pragma unroll
       for (int v = 0; v < 2; ++v) {
         sa[set][v] = __builtin_amdgcn_raw_buffer_load_b128(rA, vA[v], 0, 0);
@@ -722,7 +726,8 @@ hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_i
   a.ep = (d.beta0 ? EP_BETA0 : 0) | (d.bias ? EP_BIAS : 0) | (d.relu ? EP_RELU : 0) | (d.vnni_c ? EP_VNNI_C : 0);
   a.tiles_m = a.tiles_n = 0;
   const bool tiles_ok = vec_ok && d.n % 4 == 0 && d.k % GK == 0; // 16-byte pieces; ragged m / n edges are predicated
-  const bool vec = tiles_ok && d.dtype == DT_F32 && !d.vnni_b && !((d.lda | d.ldb | d.stride_a | d.stride_b) & 3);
+  const bool vec = tiles_ok && d.dtype == DT_F32 && !d.vnni_b && !((d.lda | d.ldb | d.stride_a | d.stride_b) & 3) &&
+                   d.lda < (1 << 24) && d.ldb < (1 << 24); // (32-bit tile-relative lane offsets: 32 rows x ld x 4 B < 2^31)
   // f32 tiles with k a multiple of 64 (mlir-gen --tiles=64,64,64, the most common setting of the reference's
   // benchmark configs): the fast tile families in grouped mode, the largest tile that still yields about one
   // workgroup per CU over the whole work list (the same rule as pick_f32_variant)
@@ -873,7 +878,8 @@ hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C,
   }
   // everything else: the grouped kernel with a single, inline work item
   const bool tiles_ok = aligned16 && d.n % 4 == 0 && d.k % GK == 0; // ragged m / n edges are predicated
-  const bool vec = tiles_ok && d.dtype == DT_F32 && !d.vnni_b && !((d.lda | d.ldb | d.stride_a | d.stride_b) & 3);
+  const bool vec = tiles_ok && d.dtype == DT_F32 && !d.vnni_b && !((d.lda | d.ldb | d.stride_a | d.stride_b) & 3) &&
+                   d.lda < (1 << 24) && d.ldb < (1 << 24); // (32-bit tile-relative lane offsets)
   const bool vec16 = tiles_ok && d.dtype == DT_BF16 && d.vnni_b && !((d.lda | d.stride_a | d.stride_b) & 7) && !(d.ldb & 3) &&
                      d.lda < (1 << 21) && d.ldb < (1 << 21); // (32-bit lane offsets)
   if (d.dtype == DT_F32) return vec ? launch_grouped_t<float, false, true>(a, nullptr, 1, stream)

@@ -181,12 +181,12 @@ std::atomic<uint64_t> g_devmem_epoch{1};
 struct DeviceRanges {
   std::vector<Range> known;
   uint64_t epoch = 0;
-  void refresh() {
+  bool refresh() { // true: a new epoch began (first use on this thread since the last synchronisation point)
     const uint64_t e = g_devmem_epoch.load(std::memory_order_relaxed);
-    if (e != epoch) {
-      known.clear();
-      epoch = e;
-    }
+    if (e == epoch) return false;
+    known.clear();
+    epoch = e;
+    return true;
   }
   // index of the last hit PER OPERAND POSITION (A, B, C, D of consecutive invokes each stay in their own allocation;
   // one shared index would miss on every operand and fall into the scan)
@@ -1197,6 +1197,7 @@ struct Scheduler {
       // then streams through a backlog of finished (prefetched) lines while the producer refills in a burst, instead of
       // the two moving in lockstep with every line crossing cores just in time.
       for (unsigned spins = 0; h - (Q.head_seen = Q.head_pub.load(std::memory_order_acquire)) > PQueue::CAP / 2; ++spins) {
+        if (stop.load(std::memory_order_relaxed)) return; // the process is exiting (static destruction): nobody will consume the ring
         if (spins < 2000) cpu_relax();
         else {
           ensure_worker();
@@ -1243,12 +1244,15 @@ struct Scheduler {
       PQueue *Q = i == n ? &overflow : queues[i].load(std::memory_order_acquire);
       pending = Q && Q->clean_head.load(std::memory_order_acquire) < Q->tail_pub.load(std::memory_order_acquire);
     }
-    if (!pending) return;
+    if (!pending || stop.load(std::memory_order_relaxed)) return;
     std::atomic<int> flag{0};
     QEntry f;
     f.w.C = &flag; // desc == nullptr: a fence
     push(f);
     for (unsigned spins = 0; !flag.load(std::memory_order_acquire); ++spins) {
+      // the scheduler is being destroyed (exit() on another thread while this one flushes): its worker will not start again
+      // (ensure_worker) and the fence would never be raised - give up instead of spinning through process teardown
+      if (stop.load(std::memory_order_relaxed) && !running.load(std::memory_order_seq_cst)) return;
       if (spins < 4000) cpu_relax();
       else sched_yield();
     }
@@ -1284,8 +1288,15 @@ struct Scheduler {
     bool any = false;
     for (;;) {
       std::atomic<uint32_t> &cell = wake_cell[wake_head % WCAP];
-      const uint32_t v = cell.load(std::memory_order_seq_cst);
-      if (!v) return any;
+      uint32_t v = cell.load(std::memory_order_seq_cst);
+      if (!v) {
+        // Producers RESERVE a cell (fetch_add on wake_tail) and fill it afterwards: an empty cell below the reserved tail is a
+        // producer between its two steps. A later cell - or a warm ring - may already hold an entry that happened AFTER that
+        // producer's push (it saw the push through a barrier), so stopping here would let that entry overtake it. Wait for the
+        // laggard: the window is a few instructions unless the producer was preempted inside it.
+        if (wake_tail.load(std::memory_order_seq_cst) == wake_head) return any;
+        while (!(v = cell.load(std::memory_order_acquire))) cpu_relax();
+      }
       cell.store(0, std::memory_order_release);
       ++wake_head;
       any = true;
@@ -1435,9 +1446,26 @@ void flush_tile_queue() {
 
 // Queues one invoke of `desc`; true if queued (nothing launched yet), false if an operand is host memory (the
 // caller flushes and takes the mirrored path). `ptrs` are the item's non-null operand pointers.
+// The tile queue serves ONE device per process: the scheduler thread binds to the device of the first caller, work lists are
+// plain pinned allocations and the tile heuristics cache that device's CU count. A caller on another device would get its
+// grouped launches issued on the wrong GPU - refuse loudly instead (checked once per thread and synchronisation epoch, not per
+// invoke). Non-queued invokes launch from the calling thread and follow its current device as usual.
+std::atomic<int> g_queue_device{-1};
+void check_queue_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return; // no device: the launch itself will fail loudly
+  }
+  int expect = -1;
+  if (!g_queue_device.compare_exchange_strong(expect, dev) && expect != dev)
+    die("tpp-xsmm-hip: the tile queue serves one device per process (first used on device %d, this thread's current device is %d); "
+        "turn the queue off (xsmm_hip_set_tile_queue(0)) for multi-device processes", expect, dev);
+}
+
 bool enqueue_item(const void *desc, const WorkItem &item, const void *const *ptrs, int n_ptrs, hipStream_t s) {
   thread_local DeviceRanges devmem; // per caller: no sharing, no lock
-  devmem.refresh();
+  if (devmem.refresh()) check_queue_device();
   for (int i = 0; i < n_ptrs; ++i)
     if (!devmem.is_device(ptrs[i], i)) return false;
   InlineQueue &iq = inl();
@@ -1708,7 +1736,10 @@ extern "C" int xsmm_hip_set_async(int enable) {
 }
 extern "C" void xsmm_hip_set_stream(void *s) {
   flush_tile_queue();
-  cfg().stream.store((hipStream_t)s);
+  const hipStream_t old = cfg().stream.exchange((hipStream_t)s);
+  // xsmm_hip_synchronize / perf_stop_timer / leaving async mode drain the CURRENT stream only, and the header promises that
+  // operands may be freed after they return: work enqueued on the stream being left must not outlive that promise
+  if (old != (hipStream_t)s && cfg().async.load(std::memory_order_relaxed)) HIP_OK(hipStreamSynchronize(old));
 }
 extern "C" int xsmm_hip_set_tile_queue(int enable) {
   flush_tile_queue();
