@@ -155,6 +155,23 @@ TPP_XSMM_EXPORT int xsmm_hip_set_async(int enable);
  * queued invoke): a queued invoke from a thread whose current device differs is a fatal error. */
 TPP_XSMM_EXPORT int xsmm_hip_set_tile_queue(int enable);
 TPP_XSMM_EXPORT void xsmm_hip_flush(void);
+/* n fused_brgemm invokes in ONE call (arrays of length n, one entry per call): exactly the effect of
+ *   for (i = 0; i < n; ++i) xsmm_fused_brgemm_invoke(dtype, handles[i], a[i], off_a[i], b[i], off_b[i], c[i], off_c[i],
+ *                                                    d[i], off_d[i], num_batches[i]);
+ * (XsmmRunnerUtils.cpp:363-457 per call). This is how a harness hands over a rank's MLP step (mlir-gen's layer chain,
+ * MLIRGen.cpp:632-681: every layer one whole-layer fused_brgemm): when the calls form a CHAIN - call i+1 reads call i's
+ * output as its A operand (same pointer, lda = ldc), bf16 with a VNNI-2 B, beta 0, equal m and n, device pointers,
+ * asynchronous mode, the outputs overlap no other operand, and one of the 32x64 .. 128x128 tiles covers m x n with at most
+ * one workgroup per compute unit - the whole chain runs as ONE persistent kernel (rows of layer i+1 start as soon as the
+ * same rows of layer i are stored: no kernel boundary, the next layer's weight panels are prefetched under the epilogue).
+ * Same arithmetic as the separate launches (f32 accumulation in k order, one rounding per layer); bit-identical to them when
+ * they run on the same tile, which is the case whenever dispatch planned the layers with a loader-wave tile (variants 20 .. 23)
+ * that fits the chip. Returns 1 if the chain ran as one launch, 0 if it ran call by call.
+ * TPP_HIP_CHAIN=0 disables the single-launch path. */
+TPP_XSMM_EXPORT int xsmm_hip_fused_brgemm_chain_invoke(int64_t dtype, int64_t n, const int64_t *handles, void *const *a,
+                                                       const int64_t *off_a, void *const *b, const int64_t *off_b,
+                                                       void *const *c, const int64_t *off_c, void *const *d,
+                                                       const int64_t *off_d, const int64_t *num_batches);
 /* counters of the tile queue since process start: out[0] grouped launches, out[1] invokes queued with the full
  * dependence bookkeeping, out[2] invokes queued by replay of a recorded group (trace cache), out[3] groups ended by
  * a remembered terminator, out[4] replays abandoned (the caller left the recorded group) */
@@ -177,7 +194,8 @@ TPP_XSMM_EXPORT int xsmm_hip_device_count(void);
 /* Name of the HIP kernel variant a GEMM-like handle selected, for profiles. */
 TPP_XSMM_EXPORT const char *xsmm_hip_kernel_name(int64_t handle);
 /* Force a GEMM tile variant for A/B benchmarking and tests (-1 = automatic): f32 0..4 (64x64,
- * 64x32+K2, 32x32+K4, 128x64, 64x64+K2), 5..7 the loader-wave kernels (64x64, 64x64+K2, 64x32+K2), 8 generic, bf16 16 / 17 / 18 / 19 (64x64, 128x128, 256x256, 32x32 + K split).
+ * 64x32+K2, 32x32+K4, 128x64, 64x64+K2), 5..7 the loader-wave kernels (64x64, 64x64+K2, 64x32+K2), 8 generic, bf16 16 / 17 / 18 / 19 (64x64, 128x128, 256x256, 32x32 + K split),
+ * 20 .. 23 the bf16 loader-wave tiles for mid-size outputs (32x64 + K split, 64x64, 64x128, 128x128).
  * Honoured at dispatch when the shape divides the tile. */
 TPP_XSMM_EXPORT void xsmm_hip_force_variant(int variant);
 /* Library version string. */

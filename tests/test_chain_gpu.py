@@ -1,0 +1,287 @@
+"""The bf16 loader-wave tile family for mid-size outputs (brgemm_bf16_lw.hip, variants 20 .. 23) and the same kernel as a CHAIN
+of whole-layer fused BRGEMMs in one launch (xsmm_hip_fused_brgemm_chain_invoke), through the C-ABI on a real MI355X:
+  * every tile on small outputs against the oracle (whole output), all epilogues, strides / offsets, both accumulator starts,
+    every chunk-stream length around the ring depth;
+  * chains against the oracle layer by layer and BIT-IDENTICAL to the same layers invoked one by one on the same tile, over
+    several steps on the same buffers with changing inputs (a stale hand-off read would show as the previous step's values);
+  * the per-rank shapes of the row-sharded C4 MLP (512 / 1024 / 2048 / 4096 rows x 3 layers of 1024);
+  * every condition under which the call must fall back to separate launches - same results, return value 0.
+"""
+import importlib
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as orc
+from test_parity_gpu import BF16, VB, check_close, dev, gemm_case, host, rand
+
+pytestmark = pytest.mark.gpu
+pkg = importlib.import_module("tpp-mlir_amd")
+
+TILES = {20: (32, 64), 21: (64, 64), 22: (64, 128), 23: (128, 128)}
+
+
+@pytest.fixture(scope="module")
+def rt():
+    r = pkg.get_runtime()
+    assert r.device_count() >= 1, "no HIP device visible: the gpu tests need an MI355X"
+    return r
+
+
+# ---------------------------------------------------------------- single layers on the new tiles
+LW_CASES = [
+    # (variant, m, n, k, br, kwargs)
+    (20, 32, 64, 64, 1, dict(beta0=True)),
+    (20, 64, 128, 64, 3, dict(bias=True, relu=True, ldc=136, lda=200, offs=(8, 16, 8, 4))),
+    (20, 96, 192, 128, 2, dict(sa=64, sb=128, lda=512, beta0=True, bias=True)),
+    (20, 256, 256, 64, 9, dict(lda=640, sa=64, ldb=256, sb=64 * 256, beta0=True, relu=True)),  # XCD-mapped grid, ring wraps
+    (20, 64, 64, 64, 0, dict(beta0=True, bias=True)),                                          # empty batch: C = bias
+    (20, 64, 64, 64, 0, dict()),                                                               # empty batch, beta = 1: C unchanged
+    (20, 64, 64, 192, 1, dict()),                                                              # beta = 1
+    (21, 64, 64, 64, 1, dict(beta0=True)),
+    (21, 128, 192, 64, 3, dict(bias=True, relu=True, ldc=200)),
+    (21, 512, 128, 64, 17, dict(lda=1096, sa=64, ldb=128, sb=64 * 128, beta0=True, bias=True)),
+    (21, 64, 128, 128, 2, dict()),
+    (22, 64, 128, 64, 1, dict(beta0=True, relu=True)),
+    (22, 128, 256, 64, 5, dict(bias=True, ldc=264, offs=(8, 8, 8, 4))),
+    (22, 512, 256, 64, 4, dict(lda=256, sa=64, sb=64 * 256, beta0=True, bias=True, relu=True)),
+    (22, 64, 128, 64, 2, dict()),
+    (23, 128, 128, 64, 1, dict(beta0=True)),
+    (23, 128, 256, 64, 3, dict(bias=True, relu=True, ldc=264)),
+    (23, 1024, 256, 64, 6, dict(lda=384, sa=64, sb=64 * 256, beta0=True, bias=True)),
+    (23, 128, 128, 128, 2, dict()),
+]
+
+
+@pytest.mark.parametrize("case", LW_CASES, ids=lambda c: "v%d_m%d_n%d_k%d_br%d" % c[:5])
+def test_brgemm_bf16_lw_tiles(rt, case):
+    v, m, n, k, br, kw = case
+    name = gemm_case(rt, BF16, m, n, k, br, vnni=True, seed=v * 1000 + m + n + br, force=v, **kw)
+    assert "lw<%dx%d" % TILES[v] in name, name
+
+
+@pytest.mark.parametrize("variant", [20, 21, 22, 23])
+@pytest.mark.parametrize("k,br", [(64, 1), (64, 2), (64, 3), (64, 4), (64, 5), (64, 7), (64, 8), (64, 9), (128, 5), (192, 3),
+                                  (64, 16), (64, 17)])
+def test_brgemm_bf16_lw_chunk_stream_lengths(rt, variant, k, br):
+    """every ring position of the uniform chunk loop (1 .. 17 chunks through rings of 4 and 8 slots, chunk streams that
+    wrap inside a batch element), both accumulator starts"""
+    bm, bn = TILES[variant]
+    m, n = 2 * bm, 2 * bn
+    for beta0 in (True, False):
+        name = gemm_case(rt, BF16, m, n, k, br, lda=k * br + 8, ldb=n + 4, ldc=n + 8, sa=k, sb=k * (n + 4), vnni=True,
+                         beta0=beta0, bias=not beta0, relu=beta0, seed=variant * 100 + k + br, force=variant, offs=(8, 8, 8, 4))
+        assert "lw<" in name, name
+
+
+def test_mid_size_layers_pick_the_loader_wave_tiles(rt):
+    """the per-rank layer shapes of the row-sharded C4 MLP: one workgroup per CU"""
+    want = {512: "lw<32x64", 1024: "lw<64x64", 2048: "lw<64x128"}
+    for m, tag in want.items():
+        h = rt.fused_brgemm_dispatch(BF16, m, 1024, 64, 1024, 1024, 1024, 64, 64 * 1024, 4 | VB, 0, 5, 4, 1)
+        assert tag in rt.kernel_name(h), (m, rt.kernel_name(h))
+
+
+# ---------------------------------------------------------------- chains
+class Chain:
+    """a chain of whole-layer fused BRGEMMs on `m` rows: dims = [k0, n, n, ...] (every layer n columns)"""
+
+    def __init__(self, rt, m, dims, seed, bias=True, relu=True, force=None, pad=0):
+        self.rt, self.m, self.dims, self.bias, self.relu = rt, m, dims, bias, relu
+        self.rng = np.random.default_rng(seed)
+        self.L = len(dims) - 1
+        self.ld = [d + pad for d in dims]  # leading dimensions of x and of every activation buffer
+        self.W = [rand(self.rng, (dims[l] // 2) * 2 * dims[l + 1], BF16, -0.25, 0.25) for l in range(self.L)]
+        self.b = [rand(self.rng, dims[l + 1], BF16) for l in range(self.L)]
+        self.handles = []
+        if force is not None:
+            rt.force_variant(force)
+        try:
+            for l in range(self.L):
+                k, n = dims[l], dims[l + 1]
+                self.handles.append(rt.fused_brgemm_dispatch(BF16, m, n, 64, self.ld[l], n, self.ld[l + 1], 64, 64 * n, 4 | VB, 0,
+                                                             5 if relu else 0, 4 if bias else 0, 1 if bias else 0))
+        finally:
+            if force is not None:
+                rt.force_variant(-1)
+        self.dW, self.db = [dev(w) for w in self.W], [dev(b) for b in self.b]
+
+    def new_input(self):
+        x = np.zeros(self.m * self.ld[0], np.uint16)
+        x.reshape(self.m, self.ld[0])[:, :self.dims[0]] = rand(self.rng, self.m * self.dims[0], BF16).reshape(self.m, -1)
+        return x
+
+    def calls(self, dx, dacts):
+        cur, out = dx, []
+        for l in range(self.L):
+            out.append((self.handles[l], cur, 0, self.dW[l], 0, dacts[l], 0, self.db[l], 0, self.dims[l] // 64))
+            cur = dacts[l]
+        return out
+
+    def oracle(self, x, rows=None):
+        """layer outputs by the oracle (on `rows` = (first, count) only when given: rows are independent)"""
+        r0, rr = rows or (0, self.m)
+        cur, outs = x, []
+        for l in range(self.L):
+            k, n = self.dims[l], self.dims[l + 1]
+            out = np.zeros(self.m * self.ld[l + 1], np.uint16)
+            orc.fused_brgemm(BF16, rr, n, 64, self.ld[l], n, self.ld[l + 1], 64, 64 * n, 4 | VB, 0, 5 if self.relu else 0,
+                             4 if self.bias else 0, 1 if self.bias else 0, cur, r0 * self.ld[l], self.W[l], 0, out, r0 * self.ld[l + 1],
+                             self.b[l], 0, k // 64)
+            outs.append(out)
+            cur = out
+        return outs
+
+
+def run_chain_steps(rt, ch, steps, tile_variant, oracle_rows=None):
+    """`steps` steps on the SAME device buffers with fresh inputs: the fused launch against (a) the same calls one by one on the same tile
+    (bit-identical, every layer) and (b) the oracle"""
+    import torch
+    m = ch.m
+    poison = np.full(m * max(ch.ld), 0x7fc0, np.uint16)  # NaN pattern: an unwritten or stale element cannot pass
+    dacts_f = [dev(poison[: m * ch.ld[l + 1]]) for l in range(ch.L)]
+    dacts_s = [dev(poison[: m * ch.ld[l + 1]]) for l in range(ch.L)]
+    was_async = rt.set_async(True)
+    try:
+        for step in range(steps):
+            x = ch.new_input()
+            dx = dev(x)
+            fused = rt.fused_brgemm_chain(BF16, ch.calls(dx, dacts_f))
+            assert fused, "the chain did not run as one launch"
+            for c in ch.calls(dx, dacts_s):
+                rt.fused_brgemm(BF16, *c)
+            rt.synchronize()
+            for l in range(ch.L):
+                assert torch.equal(dacts_f[l], dacts_s[l]), "step %d layer %d: fused launch differs from the separate launches" % (step, l)
+            if step in (0, steps - 1):
+                ref = ch.oracle(x, oracle_rows)
+                r0, rr = oracle_rows or (0, m)
+                for l in range(ch.L):
+                    got = host(dacts_f[l], x)
+                    n, ld = ch.dims[l + 1], ch.ld[l + 1]
+                    sel = np.concatenate([np.arange(r * ld, r * ld + n) for r in range(r0, r0 + rr)])
+                    if l == 0:
+                        check_close(got[sel], ref[l][sel], BF16, "chain layer 0 (tile %d)" % tile_variant)
+                    else:  # feed the oracle the GPU's own previous activations: one layer's error at a time
+                        prev = host(dacts_f[l - 1], x)
+                        one = np.zeros(m * ld, np.uint16)
+                        orc.fused_brgemm(BF16, rr, n, 64, ch.ld[l], n, ld, 64, 64 * n, 4 | VB, 0, 5 if ch.relu else 0,
+                                         4 if ch.bias else 0, 1 if ch.bias else 0, prev, r0 * ch.ld[l], ch.W[l], 0, one, r0 * ld,
+                                         ch.b[l], 0, ch.dims[l] // 64)
+                        check_close(got[sel], one[sel], BF16, "chain layer %d (tile %d)" % (l, tile_variant))
+    finally:
+        rt.synchronize()
+        rt.set_async(was_async)
+
+
+@pytest.mark.parametrize("variant,m,dims", [
+    (20, 64, [128, 128, 128, 128]),        # 2 x 2 tiles of 32x64; 2 chunks per layer: no weight prefetch across the seam
+    (20, 128, [512, 512, 512]),            # 8 chunks = the ring depth: the B loader runs across the seams
+    (20, 256, [256, 512, 512, 512, 512]),  # XCD-mapped grid (8 row blocks), first layer shorter, 4 layers
+    (21, 128, [128, 256, 256]),
+    (21, 512, [512, 512, 512, 512]),
+    (22, 128, [256, 256, 256, 256]),       # 4 chunks = the ring depth of the 64x128 tile
+    (22, 512, [192, 256, 256]),
+    (23, 256, [256, 256, 256]),
+    (23, 1024, [128, 512, 512, 512]),
+], ids=lambda v: str(v).replace(" ", ""))
+def test_chain_small_against_oracle_and_separate_launches(rt, variant, m, dims):
+    bm, bn = TILES[variant]
+    assert m % bm == 0 and dims[1] % bn == 0
+    # the chain runs on the tile its layers were planned with (forced here), so the separate launches are the bit-exact reference
+    ch = Chain(rt, m, dims, seed=variant + m, force=variant)
+    run_chain_steps(rt, ch, 3, variant)
+
+
+@pytest.mark.parametrize("m", [512, 1024, 2048, 4096])
+def test_chain_c4_rank_shares(rt, m):
+    """the per-rank step of the row-sharded C4 MLP (BASELINE config 4) at 8 / 4 / 2 / 1 GPUs as ONE launch: bit-identical to
+    the three launches on the same tile over 6 steps, oracle on row samples (per layer, fed the GPU's own activations)"""
+    tile = {512: 20, 1024: 21, 2048: 22, 4096: 23}[m]
+    ch = Chain(rt, m, [1024, 1024, 1024, 1024], seed=m, force=tile)
+    run_chain_steps(rt, ch, 6, tile, oracle_rows=(m // 2 - 8, 24))
+
+
+def test_chain_no_bias_no_relu_and_padded_rows(rt):
+    ch = Chain(rt, 128, [256, 256, 256], seed=5, bias=False, relu=False, force=20, pad=8)
+    run_chain_steps(rt, ch, 2, 20)
+
+
+def test_chain_falls_back_when_it_must(rt):
+    """same results, return value False: synchronous mode, a call that does not read its predecessor's output, aliased
+    buffers (ping-pong), too many tiles for the chip, f32"""
+    import torch
+    ch = Chain(rt, 128, [256, 256, 256, 256], seed=11, force=20)
+    x = ch.new_input()
+    dx = dev(x)
+    ref = ch.oracle(x)
+    acts = [dev(np.zeros(128 * 256, np.uint16)) for _ in range(3)]
+
+    def check(tag):
+        rt.synchronize()
+        for l in range(3):
+            check_close(host(acts[l], x), ref[l], BF16, "fallback %s layer %d" % (tag, l))
+            acts[l].zero_()
+
+    was_async = rt.set_async(False)
+    try:
+        assert not rt.fused_brgemm_chain(BF16, ch.calls(dx, acts))  # synchronous mode: call by call
+        check("sync")
+        rt.set_async(True)
+        assert rt.fused_brgemm_chain(BF16, ch.calls(dx, acts))
+        check("fused")
+        # layer 2 reads a COPY of layer 1's output location? no: reads another buffer - not a chain (and then the data flow differs:
+        # run it call by call by hand for the expectation)
+        other = dev(rand(np.random.default_rng(1), 128 * 256, BF16))
+        calls = ch.calls(dx, acts)
+        broken = [calls[0], calls[1], (calls[2][0], other) + calls[2][2:]]
+        assert not rt.fused_brgemm_chain(BF16, broken)
+        rt.synchronize()
+        want = acts[2].clone()
+        rt.fused_brgemm(BF16, *broken[2])
+        rt.synchronize()
+        assert torch.equal(want, acts[2])
+        for a in acts:
+            a.zero_()
+        # ping-pong: layer 2 writes the buffer layer 0 wrote (its rows are still being read by slower workgroups of layer 1)
+        pp = [acts[0], acts[1], acts[0]]
+        assert not rt.fused_brgemm_chain(BF16, ch.calls(dx, pp))
+        rt.synchronize()
+        check_close(host(acts[0], x), ref[2], BF16, "fallback ping-pong")
+        for a in acts:
+            a.zero_()
+        # more tiles than compute units even with 128x128 tiles
+        big = Chain(rt, 8192, [64, 1024, 1024], seed=3)
+        bx = dev(big.new_input())
+        bacts = [dev(np.zeros(8192 * 1024, np.uint16)) for _ in range(2)]
+        assert not rt.fused_brgemm_chain(BF16, big.calls(bx, bacts))
+        rt.synchronize()
+    finally:
+        rt.synchronize()
+        rt.set_async(was_async)
+
+
+def test_sharded_mlp_forward_uses_the_chain(rt):
+    """tpp-mlir_amd.mlp.ShardedMlp.forward hands the rank's step over in one call"""
+    import torch
+    spec = pkg.MlpSpec(batch=1024, layers=[256, 256, 256, 256])
+    rng = np.random.default_rng(9)
+    W = [dev(rand(rng, 128 * 256 * 2, BF16, -0.25, 0.25)) for _ in range(3)]
+    b = [dev(rand(rng, 256, BF16)) for _ in range(3)]
+    x = dev(rand(rng, 256 * 256, BF16))
+    was_async = rt.set_async(True)
+    try:
+        outs = []
+        for chain in (True, False):
+            mlp = pkg.ShardedMlp(spec, rank=1, world=4, rt=rt, chain=chain)
+            acts = [torch.zeros(256 * 256, dtype=torch.int16, device="cuda") for _ in range(3)]
+            mlp.forward(x, W, b, acts)
+            rt.synchronize()
+            assert mlp.last_step_fused == chain
+            outs.append(acts)
+        for l in range(3):
+            a, c = outs[0][l], outs[1][l]
+            # (the separate launches pick their own tile: same arithmetic, a K split may round differently)
+            check_close(host(a, np.zeros(1, np.uint16)), host(c, np.zeros(1, np.uint16)), BF16, "ShardedMlp layer %d" % l)
+    finally:
+        rt.set_async(was_async)

@@ -14,8 +14,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO_NAME = "libtpp_xsmm_runner_utils.so"
 SO_PATH = os.path.join(HERE, SO_NAME)
-SOURCES = ["runtime.cpp", "brgemm_f32.hip", "brgemm_f32_lw.hip", "brgemm_bf16.hip", "brgemm_bf16_dma256.hip", "brgemm_bf16_small.hip", "eltwise.hip"]
-HEADERS = ["xsmm_desc.h", "gemm_common.h", os.path.join("..", "..", "include", "tpp_xsmm_abi.h")]
+SOURCES = ["runtime.cpp", "brgemm_f32.hip", "brgemm_f32_lw.hip", "brgemm_bf16.hip", "brgemm_bf16_dma256.hip", "brgemm_bf16_small.hip", "brgemm_bf16_lw.hip", "eltwise.hip"]
+HEADERS = ["xsmm_desc.h", "gemm_common.h", "chain_args.h", os.path.join("..", "..", "include", "tpp_xsmm_abi.h")]
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
@@ -67,7 +67,7 @@ def build_tools(verbose=False):
     this path) and tools/c2_probe (per-launch timing of C2 + the target of bench.py's rocprofv3 PMC passes)"""
     root = os.path.dirname(HERE)
     outs = []
-    for name, extra in (("tpp_replay", ["-fopenmp"]), ("c2_probe", [])):
+    for name, extra in (("tpp_replay", ["-fopenmp"]), ("c2_probe", []), ("mlp_probe", [])):
         src = os.path.join(root, "tools", name + ".cpp")
         out = os.path.join(root, "tools", name)
         if not os.path.exists(src):

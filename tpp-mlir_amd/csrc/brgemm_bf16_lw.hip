@@ -1,0 +1,472 @@
+// brgemm_bf16_lw.hip - bf16 (VNNI-2 B) batch-reduce GEMM with LOADER WAVES for MID-SIZE outputs, and the same kernel
+// as a CHAIN of whole-layer fused BRGEMMs in ONE launch (a rank's share of an MLP: layer l+1 on rows [r, r + BM)
+// depends only on layer l's same rows).
+//
+// Why a new family: the shard shapes of the row-sharded MLP (m = 512 ... 2048 rows x 1024 columns, K = 1024) ran at
+// 6-18 % of the bf16 MFMA peak on the existing tiles - the 128x128 LDS-DMA tile leaves 3/4 .. 1/2 of the CUs without
+// a workgroup, the 64x64 register-staged tile and the 32x32 fragment-from-global tile pay a ds_write pass / uncoalesced
+// fragment loads. Measured in round 2: a CU's L2 -> LDS fill path delivers 34-45 B/clk whatever the
+// tile, so the time of such a layer is (panel bytes a CU must pull) / (that rate) + the fixed cost of a launch. The
+// tiles here are chosen to put ONE workgroup on EVERY CU (32x64, 64x64, 64x128, 128x128 for 512 / 1024 / 2048 / 4096
+// rows of a 1024-wide layer) with every panel byte moved by LDS-DMA from two loader waves through a deep ring.
+//
+// Structure (as brgemm_f32_lw.hip): WM*WN*WK MFMA waves + 2 loader waves (first two hardware waves: A and B).
+//   MFMA waves : ds_read fragments + v_mfma_f32_32x32x16_bf16 + ONE raw s_barrier per 64-k chunk; a wave owns TM x TN
+//                accumulator tiles of 32x32; WK = 2 splits the four k-steps of a chunk over two wave groups (partials
+//                combined once through LDS) - the 32x64 tile keeps four SIMDs busy that way.
+//   loaders    : all LDS-DMA of the workgroup, NSLOT-1 chunks ahead through an NSLOT-slot ring, counted vmcnt.
+//   LDS images : A [BM rows][8 x 16 B], 16-byte column XOR ((row>>1)&7) applied to the SOURCE address and again by the
+//                ds_read_b128; B = the VNNI-2 pair-rows as they are [32][BN dwords] (brgemm_bf16.hip has the notes).
+//   epilogue   : (+C) / bias / relu -> v_cvt_pk_bf16_f32 (RNE, the one rounding) -> v_permlane32_swap to 16-byte
+//                pieces -> per-wave LDS tile (its OWN region, the ring keeps streaming) -> coalesced 16-byte stores.
+//
+// Chain mode (MULTI): grid = one workgroup per output tile, all co-resident (tiles <= CUs, one workgroup per CU by
+// LDS), every workgroup computes its tile (tm, tn) of EVERY layer. The seam between layer l and l+1, per row block tm:
+//   producer: tile stored WRITE-THROUGH (sc1 16-byte stores), every storing wave drains vmcnt(0), workgroup barrier,
+//             one lane adds 1 to cnt[l][tm] (relaxed, agent scope)             [guide: Guideline 16, recipe R1]
+//   consumer: the A loader polls cnt[l][tm] (relaxed sc1 load, s_sleep) until all tiles_n producers of this launch
+//             have arrived, then streams the A panel with sc1 LDS-DMA loads (L1 bypassed: no acquire fence needed
+//             when producer stored sc1 and consumer loads sc1).
+//   The B loader does not stop at a seam: the next layer's weight panels are prefetched under the epilogue (when the
+//   chunk count of a layer is a multiple of the ring depth, so that ring positions line up).
+//   Counters are monotonic: a launch adds exactly tiles_n to each, the host passes target = epoch * tiles_n; nothing
+//   is reset (no memset launch in front of the kernel). Every spin is bounded by s_memrealtime: on a timeout the
+//   workgroup sets *err and carries on (wrong numbers, never a hung GPU); the host checks *err at its sync points.
+//   Results are bit-identical to the same layers launched one by one (same tile, same k order, same rounding).
+#include "gemm_common.h"
+#include "xsmm_desc.h"
+#include "chain_args.h"
+#include <type_traits>
+
+namespace tpp {
+
+typedef __bf16 bf16x8_lw __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void lds_void_b;
+typedef unsigned int u32x2_lw __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) unsigned int g_u32_lw;
+
+constexpr int BLW_BK = 64; // k per chunk
+// The kernel's argument block, read where it lies (kernarg segment, constant address space): the layer table is indexed at
+// run time, and a by-value / by-reference copy of the struct would be spilled to scratch (640 bytes per lane) for that.
+typedef const __attribute__((address_space(4))) ChainArgs chain_kernarg_t;
+
+// s_waitcnt vmcnt(younger * PPL): this wave's DMA of all but the `younger` most recent chunks has landed
+template <int PPL> __device__ __forceinline__ void blw_wait_younger(int younger) {
+#define BLW_CASE(K)                                                                   \
+  case K:                                                                             \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((K) * PPL > 63 ? 63 : (K) * PPL) : "memory"); \
+    break;
+  switch (younger) {
+    BLW_CASE(0) BLW_CASE(1) BLW_CASE(2) BLW_CASE(3) BLW_CASE(4) BLW_CASE(5) BLW_CASE(6)
+  default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+#undef BLW_CASE
+}
+
+// chunk bodies with the ring slot as a literal: S = 0 .. N-1, then around again
+template <int S, int N, typename F> __device__ __forceinline__ bool blw_ring_pass(int &t, int T, F &f) {
+  if constexpr (S < N) {
+    f(std::integral_constant<int, S>{}, t + 1 < T);
+    if (++t == T) return true;
+    return blw_ring_pass<S + 1, N>(t, T, f);
+  } else {
+    return false;
+  }
+}
+
+// One loader wave: every LDS-DMA instruction of its panel (IS_A: the A panel [BM rows][64 k], else the B panel [32 pair-rows][BN
+// dwords]) for every chunk of every layer, NSLOT - 1 chunks ahead of the MFMA waves, and its side of the barrier schedule:
+//   per layer  P (chunk 0 published), one mid-chunk barrier per further chunk, and - between layers - R1 (WK > 1) and S1.
+// In chain mode the A loader waits at a seam for the row block's producers; the B loader prefetches across it.
+template <bool IS_A, int NSLOT, int BM, int BN, int WK, bool MULTI>
+__device__ __forceinline__ void blw_loader(chain_kernarg_t *pp, unsigned char *smem, int lane, int m0, int n0, int tm, int L) {
+  chain_kernarg_t &p = *pp;
+  constexpr int A_SLOT = BM * 128, SLOT = (BM + BN) * 128;
+  constexpr int PPL = IS_A ? BM / 8 : BN / 8; // 1 KiB DMA instructions per chunk
+  [[maybe_unused]] constexpr int RPI = 256 / BN; // VNNI pair-rows per B instruction
+  bool ahead = false; // B only: panels of the next layer are prefetched across the seam
+  int total = 0;
+  if (MULTI) {
+    ahead = !IS_A;
+    for (int l = 0; l < L; ++l) {
+      const int Tl = p.L[l].br * (p.L[l].k / BLW_BK);
+      total += Tl;
+      if (Tl % NSLOT) ahead = false; // ring positions of consecutive layers must line up
+    }
+  }
+  // issue cursor: chunk ti of layer li goes to ring slot islot; g = panel base of that chunk
+  int li = 0, ti = 0, islot = 0, issued = 0;
+  int Ti, kc, kchunks;
+  const unsigned short *g;
+  int64_t d_in, d_wrap;
+  unsigned vo0, vo1, step;
+#define BLW_LOAD_LAYER(l)                                                                                              \
+  do {                                                                                                                 \
+    kchunks = p.L[l].k / BLW_BK;                                                                                       \
+    Ti = p.L[l].br * kchunks;                                                                                          \
+    kc = 0;                                                                                                            \
+    if (IS_A) {                                                                                                        \
+      const int64_t lda_ = (l) == 0 ? p.lda : p.L[(l) > 0 ? (l)-1 : 0].ldc;                                            \
+      const unsigned short *A_ = (const unsigned short *)((l) == 0 ? p.A : p.L[(l) > 0 ? (l)-1 : 0].C);                \
+      g = A_ + (int64_t)m0 * lda_;                                                                                     \
+      d_in = BLW_BK;                                                                                                   \
+      d_wrap = p.L[l].stride_a - (int64_t)(kchunks - 1) * BLW_BK;                                                      \
+      /* instruction v covers rows 8v .. 8v+7: lane -> row 8v + lane/8, 16-byte piece lane%8 XOR ((row>>1)&7) = 4(v&1) + lane/16 */ \
+      const unsigned rowoff_ = (unsigned)((lane >> 3) * (int)lda_ * 2);                                                \
+      vo0 = rowoff_ + (unsigned)(((lane & 7) ^ (lane >> 4)) << 4);                                                     \
+      vo1 = rowoff_ + (unsigned)(((lane & 7) ^ (4 + (lane >> 4))) << 4);                                               \
+      step = (unsigned)(8 * (int)lda_ * 2);                                                                            \
+    } else {                                                                                                           \
+      g = (const unsigned short *)p.L[l].B + 2 * (int64_t)n0;                                                          \
+      d_in = (int64_t)(BLW_BK / 2) * 2 * p.L[l].ldb;                                                                   \
+      d_wrap = p.L[l].stride_b - (int64_t)(kchunks - 1) * d_in;                                                        \
+      /* instruction v covers pair-rows RPI*v ..: lane -> pair-row lane / (BN/4), 16-byte piece lane % (BN/4) */       \
+      vo0 = vo1 = (unsigned)((lane / (BN / 4)) * (int)p.L[l].ldb * 4 + ((lane % (BN / 4)) << 4));                      \
+      step = (unsigned)(RPI * (int)p.L[l].ldb * 4);                                                                    \
+    }                                                                                                                  \
+  } while (0)
+  BLW_LOAD_LAYER(0);
+#define BLW_ISSUE_NEXT()                                                                                               \
+  do {                                                                                                                 \
+    unsigned char *base_ = smem + islot * SLOT + (IS_A ? 0 : A_SLOT);                                                  \
+    const __amdgpu_buffer_rsrc_t r_ = __builtin_amdgcn_make_buffer_rsrc((void *)g, 0, 0x7fffffff, 0x00020000);         \
+    if (IS_A && MULTI && li > 0) { /* written by other workgroups in THIS launch: sc1 loads (L1 bypassed) */          \
+      _Pragma("unroll") for (int v = 0; v < PPL; ++v)                                                                  \
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(r_, (lds_void_b *)(base_ + v * 1024), 16, (v & 1) ? vo1 : vo0, v * step, 0, 16); \
+    } else {                                                                                                           \
+      _Pragma("unroll") for (int v = 0; v < PPL; ++v)                                                                  \
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(r_, (lds_void_b *)(base_ + v * 1024), 16, (v & 1) ? vo1 : vo0, v * step, 0, 0); \
+    }                                                                                                                  \
+    if (++kc == kchunks) {                                                                                             \
+      kc = 0;                                                                                                          \
+      g += d_wrap;                                                                                                     \
+    } else {                                                                                                           \
+      g += d_in;                                                                                                       \
+    }                                                                                                                  \
+    ++issued;                                                                                                          \
+    if (++islot == NSLOT) islot = 0;                                                                                   \
+    if (++ti == Ti) { /* on to the next layer (its chunk 0 goes to slot 0) */                                          \
+      ++li;                                                                                                            \
+      ti = 0;                                                                                                          \
+      islot = 0;                                                                                                       \
+      if (MULTI && li < L) BLW_LOAD_LAYER(li);                                                                         \
+    }                                                                                                                  \
+  } while (0)
+  int gbase = 0; // global index of chunk 0 of the layer being consumed
+  for (int lc = 0; lc < L; ++lc) {
+    const int T = p.L[lc].br * (p.L[lc].k / BLW_BK);
+    const int limit = ahead ? total : gbase + T; // chunks this wave may issue before the layer is over
+    if (MULTI && IS_A && lc > 0) {
+      // every producer tile of row block tm of layer lc-1 has been stored (write-through) and drained
+      g_u32_lw *c = (g_u32_lw *)(p.cnt + (size_t)(lc - 1) * p.tiles_m + tm);
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      for (;;) {
+        const unsigned v = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((int)(v - p.target) >= 0) break;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > CHAIN_TIMEOUT_TICKS) { // never hang the GPU: flag it and go on
+          if (lane == 0) __hip_atomic_store((g_u32_lw *)p.err, 1u + (unsigned)lc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      asm volatile("" ::: "memory");
+    }
+    {
+      const int want = gbase + NSLOT - 1 < limit ? gbase + NSLOT - 1 : limit;
+      while (issued < want) BLW_ISSUE_NEXT();
+    }
+    blw_wait_younger<PPL>(issued - (gbase + 1));
+    __builtin_amdgcn_s_barrier(); // P: chunk 0 of this layer published
+    for (int t = 0; t + 1 < T; ++t) {
+      blw_wait_younger<PPL>(issued - (gbase + t + 2));
+      __builtin_amdgcn_s_barrier(); // = the MFMA waves' mid-chunk barrier of chunk t: chunk t+1 published, slot of chunk t-1 retired
+      if (issued < limit && issued < gbase + t + NSLOT) BLW_ISSUE_NEXT();
+    }
+    if (lc + 1 == L) return;
+    if constexpr (WK > 1) __builtin_amdgcn_s_barrier(); // R1 (K groups combine)
+    __builtin_amdgcn_s_barrier();                        // S1 (tile stored and drained)
+    gbase += T;
+  }
+#undef BLW_ISSUE_NEXT
+#undef BLW_LOAD_LAYER
+}
+
+template <int WM, int WN, int WK, int TM, int TN, int NSLOT, bool MULTI>
+__global__ __launch_bounds__(64 * (WM * WN * WK + 2)) void brgemm_bf16_lw(ChainArgs p_by_value) {
+  chain_kernarg_t *pp = (chain_kernarg_t *)__builtin_amdgcn_kernarg_segment_ptr(); // = &p_by_value (the only explicit argument)
+  chain_kernarg_t &p = *pp;
+  constexpr int NMW = WM * WN * WK, NOUT = WM * WN; // MFMA waves; waves that own output
+  constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
+  constexpr int KS = 4 / WK, PD = KS / 2;            // k-steps of a chunk per wave; fragment prefetch distance
+  constexpr int A_SLOT = BM * 128, B_SLOT = BN * 128, SLOT = A_SLOT + B_SLOT;
+  constexpr int NA = BM / 8, NBI = BN / 8;           // 1 KiB DMA instructions per chunk of A / of B
+  constexpr int RPI = 256 / BN;                      // VNNI pair-rows per B instruction
+  constexpr int ES = 64 * TN + 16;                   // bytes per staged output row (16 B pad: conflict-free 16-byte accesses)
+  constexpr int STAGE_W = 32 * ES;                   // one 32-row block of a wave's tile
+  constexpr int OFF_STAGE = NSLOT * SLOT, OFF_RED = OFF_STAGE + NOUT * STAGE_W;
+  static_assert(WK == 1 || (WK == 2 && TM == 1 && TN == 1), "K split: two groups of single-tile waves");
+  static_assert((NSLOT - 1) * NA <= 63 && (NSLOT - 1) * NBI <= 63, "vmcnt is 6 bits");
+  static_assert(BN == 32 || BN == 64 || BN == 128, "B pair-rows per DMA instruction");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_c[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  // the loader waves are the FIRST two hardware waves (waves start in order: the first chunks are requested before the
+  // MFMA waves exist); `wave` is the role: MFMA waves 0 .. NMW-1, A loader NMW, B loader NMW+1
+  const int hw_wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = hw_wave < 2 ? NMW + hw_wave : hw_wave - 2;
+  // tile of this workgroup: all tiles_n tiles of a row block on ONE XCD (block b runs on XCD b % 8: the row block's A
+  // panel is fetched into one L2, and in chain mode its hand-off stays inside it) when the row blocks divide by 8
+  const int b = (int)blockIdx.x;
+  int tm, tn;
+  if ((p.tiles_m & 7) == 0) {
+    const int j = b >> 3;
+    tn = j % p.tiles_n;
+    tm = (b & 7) + 8 * (j / p.tiles_n);
+  } else {
+    tm = b / p.tiles_n;
+    tn = b - tm * p.tiles_n;
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int L = MULTI ? p.nlayers : 1;
+
+  if (wave >= NMW) {
+    // ---- loader waves (blw_loader below): wave NMW streams A, wave NMW + 1 streams B ---------------------------------
+    if (wave == NMW) blw_loader<true, NSLOT, BM, BN, WK, MULTI>(pp, smem_c, lane, m0, n0, tm, L);
+    else blw_loader<false, NSLOT, BM, BN, WK, MULTI>(pp, smem_c, lane, m0, n0, tm, L);
+    return; // ended waves do not take part in later barriers
+  }
+
+  // ---- MFMA waves ------------------------------------------------------------------------------------------------
+  const int wk = wave / NOUT, wmn = wave % NOUT, wm = wmn / WN, wn = wmn % WN;
+  const int li = lane & 31, lh = lane >> 5;
+  f32x16 acc[TM][TN];
+  bf16x8_lw af[KS][TM];
+  u32x4 bw[KS][TN]; // B fragments as dwords
+  int b_lane[TN];   // dword index of this lane's column of tile j in pair-row 4*lh of a k-step
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    b_lane[j] = (4 * lh) * BN + (wn * TN + j) * 32 + li;
+    asm volatile("" : "+v"(b_lane[j])); // one base VGPR per column tile: rows r, r+1 pair up as ds_read2(st64)_b32
+  }
+  auto frag_load = [&](int buf, int slot, int ks) __attribute__((always_inline)) {
+    const unsigned char *as = smem_c + slot * SLOT;
+    const unsigned int *bs = (const unsigned int *)(as + A_SLOT);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int row = (wm * TM + i) * 32 + li;
+      af[buf][i] = *(const bf16x8_lw *)(as + row * 128 + (((2 * ks + lh) ^ ((row >> 1) & 7)) << 4));
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const unsigned int *bp = bs + b_lane[j] + (8 * ks) * BN;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bw[buf][j][r] = bp[r * BN];
+    }
+  };
+  // one chunk in ring slot S: step q multiplies fragment buffer q while the fragments of step q + PD are read (the last PD
+  // steps read the first steps of chunk t+1, published by the mid-chunk barrier; after the last chunk of a layer they
+  // read a slot nobody uses - the values are dropped)
+  auto chunk = [&](auto slot_c, bool has_next) __attribute__((always_inline)) {
+    constexpr int S = decltype(slot_c)::value, NS = (S + 1) % NSLOT;
+#pragma unroll
+    for (int q = 0; q < KS; ++q) {
+      if (q + PD < KS) frag_load(q + PD, S, wk * KS + q + PD);
+      else frag_load(q + PD - KS, NS, wk * KS + q + PD - KS);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_lw, bw[q][j]), af[q][i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (q == KS / 2 - 1 && has_next) {
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+
+  for (int l = 0; l < L; ++l) {
+    const auto &Y = p.L[l];
+    const int T = Y.br * (Y.k / BLW_BK);
+    const int ep = Y.ep;
+    unsigned short *__restrict__ C = (unsigned short *)Y.C;
+    const unsigned ldcb = (unsigned)((int)Y.ldc * 2);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    // bias: fetched here (8 bytes = 4 columns per register quad), used in the epilogue - its latency hides under the K loop
+    u32x2_lw biasw[TN][4];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        biasw[j][g] = u32x2_lw{0u, 0u};
+        if (ep & EP_BIAS) biasw[j][g] = *(const u32x2_lw *)((const unsigned short *)Y.D + n0 + (wn * TN + j) * 32 + 8 * g + 4 * lh);
+      }
+    __builtin_amdgcn_s_barrier(); // P: chunk 0 published
+    __builtin_amdgcn_sched_barrier(0);
+    if (T > 0) { // (an empty batch: C = epilogue of zero)
+#pragma unroll
+      for (int s = 0; s < PD; ++s) frag_load(s, 0, wk * KS + s);
+      for (int t = 0;;)
+        if (blw_ring_pass<0, NSLOT>(t, T, chunk)) break;
+    }
+    // the fragments prefetched past the end of the layer are dead: without this the compiler sinks their reads
+#pragma unroll
+    for (int s = 0; s < PD; ++s) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(af[s][i]));
+#pragma unroll
+      for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(bw[s][j]));
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------------------------------
+    if constexpr (WK > 1) {
+      // K group 1 parks its 32x32 partial, group 0 adds it (group order: 0 + 1) and finishes the tile
+      float *red = (float *)(smem_c + OFF_RED) + wmn * 1024 + lane;
+      if (wk == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[r * 64] = acc[0][0][r];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier(); // R1
+      if (wk == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][0][r] += red[r * 64];
+      }
+    }
+    if (WK == 1 || wk == 0) {
+      // lane (li, lh) owns row 32*i + li of the wave's row block i and, in registers 4g..4g+3 of tile (i, j),
+      // columns 32*j + 8*g + 4*lh + (0..3)
+      const __amdgpu_buffer_rsrc_t rsrcC = __builtin_amdgcn_make_buffer_rsrc(
+          (void *)(C + (int64_t)(m0 + wm * 32 * TM) * Y.ldc + n0 + wn * 32 * TN), 0, 0x7fffffff, 0x00020000);
+      if constexpr (!MULTI) {
+        if (!(ep & EP_BETA0)) { // beta = 1: add C before the single rounding (8-byte loads, rare path)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                const u32x2_lw c2 = __builtin_amdgcn_raw_buffer_load_b64(
+                    rsrcC, (unsigned)(32 * i + li) * ldcb + (unsigned)((32 * j + 8 * g + 4 * lh) * 2), 0, 0);
+                acc[i][j][4 * g + 0] += __uint_as_float(c2[0] << 16);
+                acc[i][j][4 * g + 1] += __uint_as_float(c2[0] & 0xffff0000u);
+                acc[i][j][4 * g + 2] += __uint_as_float(c2[1] << 16);
+                acc[i][j][4 * g + 3] += __uint_as_float(c2[1] & 0xffff0000u);
+              }
+        }
+      }
+      const bool relu = (ep & EP_RELU) != 0;
+      unsigned char *ot = smem_c + OFF_STAGE + wmn * STAGE_W;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          float bias[4][4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const u32x2_lw b2 = biasw[j][g];
+            bias[g][0] = __uint_as_float(b2[0] << 16);
+            bias[g][1] = __uint_as_float(b2[0] & 0xffff0000u);
+            bias[g][2] = __uint_as_float(b2[1] << 16);
+            bias[g][3] = __uint_as_float(b2[1] & 0xffff0000u);
+          }
+          unsigned int pk[4][2];
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+              float v0 = acc[i][j][4 * g + 2 * h2] + bias[g][2 * h2];
+              float v1 = acc[i][j][4 * g + 2 * h2 + 1] + bias[g][2 * h2 + 1];
+              if (relu) { // wave-uniform; max(x, 0) == (x > 0 ? x : 0) incl. NaN -> 0
+                v0 = __builtin_fmaxf(v0, 0.0f);
+                v1 = __builtin_fmaxf(v1, 0.0f);
+              }
+              typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+              typedef float f32x2_t __attribute__((ext_vector_type(2)));
+              const f32x2_t vv = {v0, v1};
+              pk[g][h2] = __builtin_bit_cast(unsigned int, __builtin_convertvector(vv, bf16x2_t)); // one v_cvt_pk_bf16_f32 (RNE)
+            }
+#pragma unroll
+          for (int g = 0; g < 4; g += 2) {
+            const auto s0 = __builtin_amdgcn_permlane32_swap(pk[g][0], pk[g + 1][0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(pk[g][1], pk[g + 1][1], false, false);
+            const u32x4 out = {s0[0], s1[0], s0[1], s1[1]};
+            // lower half-wave: columns 32j + 8g .. +7 ; upper: 32j + 8(g+1) .. +7
+            *(u32x4 *)(ot + li * ES + (32 * j + 8 * g + 8 * lh) * 2) = out;
+          }
+        }
+        // the same wave reads its 32-row block back row-contiguously: 4*TN lanes x 16 B = one row
+        constexpr int LPR = 4 * TN, RPP = 64 / LPR; // lanes per row, rows per pass
+#pragma unroll
+        for (int it = 0; it < 32 / RPP; ++it) {
+          const int row = it * RPP + lane / LPR, ch = lane % LPR;
+          const u32x4 v = *(const u32x4 *)(ot + row * ES + ch * 16);
+          const unsigned voff = (unsigned)(32 * i + row) * ldcb + (unsigned)(ch * 16);
+          if (MULTI && l + 1 < L) __builtin_amdgcn_raw_buffer_store_b128(v, rsrcC, voff, 0, 16); // sc1: write-through (hand-off)
+          else __builtin_amdgcn_raw_buffer_store_b128(v, rsrcC, voff, 0, 0);
+        }
+      }
+    }
+    if (l + 1 == L) break;
+    if constexpr (MULTI) {
+      // ---- seam: publish this tile to the row block's consumers ------------------------------------------------
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // EVERY storing wave drains its write-through stores
+      __builtin_amdgcn_s_barrier();                     // S1
+      if (wave == 0 && lane == 0)
+        __hip_atomic_fetch_add((g_u32_lw *)(p.cnt + (size_t)l * p.tiles_m + tm), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+template <int WM, int WN, int WK, int TM, int TN, int NSLOT, bool MULTI> static hipError_t launch_blw_t(const ChainArgs &a, hipStream_t s) {
+  constexpr int NOUT = WM * WN, BM = 32 * WM * TM, BN = 32 * WN * TN, NT = 64 * (WM * WN * WK + 2);
+  constexpr size_t lds = (size_t)NSLOT * (BM + BN) * 128 + (size_t)NOUT * 32 * (64 * TN + 16) + (WK > 1 ? (size_t)NOUT * 4096 : 0);
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  auto kern = brgemm_bf16_lw<WM, WN, WK, TM, TN, NSLOT, MULTI>;
+  static std::atomic<unsigned long long> lds_set{0};
+  if (hipError_t e = ensure_dynamic_lds((const void *)kern, (int)lds, lds_set); e != hipSuccess) return e;
+  ChainArgs args = a;
+  args.tiles_m = a.m / BM;
+  args.tiles_n = a.n / BN;
+  const long long tiles = (long long)args.tiles_m * args.tiles_n;
+  if (tiles <= 0 || tiles > 0x7fffffffLL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(NT), lds, s, args);
+  return hipGetLastError();
+}
+
+// tile: 0 = 32x64 (K split over two wave groups), 1 = 64x64, 2 = 64x128, 3 = 128x128
+void blw_tile_dims(int tile, int *bm, int *bn) {
+  static const int BMs[4] = {32, 64, 64, 128}, BNs[4] = {64, 64, 128, 128};
+  *bm = BMs[tile & 3];
+  *bn = BNs[tile & 3];
+}
+
+// one layer (a.nlayers == 1): any chunk stream, both accumulator starts
+hipError_t launch_bf16_lw(int tile, const ChainArgs &a, hipStream_t s) {
+  switch (tile) {
+  case 0: return launch_blw_t<1, 2, 2, 1, 1, 8, false>(a, s);
+  case 1: return launch_blw_t<2, 2, 1, 1, 1, 8, false>(a, s);
+  case 2: return launch_blw_t<2, 2, 1, 1, 2, 4, false>(a, s);
+  case 3: return launch_blw_t<2, 2, 1, 2, 2, 4, false>(a, s);
+  default: return hipErrorInvalidValue;
+  }
+}
+
+// a chain of layers in one launch; the caller guarantees co-residency (tiles <= CUs), beta = 0 and disjoint buffers
+hipError_t launch_bf16_chain(int tile, const ChainArgs &a, hipStream_t s) {
+  switch (tile) {
+  case 0: return launch_blw_t<1, 2, 2, 1, 1, 8, true>(a, s);
+  case 1: return launch_blw_t<2, 2, 1, 1, 1, 8, true>(a, s);
+  case 2: return launch_blw_t<2, 2, 1, 1, 2, 4, true>(a, s);
+  case 3: return launch_blw_t<2, 2, 1, 2, 2, 4, true>(a, s);
+  default: return hipErrorInvalidValue;
+  }
+}
+
+} // namespace tpp

@@ -24,6 +24,7 @@
 //     (conflict free: 32 consecutive columns per lane group).
 #include "gemm_common.h"
 #include "xsmm_desc.h"
+#include "chain_args.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -642,6 +643,10 @@ enum GemmVariant : int {
   V_BF16_DMA128 = 17, // brgemm_bf16.hip: 128x128, LDS-DMA + loader waves
   V_BF16_DMA256 = 18, // brgemm_bf16_dma256.hip: 256x256, LDS-DMA
   V_BF16_SMALL32 = 19, // brgemm_bf16_small.hip: 32x32 tiles, 4 waves split K, fragments straight from global memory
+  V_BF16_LW_32x64 = 20,   // brgemm_bf16_lw.hip: loader-wave tiles for mid-size outputs (one workgroup per CU), 32x64 + K2
+  V_BF16_LW_64x64 = 21,
+  V_BF16_LW_64x128 = 22,
+  V_BF16_LW_128x128 = 23,
 };
 
 template <int WM, int WN, int WK, int NACC, bool DMA>
@@ -790,8 +795,33 @@ static int pick_f32_variant(const GemmDesc &d) {
   return V_GENERIC;
 }
 
+// Mid-size bf16 outputs: the loader-wave family (brgemm_bf16_lw.hip), tile chosen so that the grid is about one workgroup per
+// CU - the largest tile that still gives >= 3/4 of the CUs a workgroup, else the smallest tile that divides the output.
+// Returns the tile index (0 .. 3) or -1. TPP_HIP_BF16_LW=0 switches the family off (A/B runs).
+static int pick_bf16_lw_tile(const GemmDesc &d) {
+  static const int enabled = [] {
+    const char *e = getenv("TPP_HIP_BF16_LW");
+    return e ? atoi(e) : 1;
+  }();
+  if (!enabled) return -1;
+  int best = -1;
+  for (int t = 3; t >= 0; --t) {
+    int bm, bn;
+    blw_tile_dims(t, &bm, &bn);
+    if (d.m % bm || d.n % bn) continue;
+    const int64_t tiles = (d.m / bm) * (d.n / bn);
+    if (tiles * 4 >= 3 * (int64_t)g_num_cus) return t;
+    if (tiles * 2 >= (int64_t)g_num_cus) best = t; // keeps shrinking: ends at the smallest tile that divides
+  }
+  return best; // (-1: fewer than half the CUs would get a workgroup - the 32x32 K-split family serves those)
+}
+
 static const char *variant_name(int v) {
   switch (v) {
+  case V_BF16_LW_32x64: return "brgemm_bf16_lw<32x64,k2>";
+  case V_BF16_LW_64x64: return "brgemm_bf16_lw<64x64>";
+  case V_BF16_LW_64x128: return "brgemm_bf16_lw<64x128>";
+  case V_BF16_LW_128x128: return "brgemm_bf16_lw<128x128>";
   case V_F32_64x64: return "brgemm_f32_fast<64x64,k1>";
   case V_F32_64x32K2: return "brgemm_f32_fast<64x32,k2>";
   case V_F32_32x32K4: return "brgemm_f32_fast<32x32,k4>";
@@ -819,9 +849,20 @@ bool plan_gemm(GemmDesc &d, int forced_variant) {
     // every CU a workgroup. Measured crossover with the 64x64 family (n = 1024, K = 1024): 5.1 vs 8.4 us at 64
     // tiles of 64x64, 7.5 vs 8.5 at 128, 12.3 vs 8.9 at 256 (profiles/r01_sweep_shapes.txt)
     if (v == V_BF16_FAST && bf16_small_eligible(d) && (d.m / 64) * (d.n / 64) < (3 * g_num_cus) / 4) v = V_BF16_SMALL32;
+    // mid-size outputs (the 64x64 / 32x32 families, or 128x128 tiles for fewer than 3/4 of the CUs): one loader-wave workgroup
+    // per CU. Measured (profiles/r03_sweep_shapes.txt, 1024-wide layer, K = 1024): see DESIGN.md 4.2.
+    if (v == V_BF16_FAST || v == V_BF16_SMALL32 || (v == V_BF16_DMA128 && (d.m / 128) * (d.n / 128) * 4 < 3 * (int64_t)g_num_cus)) {
+      const int lw = pick_bf16_lw_tile(d);
+      if (lw >= 0 && !(lw == 3 && v == V_BF16_DMA128)) v = V_BF16_LW_32x64 + lw;
+    }
     const int tile = forced_variant - V_BF16_FAST; // a forced bf16 tile is honoured if the shape divides it
     if (tile >= 0 && tile <= 2 && d.m % (64 << tile) == 0 && d.n % (64 << tile) == 0) v = forced_variant;
     if (forced_variant == V_BF16_SMALL32 && bf16_small_eligible(d)) v = forced_variant;
+    if (forced_variant >= V_BF16_LW_32x64 && forced_variant <= V_BF16_LW_128x128) {
+      int bm, bn;
+      blw_tile_dims(forced_variant - V_BF16_LW_32x64, &bm, &bn);
+      if (d.m % bm == 0 && d.n % bn == 0) v = forced_variant;
+    }
   } else if (d.dtype == DT_BF16 && bf16_small_eligible(d)) {
     v = V_BF16_SMALL32; // k a multiple of 16 only (e.g. the compiler-native 32x32x32 tile), m or n a multiple of 32 only
   }
@@ -874,6 +915,16 @@ hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C,
   case V_BF16_DMA128:
   case V_BF16_DMA256: return launch_gemm_bf16_fast(v - V_BF16_FAST, a, stream);
   case V_BF16_SMALL32: return launch_bf16_small32(a, nullptr, 1, stream);
+  case V_BF16_LW_32x64:
+  case V_BF16_LW_64x64:
+  case V_BF16_LW_64x128:
+  case V_BF16_LW_128x128: {
+    ChainArgs c;
+    c.A = a.A; c.lda = a.lda; c.cnt = nullptr; c.err = nullptr; c.target = 0;
+    c.m = a.m; c.n = a.n; c.nlayers = 1; c.tiles_m = c.tiles_n = 0;
+    c.L[0] = ChainLayer{a.B, a.D, a.C, a.ldb, a.ldc, a.stride_a, a.stride_b, a.k, a.br, a.ep, 0};
+    return launch_bf16_lw(v - V_BF16_LW_32x64, c, stream);
+  }
   default: break;
   }
   // everything else: the grouped kernel with a single, inline work item

@@ -1,0 +1,37 @@
+// chain_args.h - kernel arguments of brgemm_bf16_lw.hip: one whole-layer (fused) bf16 BRGEMM, or a CHAIN of them run in
+// one launch (layer l+1 reads layer l's output rows; xsmm_hip_fused_brgemm_chain_invoke in runtime.cpp).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tpp {
+
+constexpr int CH_MAXL = 8;                                  // layers per chain launch
+constexpr unsigned long long CHAIN_TIMEOUT_TICKS = 5000000; // bound of every in-kernel spin: 50 ms of s_memrealtime (100 MHz)
+
+struct ChainLayer {
+  const void *B;   // VNNI-2 weights [K/2][ldb][2]
+  const void *D;   // bias row (EP_BIAS)
+  void *C;         // output [m][ldc]; the A operand of the next layer
+  int64_t ldb, ldc, stride_a, stride_b; // elements (stride_a applies to this layer's A = previous C / the chain input)
+  int k, br, ep, pad;                   // k per batch element (multiple of 64), batch count, EP_* bits
+};
+
+struct ChainArgs {
+  const void *A;   // input of layer 0 [m][lda]
+  int64_t lda;
+  unsigned *cnt;   // chain mode: arrival counters [nlayers - 1][tiles_m], monotonic across launches
+  unsigned *err;   // chain mode: set to 1 + layer by a workgroup whose hand-off wait timed out
+  unsigned target; // chain mode: value every counter reaches in this launch (epoch * tiles_n)
+  int m, n;        // rows and columns of every layer's output
+  int nlayers;
+  int tiles_m, tiles_n; // filled by the launcher
+  ChainLayer L[CH_MAXL];
+};
+
+// tile: 0 = 32x64 (K split over two wave groups), 1 = 64x64, 2 = 64x128, 3 = 128x128
+void blw_tile_dims(int tile, int *bm, int *bn);
+hipError_t launch_bf16_lw(int tile, const ChainArgs &a, hipStream_t s);
+hipError_t launch_bf16_chain(int tile, const ChainArgs &a, hipStream_t s);
+
+} // namespace tpp

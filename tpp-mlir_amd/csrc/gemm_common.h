@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "xsmm_desc.h"
 
 namespace tpp {
 
@@ -10,7 +11,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-enum : int { EP_BETA0 = 1, EP_BIAS = 2, EP_RELU = 4, EP_VNNI_C = 8 };
+// EP_* epilogue bits: xsmm_desc.h
 
 struct GemmArgs {
   const void *A;

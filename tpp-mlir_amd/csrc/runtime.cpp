@@ -12,6 +12,7 @@
 //  * there is NO CPU fallback: without a HIP device every invoke fails loudly.
 #include "../../include/tpp_xsmm_abi.h"
 #include "xsmm_desc.h"
+#include "chain_args.h"
 
 #include <dlfcn.h>
 #include <linux/membarrier.h>
@@ -1531,6 +1532,134 @@ void gemm_invoke_common(const char *who, bool want_fused, int64_t dtype, int64_t
   finish(ops, s);
 }
 
+// ---- chains of whole-layer fused BRGEMMs in one launch (xsmm_hip_fused_brgemm_chain_invoke) -----------------------------
+// Hand-off state of the chain kernel (brgemm_bf16_lw.hip, chain mode): arrival counters that only grow - a launch adds
+// tiles_n to each, its target is epoch * tiles_n - so a block of counters is tied to ONE (stream, tile grid, layer count):
+// launches of one block are ordered by their stream and issued under the mutex (epoch order = stream order). The err word
+// lives in pinned host memory: a workgroup whose wait timed out writes it over PCIe, the host reads it at its sync points.
+struct ChainBlock {
+  hipStream_t stream;
+  int tiles_m, tiles_n, nlayers;
+  unsigned *cnt; // device: (CH_MAXL - 1) * tiles_m counters
+  unsigned *err; // pinned host
+  unsigned epoch;
+};
+std::mutex g_chain_mu;
+std::vector<ChainBlock> g_chain_blocks;
+std::atomic<int> g_chain_launched{0}; // chain launches since the last check of the err words
+
+ChainBlock &chain_block(hipStream_t s, int tiles_m, int tiles_n, int nlayers) { // under g_chain_mu
+  for (ChainBlock &b : g_chain_blocks)
+    if (b.stream == s && b.tiles_m == tiles_m && b.tiles_n == tiles_n && b.nlayers == nlayers) return b;
+  ChainBlock b{s, tiles_m, tiles_n, nlayers, nullptr, nullptr, 0};
+  const size_t bytes = sizeof(unsigned) * (size_t)(CH_MAXL - 1) * (size_t)tiles_m;
+  HIP_OK(hipMalloc((void **)&b.cnt, bytes));
+  HIP_OK(hipMemset(b.cnt, 0, bytes));
+  HIP_OK(hipHostMalloc((void **)&b.err, sizeof(unsigned), hipHostMallocDefault));
+  *b.err = 0;
+  g_chain_blocks.push_back(b);
+  return g_chain_blocks.back();
+}
+// after the stream has been drained: did a hand-off of any chain launch time out?
+void check_chain_errors() {
+  if (!g_chain_launched.exchange(0, std::memory_order_acq_rel)) return;
+  std::lock_guard<std::mutex> lk(g_chain_mu);
+  for (ChainBlock &b : g_chain_blocks) {
+    const unsigned e = *(volatile unsigned *)b.err;
+    if (e) die("tpp-xsmm-hip: a fused-brgemm chain launch timed out waiting for the producers of layer %u's input (hand-off inside the "
+               "launch; were all workgroups resident?) - results of that launch are invalid", e - 1);
+  }
+}
+
+int chip_cus() { // compute units of the current device (0: unknown)
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+bool ranges_overlap(const void *a, size_t na, const void *b, size_t nb) {
+  return (const char *)a < (const char *)b + nb && (const char *)b < (const char *)a + na;
+}
+
+// true: the chain was launched as ONE kernel. false: the caller runs the invokes one by one (same result).
+bool try_chain_launch(int n, const GemmDesc *const *d, void *const *pa, void *const *pb, void *const *pc, void *const *pd, const int64_t *br,
+                      hipStream_t s) {
+  if (n < 2 || n > CH_MAXL || !cfg().async.load(std::memory_order_relaxed)) return false;
+  static const int enabled = [] {
+    const char *e = getenv("TPP_HIP_CHAIN");
+    return e ? atoi(e) : 1;
+  }();
+  if (!enabled) return false;
+  const int64_t m = d[0]->m, nn = d[0]->n;
+  thread_local DeviceRanges devmem;
+  devmem.refresh();
+  for (int i = 0; i < n; ++i) {
+    const GemmDesc &g = *d[i];
+    if (g.dtype != DT_BF16 || !g.vnni_b || g.vnni_c || !g.beta0 || !bf16_fast_eligible(g) || g.m != m || g.n != nn || br[i] < 1) return false;
+    if (g.variant == GEMM_VARIANT_GENERIC) return false; // (a forced generic kernel stays generic)
+    if (((uintptr_t)pa[i] | (uintptr_t)pb[i] | (uintptr_t)pc[i]) & 15) return false;
+    if (g.bias && (!pd[i] || ((uintptr_t)pd[i] & 7))) return false;
+    if (i > 0 && (pa[i] != pc[i - 1] || g.lda != d[i - 1]->ldc)) return false; // not a chain: layer i must read layer i-1's output
+    if (!devmem.is_device(pa[i], 0) || !devmem.is_device(pb[i], 1) || !devmem.is_device(pc[i], 2) || (g.bias && !devmem.is_device(pd[i], 3)))
+      return false;
+  }
+  // The tile: all workgroups must be co-resident (one per CU by LDS), so the grid may not exceed the CUs. If every layer was planned
+  // with the same loader-wave tile and that tile fits, use it - the launch is then bit-identical to the separate launches; else
+  // the smallest tile that fits (most CUs busy).
+  int tile = -1, bm = 0, bn = 0;
+  const int64_t cus = chip_cus();
+  auto fits = [&](int t) {
+    blw_tile_dims(t, &bm, &bn);
+    return m % bm == 0 && nn % bn == 0 && (m / bm) * (nn / bn) <= cus;
+  };
+  const int planned = d[0]->variant - GEMM_VARIANT_BF16_LW0;
+  bool same = planned >= 0 && planned < 4;
+  for (int i = 1; i < n && same; ++i) same = d[i]->variant == d[0]->variant;
+  if (same && fits(planned)) tile = planned;
+  for (int t = 0; t < 4 && tile < 0; ++t)
+    if (fits(t)) tile = t;
+  if (tile < 0) return false;
+  (void)fits(tile); // bm, bn of the chosen tile
+  // no operand of the launch may overlap an output (a layer's input rows are read by other workgroups while later layers store)
+  Operand A, B, C, D;
+  struct Span { const void *p; size_t n; };
+  std::vector<Span> outs, ins;
+  for (int i = 0; i < n; ++i) {
+    gemm_operands(d[i], pa[i], pb[i], pc[i], pd[i], br[i], A, B, C, D);
+    outs.push_back({C.ptr, C.bytes});
+    ins.push_back({B.ptr, B.bytes});
+    if (d[i]->bias) ins.push_back({D.ptr, D.bytes});
+    if (i == 0) ins.push_back({A.ptr, A.bytes});
+  }
+  for (size_t i = 0; i < outs.size(); ++i) {
+    for (size_t j = i + 1; j < outs.size(); ++j)
+      if (ranges_overlap(outs[i].p, outs[i].n, outs[j].p, outs[j].n)) return false;
+    for (const Span &x : ins)
+      if (ranges_overlap(outs[i].p, outs[i].n, x.p, x.n)) return false;
+  }
+  ChainArgs c;
+  memset(&c, 0, sizeof(c));
+  c.A = pa[0];
+  c.lda = d[0]->lda;
+  c.m = (int)m;
+  c.n = (int)nn;
+  c.nlayers = n;
+  for (int i = 0; i < n; ++i)
+    c.L[i] = ChainLayer{pb[i], pd[i], pc[i], d[i]->ldb, d[i]->ldc, d[i]->stride_a, d[i]->stride_b, (int)d[i]->k, (int)br[i],
+                        EP_BETA0 | (d[i]->bias ? EP_BIAS : 0) | (d[i]->relu ? EP_RELU : 0), 0};
+  std::lock_guard<std::mutex> lk(g_chain_mu);
+  ChainBlock &blk = chain_block(s, (int)(m / bm), (int)(nn / bn), n);
+  c.cnt = blk.cnt;
+  c.err = blk.err;
+  c.target = ++blk.epoch * (unsigned)blk.tiles_n;
+  HIP_OK(launch_bf16_chain(tile, c, s));
+  g_chain_launched.store(1, std::memory_order_release);
+  return true;
+}
+
 } // namespace
 
 // =============================== dispatch ==========================================
@@ -1717,7 +1846,10 @@ extern "C" int64_t perf_start_timer(void) {
 extern "C" double perf_stop_timer(int64_t start) {
   flush_tile_queue();
   g_devmem_epoch.fetch_add(1, std::memory_order_relaxed);
-  if (cfg().async.load()) HIP_OK(hipStreamSynchronize(cfg().stream.load())); // an asynchronous kernel fault must not read as a timing
+  if (cfg().async.load()) {
+    HIP_OK(hipStreamSynchronize(cfg().stream.load())); // an asynchronous kernel fault must not read as a timing
+    check_chain_errors();
+  }
   const int64_t now = std::chrono::duration_cast<std::chrono::nanoseconds>(
                           std::chrono::high_resolution_clock::now().time_since_epoch())
                           .count();
@@ -1730,6 +1862,7 @@ extern "C" int xsmm_hip_set_async(int enable) {
   const int prev = cfg().async.exchange(enable != 0);
   if (prev && !enable) { // leaving async mode restores "results visible on return" for everything already enqueued
     HIP_OK(hipStreamSynchronize(cfg().stream.load()));
+    check_chain_errors();
     g_devmem_epoch.fetch_add(1, std::memory_order_relaxed);
   }
   return prev;
@@ -1739,13 +1872,50 @@ extern "C" void xsmm_hip_set_stream(void *s) {
   const hipStream_t old = cfg().stream.exchange((hipStream_t)s);
   // xsmm_hip_synchronize / perf_stop_timer / leaving async mode drain the CURRENT stream only, and the header promises that
   // operands may be freed after they return: work enqueued on the stream being left must not outlive that promise
-  if (old != (hipStream_t)s && cfg().async.load(std::memory_order_relaxed)) HIP_OK(hipStreamSynchronize(old));
+  if (old != (hipStream_t)s && cfg().async.load(std::memory_order_relaxed)) {
+    HIP_OK(hipStreamSynchronize(old));
+    check_chain_errors();
+  }
 }
 extern "C" int xsmm_hip_set_tile_queue(int enable) {
   flush_tile_queue();
   return cfg().tile_queue.exchange(enable != 0);
 }
 extern "C" void xsmm_hip_flush(void) { flush_tile_queue(); }
+// n fused_brgemm invokes in one call: exactly the effect of xsmm_fused_brgemm_invoke(dtype, handles[i], ...) for i = 0 .. n-1 in
+// order. When the calls form a chain the chip can run as one launch (see include/tpp_xsmm_abi.h) they run as ONE kernel.
+extern "C" int xsmm_hip_fused_brgemm_chain_invoke(int64_t dtype, int64_t n, const int64_t *handles, void *const *a, const int64_t *off_a,
+                                                  void *const *b, const int64_t *off_b, void *const *c, const int64_t *off_c,
+                                                  void *const *d, const int64_t *off_d, const int64_t *num_batches) {
+  const char *who = "xsmm_hip_fused_brgemm_chain_invoke";
+  if (n <= 0) return 0;
+  if (n <= CH_MAXL) {
+    const GemmDesc *desc[CH_MAXL];
+    void *pa[CH_MAXL], *pb[CH_MAXL], *pc[CH_MAXL], *pd[CH_MAXL];
+    bool ok = true;
+    const size_t es = esize(dtype);
+    for (int64_t i = 0; i < n; ++i) {
+      desc[i] = as_desc<GemmDesc>(handles[i], KIND_GEMM, who);
+      if (desc[i]->dtype != dtype) die("%s: invoke dtype %ld != dispatch dtype %ld", who, (long)dtype, (long)desc[i]->dtype);
+      if (!desc[i]->fused) die("%s: handle %ld was not dispatched by xsmm_fused_brgemm_dispatch", who, (long)i);
+      if (num_batches[i] < 0) die("%s: negative batch count %ld", who, (long)num_batches[i]);
+      pa[i] = (char *)a[i] + off_a[i] * es;
+      pb[i] = (char *)b[i] + off_b[i] * es;
+      pc[i] = (char *)c[i] + off_c[i] * es;
+      pd[i] = d[i] ? (char *)d[i] + off_d[i] * es : nullptr;
+      if (desc[i]->bias && !d[i]) die("%s: fused bias operand of call %ld is null", who, (long)i);
+      ok = ok && desc[i]->m > 0 && desc[i]->n > 0;
+    }
+    if (ok) {
+      flush_tile_queue();
+      TraceRange trace_range(who, desc[0]->trace);
+      if (try_chain_launch((int)n, desc, pa, pb, pc, pd, num_batches, cfg().stream.load(std::memory_order_relaxed))) return 1;
+    }
+  }
+  for (int64_t i = 0; i < n; ++i)
+    xsmm_fused_brgemm_invoke(dtype, handles[i], a[i], off_a[i], b[i], off_b[i], c[i], off_c[i], d[i], off_d[i], num_batches[i]);
+  return 0;
+}
 extern "C" void xsmm_hip_tile_queue_stats(int64_t out[5]) {
   out[0] = g_q_launches.load(std::memory_order_relaxed);
   out[1] = g_q_checked.load(std::memory_order_relaxed);
@@ -1758,6 +1928,7 @@ extern "C" void xsmm_hip_synchronize(void) {
   flush_tile_queue();
   g_devmem_epoch.fetch_add(1, std::memory_order_relaxed);
   HIP_OK(hipStreamSynchronize(cfg().stream.load()));
+  check_chain_errors();
 }
 // ---- host residents (see the comment at Resident) ---------------------------------------------------------
 extern "C" int xsmm_hip_host_resident(const void *ptr, int64_t bytes) {

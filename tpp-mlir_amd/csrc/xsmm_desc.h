@@ -10,6 +10,7 @@ namespace tpp {
 enum : int { KIND_GEMM = 0x47454d4d /*'GEMM'*/, KIND_UNARY = 0x554e4152, KIND_BINARY = 0x42494e41,
              KIND_AMX = 0x414d5843 };
 enum : int64_t { DT_F32 = 1, DT_BF16 = 2 };
+enum : int { EP_BETA0 = 1, EP_BIAS = 2, EP_RELU = 4, EP_VNNI_C = 8 }; // epilogue bits of the kernel argument blocks
 
 // One descriptor type for gemm / brgemm / fused_brgemm (a gemm is a brgemm with
 // one batch and no strides; a brgemm is a fused_brgemm with no epilogue).
@@ -63,6 +64,11 @@ hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_i
                                hipStream_t stream);
 // fills d.variant / d.name; returns false if no kernel can run the descriptor
 bool plan_gemm(GemmDesc &d, int forced_variant);
+constexpr int GEMM_VARIANT_BF16_LW0 = 20; // = V_BF16_LW_32x64: first of the four loader-wave bf16 tiles (brgemm_bf16_lw.hip)
+constexpr int GEMM_VARIANT_GENERIC = 8; // = V_GENERIC of brgemm_f32.hip: the generic kernel was chosen (or forced) at dispatch
+// bf16 + VNNI-2 B, k a multiple of 64, m and n of 64, 16-byte-aligned leading dimensions within the 32-bit lane offsets: what the
+// LDS-DMA bf16 tile families (brgemm_bf16.hip, brgemm_bf16_lw.hip) need
+bool bf16_fast_eligible(const GemmDesc &d);
 hipError_t launch_unary(const UnaryDesc &d, const void *in, float scalar, bool use_scalar, void *out,
                         hipStream_t stream);
 hipError_t launch_binary(const BinaryDesc &d, const void *lhs, const void *rhs, void *out,

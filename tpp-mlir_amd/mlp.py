@@ -71,8 +71,9 @@ class ShardedMlp:
     """One rank's share of the MLP. `rt` is an XsmmRuntime (product) - tests inject an
     object with the same fused_brgemm_dispatch / fused_brgemm methods."""
 
-    def __init__(self, spec, rank=0, world=1, rt=None):
+    def __init__(self, spec, rank=0, world=1, rt=None, chain=True):
         self.spec, self.rank, self.world, self.rt = spec, rank, world, rt
+        self.chain, self.last_step_fused = chain, False
         self.row0, self.rows = row_partition(spec.batch, world, rank)
         self.handles = []
         for k, n in zip(spec.layers[:-1], spec.layers[1:]):
@@ -88,10 +89,19 @@ class ShardedMlp:
             return None
         cur = x_local
         dummy = biases[0] if biases else cur
+        calls = []
         for l, (h, br) in enumerate(self.handles):
             d = biases[l] if self.spec.bias else dummy
-            self.rt.fused_brgemm(self.spec.dtype, h, cur, 0, weights[l], 0, acts[l], 0, d, 0, br)
+            calls.append((h, cur, 0, weights[l], 0, acts[l], 0, d, 0, br))
             cur = acts[l]
+        if self.chain and hasattr(self.rt, "fused_brgemm_chain"):
+            # ONE call for the rank's whole step: the runtime runs the layer chain as a single persistent launch when it can
+            # (bf16, device buffers, async mode: xsmm_hip_fused_brgemm_chain_invoke), else call by call - same result
+            self.last_step_fused = self.rt.fused_brgemm_chain(self.spec.dtype, calls)
+        else:
+            self.last_step_fused = False
+            for c in calls:
+                self.rt.fused_brgemm(self.spec.dtype, *c)
         return cur
 
 

@@ -77,6 +77,10 @@ _SIGNATURES = {
     "xsmm_hip_set_stream": (None, [VP]),
     "xsmm_hip_set_tile_queue": (ctypes.c_int, [ctypes.c_int]),
     "xsmm_hip_flush": (None, []),
+    "xsmm_hip_fused_brgemm_chain_invoke": (ctypes.c_int, [I64, I64, ctypes.POINTER(I64), ctypes.POINTER(VP), ctypes.POINTER(I64),
+                                                          ctypes.POINTER(VP), ctypes.POINTER(I64), ctypes.POINTER(VP),
+                                                          ctypes.POINTER(I64), ctypes.POINTER(VP), ctypes.POINTER(I64),
+                                                          ctypes.POINTER(I64)]),
     "xsmm_hip_tile_queue_stats": (None, [ctypes.POINTER(ctypes.c_int64)]),
     "xsmm_hip_get_stream": (VP, []),
     "xsmm_hip_synchronize": (None, []),
@@ -201,6 +205,21 @@ class XsmmRuntime:
 
     def flush(self):
         self.lib.xsmm_hip_flush()
+
+    def fused_brgemm_chain(self, dtype, calls):
+        """calls: [(handle, a, off_a, b, off_b, c, off_c, d, off_d, num_batches)] - the effect of fused_brgemm on each in
+        order; returns True if the chain ran as ONE launch (see the header), False if it ran call by call"""
+        return bool(self.lib.xsmm_hip_fused_brgemm_chain_invoke(dtype, len(calls), *self.pack_chain(calls)))
+
+    @staticmethod
+    def pack_chain(calls):
+        """the argument arrays of xsmm_hip_fused_brgemm_chain_invoke for `calls` (reusable: a timing loop packs once)"""
+        n = len(calls)
+        cols = list(zip(*calls))
+        i64 = lambda v: (I64 * n)(*[int(x) for x in v])  # noqa: E731
+        ptr = lambda v: (VP * n)(*[_addr(x) for x in v])  # noqa: E731
+        return (i64(cols[0]), ptr(cols[1]), i64(cols[2]), ptr(cols[3]), i64(cols[4]), ptr(cols[5]), i64(cols[6]),
+                ptr(cols[7]), i64(cols[8]), i64(cols[9]))
 
     def tile_queue_stats(self):
         """(grouped launches, invokes with full bookkeeping, invokes replayed, groups ended by a known terminator, replays abandoned)"""
