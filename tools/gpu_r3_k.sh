@@ -1,0 +1,5 @@
+#!/bin/bash
+TAG=${1:-r3_k}; OUT=gpurun_out/$TAG; mkdir -p $OUT
+export TMPDIR=/tmp
+timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
+grep -E "passed|failed|error|rc=|FAILED" $OUT/pytest_gpu.log | tail -15

@@ -50,6 +50,12 @@ constexpr int BLW_BK = 64; // k per chunk
 // run time, and a by-value / by-reference copy of the struct would be spilled to scratch (640 bytes per lane) for that.
 typedef const __attribute__((address_space(4))) ChainArgs chain_kernarg_t;
 
+// profiling stamps (chain mode, TPP_HIP_CHAIN_STAMPS): slot of (workgroup, layer): 0 layer start, 1 chunk 0 published, 2 K loop done,
+// 3 tile stores issued, 4 stores drained + S1 (MFMA wave 0); 5 A loader starts waiting, 6 producers have arrived, 7 first chunks requested
+__device__ __forceinline__ void blw_stamp(chain_kernarg_t &p, int layer, int slot, int lane) {
+  if (p.stamps && lane == 0) p.stamps[((size_t)blockIdx.x * CH_MAXL + layer) * 8 + slot] = __builtin_amdgcn_s_memrealtime();
+}
+
 // s_waitcnt vmcnt(younger * PPL): this wave's DMA of all but the `younger` most recent chunks has landed
 template <int PPL> __device__ __forceinline__ void blw_wait_younger(int younger) {
 #define BLW_CASE(K)                                                                   \
@@ -74,68 +80,78 @@ template <int S, int N, typename F> __device__ __forceinline__ bool blw_ring_pas
   }
 }
 
-// One loader wave: every LDS-DMA instruction of its panel (IS_A: the A panel [BM rows][64 k], else the B panel [32 pair-rows][BN
+// One loader wave: LDS-DMA instructions of its panel (IS_A: the A panel [BM rows][64 k], else the B panel [32 pair-rows][BN
 // dwords]) for every chunk of every layer, NSLOT - 1 chunks ahead of the MFMA waves, and its side of the barrier schedule:
-//   per layer  P (chunk 0 published), one mid-chunk barrier per further chunk, and - between layers - R1 (WK > 1) and S1.
-// In chain mode the A loader waits at a seam for the row block's producers; the B loader prefetches across it.
-template <bool IS_A, int NSLOT, int BM, int BN, int WK, bool MULTI>
-__device__ __forceinline__ void blw_loader(chain_kernarg_t *pp, unsigned char *smem, int lane, int m0, int n0, int tm, int L) {
+//   per layer  [S2]  P (chunk 0 published), one mid-chunk barrier per further chunk, and - between layers - R1 (WK > 1) and S1.
+// NL loader waves share a panel: wave `part` issues the instructions v = part, part + NL, ... of every chunk.
+// In chain mode A loader 0 waits at a seam for the row block's producers (with NLA > 1 the others learn it through S2); the B
+// loaders prefetch the next layer's panels across the seam when every layer's chunk count is a multiple of the ring depth.
+// The steady-state loop is a literal s_waitcnt + s_barrier + the DMA instructions + ~10 scalar instructions: measured on the
+// first version of this function (one general loop with a switch over the wait count, the layer bookkeeping and an argument load
+// inside), a 16-chunk layer took 5.7 us with NO loads and NO MFMAs at all - the loader's own instruction stream set the pace.
+template <bool IS_A, int NL, int NLA, int NSLOT, int BM, int BN, int WK, bool MULTI>
+__device__ __forceinline__ void blw_loader(chain_kernarg_t *pp, unsigned char *smem, int lane, int m0, int n0, int tm, int L, int part) {
   chain_kernarg_t &p = *pp;
   constexpr int A_SLOT = BM * 128, SLOT = (BM + BN) * 128;
-  constexpr int PPL = IS_A ? BM / 8 : BN / 8; // 1 KiB DMA instructions per chunk
-  [[maybe_unused]] constexpr int RPI = 256 / BN; // VNNI pair-rows per B instruction
-  bool ahead = false; // B only: panels of the next layer are prefetched across the seam
-  int total = 0;
-  if (MULTI) {
-    ahead = !IS_A;
+  constexpr int PPL = (IS_A ? BM / 8 : BN / 8) / NL; // 1 KiB DMA instructions per chunk issued by this wave
+  [[maybe_unused]] constexpr int RPI = 256 / BN;     // VNNI pair-rows per B instruction
+  static_assert(PPL >= 1 && (IS_A ? BM / 8 : BN / 8) % NL == 0 && (!IS_A || NL == 1 || NL % 2 == 0), "panel instructions divide over the loader waves");
+  static_assert(NSLOT >= 3, "ring depth");
+  const int dbg = p.dbg;
+  const bool no_dma = (dbg & (16 | (IS_A ? 128 : 64))) != 0; // timing experiments: this panel is not fetched
+  bool ahead = false;
+  if (MULTI && !IS_A) {
+    ahead = true;
     for (int l = 0; l < L; ++l) {
       const int Tl = p.L[l].br * (p.L[l].k / BLW_BK);
-      total += Tl;
-      if (Tl % NSLOT) ahead = false; // ring positions of consecutive layers must line up
+      if (Tl % NSLOT || Tl < NSLOT) ahead = false; // ring positions of consecutive layers must line up
     }
   }
-  // issue cursor: chunk ti of layer li goes to ring slot islot; g = panel base of that chunk
-  int li = 0, ti = 0, islot = 0, issued = 0;
-  int Ti, kc, kchunks;
-  const unsigned short *g;
-  int64_t d_in, d_wrap;
-  unsigned vo0, vo1, step;
-#define BLW_LOAD_LAYER(l)                                                                                              \
+  // issue state: the panel base of the next chunk to request (of layer state_layer) and the constants of that layer
+  int state_layer = -1, kc = 0, kchunks = 1;
+  const unsigned short *g = nullptr;
+  int64_t d_in = 0, d_wrap = 0;
+  unsigned vo0 = 0, vo1 = 0, step = 0;
+  bool sc1 = false;
+#define BLW_LOAD_STATE(l)                                                                                              \
   do {                                                                                                                 \
+    state_layer = (l);                                                                                                 \
     kchunks = p.L[l].k / BLW_BK;                                                                                       \
-    Ti = p.L[l].br * kchunks;                                                                                          \
     kc = 0;                                                                                                            \
     if (IS_A) {                                                                                                        \
       const int64_t lda_ = (l) == 0 ? p.lda : p.L[(l) > 0 ? (l)-1 : 0].ldc;                                            \
       const unsigned short *A_ = (const unsigned short *)((l) == 0 ? p.A : p.L[(l) > 0 ? (l)-1 : 0].C);                \
-      g = A_ + (int64_t)m0 * lda_;                                                                                     \
+      g = A_ + (int64_t)(m0 + 8 * part) * lda_;                                                                        \
       d_in = BLW_BK;                                                                                                   \
       d_wrap = p.L[l].stride_a - (int64_t)(kchunks - 1) * BLW_BK;                                                      \
-      /* instruction v covers rows 8v .. 8v+7: lane -> row 8v + lane/8, 16-byte piece lane%8 XOR ((row>>1)&7) = 4(v&1) + lane/16 */ \
+      /* instruction v covers rows 8v .. 8v+7: lane -> row 8v + lane/8, 16-byte piece lane%8 XOR ((row>>1)&7) = 4(v&1) + lane/16; */ \
+      /* this wave's instructions are v = part + NL * i: NL even -> one parity (one swizzle term), NL == 1 -> alternating */ \
       const unsigned rowoff_ = (unsigned)((lane >> 3) * (int)lda_ * 2);                                                \
-      vo0 = rowoff_ + (unsigned)(((lane & 7) ^ (lane >> 4)) << 4);                                                     \
-      vo1 = rowoff_ + (unsigned)(((lane & 7) ^ (4 + (lane >> 4))) << 4);                                               \
-      step = (unsigned)(8 * (int)lda_ * 2);                                                                            \
+      vo0 = rowoff_ + (unsigned)(((lane & 7) ^ (4 * (part & 1) + (lane >> 4))) << 4);                                  \
+      vo1 = NL == 1 ? rowoff_ + (unsigned)(((lane & 7) ^ (4 + (lane >> 4))) << 4) : vo0;                               \
+      step = (unsigned)(NL * 8 * (int)lda_ * 2);                                                                       \
+      sc1 = MULTI && (l) > 0 && !(dbg & 1); /* written by other workgroups in THIS launch: sc1 loads (L1 bypassed) */  \
     } else {                                                                                                           \
-      g = (const unsigned short *)p.L[l].B + 2 * (int64_t)n0;                                                          \
+      g = (const unsigned short *)p.L[l].B + 2 * (int64_t)n0 + (int64_t)part * RPI * 2 * p.L[l].ldb;                   \
       d_in = (int64_t)(BLW_BK / 2) * 2 * p.L[l].ldb;                                                                   \
       d_wrap = p.L[l].stride_b - (int64_t)(kchunks - 1) * d_in;                                                        \
       /* instruction v covers pair-rows RPI*v ..: lane -> pair-row lane / (BN/4), 16-byte piece lane % (BN/4) */       \
       vo0 = vo1 = (unsigned)((lane / (BN / 4)) * (int)p.L[l].ldb * 4 + ((lane % (BN / 4)) << 4));                      \
-      step = (unsigned)(RPI * (int)p.L[l].ldb * 4);                                                                    \
+      step = (unsigned)(NL * RPI * (int)p.L[l].ldb * 4);                                                               \
     }                                                                                                                  \
   } while (0)
-  BLW_LOAD_LAYER(0);
-#define BLW_ISSUE_NEXT()                                                                                               \
+  // request the next chunk of the issue state into ring slot `slot`, advance the state and the slot
+#define BLW_ISSUE(slot)                                                                                                \
   do {                                                                                                                 \
-    unsigned char *base_ = smem + islot * SLOT + (IS_A ? 0 : A_SLOT);                                                  \
+    unsigned char *base_ = smem + (slot) * SLOT + (IS_A ? 0 : A_SLOT) + part * 1024;                                   \
     const __amdgpu_buffer_rsrc_t r_ = __builtin_amdgcn_make_buffer_rsrc((void *)g, 0, 0x7fffffff, 0x00020000);         \
-    if (IS_A && MULTI && li > 0) { /* written by other workgroups in THIS launch: sc1 loads (L1 bypassed) */          \
+    if (no_dma) {                                                                                                      \
+    } else if (IS_A && sc1) {                                                                                          \
       _Pragma("unroll") for (int v = 0; v < PPL; ++v)                                                                  \
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(r_, (lds_void_b *)(base_ + v * 1024), 16, (v & 1) ? vo1 : vo0, v * step, 0, 16); \
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(r_, (lds_void_b *)(base_ + v * NL * 1024), 16, (v & 1) ? vo1 : vo0, v * step, 0, 16); \
     } else {                                                                                                           \
       _Pragma("unroll") for (int v = 0; v < PPL; ++v)                                                                  \
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(r_, (lds_void_b *)(base_ + v * 1024), 16, (v & 1) ? vo1 : vo0, v * step, 0, 0); \
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(r_, (lds_void_b *)(base_ + v * NL * 1024), 16, (v & 1) ? vo1 : vo0, v * step, 0, 0); \
     }                                                                                                                  \
     if (++kc == kchunks) {                                                                                             \
       kc = 0;                                                                                                          \
@@ -143,56 +159,76 @@ __device__ __forceinline__ void blw_loader(chain_kernarg_t *pp, unsigned char *s
     } else {                                                                                                           \
       g += d_in;                                                                                                       \
     }                                                                                                                  \
-    ++issued;                                                                                                          \
-    if (++islot == NSLOT) islot = 0;                                                                                   \
-    if (++ti == Ti) { /* on to the next layer (its chunk 0 goes to slot 0) */                                          \
-      ++li;                                                                                                            \
-      ti = 0;                                                                                                          \
-      islot = 0;                                                                                                       \
-      if (MULTI && li < L) BLW_LOAD_LAYER(li);                                                                         \
-    }                                                                                                                  \
+    slot = slot + 1 == NSLOT ? 0 : slot + 1;                                                                           \
   } while (0)
-  int gbase = 0; // global index of chunk 0 of the layer being consumed
+  const bool poller = MULTI && IS_A && part == 0;
   for (int lc = 0; lc < L; ++lc) {
     const int T = p.L[lc].br * (p.L[lc].k / BLW_BK);
-    const int limit = ahead ? total : gbase + T; // chunks this wave may issue before the layer is over
-    if (MULTI && IS_A && lc > 0) {
+    int pre = NSLOT - 2; // chunks of this layer already requested by the run-ahead of the previous layer's tail
+    if (state_layer != lc) {
+      BLW_LOAD_STATE(lc);
+      pre = 0;
+    }
+    if (poller) blw_stamp(p, lc, 5, lane);
+    if (poller && lc > 0 && !(dbg & 2)) {
       // every producer tile of row block tm of layer lc-1 has been stored (write-through) and drained
-      g_u32_lw *c = (g_u32_lw *)(p.cnt + (size_t)(lc - 1) * p.tiles_m + tm);
+      g_u32_lw *c = (g_u32_lw *)(p.cnt + ((size_t)(lc - 1) * p.tiles_m + tm) * CHAIN_CNT_STRIDE);
+      const unsigned target = p.target;
       const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
       for (;;) {
         const unsigned v = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((int)(v - p.target) >= 0) break;
+        if ((int)(v - target) >= 0) break;
         if (__builtin_amdgcn_s_memrealtime() - t0 > CHAIN_TIMEOUT_TICKS) { // never hang the GPU: flag it and go on
           if (lane == 0) __hip_atomic_store((g_u32_lw *)p.err, 1u + (unsigned)lc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           break;
         }
-        __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_s_sleep(1);
       }
       asm volatile("" ::: "memory");
     }
-    {
-      const int want = gbase + NSLOT - 1 < limit ? gbase + NSLOT - 1 : limit;
-      while (issued < want) BLW_ISSUE_NEXT();
-    }
-    blw_wait_younger<PPL>(issued - (gbase + 1));
+    if (poller) blw_stamp(p, lc, 6, lane);
+    if (MULTI && NLA > 1 && lc > 0) __builtin_amdgcn_s_barrier(); // S2: the polling wave has seen the producers arrive
+    // Prologue: the whole ring but one slot is requested before chunk 0 is waited for. (Requesting two chunks, publishing chunk 0
+    // and filling the ring two chunks per barrier was measured: chunk 0 is ready 0.4 us earlier, the 16-chunk loop of the 32x64
+    // tile takes 1.0 us longer - the loader is the pace-maker and the ramp costs it a second ISSUE per iteration.)
+    const int npro = T < NSLOT - 1 ? T : NSLOT - 1;
+    int slot = pre;
+    for (int c = pre; c < npro; ++c) BLW_ISSUE(slot);
+    if (poller) blw_stamp(p, lc, 7, lane);
+    blw_wait_younger<PPL>(npro - 1);
     __builtin_amdgcn_s_barrier(); // P: chunk 0 of this layer published
-    for (int t = 0; t + 1 < T; ++t) {
-      blw_wait_younger<PPL>(issued - (gbase + t + 2));
-      __builtin_amdgcn_s_barrier(); // = the MFMA waves' mid-chunk barrier of chunk t: chunk t+1 published, slot of chunk t-1 retired
-      if (issued < limit && issued < gbase + t + NSLOT) BLW_ISSUE_NEXT();
+    int t = 0;
+    // steady state: chunk t+1 has landed when all but the NSLOT - 3 youngest requests have; the barrier (= the MFMA waves'
+    // mid-chunk barrier of chunk t) publishes it and retires the slot of chunk t-1, which takes chunk t + NSLOT - 1
+    for (; t + NSLOT - 1 < T; ++t) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSLOT - 3) * PPL) : "memory");
+      __builtin_amdgcn_s_barrier();
+      BLW_ISSUE(slot);
+    }
+    // the last NSLOT - 2 barriers of the layer: nothing of THIS layer is left to request
+    if (MULTI && ahead && lc + 1 < L) {
+      BLW_LOAD_STATE(lc + 1); // (T is a multiple of the ring depth: the slot rotation carries over)
+      for (; t + 1 < T; ++t) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSLOT - 3) * PPL) : "memory");
+        __builtin_amdgcn_s_barrier();
+        BLW_ISSUE(slot);
+      }
+    } else {
+      for (; t + 1 < T; ++t) {
+        blw_wait_younger<PPL>(T - 2 - t);
+        __builtin_amdgcn_s_barrier();
+      }
     }
     if (lc + 1 == L) return;
     if constexpr (WK > 1) __builtin_amdgcn_s_barrier(); // R1 (K groups combine)
     __builtin_amdgcn_s_barrier();                        // S1 (tile stored and drained)
-    gbase += T;
   }
-#undef BLW_ISSUE_NEXT
-#undef BLW_LOAD_LAYER
+#undef BLW_ISSUE
+#undef BLW_LOAD_STATE
 }
 
-template <int WM, int WN, int WK, int TM, int TN, int NSLOT, bool MULTI>
-__global__ __launch_bounds__(64 * (WM * WN * WK + 2)) void brgemm_bf16_lw(ChainArgs p_by_value) {
+template <int WM, int WN, int WK, int TM, int TN, int NSLOT, int NLA, int NLB, bool MULTI>
+__global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_lw(ChainArgs p_by_value) {
   chain_kernarg_t *pp = (chain_kernarg_t *)__builtin_amdgcn_kernarg_segment_ptr(); // = &p_by_value (the only explicit argument)
   chain_kernarg_t &p = *pp;
   constexpr int NMW = WM * WN * WK, NOUT = WM * WN; // MFMA waves; waves that own output
@@ -200,28 +236,30 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + 2)) void brgemm_bf16_lw(ChainA
   constexpr int KS = 4 / WK, PD = KS / 2;            // k-steps of a chunk per wave; fragment prefetch distance
   constexpr int A_SLOT = BM * 128, B_SLOT = BN * 128, SLOT = A_SLOT + B_SLOT;
   constexpr int NA = BM / 8, NBI = BN / 8;           // 1 KiB DMA instructions per chunk of A / of B
-  constexpr int RPI = 256 / BN;                      // VNNI pair-rows per B instruction
   constexpr int ES = 64 * TN + 16;                   // bytes per staged output row (16 B pad: conflict-free 16-byte accesses)
   constexpr int STAGE_W = 32 * ES;                   // one 32-row block of a wave's tile
   constexpr int OFF_STAGE = NSLOT * SLOT, OFF_RED = OFF_STAGE + NOUT * STAGE_W;
   static_assert(WK == 1 || (WK == 2 && TM == 1 && TN == 1), "K split: two groups of single-tile waves");
-  static_assert((NSLOT - 1) * NA <= 63 && (NSLOT - 1) * NBI <= 63, "vmcnt is 6 bits");
+  static_assert((NSLOT - 1) * NA / NLA <= 63 && (NSLOT - 1) * NBI / NLB <= 63, "vmcnt is 6 bits");
+  constexpr int NLW = NLA + NLB; // loader waves
   static_assert(BN == 32 || BN == 64 || BN == 128, "B pair-rows per DMA instruction");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_c[];
 
   const int tid = threadIdx.x, lane = tid & 63;
-  // the loader waves are the FIRST two hardware waves (waves start in order: the first chunks are requested before the
-  // MFMA waves exist); `wave` is the role: MFMA waves 0 .. NMW-1, A loader NMW, B loader NMW+1
+  // the loader waves are the FIRST hardware waves (waves start in order: the first chunks are requested before the
+  // MFMA waves exist); `wave` is the role: MFMA waves 0 .. NMW-1, A loaders NMW .. NMW+NLA-1, then the B loaders
   const int hw_wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wave = hw_wave < 2 ? NMW + hw_wave : hw_wave - 2;
-  // tile of this workgroup: all tiles_n tiles of a row block on ONE XCD (block b runs on XCD b % 8: the row block's A
-  // panel is fetched into one L2, and in chain mode its hand-off stays inside it) when the row blocks divide by 8
+  const int wave = hw_wave < NLW ? NMW + hw_wave : hw_wave - NLW;
+  // tile of this workgroup. Block b runs on XCD b % 8 (observed, used for speed only) and every XCD's L2 fetches the panels of
+  // its workgroups itself: the XCDs form an xm x xn grid over the tile grid (chosen by the launcher to minimise the bytes all
+  // eight L2s pull together, xn * |A| + xm * |W|: a 512-row layer on 8 x 1 makes every L2 fetch ALL of W)
   const int b = (int)blockIdx.x;
   int tm, tn;
-  if ((p.tiles_m & 7) == 0) {
-    const int j = b >> 3;
-    tn = j % p.tiles_n;
-    tm = (b & 7) + 8 * (j / p.tiles_n);
+  if (p.xm > 0) {
+    const int xn = 8 / p.xm, xcd = b & 7, j = b >> 3;
+    const int lm = p.tiles_m / p.xm, ln = p.tiles_n / xn; // tiles per XCD
+    tm = (xcd / xn) * lm + j / ln;
+    tn = (xcd % xn) * ln + j % ln;
   } else {
     tm = b / p.tiles_n;
     tn = b - tm * p.tiles_n;
@@ -230,9 +268,9 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + 2)) void brgemm_bf16_lw(ChainA
   const int L = MULTI ? p.nlayers : 1;
 
   if (wave >= NMW) {
-    // ---- loader waves (blw_loader below): wave NMW streams A, wave NMW + 1 streams B ---------------------------------
-    if (wave == NMW) blw_loader<true, NSLOT, BM, BN, WK, MULTI>(pp, smem_c, lane, m0, n0, tm, L);
-    else blw_loader<false, NSLOT, BM, BN, WK, MULTI>(pp, smem_c, lane, m0, n0, tm, L);
+    // ---- loader waves (blw_loader above) ---------------------------------------------------------------------------
+    if (wave < NMW + NLA) blw_loader<true, NLA, NLA, NSLOT, BM, BN, WK, MULTI>(pp, smem_c, lane, m0, n0, tm, L, wave - NMW);
+    else blw_loader<false, NLB, NLA, NSLOT, BM, BN, WK, MULTI>(pp, smem_c, lane, m0, n0, tm, L, wave - NMW - NLA);
     return; // ended waves do not take part in later barriers
   }
 
@@ -240,8 +278,15 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + 2)) void brgemm_bf16_lw(ChainA
   const int wk = wave / NOUT, wmn = wave % NOUT, wm = wmn / WN, wn = wmn % WN;
   const int li = lane & 31, lh = lane >> 5;
   f32x16 acc[TM][TN];
-  bf16x8_lw af[KS][TM];
-  u32x4 bw[KS][TN]; // B fragments as dwords
+  // Fragment buffers. Tiles with one or two accumulators per wave (TM * TN <= 2) keep TWO chunks of fragments: a k-step is only
+  // 1-2 MFMAs (32-64 cycles), less than an LDS read takes to come back, so the fragments of chunk t+1 are all read during the
+  // second half of chunk t (measured on the 64x64 tile with a two-step lookahead: 420 cycles per chunk for 128 cycles of MFMA).
+  // The 128x128 tile (four accumulators, 128 cycles per k-step) reads two k-steps ahead out of one set.
+  constexpr bool FULLPF = TM * TN <= 2;
+  constexpr int NFB = FULLPF ? 2 * KS : KS;
+  static_assert(!FULLPF || NSLOT % 2 == 0, "chunk parity from the ring slot");
+  bf16x8_lw af[NFB][TM];
+  u32x4 bw[NFB][TN]; // B fragments as dwords
   int b_lane[TN];   // dword index of this lane's column of tile j in pair-row 4*lh of a k-step
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
@@ -263,21 +308,37 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + 2)) void brgemm_bf16_lw(ChainA
       for (int r = 0; r < 4; ++r) bw[buf][j][r] = bp[r * BN];
     }
   };
+  const int dbg = p.dbg;
+  const bool skip_math = (dbg & 32) != 0; // timing experiments: barriers only
   // one chunk in ring slot S: step q multiplies fragment buffer q while the fragments of step q + PD are read (the last PD
   // steps read the first steps of chunk t+1, published by the mid-chunk barrier; after the last chunk of a layer they
   // read a slot nobody uses - the values are dropped)
   auto chunk = [&](auto slot_c, bool has_next) __attribute__((always_inline)) {
     constexpr int S = decltype(slot_c)::value, NS = (S + 1) % NSLOT;
+    constexpr int CUR = FULLPF ? (S & 1) * KS : 0, NXT = FULLPF ? ((S & 1) ^ 1) * KS : 0; // fragment sets of chunk t / t+1
 #pragma unroll
     for (int q = 0; q < KS; ++q) {
-      if (q + PD < KS) frag_load(q + PD, S, wk * KS + q + PD);
-      else frag_load(q + PD - KS, NS, wk * KS + q + PD - KS);
+      if (!skip_math) {
+        if constexpr (FULLPF) {
+          // second half of the chunk (chunk t+1 is published): two of its k-steps per step
+          if (q >= KS / 2) {
+            const int r = 2 * (q - KS / 2);
+            frag_load(NXT + r, NS, wk * KS + r);
+            if (r + 1 < KS) frag_load(NXT + r + 1, NS, wk * KS + r + 1);
+          }
+        } else {
+          if (q + PD < KS) frag_load(q + PD, S, wk * KS + q + PD);
+          else frag_load(q + PD - KS, NS, wk * KS + q + PD - KS);
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
+      if (!skip_math) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_lw, bw[q][j]), af[q][i], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_lw, bw[CUR + q][j]), af[CUR + q][i], acc[i][j], 0, 0, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
       if (q == KS / 2 - 1 && has_next) {
         __builtin_amdgcn_s_barrier();
@@ -307,23 +368,27 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + 2)) void brgemm_bf16_lw(ChainA
         biasw[j][g] = u32x2_lw{0u, 0u};
         if (ep & EP_BIAS) biasw[j][g] = *(const u32x2_lw *)((const unsigned short *)Y.D + n0 + (wn * TN + j) * 32 + 8 * g + 4 * lh);
       }
+    if (MULTI && wave == 0) blw_stamp(p, l, 0, lane);
+    if (MULTI && NLA > 1 && l > 0) __builtin_amdgcn_s_barrier(); // S2 (the loaders' rendezvous after the seam wait)
     __builtin_amdgcn_s_barrier(); // P: chunk 0 published
     __builtin_amdgcn_sched_barrier(0);
-    if (T > 0) { // (an empty batch: C = epilogue of zero)
+    if (MULTI && wave == 0) blw_stamp(p, l, 1, lane);
+    // (T >= 1: the launchers send empty batches to the generic kernel - a branch around this loop costs the 128-wide tiles
+    // a second copy of the accumulators and 250 spilled registers)
 #pragma unroll
-      for (int s = 0; s < PD; ++s) frag_load(s, 0, wk * KS + s);
-      for (int t = 0;;)
-        if (blw_ring_pass<0, NSLOT>(t, T, chunk)) break;
-    }
+    for (int s = 0; s < (FULLPF ? KS : PD); ++s) frag_load(s, 0, wk * KS + s);
+    for (int t = 0;;)
+      if (blw_ring_pass<0, NSLOT>(t, T, chunk)) break;
     // the fragments prefetched past the end of the layer are dead: without this the compiler sinks their reads
 #pragma unroll
-    for (int s = 0; s < PD; ++s) {
+    for (int s = 0; s < (FULLPF ? NFB : PD); ++s) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(af[s][i]));
 #pragma unroll
       for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(bw[s][j]));
     }
 
+    if (MULTI && wave == 0) blw_stamp(p, l, 2, lane);
     // ---- epilogue ------------------------------------------------------------------------------------------------
     if constexpr (WK > 1) {
       // K group 1 parks its 32x32 partial, group 0 adds it (group order: 0 + 1) and finishes the tile
@@ -408,27 +473,31 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + 2)) void brgemm_bf16_lw(ChainA
           const int row = it * RPP + lane / LPR, ch = lane % LPR;
           const u32x4 v = *(const u32x4 *)(ot + row * ES + ch * 16);
           const unsigned voff = (unsigned)(32 * i + row) * ldcb + (unsigned)(ch * 16);
-          if (MULTI && l + 1 < L) __builtin_amdgcn_raw_buffer_store_b128(v, rsrcC, voff, 0, 16); // sc1: write-through (hand-off)
+          if (MULTI && l + 1 < L && !(dbg & 4)) __builtin_amdgcn_raw_buffer_store_b128(v, rsrcC, voff, 0, 16); // sc1: write-through (hand-off)
           else __builtin_amdgcn_raw_buffer_store_b128(v, rsrcC, voff, 0, 0);
         }
       }
     }
+    if (MULTI && wave == 0) blw_stamp(p, l, 3, lane);
     if (l + 1 == L) break;
     if constexpr (MULTI) {
       // ---- seam: publish this tile to the row block's consumers ------------------------------------------------
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // EVERY storing wave drains its write-through stores
       __builtin_amdgcn_s_barrier();                     // S1
       if (wave == 0 && lane == 0)
-        __hip_atomic_fetch_add((g_u32_lw *)(p.cnt + (size_t)l * p.tiles_m + tm), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add((g_u32_lw *)(p.cnt + ((size_t)l * p.tiles_m + tm) * CHAIN_CNT_STRIDE), 1u, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+      if (wave == 0) blw_stamp(p, l, 4, lane);
     }
   }
 }
 
-template <int WM, int WN, int WK, int TM, int TN, int NSLOT, bool MULTI> static hipError_t launch_blw_t(const ChainArgs &a, hipStream_t s) {
-  constexpr int NOUT = WM * WN, BM = 32 * WM * TM, BN = 32 * WN * TN, NT = 64 * (WM * WN * WK + 2);
+template <int WM, int WN, int WK, int TM, int TN, int NSLOT, int NLA, int NLB, bool MULTI>
+static hipError_t launch_blw_t(const ChainArgs &a, hipStream_t s) {
+  constexpr int NOUT = WM * WN, BM = 32 * WM * TM, BN = 32 * WN * TN, NT = 64 * (WM * WN * WK + NLA + NLB);
   constexpr size_t lds = (size_t)NSLOT * (BM + BN) * 128 + (size_t)NOUT * 32 * (64 * TN + 16) + (WK > 1 ? (size_t)NOUT * 4096 : 0);
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto kern = brgemm_bf16_lw<WM, WN, WK, TM, TN, NSLOT, MULTI>;
+  auto kern = brgemm_bf16_lw<WM, WN, WK, TM, TN, NSLOT, NLA, NLB, MULTI>;
   static std::atomic<unsigned long long> lds_set{0};
   if (hipError_t e = ensure_dynamic_lds((const void *)kern, (int)lds, lds_set); e != hipSuccess) return e;
   ChainArgs args = a;
@@ -436,6 +505,22 @@ template <int WM, int WN, int WK, int TM, int TN, int NSLOT, bool MULTI> static 
   args.tiles_n = a.n / BN;
   const long long tiles = (long long)args.tiles_m * args.tiles_n;
   if (tiles <= 0 || tiles > 0x7fffffffLL) return hipErrorInvalidValue;
+  // XCD grid xm x (8 / xm) over the tile grid: minimise xn * m + xm * n (bytes of A and W all eight L2s fetch, in units of 2K)
+  args.xm = 0;
+  static const int forced_xm = [] {
+    const char *e = getenv("TPP_HIP_BF16_LW_XM"); // A/B runs: 1, 2, 4, 8, or 0 = linear mapping
+    return e ? atoi(e) : -1;
+  }();
+  long long best = -1;
+  for (int xm = 8; xm >= 1; xm >>= 1) {
+    const int xn = 8 / xm;
+    if (args.tiles_m % xm || args.tiles_n % xn) continue;
+    const long long cost = (long long)xn * a.m + (long long)xm * a.n;
+    if (forced_xm >= 0 ? xm == forced_xm : (best < 0 || cost < best)) {
+      best = cost;
+      args.xm = xm;
+    }
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(NT), lds, s, args);
   return hipGetLastError();
 }
@@ -447,26 +532,27 @@ void blw_tile_dims(int tile, int *bm, int *bn) {
   *bn = BNs[tile & 3];
 }
 
-// one layer (a.nlayers == 1): any chunk stream, both accumulator starts
-hipError_t launch_bf16_lw(int tile, const ChainArgs &a, hipStream_t s) {
-  switch (tile) {
-  case 0: return launch_blw_t<1, 2, 2, 1, 1, 8, false>(a, s);
-  case 1: return launch_blw_t<2, 2, 1, 1, 1, 8, false>(a, s);
-  case 2: return launch_blw_t<2, 2, 1, 1, 2, 4, false>(a, s);
-  case 3: return launch_blw_t<2, 2, 1, 2, 2, 4, false>(a, s);
-  default: return hipErrorInvalidValue;
+// Loader waves per tile (NLA + NLB), same-box A/B (profiles/r03_blw_loader_split.txt): 32x64 1 + 2 (1 + 1: +2 %, 2 + 2: +5 %),
+// 64x64 1 + 1 (1 + 2: +2 %, 2 + 2: +7 %), 64x128 1 + 2 (1 + 1: same, 2 + 4: +5 %), 128x128 1 + 1 (2 + 2, 1 + 2: same).
+#define BLW_DISPATCH(MULTI)                                                     \
+  switch (tile) {                                                               \
+  case 0: return launch_blw_t<1, 2, 2, 1, 1, 8, 1, 2, MULTI>(a, s);             \
+  case 1: return launch_blw_t<2, 2, 1, 1, 1, 8, 1, 1, MULTI>(a, s);             \
+  case 2: return launch_blw_t<2, 2, 1, 1, 2, 4, 1, 2, MULTI>(a, s);             \
+  case 3: return launch_blw_t<2, 2, 1, 2, 2, 4, 1, 1, MULTI>(a, s);             \
+  default: return hipErrorInvalidValue;                                         \
   }
+
+// one layer (a.nlayers == 1): any chunk stream of at least one chunk, both accumulator starts
+hipError_t launch_bf16_lw(int tile, const ChainArgs &a, hipStream_t s) {
+  if (a.L[0].br < 1 || a.L[0].k < BLW_BK || tile < 0 || tile > 3) return hipErrorInvalidValue;
+  BLW_DISPATCH(false)
 }
 
 // a chain of layers in one launch; the caller guarantees co-residency (tiles <= CUs), beta = 0 and disjoint buffers
 hipError_t launch_bf16_chain(int tile, const ChainArgs &a, hipStream_t s) {
-  switch (tile) {
-  case 0: return launch_blw_t<1, 2, 2, 1, 1, 8, true>(a, s);
-  case 1: return launch_blw_t<2, 2, 1, 1, 1, 8, true>(a, s);
-  case 2: return launch_blw_t<2, 2, 1, 1, 2, 4, true>(a, s);
-  case 3: return launch_blw_t<2, 2, 1, 2, 2, 4, true>(a, s);
-  default: return hipErrorInvalidValue;
-  }
+  if (tile < 0 || tile > 3) return hipErrorInvalidValue;
+  BLW_DISPATCH(true)
 }
 
 } // namespace tpp

@@ -795,8 +795,9 @@ static int pick_f32_variant(const GemmDesc &d) {
   return V_GENERIC;
 }
 
-// Mid-size bf16 outputs: the loader-wave family (brgemm_bf16_lw.hip), tile chosen so that the grid is about one workgroup per
-// CU - the largest tile that still gives >= 3/4 of the CUs a workgroup, else the smallest tile that divides the output.
+// Mid-size bf16 outputs: the loader-wave family (brgemm_bf16_lw.hip), the largest tile that still gives at least 3/4 of the CUs
+// a workgroup (one workgroup per CU: 160 KiB of LDS). Outputs too small for that even with 32x64 tiles stay with the 32x32 K-split
+// family (m = 256, n = 1024, K = 1024: 4.9 us against 5.7 on 128 tiles of 32x64, profiles/r03_sweep_shapes.txt).
 // Returns the tile index (0 .. 3) or -1. TPP_HIP_BF16_LW=0 switches the family off (A/B runs).
 static int pick_bf16_lw_tile(const GemmDesc &d) {
   static const int enabled = [] {
@@ -804,16 +805,13 @@ static int pick_bf16_lw_tile(const GemmDesc &d) {
     return e ? atoi(e) : 1;
   }();
   if (!enabled) return -1;
-  int best = -1;
   for (int t = 3; t >= 0; --t) {
     int bm, bn;
     blw_tile_dims(t, &bm, &bn);
     if (d.m % bm || d.n % bn) continue;
-    const int64_t tiles = (d.m / bm) * (d.n / bn);
-    if (tiles * 4 >= 3 * (int64_t)g_num_cus) return t;
-    if (tiles * 2 >= (int64_t)g_num_cus) best = t; // keeps shrinking: ends at the smallest tile that divides
+    if ((d.m / bm) * (d.n / bn) * 4 >= 3 * (int64_t)g_num_cus) return t;
   }
-  return best; // (-1: fewer than half the CUs would get a workgroup - the 32x32 K-split family serves those)
+  return -1;
 }
 
 static const char *variant_name(int v) {
@@ -865,6 +863,11 @@ bool plan_gemm(GemmDesc &d, int forced_variant) {
     }
   } else if (d.dtype == DT_BF16 && bf16_small_eligible(d)) {
     v = V_BF16_SMALL32; // k a multiple of 16 only (e.g. the compiler-native 32x32x32 tile), m or n a multiple of 32 only
+    if (forced_variant == V_BF16_LW_32x64) { // the 32x64 loader-wave tile needs m % 32 only (bf16_fast_eligible asks for 64)
+      GemmDesc e = d;
+      e.m = (d.m + 63) / 64 * 64;
+      if (d.m % 32 == 0 && d.n % 64 == 0 && bf16_fast_eligible(e)) v = forced_variant;
+    }
   }
   if (forced_variant >= 0 && d.dtype == DT_F32 && v != V_GENERIC) {
     // honour the forced tile only if the shape divides it
@@ -896,6 +899,7 @@ hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C,
   // the bf16 kernel stores 16-byte row pieces and reads the bias 8 bytes at a time
   if (v >= V_BF16_FAST && v != V_BF16_SMALL32 && ((((uintptr_t)C) & 15) || (d.bias && (((uintptr_t)D) & 7)))) v = V_GENERIC;
   if (v == V_BF16_SMALL32 && ((((uintptr_t)C) & 7) || (d.bias && (((uintptr_t)D) & 7)))) v = V_GENERIC;
+  if (v >= V_BF16_LW_32x64 && v <= V_BF16_LW_128x128 && a.br < 1) v = V_GENERIC; // empty batch (C = epilogue of nothing): the loader-wave kernels assume a chunk
   switch (v) {
   // LDS-DMA panels for every tile but the smallest: measured C2 +3 %, C3 +8 %, 4096^3 +3 %, 3 x 1024 MLP
   // at batch 512 / 1024 +5 % / +3 % over register staging. 32x32 tiles with 4 K-split waves have
@@ -921,7 +925,12 @@ hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C,
   case V_BF16_LW_128x128: {
     ChainArgs c;
     c.A = a.A; c.lda = a.lda; c.cnt = nullptr; c.err = nullptr; c.target = 0;
-    c.m = a.m; c.n = a.n; c.nlayers = 1; c.tiles_m = c.tiles_n = 0;
+    c.m = a.m; c.n = a.n; c.nlayers = 1; c.tiles_m = c.tiles_n = 0; c.xm = 0; c.stamps = nullptr;
+    static const int lw_dbg = [] {
+      const char *e = getenv("TPP_HIP_CHAIN_DBG"); // timing experiments only (brgemm_bf16_lw.hip): results may be wrong
+      return e ? atoi(e) : 0;
+    }();
+    c.dbg = lw_dbg;
     c.L[0] = ChainLayer{a.B, a.D, a.C, a.ldb, a.ldc, a.stride_a, a.stride_b, a.k, a.br, a.ep, 0};
     return launch_bf16_lw(v - V_BF16_LW_32x64, c, stream);
   }

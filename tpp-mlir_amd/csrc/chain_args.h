@@ -7,6 +7,7 @@
 namespace tpp {
 
 constexpr int CH_MAXL = 8;                                  // layers per chain launch
+constexpr int CHAIN_CNT_STRIDE = 32;                         // counters 128 B apart: device-scope atomics on ONE line serialise (~12 ns each)
 constexpr unsigned long long CHAIN_TIMEOUT_TICKS = 5000000; // bound of every in-kernel spin: 50 ms of s_memrealtime (100 MHz)
 
 struct ChainLayer {
@@ -20,12 +21,16 @@ struct ChainLayer {
 struct ChainArgs {
   const void *A;   // input of layer 0 [m][lda]
   int64_t lda;
-  unsigned *cnt;   // chain mode: arrival counters [nlayers - 1][tiles_m], monotonic across launches
+  unsigned *cnt;   // chain mode: arrival counters [nlayers - 1][tiles_m] (CHAIN_CNT_STRIDE words apart), monotonic across launches
   unsigned *err;   // chain mode: set to 1 + layer by a workgroup whose hand-off wait timed out
   unsigned target; // chain mode: value every counter reaches in this launch (epoch * tiles_n)
   int m, n;        // rows and columns of every layer's output
   int nlayers;
   int tiles_m, tiles_n; // filled by the launcher
+  int xm;               // filled by the launcher: XCD grid xm x (8 / xm) over the tile grid, 0 = linear tile order
+  int dbg;              // timing experiments only (TPP_HIP_CHAIN_DBG): 1 plain A loads, 2 no wait at the seams, 4 plain stores,
+                        // 16 no DMA, 32 no fragment reads / MFMAs, 64 no B DMA, 128 no A DMA
+  unsigned long long *stamps; // profiling (TPP_HIP_CHAIN_STAMPS=file): [workgroup][layer][8] s_memrealtime stamps, else nullptr
   ChainLayer L[CH_MAXL];
 };
 

@@ -1540,7 +1540,7 @@ void gemm_invoke_common(const char *who, bool want_fused, int64_t dtype, int64_t
 struct ChainBlock {
   hipStream_t stream;
   int tiles_m, tiles_n, nlayers;
-  unsigned *cnt; // device: (CH_MAXL - 1) * tiles_m counters
+  unsigned *cnt; // device: (CH_MAXL - 1) * tiles_m counters, CHAIN_CNT_STRIDE words apart
   unsigned *err; // pinned host
   unsigned epoch;
 };
@@ -1552,7 +1552,7 @@ ChainBlock &chain_block(hipStream_t s, int tiles_m, int tiles_n, int nlayers) { 
   for (ChainBlock &b : g_chain_blocks)
     if (b.stream == s && b.tiles_m == tiles_m && b.tiles_n == tiles_n && b.nlayers == nlayers) return b;
   ChainBlock b{s, tiles_m, tiles_n, nlayers, nullptr, nullptr, 0};
-  const size_t bytes = sizeof(unsigned) * (size_t)(CH_MAXL - 1) * (size_t)tiles_m;
+  const size_t bytes = sizeof(unsigned) * (size_t)(CH_MAXL - 1) * (size_t)tiles_m * CHAIN_CNT_STRIDE;
   HIP_OK(hipMalloc((void **)&b.cnt, bytes));
   HIP_OK(hipMemset(b.cnt, 0, bytes));
   HIP_OK(hipHostMalloc((void **)&b.err, sizeof(unsigned), hipHostMallocDefault));
@@ -1561,9 +1561,11 @@ ChainBlock &chain_block(hipStream_t s, int tiles_m, int tiles_n, int nlayers) { 
   return g_chain_blocks.back();
 }
 // after the stream has been drained: did a hand-off of any chain launch time out?
+void dump_chain_stamps();
 void check_chain_errors() {
   if (!g_chain_launched.exchange(0, std::memory_order_acq_rel)) return;
   std::lock_guard<std::mutex> lk(g_chain_mu);
+  dump_chain_stamps();
   for (ChainBlock &b : g_chain_blocks) {
     const unsigned e = *(volatile unsigned *)b.err;
     if (e) die("tpp-xsmm-hip: a fused-brgemm chain launch timed out waiting for the producers of layer %u's input (hand-off inside the "
@@ -1580,6 +1582,34 @@ int chip_cus() { // compute units of the current device (0: unknown)
   return n;
 }
 
+// profiling: TPP_HIP_CHAIN_STAMPS=<file> makes every chain launch record s_memrealtime stamps (100 MHz) per workgroup and layer
+// (see blw_stamp in brgemm_bf16_lw.hip) into pinned host memory; the LAST launch's stamps are written to the file at every sync point.
+unsigned long long *g_stamps = nullptr;
+size_t g_stamps_wgs = 0;
+unsigned long long *chain_stamps(size_t wgs) { // under g_chain_mu
+  static const char *path = getenv("TPP_HIP_CHAIN_STAMPS");
+  if (!path) return nullptr;
+  if (!g_stamps) HIP_OK(hipHostMalloc((void **)&g_stamps, sizeof(unsigned long long) * 8 * CH_MAXL * 1024, hipHostMallocDefault));
+  if (wgs > 1024) return nullptr;
+  g_stamps_wgs = wgs;
+  return g_stamps;
+}
+void dump_chain_stamps() {
+  const char *path = getenv("TPP_HIP_CHAIN_STAMPS");
+  if (!path || !g_stamps || !g_stamps_wgs) return;
+  if (FILE *f = fopen(path, "w")) {
+    for (size_t w = 0; w < g_stamps_wgs; ++w)
+      for (int l = 0; l < CH_MAXL; ++l) {
+        const unsigned long long *s = g_stamps + (w * CH_MAXL + l) * 8;
+        if (!s[0] && !s[5]) continue;
+        fprintf(f, "%zu %d", w, l);
+        for (int i = 0; i < 8; ++i) fprintf(f, " %llu", s[i]);
+        fputc('\n', f);
+      }
+    fclose(f);
+  }
+}
+
 bool ranges_overlap(const void *a, size_t na, const void *b, size_t nb) {
   return (const char *)a < (const char *)b + nb && (const char *)b < (const char *)a + na;
 }
@@ -1587,24 +1617,32 @@ bool ranges_overlap(const void *a, size_t na, const void *b, size_t nb) {
 // true: the chain was launched as ONE kernel. false: the caller runs the invokes one by one (same result).
 bool try_chain_launch(int n, const GemmDesc *const *d, void *const *pa, void *const *pb, void *const *pc, void *const *pd, const int64_t *br,
                       hipStream_t s) {
-  if (n < 2 || n > CH_MAXL || !cfg().async.load(std::memory_order_relaxed)) return false;
+  // with TPP_HIP_TRACE >= 1 the reason for running call by call goes to stderr
+#define NOCHAIN(why)                                                                             \
+  do {                                                                                           \
+    if (cfg().trace) fprintf(stderr, "[tpp-xsmm-hip] fused_brgemm_chain: call by call (%s)\n", why); \
+    return false;                                                                                \
+  } while (0)
+  if (n < 2 || n > CH_MAXL) NOCHAIN("fewer than 2 or more than 8 calls");
+  if (!cfg().async.load(std::memory_order_relaxed)) NOCHAIN("synchronous mode");
   static const int enabled = [] {
     const char *e = getenv("TPP_HIP_CHAIN");
     return e ? atoi(e) : 1;
   }();
-  if (!enabled) return false;
+  if (!enabled) NOCHAIN("TPP_HIP_CHAIN=0");
   const int64_t m = d[0]->m, nn = d[0]->n;
   thread_local DeviceRanges devmem;
   devmem.refresh();
   for (int i = 0; i < n; ++i) {
     const GemmDesc &g = *d[i];
-    if (g.dtype != DT_BF16 || !g.vnni_b || g.vnni_c || !g.beta0 || !bf16_fast_eligible(g) || g.m != m || g.n != nn || br[i] < 1) return false;
-    if (g.variant == GEMM_VARIANT_GENERIC) return false; // (a forced generic kernel stays generic)
-    if (((uintptr_t)pa[i] | (uintptr_t)pb[i] | (uintptr_t)pc[i]) & 15) return false;
-    if (g.bias && (!pd[i] || ((uintptr_t)pd[i] & 7))) return false;
-    if (i > 0 && (pa[i] != pc[i - 1] || g.lda != d[i - 1]->ldc)) return false; // not a chain: layer i must read layer i-1's output
+    if (g.dtype != DT_BF16 || !g.vnni_b || g.vnni_c || !g.beta0 || !bf16_fast_eligible(g)) NOCHAIN("a call is not bf16 / VNNI-2 B / beta 0 / aligned for the LDS-DMA tiles");
+    if (g.m != m || g.n != nn || br[i] < 1) NOCHAIN("the calls differ in m or n, or a batch is empty");
+    if (g.variant == GEMM_VARIANT_GENERIC) NOCHAIN("a call was dispatched to the generic kernel"); // (a forced generic kernel stays generic)
+    if (((uintptr_t)pa[i] | (uintptr_t)pb[i] | (uintptr_t)pc[i]) & 15) NOCHAIN("an operand is not 16-byte aligned");
+    if (g.bias && (!pd[i] || ((uintptr_t)pd[i] & 7))) NOCHAIN("a bias operand is not 8-byte aligned");
+    if (i > 0 && (pa[i] != pc[i - 1] || g.lda != d[i - 1]->ldc)) NOCHAIN("not a chain: a call does not read its predecessor's output");
     if (!devmem.is_device(pa[i], 0) || !devmem.is_device(pb[i], 1) || !devmem.is_device(pc[i], 2) || (g.bias && !devmem.is_device(pd[i], 3)))
-      return false;
+      NOCHAIN("a host operand");
   }
   // The tile: all workgroups must be co-resident (one per CU by LDS), so the grid may not exceed the CUs. If every layer was planned
   // with the same loader-wave tile and that tile fits, use it - the launch is then bit-identical to the separate launches; else
@@ -1621,25 +1659,27 @@ bool try_chain_launch(int n, const GemmDesc *const *d, void *const *pa, void *co
   if (same && fits(planned)) tile = planned;
   for (int t = 0; t < 4 && tile < 0; ++t)
     if (fits(t)) tile = t;
-  if (tile < 0) return false;
+  if (tile < 0) NOCHAIN("more tiles than compute units");
   (void)fits(tile); // bm, bn of the chosen tile
   // no operand of the launch may overlap an output (a layer's input rows are read by other workgroups while later layers store)
   Operand A, B, C, D;
   struct Span { const void *p; size_t n; };
-  std::vector<Span> outs, ins;
+  Span outs[CH_MAXL], ins[2 * CH_MAXL + 1];
+  int n_ins = 0;
   for (int i = 0; i < n; ++i) {
     gemm_operands(d[i], pa[i], pb[i], pc[i], pd[i], br[i], A, B, C, D);
-    outs.push_back({C.ptr, C.bytes});
-    ins.push_back({B.ptr, B.bytes});
-    if (d[i]->bias) ins.push_back({D.ptr, D.bytes});
-    if (i == 0) ins.push_back({A.ptr, A.bytes});
+    outs[i] = Span{C.ptr, C.bytes};
+    ins[n_ins++] = Span{B.ptr, B.bytes};
+    if (d[i]->bias) ins[n_ins++] = Span{D.ptr, D.bytes};
+    if (i == 0) ins[n_ins++] = Span{A.ptr, A.bytes};
   }
-  for (size_t i = 0; i < outs.size(); ++i) {
-    for (size_t j = i + 1; j < outs.size(); ++j)
-      if (ranges_overlap(outs[i].p, outs[i].n, outs[j].p, outs[j].n)) return false;
-    for (const Span &x : ins)
-      if (ranges_overlap(outs[i].p, outs[i].n, x.p, x.n)) return false;
+  for (int i = 0; i < n; ++i) {
+    for (int j = i + 1; j < n; ++j)
+      if (ranges_overlap(outs[i].p, outs[i].n, outs[j].p, outs[j].n)) NOCHAIN("two outputs overlap");
+    for (int j = 0; j < n_ins; ++j)
+      if (ranges_overlap(outs[i].p, outs[i].n, ins[j].p, ins[j].n)) NOCHAIN("an output overlaps an input");
   }
+#undef NOCHAIN
   ChainArgs c;
   memset(&c, 0, sizeof(c));
   c.A = pa[0];
@@ -1647,6 +1687,11 @@ bool try_chain_launch(int n, const GemmDesc *const *d, void *const *pa, void *co
   c.m = (int)m;
   c.n = (int)nn;
   c.nlayers = n;
+  static const int dbg = [] {
+    const char *e = getenv("TPP_HIP_CHAIN_DBG"); // timing experiments only: results may be wrong
+    return e ? atoi(e) : 0;
+  }();
+  c.dbg = dbg;
   for (int i = 0; i < n; ++i)
     c.L[i] = ChainLayer{pb[i], pd[i], pc[i], d[i]->ldb, d[i]->ldc, d[i]->stride_a, d[i]->stride_b, (int)d[i]->k, (int)br[i],
                         EP_BETA0 | (d[i]->bias ? EP_BIAS : 0) | (d[i]->relu ? EP_RELU : 0), 0};
@@ -1655,6 +1700,7 @@ bool try_chain_launch(int n, const GemmDesc *const *d, void *const *pa, void *co
   c.cnt = blk.cnt;
   c.err = blk.err;
   c.target = ++blk.epoch * (unsigned)blk.tiles_n;
+  c.stamps = chain_stamps((size_t)blk.tiles_m * (size_t)blk.tiles_n);
   HIP_OK(launch_bf16_chain(tile, c, s));
   g_chain_launched.store(1, std::memory_order_release);
   return true;
