@@ -205,3 +205,47 @@ class TensorInit:
             lib().tinit_destroy(self._h)
         except Exception:
             pass
+
+
+# ---------------------------------------------------------------- mlir-gen's inputs for the MLP benchmark (test infrastructure)
+def glibc_rand_sequence(seed, n):
+    """the first n values of glibc's rand() after srand(seed) (TYPE_3 additive feedback generator r[i] = r[i-3] + r[i-31],
+    310 values discarded, top 31 bits returned) - what mlir-gen's getRand() draws its per-tensor seeds from
+    (tools/mlir-gen/MLIRGen.cpp:131-137: srand(seed); :810-819: `temp = seed; seed = rand(); return temp`)"""
+    seed &= 0xffffffff
+    r = [seed if seed else 1]
+    for i in range(1, 31):
+        prev = r[i - 1] if r[i - 1] < 2 ** 31 else r[i - 1] - 2 ** 32
+        hi, lo = divmod(prev, 127773)
+        v = 16807 * lo - 2836 * hi
+        r.append(v + 2147483647 if v < 0 else v)
+    r += r[0:3]
+    out = []
+    for i in range(34, 344 + n):
+        r.append((r[i - 31] + r[i - 3]) & 0xffffffff)
+        if i >= 344:
+            out.append(r[i] >> 1)
+    return out
+
+
+def mlir_gen_seed_chain(seed, n):
+    """the seeds mlir-gen hands to its n dense constants, in creation order: seed, rand(), rand(), ... (MLIRGen.cpp:810-819)"""
+    return ([seed] + glibc_rand_sequence(seed, n))[:n]
+
+
+def mlir_gen_mlp_tensors(layers, seed=123, dt=BF16, bias=True):
+    """weights ([K][N] flat) and biases of `mlir-gen --kernel=const --seed=S --layers=...` in creation order W0, b0, W1, b1, ...
+    (MLIRGen.cpp:243-262: createDenseTensor(initType, type, getRand()) per tensor): EVERY tensor has its own `normal`
+    generator (TensorInit.cpp:75-96: one cached generator per (type, dtype, seed)) seeded from the chain. The kernel's input
+    is a function argument: tpp-run fills it from ITS --seed (MLIRBench.cpp:207-246) - TensorInit('normal', seed).fill()."""
+    n_t = (len(layers) - 1) * (2 if bias else 1)
+    seeds = mlir_gen_seed_chain(seed, n_t)
+    W, Bs, i = [], [], 0
+    for k, n in zip(layers[:-1], layers[1:]):
+        W.append(TensorInit("normal", seeds[i]).fill(k * n, dt))
+        i += 1
+        if bias:
+            Bs.append(TensorInit("normal", seeds[i]).fill(n, dt))
+            i += 1
+    return W, Bs, seeds
+

@@ -44,3 +44,17 @@ def test_layer_dispatch_tuple_matches_reference_fused_call():
     spec = pkg.MlpSpec()
     args, _ = pkg.layer_dispatch_args(spec, 512, 1024, 1024)
     assert args["gemm_flags"] == 4 | 2048  # BETA_0 | wire value of vnni_b
+
+
+def test_mlir_gen_seed_chain_matches_glibc():
+    """oracle.pyoracle.glibc_rand_sequence restates glibc's rand() (mlir-gen seeds its dense constants from srand(seed) / rand(),
+    MLIRGen.cpp:131-137, 810-819): pinned by the values glibc itself returns, and checked live against this host's libc"""
+    import ctypes
+    from oracle import pyoracle as orc
+    assert orc.glibc_rand_sequence(123, 5) == [128959393, 1692901013, 436085873, 748533630, 776550279]
+    assert orc.mlir_gen_seed_chain(123, 3) == [123, 128959393, 1692901013]
+    libc = ctypes.CDLL(None)
+    for seed in (1, 123, 2024, 0x7fffffff):
+        libc.srand(seed)
+        assert [libc.rand() for _ in range(40)] == orc.glibc_rand_sequence(seed, 40)
+

@@ -26,6 +26,7 @@
 
 int main(int argc, char **argv) {
   int iters = 200, variant = -1, br_arg = 16;
+  bool c3 = false; // --c3: BASELINE config 3 instead (fused_brgemm + bias + relu, 512 x 1024 x 1024)
   std::string init = "uniform";
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
@@ -33,11 +34,12 @@ int main(int argc, char **argv) {
     else if (a == "--init" && i + 1 < argc) init = argv[++i];
     else if (a == "--variant" && i + 1 < argc) variant = atoi(argv[++i]);
     else if (a == "--br" && i + 1 < argc) br_arg = atoi(argv[++i]); // 0..16 batch elements (kernel-time anatomy: fixed cost vs per chunk)
+    else if (a == "--c3") c3 = true;
     else { fprintf(stderr, "unknown flag %s\n", a.c_str()); return 2; }
   }
   if (xsmm_hip_device_count() < 1) { fprintf(stderr, "c2_probe: no HIP device (there is no CPU fallback)\n"); return 1; }
   if (br_arg < 0 || br_arg > 16) { fprintf(stderr, "--br must be 0..16\n"); return 2; }
-  const int64_t m = 1024, n = 1024, k = 64, br = br_arg;
+  const int64_t m = c3 ? 512 : 1024, n = 1024, k = 64, br = br_arg;
   const size_t elems = 1024 * 1024;
   std::vector<float> hA(elems), hB(elems), hC(elems);
   std::default_random_engine eng(123);
@@ -53,7 +55,9 @@ int main(int argc, char **argv) {
     for (auto &v : hB) v = d(eng);
     for (auto &v : hC) v = d(eng);
   }
-  float *A, *B, *C;
+  float *A, *B, *C, *D;
+  CHECK(hipMalloc((void **)&D, 1024 * 4));
+  CHECK(hipMemcpy(D, hC.data(), 1024 * 4, hipMemcpyHostToDevice)); // bias row of --c3
   CHECK(hipMalloc((void **)&A, elems * 4));
   CHECK(hipMalloc((void **)&B, elems * 4));
   CHECK(hipMalloc((void **)&C, elems * 4));
@@ -62,9 +66,14 @@ int main(int argc, char **argv) {
   CHECK(hipMemcpy(C, hC.data(), elems * 4, hipMemcpyHostToDevice));
   xsmm_hip_set_async(1);
   if (variant >= 0) xsmm_hip_force_variant(variant);
-  const int64_t h = xsmm_brgemm_dispatch(1, m, n, k, 1024, 1024, 1024, 64, 65536, XSMM_GEMM_FLAG_BETA_0);
+  const int64_t h = c3 ? xsmm_fused_brgemm_dispatch(1, m, n, k, 1024, 1024, 1024, 64, 65536, XSMM_GEMM_FLAG_BETA_0, 0, XSMM_UNARY_RELU,
+                                                    XSMM_BINARY_FLAG_BCAST_COL_IN_0, XSMM_BINARY_ADD)
+                       : xsmm_brgemm_dispatch(1, m, n, k, 1024, 1024, 1024, 64, 65536, XSMM_GEMM_FLAG_BETA_0);
   xsmm_hip_force_variant(-1);
-  auto step = [&]() { xsmm_brgemm_invoke(1, h, A, 0, B, 0, C, 0, br); };
+  auto step = [&]() {
+    if (c3) xsmm_fused_brgemm_invoke(1, h, A, 0, B, 0, C, 0, D, 0, br);
+    else xsmm_brgemm_invoke(1, h, A, 0, B, 0, C, 0, br);
+  };
   const double flops = 2.0 * m * n * k * br;
 
   // clocks up: ~60 ms of load before anything is timed

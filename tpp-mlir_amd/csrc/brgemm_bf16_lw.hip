@@ -112,7 +112,7 @@ __device__ __forceinline__ void blw_loader(chain_kernarg_t *pp, unsigned char *s
   const unsigned short *g = nullptr;
   int64_t d_in = 0, d_wrap = 0;
   unsigned vo0 = 0, vo1 = 0, step = 0;
-  bool sc1 = false;
+  bool sc1 = false, flat = false;
 #define BLW_LOAD_STATE(l)                                                                                              \
   do {                                                                                                                 \
     state_layer = (l);                                                                                                 \
@@ -139,6 +139,7 @@ __device__ __forceinline__ void blw_loader(chain_kernarg_t *pp, unsigned char *s
       vo0 = vo1 = (unsigned)((lane / (BN / 4)) * (int)p.L[l].ldb * 4 + ((lane % (BN / 4)) << 4));                      \
       step = (unsigned)(NL * RPI * (int)p.L[l].ldb * 4);                                                               \
     }                                                                                                                  \
+    flat = d_wrap == d_in;                                                                                             \
   } while (0)
   // request the next chunk of the issue state into ring slot `slot`, advance the state and the slot
 #define BLW_ISSUE(slot)                                                                                                \
@@ -153,7 +154,9 @@ __device__ __forceinline__ void blw_loader(chain_kernarg_t *pp, unsigned char *s
       _Pragma("unroll") for (int v = 0; v < PPL; ++v)                                                                  \
           __builtin_amdgcn_raw_ptr_buffer_load_lds(r_, (lds_void_b *)(base_ + v * NL * 1024), 16, (v & 1) ? vo1 : vo0, v * step, 0, 0); \
     }                                                                                                                  \
-    if (++kc == kchunks) {                                                                                             \
+    if (flat) { /* the batch elements continue each other (whole-layer dispatches): one 64-bit add */               \
+      g += d_in;                                                                                                       \
+    } else if (++kc == kchunks) {                                                                                      \
       kc = 0;                                                                                                          \
       g += d_wrap;                                                                                                     \
     } else {                                                                                                           \
