@@ -54,6 +54,10 @@ def parse():
                     help="input stream `value` is quoted on. reference: tpp-run's normal init stream (what the reference "
                          "benchmarks run on); uniform: U[-1,1) (sign cancellation, highest switching power). The OTHER "
                          "stream is always measured too and reported as roofline_uniform / roofline_reference")
+    ap.add_argument("--gather", choices=["peer", "rccl"], default="peer",
+                    help="all-gather of the MLP output at N > 1: peer = every rank stores its rows into every peer's buffer through "
+                         "IPC-mapped pointers (csrc/peer_gather.hip), falling back to RCCL if the buffers cannot be mapped; rccl = "
+                         "dist.all_gather_into_tensor")
     ap.add_argument("--no-pmc", action="store_true",
                     help="do not run the rocprofv3 PMC passes for roofline.traffic (use when bench.py itself runs under a profiler)")
     return ap.parse_args()
@@ -463,6 +467,15 @@ def main():
             X_ = torch.from_numpy(x_gen.fill(max(sh_.rows, 1) * N, BF16).view(np.int16)).cuda()
             acts_ = [torch.empty(max(sh_.rows, 1), N, dtype=torch.bfloat16, device="cuda") for _ in range(3)]
             full_ = torch.empty(batch, N, dtype=torch.bfloat16, device="cuda")
+            pg_ = None
+            if use_dist and args.gather == "peer" and as_world is None and batch % (128 * world) == 0:
+                pg_ = pkg.PeerGather.create(rt, rank, world, batch * N * 2)
+                ok_ = torch.tensor([1 if pg_ is not None else 0], device="cuda")
+                dist.all_reduce(ok_, op=dist.ReduceOp.MIN)  # every rank or none
+                if int(ok_[0]) == 0:
+                    pg_ = None
+            gather_used.append("peer-store (IPC-mapped peer buffers, 2 launches per step)" if pg_ is not None else
+                               "rccl all_gather_into_tensor" if use_dist else "none (one rank)")
             sync()
 
             def compute_only():
@@ -470,7 +483,9 @@ def main():
 
             def with_gather():
                 out = sh_.forward(X_, Wv, Bs, acts_)
-                if use_dist:
+                if pg_ is not None:
+                    pg_.gather(out, sh_.rows * N * 2, sh_.row0 * N * 2)
+                elif use_dist:
                     pkg.all_gather_rows(out, full_, spec_, world)
 
             res = []
@@ -482,8 +497,11 @@ def main():
                 if use_dist:
                     dist.all_reduce(tw, op=dist.ReduceOp.MAX)
                 res.append(float(tw[0]) / steps)
+            if pg_ is not None:
+                pg_.check()
             return spec_, sh_, res[1], res[0]
 
+        gather_used = []
         spec, sh, mstep, mcompute = run_mlp(4096, K, W)
         fused_flag = bool(sh.last_step_fused)
         mlp = {"workload": "3-layer MLP 1024x3 bf16 bs=4096 bias+relu, rows sharded over %d GPU(s)%s" % (
@@ -493,7 +511,7 @@ def main():
                "flops_per_step": spec.flops(),
                "frac_of_bf16_mfma_peak": round(spec.flops() / mstep / 1e12 / (PEAK_BF16_MFMA_TFLOPS * world), 4),
                "kernel": rt.kernel_name(sh.handles[0][0]) if sh.rows else "",
-               "step_is_one_chain_launch": fused_flag,
+               "step_is_one_chain_launch": fused_flag, "gather": gather_used[0],
                "inputs": "weights / biases: mlir-gen --seed 123 dense constants (seed chain 123, rand(), ...), input: tpp-run normal init seed 123",
                "note": "25.8 GFLOP per step; a rank's three layers run as ONE persistent launch (xsmm_hip_fused_brgemm_chain_invoke) "
                        "when the chain fits the chip, see DESIGN.md sections 4.2 / 5"}

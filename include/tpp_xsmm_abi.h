@@ -172,6 +172,20 @@ TPP_XSMM_EXPORT int xsmm_hip_fused_brgemm_chain_invoke(int64_t dtype, int64_t n,
                                                        const int64_t *off_a, void *const *b, const int64_t *off_b,
                                                        void *const *c, const int64_t *off_c, void *const *d,
                                                        const int64_t *off_d, const int64_t *num_batches);
+/* Peer-store all-gather (one process per GPU, no collective library call): every rank stores its row block straight into
+ * every peer's output buffer through IPC-mapped pointers, completion by flags (csrc/peer_gather.hip; host-side protocol:
+ * tpp-mlir_amd/peer.py). _peer_alloc returns a dedicated zeroed device allocation (IPC handles name whole allocations);
+ * _ipc_export writes its 64-byte handle; _ipc_open maps a peer's handle (nullptr on failure); _peer_gather enqueues one step on
+ * the runtime's stream: scatter of `bytes` from src to dst[w] + dst_offset for every w < world, then a wait until every peer's
+ * block has landed in THIS rank's buffer. dst / flags / ready: `world` pointers each; epoch: 1, 2, 3, ... (the same on every rank). */
+TPP_XSMM_EXPORT void *xsmm_hip_peer_alloc(int64_t bytes);
+TPP_XSMM_EXPORT void xsmm_hip_peer_free(void *ptr);
+TPP_XSMM_EXPORT int xsmm_hip_ipc_export(void *ptr, void *handle_out_64_bytes);
+TPP_XSMM_EXPORT void *xsmm_hip_ipc_open(const void *handle_64_bytes);
+TPP_XSMM_EXPORT int xsmm_hip_ipc_close(void *ptr);
+TPP_XSMM_EXPORT void xsmm_hip_peer_gather(const void *src, int64_t bytes, int64_t dst_offset, int64_t world, int64_t rank,
+                                          void *const *dst, void *const *flags, void *const *ready, void *my_flags, void *my_ready,
+                                          void *ticket, void *err, int64_t epoch);
 /* counters of the tile queue since process start: out[0] grouped launches, out[1] invokes queued with the full
  * dependence bookkeeping, out[2] invokes queued by replay of a recorded group (trace cache), out[3] groups ended by
  * a remembered terminator, out[4] replays abandoned (the caller left the recorded group) */

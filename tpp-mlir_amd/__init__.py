@@ -10,4 +10,5 @@ from .runtime import (BinaryFlags, BinaryKind, DataType, GemmFlags, REFERENCE_SY
                       UnaryKind, XsmmRuntime, get_runtime, library_path, load_library)
 from .mlp import (ColumnShardedMlp, MlpSpec, ShardedMlp, all_gather_rows, gathered_to_rows,  # noqa: F401
                   layer_dispatch_args, row_partition)
+from .peer import PeerGather  # noqa: F401
 from .build import build, build_tools  # noqa: F401

@@ -81,6 +81,12 @@ _SIGNATURES = {
                                                           ctypes.POINTER(VP), ctypes.POINTER(I64), ctypes.POINTER(VP),
                                                           ctypes.POINTER(I64), ctypes.POINTER(VP), ctypes.POINTER(I64),
                                                           ctypes.POINTER(I64)]),
+    "xsmm_hip_peer_alloc": (VP, [I64]),
+    "xsmm_hip_peer_free": (None, [VP]),
+    "xsmm_hip_ipc_export": (ctypes.c_int, [VP, VP]),
+    "xsmm_hip_ipc_open": (VP, [VP]),
+    "xsmm_hip_ipc_close": (ctypes.c_int, [VP]),
+    "xsmm_hip_peer_gather": (None, [VP, I64, I64, I64, I64, ctypes.POINTER(VP), ctypes.POINTER(VP), ctypes.POINTER(VP), VP, VP, VP, VP, I64]),
     "xsmm_hip_tile_queue_stats": (None, [ctypes.POINTER(ctypes.c_int64)]),
     "xsmm_hip_get_stream": (VP, []),
     "xsmm_hip_synchronize": (None, []),
