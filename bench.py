@@ -340,6 +340,33 @@ def cpu_baseline(seconds, A, B, C):
         vendor = {"torch_cpu_matmul_gflops": round(flops * n_v / (time.perf_counter() - t1) / 1e9, 1), "torch_threads": torch.get_num_threads()}
     except Exception:
         pass
+    # the reference's HEADLINE benchmark shape on the same host: mlir-gen --kernel=const --batch=256 --layers=1024,1024,1024,1024
+    # --tiles=32,32,32 (benchmarks/config/base/base.json:32-38 gemm_fp32_mlir): three chained 256x1024x1024 layers, each 8 x 32
+    # tile invokes with br = 32 over packed blocks (the output blocks of a layer ARE the next layer's A blocks)
+    headline = None
+    try:
+        hm, hn = 256, 1024
+        rngh = np.random.default_rng(3)
+        xs = rngh.uniform(0, 1, hm * hn).astype(np.float32)
+        ws = [rngh.uniform(0, 0.01, hn * hn).astype(np.float32) for _ in range(3)]
+        xp, w0p, o0 = cb.pack(xs, ws[0], np.zeros(hm * hn, np.float32), hm, hn, hn)
+        wps = [w0p] + [cb.pack(xs, w_, xs, hm, hn, hn)[1] for w_ in ws[1:]]
+        bufs = [xp, o0, np.empty_like(o0), np.empty_like(o0)]
+
+        def layers():
+            for l in range(3):
+                cb.run(hm, hn, hn, bufs[l], wps[l], bufs[l + 1], True, 1)
+        layers()
+        n_h, t1 = 0, time.perf_counter()
+        while time.perf_counter() - t1 < min(3.0, seconds / 3):
+            layers()
+            n_h += 1
+        el_h = time.perf_counter() - t1
+        headline = {"workload": "mlir-gen gemm 3 x (256x1024x1024) fp32, tiles 32,32,32 (base.json gemm_fp32_mlir), same call structure",
+                    "value": round(3 * 2.0 * hm * hn * hn * n_h / el_h / 1e9, 1), "unit": "GFLOP/s",
+                    "us_per_iteration": round(el_h / n_h * 1e6, 1), "iterations": n_h}
+    except Exception as ex:
+        headline = {"error": str(ex)}
     cpu_model = ""
     try:
         cpu_model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
@@ -347,7 +374,7 @@ def cpu_baseline(seconds, A, B, C):
         pass
     return {"value": round(tiled, 2), "unit": "GFLOP/s", "cores": cb.threads(), "kind": "port", "cpu": cpu_model,
             "build": cb.flags, "matches_oracle": ok,
-            "naive_oracle_loop_gflops": round(naive, 2), "vendor_cpu_gemm": vendor,
+            "naive_oracle_loop_gflops": round(naive, 2), "vendor_cpu_gemm": vendor, "headline_shape": headline,
             "sample": "%d full passes of the same BRGEMM 1024^3 (%.1f s) as 32x32 tile invokes with br=32 over packed "
                       "32x32x32 blocks, OpenMP over the 32x32 tile grid (oracle/cpu_baseline.c; libxsmm itself is not in the image)" % (reps, el)}
 
@@ -485,7 +512,7 @@ def main():
                 out = sh_.forward(X_, Wv, Bs, acts_)
                 if pg_ is not None:
                     pg_.gather(out, sh_.rows * N * 2, sh_.row0 * N * 2)
-                elif use_dist:
+                elif use_dist and as_world is None:
                     pkg.all_gather_rows(out, full_, spec_, world)
 
             res = []

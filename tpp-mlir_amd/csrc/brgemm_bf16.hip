@@ -25,7 +25,7 @@ namespace tpp {
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
-// Timing-only ablation masks: SIDE builds only (tools/ablate_bf16.sh compiles this file with -DTPP_ABLATE=mask into
+// Timing-only ablation masks: SIDE builds only (tools/sessions/ablate_bf16.sh compiles this file with -DTPP_ABLATE=mask into
 // build/libabl_*.so); the shipped library is built with 0 and every `if (TPP_ABLATE & ...)` below folds away.
 #ifndef TPP_ABLATE
 #define TPP_ABLATE 0
@@ -781,7 +781,7 @@ hipError_t launch_bf16_dma256(const GemmArgs &a, hipStream_t s); // brgemm_bf16_
 //    so a grid of t tiles takes ceil(t / 256) rounds;
 //  * 128 x 128 as soon as the 64 x 64 family would need a second round of workgroups (more than 256 tiles of
 //    64 x 64 = more than 64 of 128 x 128): measured (n = 1024, K = 1024) the DMA kernel takes 9.2-9.4 us from 64
-//    to 256 tiles while the 64 x 64 family jumps from 9.1 to 12.8 us past one tile per CU (tools/mid_probe.py);
+//    to 256 tiles while the 64 x 64 family jumps from 9.1 to 12.8 us past one tile per CU (tools/sessions/mid_probe.py);
 //  * 64 x 64 below that, so that more CUs have work.
 int pick_bf16_tile(const GemmDesc &d) {
   constexpr int64_t t256_min = 240, t128_min = 65; // crossovers measured in profiles/r01_sweep_shapes.txt

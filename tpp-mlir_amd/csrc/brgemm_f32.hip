@@ -781,7 +781,7 @@ static int pick_f32_variant(const GemmDesc &d) {
   // Outputs with at least one 64x64 tile per CU: 64x64 or 128x64 tiles, whichever needs less time over its rounds
   // of workgroups (one per CU at a time). A 128x64 round takes ~1.85x a 64x64 round (measured, K = 1024: 32.7 vs
   // 17.6 us), so 128x64 wins at 1280-2048 x 1024 (one round instead of two) and for large outputs (0.93x), and
-  // loses e.g. at 3072 x 1024 (two rounds against three; tools/mid_probe.py).
+  // loses e.g. at 3072 x 1024 (two rounds against three; tools/sessions/mid_probe.py).
   if (tiles(64, 64) >= g_num_cus) {
     const int64_t r64 = (tiles(64, 64) + g_num_cus - 1) / g_num_cus, r128 = (tiles(128, 64) + g_num_cus - 1) / g_num_cus;
     if (tiles(128, 64) > 0 && 1.85 * (double)r128 < (double)r64) return V_F32_128x64;

@@ -167,9 +167,10 @@ extern "C" void xsmm_hip_peer_gather(const void *src, int64_t bytes, int64_t dst
   a.epoch = (unsigned)epoch;
   a.world = (int)world;
   a.rank = (int)rank;
-  // about 64 KiB per block, at most 64 blocks per peer: a 1 MiB block is 16 blocks x world
-  long long chunks = (bytes + 65535) / 65536;
-  a.chunks = (int)(chunks < 1 ? 1 : chunks > 64 ? 64 : chunks);
+  // about 16 KiB per block (4 x 16 bytes per lane), at most ~1024 blocks in the launch: a 1 MiB block is 64 blocks x world
+  long long chunks = (bytes + 16383) / 16384;
+  const long long cap = 1024 / world > 1 ? 1024 / world : 1;
+  a.chunks = (int)(chunks < 1 ? 1 : chunks > cap ? cap : chunks);
   hipStream_t s = (hipStream_t)xsmm_hip_get_stream();
   hipLaunchKernelGGL(peer_scatter_kernel, dim3((unsigned)a.chunks, (unsigned)world), dim3(256), 0, s, a);
   PG_OK(hipGetLastError());
