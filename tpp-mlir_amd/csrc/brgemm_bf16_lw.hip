@@ -191,15 +191,19 @@ __device__ __forceinline__ void blw_loader(chain_kernarg_t *pp, unsigned char *s
     }
     if (poller) blw_stamp(p, lc, 6, lane);
     if (MULTI && NLA > 1 && lc > 0) __builtin_amdgcn_s_barrier(); // S2: the polling wave has seen the producers arrive
-    // Prologue: the whole ring but one slot is requested before chunk 0 is waited for. (Requesting two chunks, publishing chunk 0
-    // and filling the ring two chunks per barrier was measured: chunk 0 is ready 0.4 us earlier, the 16-chunk loop of the 32x64
-    // tile takes 1.0 us longer - the loader is the pace-maker and the ramp costs it a second ISSUE per iteration.)
+    // Prologue. (Filling the ring two chunks per barrier - a ramp through the first iterations - was measured: chunk 0 is ready
+    // 0.4 us earlier, the 16-chunk loop of the 32x64 tile takes 1.0 us longer: the loader is the pace-maker and the ramp costs it
+    // a second ISSUE and a variable wait per iteration. So: one burst, but behind the barrier that publishes chunk 0.)
     const int npro = T < NSLOT - 1 ? T : NSLOT - 1;
-    int slot = pre;
-    for (int c = pre; c < npro; ++c) BLW_ISSUE(slot);
+    // chunks 0 and 1 first, chunk 0 PUBLISHED as soon as it has landed, the rest of the prologue behind the barrier (the MFMA
+    // waves work on chunk 0 while it is issued; dbg & 256: everything before the barrier, for A/B runs)
+    const int nfirst = (dbg & 256) ? npro : (npro < 2 ? npro : 2);
+    int slot = pre, c = pre;
+    for (; c < nfirst; ++c) BLW_ISSUE(slot);
     if (poller) blw_stamp(p, lc, 7, lane);
-    blw_wait_younger<PPL>(npro - 1);
+    blw_wait_younger<PPL>((c > nfirst ? c : nfirst) - 1);
     __builtin_amdgcn_s_barrier(); // P: chunk 0 of this layer published
+    for (; c < npro; ++c) BLW_ISSUE(slot);
     int t = 0;
     // steady state: chunk t+1 has landed when all but the NSLOT - 3 youngest requests have; the barrier (= the MFMA waves'
     // mid-chunk barrier of chunk t) publishes it and retires the slot of chunk t-1, which takes chunk t + NSLOT - 1

@@ -109,11 +109,15 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + 2)) void brgemm_f32_lw(GemmArg
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NB) : "memory");
       }
     };
+    // Prologue: chunks 0 and 1 are requested, chunk 0 is PUBLISHED as soon as it has landed, chunk 2 follows behind the barrier.
+    // (Round 2 requested all three first: an LDS-DMA instruction takes ~25 ns to issue, a chunk is 16 of them per loader - the MFMA
+    // waves waited ~0.4 us for requests they would not need for two chunk times; a chunk is 0.92 us of MFMA here, so the loader has
+    // all the time it needs behind the barrier. Stamped on the bf16 twin of this kernel: profiles/r03_chain_anatomy.txt.)
     if (T > 0) issue(0);
     if (T > 1) issue(1);
-    if (T > 2) issue(2);
-    wait_left(T > 2 ? 2 : T > 1 ? 1 : 0);
+    wait_left(T > 1 ? 1 : 0);
     __builtin_amdgcn_s_barrier(); // chunk 0 published
+    if (T > 2) issue(2);
     for (int t = 0; t + 1 < T; ++t) {
       wait_left(t + 2 < T ? 1 : 0); // chunk t+1 has landed (chunk t+2 may still fly)
       __builtin_amdgcn_s_barrier();  // = the MFMA waves' mid-chunk barrier of chunk t
@@ -214,17 +218,28 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + 2)) void brgemm_f32_lw(GemmArg
       for (int r = 0; r < 16; ++r) dst[r * 64] = acc[r];
     }
     __syncthreads();
-    constexpr int RPG = 16 / WK;
+    // The parked partials are [register r][lane = column li + 32 * lh]: four consecutive columns of one output row (r, lh) are
+    // 16 contiguous bytes. A lane finishes float4 pieces - 8 lanes x 16 B = one 128-byte row of the tile, a wave instruction 8
+    // rows - so a tile is 4 x 16-byte stores per lane split over the K groups, instead of 16 dword stores (round 2).
+    constexpr int IPG = 4 / WK; // store instructions per lane per group
+    const int c4 = lane & 7, rsel = lane >> 3; // 16-byte column piece, row within the instruction's 8 rows
+    f32x4 bias4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (p.ep & EP_BIAS) bias4 = *(const f32x4 *)((const float *)it.D + n0 + wn * 32 + 4 * c4);
 #pragma unroll
-    for (int j = 0; j < RPG; ++j) {
-      const int r = wk * RPG + j;
-      float v = red[wmn * 1024 + r * 64 + lane];
+    for (int j = 0; j < IPG; ++j) {
+      const int q = 8 * (wk * IPG + j) + rsel;  // row of the 32x32 tile: q = (r & 3) + 4 * lh + 8 * (r >> 2)
+      const int r = (q & 3) + 4 * (q >> 3), lh2 = (q >> 2) & 1;
+      const float *src = red + wmn * 1024 + r * 64 + lh2 * 32 + 4 * c4;
+      f32x4 v = *(const f32x4 *)src;
 #pragma unroll
-      for (int g = 1; g < WK; ++g) v += red[(g * (WM * WN) + wmn) * 1024 + r * 64 + lane];
-      v += bias;
-      if (p.ep & EP_RELU) v = v > 0.0f ? v : 0.0f;
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrcC, voffC,
-                                            (unsigned)((r & 3) + 8 * (r >> 2)) * ldcb, 0);
+      for (int g = 1; g < WK; ++g) v += *(const f32x4 *)(src + g * (WM * WN) * 1024);
+      v += bias4;
+      if (p.ep & EP_RELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrcC,
+                                             (unsigned)(((wm * 32 + q) * (int)p.ldc + wn * 32 + 4 * c4) * 4), 0, 0);
     }
     return;
   }
