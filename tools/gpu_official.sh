@@ -1,16 +1,43 @@
 #!/bin/bash
-# Round deliverable session: full parity suite, smoke, the driver's bench command, rocprofv3 kernel stats of the SAME
-# bench command, default bench, shape sweeps, tile-queue replays, eltwise bandwidth. Results in gpurun_out/<tag>/.
+# Round deliverable session: full parity suite, smoke, the driver's bench command, rocprofv3 kernel stats of the SAME bench
+# command, default bench, MFMA-busy PMC passes, the per-rank MLP step probe + in-kernel stamps, shape sweeps, tile-queue replays,
+# eltwise bandwidth. Results in gpurun_out/<tag>/.   usage: gpurun --timeout 2400 -- 'bash tools/gpu_official.sh r03_official1'
 TAG=${1:-official}; OUT=gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider -s > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
-grep -E "passed|failed|error|\[parity\]|rc=" $OUT/pytest_gpu.log | tail -5
+grep -E "passed|failed|error|\[parity\]|rc=|us per step" $OUT/pytest_gpu.log | tail -12
 timeout 600 python __graft_entry__.py --smoke > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_steps20.json 2> $OUT/bench_steps20.err
 timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o bench -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-pmc > $R/$OUT/rocprof_stats_run.json 2> $R/$OUT/rocprof_stats.err )
 find /tmp/prof_stats -name "*kernel_stats.csv" -exec cp {} $OUT/rocprof_kernel_stats.csv \;
+# MFMA-busy passes (PMC alone) + kernel stats of the same commands: C2, C3, the C4 layer kernel, the chain kernels
+( cd /tmp
+for what in "c2:$R/tools/c2_probe --iters 40 --init reference" "c3:$R/tools/c2_probe --c3 --iters 40 --init reference" "c4layer:$R/tools/mlp_probe --rows 4096 --only layers --iters 40" "c4chain:$R/tools/mlp_probe --rows 4096,2048,1024,512 --only chain --iters 40"; do
+  tag=${what%%:*}; cmd=${what#*:}
+  timeout 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES --output-format csv -d /tmp/mf_$tag -o p -- $cmd > /dev/null 2>&1
+  f=$(find /tmp/mf_$tag -name "*counter_collection.csv" | head -1)
+  [ -n "$f" ] && python - "$f" "$tag" >> $R/$OUT/mfma_busy.txt <<'PY'
+import csv, sys, collections
+acc = collections.defaultdict(lambda: [0.0, 0])
+for r in csv.DictReader(open(sys.argv[1])):
+    k = (r["Kernel_Name"][:70], r["Counter_Name"], r.get("Grid_Size", ""))
+    acc[k][0] += float(r["Counter_Value"]); acc[k][1] += 1
+for (kn, cn, g), (v, n) in sorted(acc.items()):
+    if "brgemm" in kn:
+        print("%-8s %-72s grid %-9s %-28s mean %.0f over %d launches" % (sys.argv[2], kn, g, cn, v / n, n))
+PY
+  timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$tag -o p -- $cmd > /dev/null 2>&1
+  f=$(find /tmp/ks_$tag -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && grep brgemm $f | cut -c1-170 | sed "s/^/$tag /" >> $R/$OUT/mfma_busy.txt
+done )
+# the per-rank step of the row-sharded C4 MLP (one chain launch vs three launches), forced tiles, and the chain kernel's phases
+for i in 1 2 3; do timeout 100 tools/mlp_probe; done > $OUT/mlp_probe.txt 2>&1
+for v in 16 17 19 20 21 22 23; do timeout 60 tools/mlp_probe --variant $v --only layers --rows 256,512,1024,2048,4096; done > $OUT/mlp_probe_forced.txt 2>&1
+for rows in 512 1024 2048 4096; do
+  TPP_HIP_CHAIN_STAMPS=$OUT/stamps_${rows}.txt timeout 60 tools/mlp_probe --only chain --rows $rows --iters 50 > /dev/null 2>&1
+  echo "== rows $rows"; python tools/stamps_report.py $OUT/stamps_${rows}.txt; done > $OUT/chain_anatomy.txt 2>&1
+for dbg in 0 16 32 48 2 6 7; do echo "dbg=$dbg"; TPP_HIP_CHAIN_DBG=$dbg timeout 100 tools/mlp_probe 2>&1; done > $OUT/chain_ablation.txt
 python tools/sweep.py 2>/dev/null | grep -E "^(f32|bf16)" > $OUT/sweep.txt
 python tools/sweep.py big 2>/dev/null | grep -E "^(f32|bf16)" >> $OUT/sweep.txt
 python tools/sweep.py shards 2>/dev/null | grep -E "^bf16" >> $OUT/sweep.txt
@@ -18,4 +45,4 @@ python tools/sweep.py small 2>/dev/null | grep -E "^bf16" >> $OUT/sweep.txt
 bash tools/gpu_replay.sh $TAG > /dev/null 2>&1
 python tools/eltwise_bw.py > $OUT/eltwise_bw.txt 2>/dev/null
 python tools/vendor_compare.py > $OUT/vendor_compare.txt 2>/dev/null
-head -c 700 $OUT/bench_steps20.json; echo; head -8 $OUT/rocprof_kernel_stats.csv | cut -c1-160
+tail -n 1 $OUT/bench_steps20.json | head -c 900; echo; head -8 $OUT/rocprof_kernel_stats.csv | cut -c1-160; cat $OUT/mlp_probe.txt | cut -c1-14,50-200 | tail -4
