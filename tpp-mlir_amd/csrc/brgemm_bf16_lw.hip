@@ -72,7 +72,7 @@ template <int PPL> __device__ __forceinline__ void blw_wait_younger(int younger)
 // chunk bodies with the ring slot as a literal: S = 0 .. N-1, then around again
 template <int S, int N, typename F> __device__ __forceinline__ bool blw_ring_pass(int &t, int T, F &f) {
   if constexpr (S < N) {
-    f(std::integral_constant<int, S>{}, t + 1 < T);
+    f(std::integral_constant<int, S>{}, t, T);
     if (++t == T) return true;
     return blw_ring_pass<S + 1, N>(t, T, f);
   } else {
@@ -89,21 +89,26 @@ template <int S, int N, typename F> __device__ __forceinline__ bool blw_ring_pas
 // The steady-state loop is a literal s_waitcnt + s_barrier + the DMA instructions + ~10 scalar instructions: measured on the
 // first version of this function (one general loop with a switch over the wait count, the layer bookkeeping and an argument load
 // inside), a 16-chunk layer took 5.7 us with NO loads and NO MFMAs at all - the loader's own instruction stream set the pace.
-template <bool IS_A, int NL, int NLA, int NSLOT, int BM, int BN, int WK, bool MULTI>
+template <bool IS_A, int NL, int NLA, int NSLOT_C, int SUP, int BM, int BN, int WK, bool MULTI>
 __device__ __forceinline__ void blw_loader(chain_kernarg_t *pp, unsigned char *smem, int lane, int m0, int n0, int tm, int L, int part) {
   chain_kernarg_t &p = *pp;
   constexpr int A_SLOT = BM * 128, SLOT = (BM + BN) * 128;
-  constexpr int PPL = (IS_A ? BM / 8 : BN / 8) / NL; // 1 KiB DMA instructions per chunk issued by this wave
+  // SUP = chunks per barrier (the unit everything below counts in: a "chunk" of this function is SUP 64-k chunks, a "slot" SUP
+  // consecutive ring slots). SUP = 2 halves the barrier count and the loader's per-iteration scalar work for the small tiles, whose
+  // 16-chunk layers spent 75 % of their time in the barrier / bookkeeping skeleton (timing with loads AND MFMAs switched off).
+  constexpr int NSLOT = NSLOT_C / SUP;
+  constexpr int PPC = (IS_A ? BM / 8 : BN / 8) / NL; // 1 KiB DMA instructions per 64-k chunk issued by this wave
+  constexpr int PPL = SUP * PPC;                     // ... per barrier interval
   [[maybe_unused]] constexpr int RPI = 256 / BN;     // VNNI pair-rows per B instruction
-  static_assert(PPL >= 1 && (IS_A ? BM / 8 : BN / 8) % NL == 0 && (!IS_A || NL == 1 || NL % 2 == 0), "panel instructions divide over the loader waves");
-  static_assert(NSLOT >= 3, "ring depth");
+  static_assert(PPC >= 1 && (IS_A ? BM / 8 : BN / 8) % NL == 0 && (!IS_A || NL == 1 || NL % 2 == 0), "panel instructions divide over the loader waves");
+  static_assert(NSLOT >= 3 && NSLOT_C % SUP == 0 && (NSLOT - 1) * PPL <= 63, "ring depth / vmcnt is 6 bits");
   const int dbg = p.dbg;
   const bool no_dma = (dbg & (16 | (IS_A ? 128 : 64))) != 0; // timing experiments: this panel is not fetched
   bool ahead = false;
   if (MULTI && !IS_A) {
     ahead = true;
     for (int l = 0; l < L; ++l) {
-      const int Tl = p.L[l].br * (p.L[l].k / BLW_BK);
+      const int Tl = p.L[l].br * (p.L[l].k / BLW_BK) / SUP;
       if (Tl % NSLOT || Tl < NSLOT) ahead = false; // ring positions of consecutive layers must line up
     }
   }
@@ -141,32 +146,34 @@ __device__ __forceinline__ void blw_loader(chain_kernarg_t *pp, unsigned char *s
     }                                                                                                                  \
     flat = d_wrap == d_in;                                                                                             \
   } while (0)
-  // request the next chunk of the issue state into ring slot `slot`, advance the state and the slot
+  // request the next SUP 64-k chunks of the issue state into ring slot `slot` (SUP consecutive 64-k slots), advance state and slot
 #define BLW_ISSUE(slot)                                                                                                \
   do {                                                                                                                 \
-    unsigned char *base_ = smem + (slot) * SLOT + (IS_A ? 0 : A_SLOT) + part * 1024;                                   \
-    const __amdgpu_buffer_rsrc_t r_ = __builtin_amdgcn_make_buffer_rsrc((void *)g, 0, 0x7fffffff, 0x00020000);         \
-    if (no_dma) {                                                                                                      \
-    } else if (IS_A && sc1) {                                                                                          \
-      _Pragma("unroll") for (int v = 0; v < PPL; ++v)                                                                  \
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(r_, (lds_void_b *)(base_ + v * NL * 1024), 16, (v & 1) ? vo1 : vo0, v * step, 0, 16); \
-    } else {                                                                                                           \
-      _Pragma("unroll") for (int v = 0; v < PPL; ++v)                                                                  \
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(r_, (lds_void_b *)(base_ + v * NL * 1024), 16, (v & 1) ? vo1 : vo0, v * step, 0, 0); \
-    }                                                                                                                  \
-    if (flat) { /* the batch elements continue each other (whole-layer dispatches): one 64-bit add */               \
-      g += d_in;                                                                                                       \
-    } else if (++kc == kchunks) {                                                                                      \
-      kc = 0;                                                                                                          \
-      g += d_wrap;                                                                                                     \
-    } else {                                                                                                           \
-      g += d_in;                                                                                                       \
+    _Pragma("unroll") for (int sub_ = 0; sub_ < SUP; ++sub_) {                                                         \
+      unsigned char *base_ = smem + ((slot) * SUP + sub_) * SLOT + (IS_A ? 0 : A_SLOT) + part * 1024;                  \
+      const __amdgpu_buffer_rsrc_t r_ = __builtin_amdgcn_make_buffer_rsrc((void *)g, 0, 0x7fffffff, 0x00020000);       \
+      if (no_dma) {                                                                                                    \
+      } else if (IS_A && sc1) {                                                                                        \
+        _Pragma("unroll") for (int v = 0; v < PPC; ++v)                                                                \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_, (lds_void_b *)(base_ + v * NL * 1024), 16, (v & 1) ? vo1 : vo0, v * step, 0, 16); \
+      } else {                                                                                                         \
+        _Pragma("unroll") for (int v = 0; v < PPC; ++v)                                                                \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_, (lds_void_b *)(base_ + v * NL * 1024), 16, (v & 1) ? vo1 : vo0, v * step, 0, 0); \
+      }                                                                                                                \
+      if (flat) { /* the batch elements continue each other (whole-layer dispatches): one 64-bit add */               \
+        g += d_in;                                                                                                     \
+      } else if (++kc == kchunks) {                                                                                    \
+        kc = 0;                                                                                                        \
+        g += d_wrap;                                                                                                   \
+      } else {                                                                                                         \
+        g += d_in;                                                                                                     \
+      }                                                                                                                \
     }                                                                                                                  \
     slot = slot + 1 == NSLOT ? 0 : slot + 1;                                                                           \
   } while (0)
   const bool poller = MULTI && IS_A && part == 0;
   for (int lc = 0; lc < L; ++lc) {
-    const int T = p.L[lc].br * (p.L[lc].k / BLW_BK);
+    const int T = p.L[lc].br * (p.L[lc].k / BLW_BK) / SUP; // (a multiple of SUP: the launcher picks SUP = 1 otherwise)
     int pre = NSLOT - 2; // chunks of this layer already requested by the run-ahead of the previous layer's tail
     if (state_layer != lc) {
       BLW_LOAD_STATE(lc);
@@ -234,7 +241,7 @@ __device__ __forceinline__ void blw_loader(chain_kernarg_t *pp, unsigned char *s
 #undef BLW_LOAD_STATE
 }
 
-template <int WM, int WN, int WK, int TM, int TN, int NSLOT, int NLA, int NLB, bool MULTI>
+template <int WM, int WN, int WK, int TM, int TN, int NSLOT, int NLA, int NLB, int SUP, bool MULTI>
 __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_lw(ChainArgs p_by_value) {
   chain_kernarg_t *pp = (chain_kernarg_t *)__builtin_amdgcn_kernarg_segment_ptr(); // = &p_by_value (the only explicit argument)
   chain_kernarg_t &p = *pp;
@@ -242,12 +249,11 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
   constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
   constexpr int KS = 4 / WK, PD = KS / 2;            // k-steps of a chunk per wave; fragment prefetch distance
   constexpr int A_SLOT = BM * 128, B_SLOT = BN * 128, SLOT = A_SLOT + B_SLOT;
-  constexpr int NA = BM / 8, NBI = BN / 8;           // 1 KiB DMA instructions per chunk of A / of B
   constexpr int ES = 64 * TN + 16;                   // bytes per staged output row (16 B pad: conflict-free 16-byte accesses)
   constexpr int STAGE_W = 32 * ES;                   // one 32-row block of a wave's tile
   constexpr int OFF_STAGE = NSLOT * SLOT, OFF_RED = OFF_STAGE + NOUT * STAGE_W;
   static_assert(WK == 1 || (WK == 2 && TM == 1 && TN == 1), "K split: two groups of single-tile waves");
-  static_assert((NSLOT - 1) * NA / NLA <= 63 && (NSLOT - 1) * NBI / NLB <= 63, "vmcnt is 6 bits");
+  static_assert(SUP == 1 || (SUP == 2 && TM * TN <= 2 && NSLOT % 2 == 0), "two chunks per barrier: the tiles that read a whole chunk of fragments ahead");
   constexpr int NLW = NLA + NLB; // loader waves
   static_assert(BN == 32 || BN == 64 || BN == 128, "B pair-rows per DMA instruction");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_c[];
@@ -276,8 +282,8 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
 
   if (wave >= NMW) {
     // ---- loader waves (blw_loader above) ---------------------------------------------------------------------------
-    if (wave < NMW + NLA) blw_loader<true, NLA, NLA, NSLOT, BM, BN, WK, MULTI>(pp, smem_c, lane, m0, n0, tm, L, wave - NMW);
-    else blw_loader<false, NLB, NLA, NSLOT, BM, BN, WK, MULTI>(pp, smem_c, lane, m0, n0, tm, L, wave - NMW - NLA);
+    if (wave < NMW + NLA) blw_loader<true, NLA, NLA, NSLOT, SUP, BM, BN, WK, MULTI>(pp, smem_c, lane, m0, n0, tm, L, wave - NMW);
+    else blw_loader<false, NLB, NLA, NSLOT, SUP, BM, BN, WK, MULTI>(pp, smem_c, lane, m0, n0, tm, L, wave - NMW - NLA);
     return; // ended waves do not take part in later barriers
   }
 
@@ -320,8 +326,13 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
   // one chunk in ring slot S: step q multiplies fragment buffer q while the fragments of step q + PD are read (the last PD
   // steps read the first steps of chunk t+1, published by the mid-chunk barrier; after the last chunk of a layer they
   // read a slot nobody uses - the values are dropped)
-  auto chunk = [&](auto slot_c, bool has_next) __attribute__((always_inline)) {
+  // t, T: this chunk's index and the layer's chunk count. The workgroup barrier sits in the middle of every SUP-th chunk (S a
+  // multiple of SUP: layers start at slot 0) when another barrier interval follows: it publishes the next SUP chunks and retires
+  // the previous SUP slots. (With SUP = 2 the fragments of the odd chunk are read during the even chunk's second half - the same
+  // interval, already published - and those of the next even chunk during the odd chunk's, behind the barrier.)
+  auto chunk = [&](auto slot_c, int t, int T) __attribute__((always_inline)) {
     constexpr int S = decltype(slot_c)::value, NS = (S + 1) % NSLOT;
+    const bool has_next = (S % SUP == 0) && t + SUP < T;
     constexpr int CUR = FULLPF ? (S & 1) * KS : 0, NXT = FULLPF ? ((S & 1) ^ 1) * KS : 0; // fragment sets of chunk t / t+1
 #pragma unroll
     for (int q = 0; q < KS; ++q) {
@@ -347,7 +358,7 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_lw, bw[CUR + q][j]), af[CUR + q][i], acc[i][j], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (q == KS / 2 - 1 && has_next) {
+      if (q == KS / 2 - 1 && (S % SUP == 0) && has_next) {
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -499,12 +510,12 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
   }
 }
 
-template <int WM, int WN, int WK, int TM, int TN, int NSLOT, int NLA, int NLB, bool MULTI>
+template <int WM, int WN, int WK, int TM, int TN, int NSLOT, int NLA, int NLB, int SUP, bool MULTI>
 static hipError_t launch_blw_t(const ChainArgs &a, hipStream_t s) {
   constexpr int NOUT = WM * WN, BM = 32 * WM * TM, BN = 32 * WN * TN, NT = 64 * (WM * WN * WK + NLA + NLB);
   constexpr size_t lds = (size_t)NSLOT * (BM + BN) * 128 + (size_t)NOUT * 32 * (64 * TN + 16) + (WK > 1 ? (size_t)NOUT * 4096 : 0);
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto kern = brgemm_bf16_lw<WM, WN, WK, TM, TN, NSLOT, NLA, NLB, MULTI>;
+  auto kern = brgemm_bf16_lw<WM, WN, WK, TM, TN, NSLOT, NLA, NLB, SUP, MULTI>;
   static std::atomic<unsigned long long> lds_set{0};
   if (hipError_t e = ensure_dynamic_lds((const void *)kern, (int)lds, lds_set); e != hipSuccess) return e;
   ChainArgs args = a;
@@ -541,24 +552,42 @@ void blw_tile_dims(int tile, int *bm, int *bn) {
 
 // Loader waves per tile (NLA + NLB), same-box A/B (profiles/r03_blw_loader_split.txt): 32x64 1 + 2 (1 + 1: +2 %, 2 + 2: +5 %),
 // 64x64 1 + 1 (1 + 2: +2 %, 2 + 2: +7 %), 64x128 1 + 2 (1 + 1: same, 2 + 4: +5 %), 128x128 1 + 1 (2 + 2, 1 + 2: same).
-#define BLW_DISPATCH(MULTI)                                                     \
-  switch (tile) {                                                               \
-  case 0: return launch_blw_t<1, 2, 2, 1, 1, 8, 1, 2, MULTI>(a, s);             \
-  case 1: return launch_blw_t<2, 2, 1, 1, 1, 8, 1, 1, MULTI>(a, s);             \
-  case 2: return launch_blw_t<2, 2, 1, 1, 2, 4, 1, 2, MULTI>(a, s);             \
-  case 3: return launch_blw_t<2, 2, 1, 2, 2, 4, 1, 1, MULTI>(a, s);             \
-  default: return hipErrorInvalidValue;                                         \
+// SUP = 2 (one workgroup barrier per TWO chunks) for the 32x64 and 64x64 tiles when every layer has an even chunk count
+// (TPP_HIP_BLW_SUP=1 forces one chunk per barrier for A/B runs)
+#define BLW_DISPATCH(MULTI)                                                                  \
+  switch (tile * 2 + (sup2 ? 1 : 0)) {                                                       \
+  case 0: return launch_blw_t<1, 2, 2, 1, 1, 8, 1, 2, 1, MULTI>(a, s);                       \
+  case 1: return launch_blw_t<1, 2, 2, 1, 1, 8, 1, 2, 2, MULTI>(a, s);                       \
+  case 2: return launch_blw_t<2, 2, 1, 1, 1, 8, 1, 1, 1, MULTI>(a, s);                       \
+  case 3: return launch_blw_t<2, 2, 1, 1, 1, 8, 1, 1, 2, MULTI>(a, s);                       \
+  case 4:                                                                                    \
+  case 5: return launch_blw_t<2, 2, 1, 1, 2, 4, 1, 2, 1, MULTI>(a, s);                       \
+  case 6:                                                                                    \
+  case 7: return launch_blw_t<2, 2, 1, 2, 2, 4, 1, 1, 1, MULTI>(a, s);                       \
+  default: return hipErrorInvalidValue;                                                      \
   }
+static bool blw_sup2(const ChainArgs &a) {
+  static const int forced = [] {
+    const char *e = getenv("TPP_HIP_BLW_SUP");
+    return e ? atoi(e) : 0;
+  }();
+  if (forced == 1) return false;
+  for (int l = 0; l < a.nlayers; ++l)
+    if ((a.L[l].br * (a.L[l].k / BLW_BK)) & 1) return false;
+  return true;
+}
 
 // one layer (a.nlayers == 1): any chunk stream of at least one chunk, both accumulator starts
 hipError_t launch_bf16_lw(int tile, const ChainArgs &a, hipStream_t s) {
   if (a.L[0].br < 1 || a.L[0].k < BLW_BK || tile < 0 || tile > 3) return hipErrorInvalidValue;
+  const bool sup2 = blw_sup2(a);
   BLW_DISPATCH(false)
 }
 
 // a chain of layers in one launch; the caller guarantees co-residency (tiles <= CUs), beta = 0 and disjoint buffers
 hipError_t launch_bf16_chain(int tile, const ChainArgs &a, hipStream_t s) {
   if (tile < 0 || tile > 3) return hipErrorInvalidValue;
+  const bool sup2 = blw_sup2(a);
   BLW_DISPATCH(true)
 }
 
