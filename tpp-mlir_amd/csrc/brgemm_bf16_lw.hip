@@ -69,17 +69,6 @@ template <int PPL> __device__ __forceinline__ void blw_wait_younger(int younger)
 #undef BLW_CASE
 }
 
-// chunk bodies with the ring slot as a literal: S = 0 .. N-1, then around again
-template <int S, int N, typename F> __device__ __forceinline__ bool blw_ring_pass(int &t, int T, F &f) {
-  if constexpr (S < N) {
-    f(std::integral_constant<int, S>{}, t, T);
-    if (++t == T) return true;
-    return blw_ring_pass<S + 1, N>(t, T, f);
-  } else {
-    return false;
-  }
-}
-
 // One loader wave: LDS-DMA instructions of its panel (IS_A: the A panel [BM rows][64 k], else the B panel [32 pair-rows][BN
 // dwords]) for every chunk of every layer, NSLOT - 1 chunks ahead of the MFMA waves, and its side of the barrier schedule:
 //   per layer  [S2]  P (chunk 0 published), one mid-chunk barrier per further chunk, and - between layers - R1 (WK > 1) and S1.
@@ -109,7 +98,7 @@ __device__ __forceinline__ void blw_loader(chain_kernarg_t *pp, unsigned char *s
     ahead = true;
     for (int l = 0; l < L; ++l) {
       const int Tl = p.L[l].br * (p.L[l].k / BLW_BK) / SUP;
-      if (Tl % NSLOT || Tl < NSLOT) ahead = false; // ring positions of consecutive layers must line up
+      if (Tl < NSLOT) ahead = false; // (the run-ahead issues NSLOT - 2 chunks of the next layer during this layer's tail)
     }
   }
   // issue state: the panel base of the next chunk to request (of layer state_layer) and the constants of that layer
@@ -172,12 +161,14 @@ __device__ __forceinline__ void blw_loader(chain_kernarg_t *pp, unsigned char *s
     slot = slot + 1 == NSLOT ? 0 : slot + 1;                                                                           \
   } while (0)
   const bool poller = MULTI && IS_A && part == 0;
+  int slot = 0, s0 = 0; // next ring slot to fill; slot of the current layer's chunk 0 (the layers follow each other through the ring)
   for (int lc = 0; lc < L; ++lc) {
     const int T = p.L[lc].br * (p.L[lc].k / BLW_BK) / SUP; // (a multiple of SUP: the launcher picks SUP = 1 otherwise)
     int pre = NSLOT - 2; // chunks of this layer already requested by the run-ahead of the previous layer's tail
     if (state_layer != lc) {
       BLW_LOAD_STATE(lc);
       pre = 0;
+      slot = s0;
     }
     if (poller) blw_stamp(p, lc, 5, lane);
     if (poller && lc > 0 && !(dbg & 2)) {
@@ -205,7 +196,7 @@ __device__ __forceinline__ void blw_loader(chain_kernarg_t *pp, unsigned char *s
     // chunks 0 and 1 first, chunk 0 PUBLISHED as soon as it has landed, the rest of the prologue behind the barrier (the MFMA
     // waves work on chunk 0 while it is issued; dbg & 256: everything before the barrier, for A/B runs)
     const int nfirst = (dbg & 256) ? npro : (npro < 2 ? npro : 2);
-    int slot = pre, c = pre;
+    int c = pre;
     for (; c < nfirst; ++c) BLW_ISSUE(slot);
     if (poller) blw_stamp(p, lc, 7, lane);
     blw_wait_younger<PPL>((c > nfirst ? c : nfirst) - 1);
@@ -221,7 +212,7 @@ __device__ __forceinline__ void blw_loader(chain_kernarg_t *pp, unsigned char *s
     }
     // the last NSLOT - 2 barriers of the layer: nothing of THIS layer is left to request
     if (MULTI && ahead && lc + 1 < L) {
-      BLW_LOAD_STATE(lc + 1); // (T is a multiple of the ring depth: the slot rotation carries over)
+      BLW_LOAD_STATE(lc + 1); // (the slot rotation carries over into the next layer)
       for (; t + 1 < T; ++t) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSLOT - 3) * PPL) : "memory");
         __builtin_amdgcn_s_barrier();
@@ -236,6 +227,7 @@ __device__ __forceinline__ void blw_loader(chain_kernarg_t *pp, unsigned char *s
     if (lc + 1 == L) return;
     if constexpr (WK > 1) __builtin_amdgcn_s_barrier(); // R1 (K groups combine)
     __builtin_amdgcn_s_barrier();                        // S1 (tile stored and drained)
+    s0 = (s0 + T) % NSLOT;
   }
 #undef BLW_ISSUE
 #undef BLW_LOAD_STATE
@@ -251,7 +243,14 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
   constexpr int A_SLOT = BM * 128, B_SLOT = BN * 128, SLOT = A_SLOT + B_SLOT;
   constexpr int ES = 64 * TN + 16;                   // bytes per staged output row (16 B pad: conflict-free 16-byte accesses)
   constexpr int STAGE_W = 32 * ES;                   // one 32-row block of a wave's tile
-  constexpr int OFF_STAGE = NSLOT * SLOT, OFF_RED = OFF_STAGE + NOUT * STAGE_W;
+  // The epilogue's per-wave staging tiles live in the A halves of RETIRED ring slots (the whole LDS belongs to the ring: a fifth
+  // slot for the 128x128 tile, a sixth for 64x128). After the last workgroup barrier of a layer only the slots of its last
+  // 2 * SUP chunks can still be read by a slower wave; the next layer's A panels are requested after the seam barrier S1 (behind
+  // every wave's epilogue), and the B loaders' run-ahead writes B halves only.
+  constexpr int WPS = A_SLOT / STAGE_W;              // staging tiles per A half
+  constexpr int STAGE_SLOTS = (NOUT + WPS - 1) / WPS;
+  static_assert(WPS >= 1 && STAGE_SLOTS + 2 * SUP <= NSLOT, "staging tiles fit into the retired slots");
+  constexpr int OFF_RED = NSLOT * SLOT;
   static_assert(WK == 1 || (WK == 2 && TM == 1 && TN == 1), "K split: two groups of single-tile waves");
   static_assert(SUP == 1 || (SUP == 2 && TM * TN <= 2 && NSLOT % 2 == 0), "two chunks per barrier: the tiles that read a whole chunk of fragments ahead");
   constexpr int NLW = NLA + NLB; // loader waves
@@ -365,6 +364,7 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
     }
   };
 
+  int s0 = 0; // ring slot of the current layer's chunk 0
   for (int l = 0; l < L; ++l) {
     const auto &Y = p.L[l];
     const int T = Y.br * (Y.k / BLW_BK);
@@ -393,10 +393,36 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
     if (MULTI && wave == 0) blw_stamp(p, l, 1, lane);
     // (T >= 1: the launchers send empty batches to the generic kernel - a branch around this loop costs the 128-wide tiles
     // a second copy of the accumulators and 250 spilled registers)
+    // the layers follow each other through the ring: this one starts at slot s0 (the loaders count the same way)
+    const int last_slot = (s0 + T - 1) % NSLOT;
+    if (!FULLPF || !(s0 & 1)) {
 #pragma unroll
-    for (int s = 0; s < (FULLPF ? KS : PD); ++s) frag_load(s, 0, wk * KS + s);
-    for (int t = 0;;)
-      if (blw_ring_pass<0, NSLOT>(t, T, chunk)) break;
+      for (int s = 0; s < (FULLPF ? KS : PD); ++s) frag_load(s, s0, wk * KS + s);
+    } else { // (chunk parity = slot parity selects the fragment set)
+#pragma unroll
+      for (int s = 0; s < KS; ++s) frag_load(FULLPF ? KS + s : s, s0, wk * KS + s);
+    }
+    {
+      int t = 0;
+      [&]() __attribute__((always_inline)) {
+#define BLW_RING_CASE(S)                                           \
+  case S:                                                          \
+    if constexpr (S < NSLOT) {                                     \
+      chunk(std::integral_constant<int, S>{}, t, T);               \
+      if (++t == T) return;                                        \
+    }                                                              \
+    [[fallthrough]];
+        for (int first = s0;; first = 0) { // one body per ring slot (literal LDS offsets), entered at the layer's first slot
+          switch (first) {
+            BLW_RING_CASE(0) BLW_RING_CASE(1) BLW_RING_CASE(2) BLW_RING_CASE(3) BLW_RING_CASE(4) BLW_RING_CASE(5)
+            BLW_RING_CASE(6) BLW_RING_CASE(7) BLW_RING_CASE(8) BLW_RING_CASE(9) BLW_RING_CASE(10) BLW_RING_CASE(11)
+          default: break;
+          }
+        }
+#undef BLW_RING_CASE
+      }();
+    }
+    s0 = (s0 + T) % NSLOT;
     // the fragments prefetched past the end of the layer are dead: without this the compiler sinks their reads
 #pragma unroll
     for (int s = 0; s < (FULLPF ? NFB : PD); ++s) {
@@ -445,7 +471,7 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
         }
       }
       const bool relu = (ep & EP_RELU) != 0;
-      unsigned char *ot = smem_c + OFF_STAGE + wmn * STAGE_W;
+      unsigned char *ot = smem_c + ((last_slot + 1 + wmn / WPS) % NSLOT) * SLOT + (wmn % WPS) * STAGE_W;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -513,7 +539,7 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
 template <int WM, int WN, int WK, int TM, int TN, int NSLOT, int NLA, int NLB, int SUP, bool MULTI>
 static hipError_t launch_blw_t(const ChainArgs &a, hipStream_t s) {
   constexpr int NOUT = WM * WN, BM = 32 * WM * TM, BN = 32 * WN * TN, NT = 64 * (WM * WN * WK + NLA + NLB);
-  constexpr size_t lds = (size_t)NSLOT * (BM + BN) * 128 + (size_t)NOUT * 32 * (64 * TN + 16) + (WK > 1 ? (size_t)NOUT * 4096 : 0);
+  constexpr size_t lds = (size_t)NSLOT * (BM + BN) * 128 + (WK > 1 ? (size_t)NOUT * 4096 : 0);
   static_assert(lds <= 160 * 1024, "LDS budget");
   auto kern = brgemm_bf16_lw<WM, WN, WK, TM, TN, NSLOT, NLA, NLB, SUP, MULTI>;
   static std::atomic<unsigned long long> lds_set{0};
@@ -553,7 +579,8 @@ void blw_tile_dims(int tile, int *bm, int *bn) {
 // Loader waves per tile (NLA + NLB), same-box A/B (profiles/r03_blw_loader_split.txt): 32x64 1 + 2 (1 + 1: +2 %, 2 + 2: +5 %),
 // 64x64 1 + 1 (1 + 2: +2 %, 2 + 2: +7 %), 64x128 1 + 2 (1 + 1: same, 2 + 4: +5 %), 128x128 1 + 1 (2 + 2, 1 + 2: same).
 // SUP = 2 (one workgroup barrier per TWO chunks) for the 32x64 and 64x64 tiles when every layer has an even chunk count
-// (TPP_HIP_BLW_SUP=1 forces one chunk per barrier for A/B runs)
+// (TPP_HIP_BLW_SUP=1 forces one chunk per barrier for A/B runs). Ring depths: 8 / 8 / 6 / 4 slots; a 5-slot ring with 2 + 2
+// loaders for the 128x128 tile and 4 against 6 slots for 64x128 measured the same (same box, +-0.5 %).
 #define BLW_DISPATCH(MULTI)                                                                  \
   switch (tile * 2 + (sup2 ? 1 : 0)) {                                                       \
   case 0: return launch_blw_t<1, 2, 2, 1, 1, 8, 1, 2, 1, MULTI>(a, s);                       \
@@ -561,7 +588,7 @@ void blw_tile_dims(int tile, int *bm, int *bn) {
   case 2: return launch_blw_t<2, 2, 1, 1, 1, 8, 1, 1, 1, MULTI>(a, s);                       \
   case 3: return launch_blw_t<2, 2, 1, 1, 1, 8, 1, 1, 2, MULTI>(a, s);                       \
   case 4:                                                                                    \
-  case 5: return launch_blw_t<2, 2, 1, 1, 2, 4, 1, 2, 1, MULTI>(a, s);                       \
+  case 5: return launch_blw_t<2, 2, 1, 1, 2, 6, 1, 2, 1, MULTI>(a, s);                       \
   case 6:                                                                                    \
   case 7: return launch_blw_t<2, 2, 1, 2, 2, 4, 1, 1, 1, MULTI>(a, s);                       \
   default: return hipErrorInvalidValue;                                                      \
