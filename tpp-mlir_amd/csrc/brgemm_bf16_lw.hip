@@ -252,7 +252,8 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
   static_assert(WPS >= 1 && STAGE_SLOTS + 2 * SUP <= NSLOT, "staging tiles fit into the retired slots");
   constexpr int OFF_RED = NSLOT * SLOT;
   static_assert(WK == 1 || (WK == 2 && TM == 1 && TN == 1), "K split: two groups of single-tile waves");
-  static_assert(SUP == 1 || (SUP == 2 && TM * TN <= 2 && NSLOT % 2 == 0), "two chunks per barrier: the tiles that read a whole chunk of fragments ahead");
+  static_assert(SUP == 1 || ((SUP == 2 || SUP == 4) && TM * TN <= 2 && NSLOT % SUP == 0 && NSLOT % 2 == 0),
+                "several chunks per barrier: the tiles that read a whole chunk of fragments ahead");
   constexpr int NLW = NLA + NLB; // loader waves
   static_assert(BN == 32 || BN == 64 || BN == 128, "B pair-rows per DMA instruction");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_c[];
@@ -580,7 +581,8 @@ void blw_tile_dims(int tile, int *bm, int *bn) {
 // 64x64 1 + 1 (1 + 2: +2 %, 2 + 2: +7 %), 64x128 1 + 2 (1 + 1: same, 2 + 4: +5 %), 128x128 1 + 1 (2 + 2, 1 + 2: same).
 // SUP = 2 (one workgroup barrier per TWO chunks) for the 32x64 and 64x64 tiles when every layer has an even chunk count
 // (TPP_HIP_BLW_SUP=1 forces one chunk per barrier for A/B runs). Ring depths: 8 / 8 / 6 / 4 slots; a 5-slot ring with 2 + 2
-// loaders for the 128x128 tile and 4 against 6 slots for 64x128 measured the same (same box, +-0.5 %).
+// loaders for the 128x128 tile and 4 against 6 slots for 64x128 measured the same (same box, +-0.5 %); FOUR chunks per barrier on
+// a 12-slot ring for the 32x64 tile measured 9 % slower than two on 8 slots (the prologue must request 8 chunks before the first barrier).
 #define BLW_DISPATCH(MULTI)                                                                  \
   switch (tile * 2 + (sup2 ? 1 : 0)) {                                                       \
   case 0: return launch_blw_t<1, 2, 2, 1, 1, 8, 1, 2, 1, MULTI>(a, s);                       \
