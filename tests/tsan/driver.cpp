@@ -109,6 +109,66 @@ static int run_mlp(bool device_operands, int reps, const char *what) {
   return bad;
 }
 
+// The steady state of compiled code: fused BRGEMM tiles (BETA_0 + relu folded in, one invoke per tile, 32 tiles per layer), the same
+// invokes iteration after iteration - recorded once, then replayed: members arrive through the direct window without the queue's
+// lock while the first caller of the next layer closes it. In odd repetitions one thread also issues an invoke the recorded group
+// does not know (a zero fill of a scratch tile) in the middle of a layer: the replay is abandoned under the other callers' feet.
+static int run_fused(int reps, const char *what) {
+  const int M2 = 256;
+  std::vector<float *> act(LAYERS + 1), w(LAYERS), ref(LAYERS + 1);
+  for (int l = 0; l <= LAYERS; ++l) {
+    act[l] = dev_alloc((size_t)M2 * N);
+    ref[l] = (float *)malloc((size_t)M2 * N * sizeof(float));
+  }
+  float *scratch = dev_alloc(TS * TS);
+  for (int l = 0; l < LAYERS; ++l) {
+    w[l] = dev_alloc((size_t)K * N);
+    fill(w[l], (size_t)K * N, 177u + l, 4);
+  }
+  fill(act[0], (size_t)M2 * K, 15u, 2);
+  memcpy(ref[0], act[0], (size_t)M2 * K * sizeof(float));
+  for (int l = 0; l < LAYERS; ++l) {
+    serial_layer(ref[l], w[l], ref[l + 1]);
+    serial_layer(ref[l] + (size_t)M * K, w[l], ref[l + 1] + (size_t)M * N);
+  }
+  int bad = 0;
+  pthread_barrier_t bar;
+  pthread_barrier_init(&bar, nullptr, NT);
+  for (int rep = 0; rep < reps; ++rep) {
+    for (int l = 1; l <= LAYERS; ++l) memset(act[l], 0xff, (size_t)M2 * N * sizeof(float));
+    std::vector<std::thread> th;
+    for (int tid = 0; tid < NT; ++tid)
+      th.emplace_back([&, tid] {
+        const int64_t hf = xsmm_fused_brgemm_dispatch(XSMM_DTYPE_F32, TS, TS, KB, K, N, N, KB, (int64_t)KB * N, XSMM_GEMM_FLAG_BETA_0, 0,
+                                                      XSMM_UNARY_RELU, 0, XSMM_BINARY_NONE);
+        const int64_t hz = xsmm_unary_dispatch(XSMM_UNARY_ZERO, XSMM_DTYPE_F32, TS, TS, TS, TS, 0);
+        const int tiles_n = N / TS, tiles = (M2 / TS) * tiles_n, per = tiles / NT;
+        for (int l = 0; l < LAYERS; ++l) {
+          for (int t = tid * per; t < (tid + 1) * per; ++t) { // static schedule: a contiguous share per thread
+            const int i = t / tiles_n, j = t % tiles_n;
+            xsmm_fused_brgemm_invoke(XSMM_DTYPE_F32, hf, act[l], (int64_t)i * TS * K, w[l], j * TS, act[l + 1], (int64_t)i * TS * N + j * TS,
+                                     nullptr, 0, K / KB);
+            if ((rep & 1) && tid == 3 && l == 1 && t == tid * per) xsmm_unary_invoke(XSMM_DTYPE_F32, hz, scratch, 0, scratch, 0);
+          }
+          pthread_barrier_wait(&bar);
+        }
+        if (tid == NT - 1) xsmm_hip_synchronize();
+      });
+    for (auto &t : th) t.join();
+    for (int l = 1; l <= LAYERS; ++l)
+      if (memcmp(act[l], ref[l], (size_t)M2 * N * sizeof(float))) ++bad;
+  }
+  pthread_barrier_destroy(&bar);
+  printf("%-46s reps %d: %s\n", what, reps, bad ? "MISMATCH" : "identical to the serial run");
+  for (int l = 0; l <= LAYERS; ++l) {
+    hipFree(act[l]);
+    free(ref[l]);
+  }
+  for (int l = 0; l < LAYERS; ++l) hipFree(w[l]);
+  hipFree(scratch);
+  return bad;
+}
+
 // A chain of dependent in-place ops on ONE tile, each step issued by a different thread, handed over through an atomic
 // (release / acquire) only: x = 0; then alternately x = 2 x and x = x + 1, i.e. after 2 n steps x = 2^n - 1 ... only if the
 // scheduler takes the steps in the order the hand-overs define (the ops do not commute).
@@ -162,10 +222,24 @@ int main(int argc, char **argv) {
   bad += run_mlp(true, 2, "sync, device operands, 8 callers");
   // 2. host operands: each invoke mirrors its operands and copies ITS tile back (neighbours belong to other threads)
   bad += run_mlp(false, 2, "sync, host operands (mirror), 8 callers");
-  // 3. the tile queue: inline bookkeeping for the first caller, then the ring + scheduler thread
+  // 3a. the tile queue, default mode: the bookkeeping under the queue's lock, replayed groups through the direct window - no
+  //     scheduler thread for a program that repeats itself
   xsmm_hip_set_async(1);
   xsmm_hip_set_tile_queue(1);
   const int threads_before = thread_count();
+  int64_t qs0[5], qs1[5];
+  xsmm_hip_tile_queue_stats(qs0);
+  bad += run_fused(12, "tile queue, fused tiles replayed, 8 callers");
+  xsmm_hip_tile_queue_stats(qs1);
+  printf("direct window: %ld invokes replayed, %ld with full bookkeeping, %ld replays abandoned, %d threads\n", (long)(qs1[2] - qs0[2]),
+         (long)(qs1[1] - qs0[1]), (long)(qs1[4] - qs0[4]), thread_count());
+  if (qs1[2] - qs0[2] < 6 * 96 || qs1[4] - qs0[4] < 3 || thread_count() != threads_before) {
+    printf("direct window: UNEXPECTED\n");
+    ++bad;
+  }
+  bad += run_mlp(true, 2, "tile queue, zero/brgemm/relu tiles, 8 callers");
+  // 3b. mode 2: several callers hand their invokes to the ring + scheduler thread
+  xsmm_hip_set_tile_queue(2);
   bad += run_mlp(true, 6, "tile queue, device operands, 8 callers");
   const int threads_busy = thread_count();
   bad += run_mlp(false, 2, "tile queue on, host operands, 8 callers");
@@ -193,6 +267,7 @@ int main(int argc, char **argv) {
   bad += run_mlp(true, 1, "back to sync");
   xsmm_hip_set_async(1);
   bad += run_mlp(true, 2, "async again");
+  bad += run_fused(4, "fused tiles through the scheduler thread");
   xsmm_hip_set_tile_queue(0);
   bad += run_mlp(true, 1, "async, queue off");
   printf("%s\n", bad ? "FAILED" : "OK");

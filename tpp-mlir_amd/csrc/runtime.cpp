@@ -71,7 +71,7 @@ struct Config {
     if (const char *e = getenv("TPP_HIP_ASYNC")) async = atoi(e) != 0;
     if (const char *e = getenv("TPP_HIP_TRACE")) trace = atoi(e);
     if (const char *e = getenv("TPP_HIP_VARIANT")) forced_variant = atoi(e);
-    if (const char *e = getenv("TPP_HIP_TILE_QUEUE")) tile_queue = atoi(e) != 0;
+    if (const char *e = getenv("TPP_HIP_TILE_QUEUE")) tile_queue = atoi(e) < 0 ? 0 : atoi(e) > 2 ? 2 : atoi(e);
   }
 };
 Config &cfg() {
@@ -696,11 +696,31 @@ struct TraceItem {
 struct Segment {
   std::vector<TraceItem> items;
   std::vector<TraceItem> terminators;
-  std::vector<uint32_t> seen; // round in which items[i] was last replayed (an invoke may join a group once)
+  std::vector<uint32_t> seen; // round in which items[i] was last replayed (an invoke may join a group once); marked with atomic
+                              // exchanges: callers mark their own arrivals while a direct window is open (DirectWindow)
   std::vector<int32_t> table; // open addressing over items, -1 = empty
   uint32_t round = 0;
   bool vec_ok = true, out_ok = true;
   uint64_t last_use = 0;
+  // The group's work list as the grouped kernels read it: items[i].w in recorded order, in pinned host memory, written once when
+  // the group is first replayed. A replay in which EVERY member arrives launches straight from it - nobody copies a work item.
+  WorkItem *list = nullptr;
+  size_t list_cap = 0;
+  bool list_valid = false, list_used = false; // holds items[] of THIS recording / a launch may still be reading it
+  hipStream_t list_stream = nullptr;           // ... on this stream
+  void ensure_list() {
+    if (list_valid) return;
+    if (list_used) HIP_OK(hipStreamSynchronize(list_stream)); // the buffer carried another recording's items: its last launch must be done
+    list_used = false;
+    if (list_cap < items.size()) {
+      if (list) HIP_OK(hipHostFree(list));
+      list_cap = items.size() < 64 ? 64 : items.size();
+      HIP_OK(hipHostMalloc((void **)&list, sizeof(WorkItem) * list_cap, hipHostMallocDefault));
+    }
+    for (size_t i = 0; i < items.size(); ++i) list[i] = items[i].w;
+    list_valid = true;
+  }
+  bool mark(int idx) { return __atomic_exchange_n(&seen[idx], round, __ATOMIC_RELAXED) != round; } // false: joined this round already
   static size_t hash(const WorkItem &w) {
     uint64_t h = (uint64_t)(uintptr_t)w.C * 0x9E3779B97F4A7C15ull;
     h ^= ((uint64_t)(uintptr_t)w.A >> 4) * 0xC2B2AE3D27D4EB4Full;
@@ -718,6 +738,7 @@ struct Segment {
     }
     seen.assign(items.size(), 0);
     round = 0;
+    list_valid = false;
   }
   int index_of(const void *d, const WorkItem &w, hipStream_t st) const {
     if (table.empty()) return -1;
@@ -730,6 +751,59 @@ struct Segment {
     for (const TraceItem &t : terminators)
       if (t.same(d, w, st)) return true;
     return false;
+  }
+};
+
+// DIRECT WINDOW: replayed members arrive without a lock. While the inline queue replays a recorded group, `cur` names it
+// (generation << 7 | segment index + 1) and a caller whose invoke is a member marks it in the segment (Segment::mark) and counts it
+// in its OWN cache line - no work item is written (the segment's pinned list already holds it) and no line is shared between
+// callers except `cur`, which changes once per group. Whoever has to change the queue state - a terminator, an invoke the cache
+// does not know, a flush point - holds the queue's lock, CLOSES the window (cur = 0) and waits until no caller is inside it:
+//   caller: busy = cur (seq_cst); re-read cur (seq_cst); ... mark, count ...; busy = 0 (release)
+//   closer: cur = 0 (seq_cst); for every caller: wait until busy == 0 (seq_cst / acquire), then read its count
+// a Dekker pair per caller: either the caller sees the closed window and takes the locked path, or the closer sees it busy and waits
+// for its arrival to be complete. Invokes are processed synchronously on this path (when xsmm_*_invoke returns, the invoke is in the
+// group or launched), so everything that happened before an invoke is in the queue state when it arrives: program order and every
+// happens-before between callers hold without time stamps. Membership was proven conflict-free when the group was recorded.
+struct DirectWindow {
+  static constexpr int MAXC = 256;
+  struct alignas(64) Caller {
+    std::atomic<uint64_t> busy{0};
+    uint64_t tag = 0;   // window the count belongs to   (written inside the busy section, read by the closer after it)
+    uint32_t count = 0; // arrivals in that window
+    uint32_t hint = 0;  // index after this caller's last arrival
+    std::atomic<int> owned{0};
+  };
+  alignas(64) std::atomic<uint64_t> cur{0};
+  alignas(64) std::atomic<int> ncallers{0}; // high-water mark of claimed caller slots
+  Caller callers[MAXC];
+  struct Lease {
+    Caller *c = nullptr;
+    ~Lease() {
+      if (c) c->owned.store(0, std::memory_order_release);
+    }
+  };
+  Caller *claim() {
+    const int n = ncallers.load(std::memory_order_acquire);
+    for (int i = 0; i < MAXC; ++i) {
+      int expect = 0;
+      if (callers[i].owned.load(std::memory_order_relaxed) == 0 && callers[i].owned.compare_exchange_strong(expect, 1, std::memory_order_seq_cst)) {
+        int hw = n;
+        while (hw < i + 1 && !ncallers.compare_exchange_weak(hw, i + 1, std::memory_order_seq_cst)) {
+        }
+        return &callers[i];
+      }
+    }
+    return nullptr; // more caller threads than slots: this one always takes the locked path
+  }
+  Caller *mine() {
+    thread_local Lease lease;
+    thread_local bool tried = false;
+    if (!tried) {
+      tried = true;
+      lease.c = claim();
+    }
+    return lease.c;
   }
 };
 
@@ -777,6 +851,66 @@ struct TileQueue {
   hipStream_t gstream[SLOTS / GROUP] = {}; // the stream the group's launches went to
   int slot = 0;
   hipStream_t stream = nullptr;
+  DirectWindow *dw = nullptr; // the inline queue's window (the scheduler thread's queue has none: its callers hand over through rings)
+  uint64_t dw_gen = 0;
+  bool window_open = false;
+  int64_t direct_groups = 0;  // groups closed with lock-free arrivals in them
+  // a grouped launch that has been decided but not issued: the whole recorded group, from its segment's list. Issued after the
+  // NEXT group's window has been opened, so the other callers enter that group while this thread is inside hipLaunchKernel.
+  struct Pending {
+    bool armed = false;
+    int kind = 0;
+    const void *desc = nullptr;
+    int seg = -1, n = 0;
+    bool vec_ok = true, out_ok = true;
+    hipStream_t stream = nullptr;
+  } pending;
+  TileQueue() { segs.reserve(NSEG); } // callers inside a direct window hold pointers into segs: it never reallocates
+
+  // no caller is inside the window any more on return; the lock-free arrivals are added to n
+  void close_window() {
+    if (!window_open) return;
+    window_open = false;
+    const uint64_t c = dw->cur.load(std::memory_order_relaxed);
+    dw->cur.store(0, std::memory_order_seq_cst);
+    const int nc = dw->ncallers.load(std::memory_order_seq_cst);
+    int arrived = 0;
+    for (int i = 0; i < nc; ++i) {
+      DirectWindow::Caller &k = dw->callers[i];
+      while (k.busy.load(std::memory_order_seq_cst) != 0) cpu_relax();
+      if (k.tag == c) arrived += (int)k.count;
+    }
+    if (arrived) {
+      n += arrived;
+      ++direct_groups;
+      g_q_replayed.store(g_q_replayed.load(std::memory_order_relaxed) + arrived, std::memory_order_relaxed);
+    }
+  }
+  void open_window(int seg) {
+    if (!dw) return;
+    ++dw_gen;
+    window_open = true;
+    dw->cur.store((dw_gen << 7) | (uint64_t)(seg + 1), std::memory_order_seq_cst);
+  }
+  // the members of the replayed group that have arrived, as a dense work list in pinned[slot] (window closed): a replay that ends
+  // before every member has joined, or is abandoned
+  void materialize() {
+    const Segment &S = segs[replay];
+    int k = 0;
+    for (size_t i = 0; i < S.items.size(); ++i)
+      if (__atomic_load_n(&S.seen[i], __ATOMIC_RELAXED) == S.round) pinned[slot][k++] = S.items[i].w;
+    if (k != n) die("tpp-xsmm-hip: internal error: %d members marked, %d counted in a replayed group", k, n);
+  }
+  void issue_pending() {
+    if (!pending.armed) return;
+    pending.armed = false;
+    Segment &S = segs[pending.seg];
+    if (pending.kind == KIND_GEMM) HIP_OK(launch_gemm_grouped(*(const GemmDesc *)pending.desc, S.list, pending.n, pending.vec_ok, pending.out_ok, pending.stream));
+    else if (pending.kind == KIND_UNARY) HIP_OK(launch_unary_grouped(*(const UnaryDesc *)pending.desc, S.list, pending.n, pending.stream));
+    else HIP_OK(launch_binary_grouped(*(const BinaryDesc *)pending.desc, S.list, pending.n, pending.stream));
+    S.list_used = true;
+    S.list_stream = pending.stream;
+  }
 
   void ensure_slot() {
     if (n != 0) return;
@@ -837,13 +971,22 @@ struct TileQueue {
     }
     return best;
   }
-  // next: the invoke whose conflict ends this group (nullptr: an external flush point)
-  void flush(const TraceItem *next = nullptr) {
-    store_recording(next);
+  // next: the invoke whose conflict ends this group (nullptr: an external flush point). defer: the launch may be left pending
+  // (the caller opens the next group first and then calls issue_pending()).
+  void flush(const TraceItem *next = nullptr, bool defer = false) {
+    issue_pending();
+    close_window();
+    const int rp = replay;
+    if (rp >= 0 && n > 0 && (size_t)n != segs[rp].items.size()) materialize();
+    const bool whole = rp >= 0 && n > 0 && (size_t)n == segs[rp].items.size(); // the recorded group, complete: launch from its own list
+    store_recording(next); // (never touches segs[rp] during a replay: nothing is being recorded)
     replay = -1;
     if (n == 0) return;
     bump(g_q_launches);
-    {
+    if (whole) {
+      pending = Pending{true, kind, desc, rp, n, vec_ok, out_ok, stream};
+      if (!defer) issue_pending();
+    } else {
       if (kind == KIND_GEMM) HIP_OK(launch_gemm_grouped(*(const GemmDesc *)desc, pinned[slot], n, vec_ok, out_ok, stream));
       else if (kind == KIND_UNARY) HIP_OK(launch_unary_grouped(*(const UnaryDesc *)desc, pinned[slot], n, stream));
       else HIP_OK(launch_binary_grouped(*(const BinaryDesc *)desc, pinned[slot], n, stream));
@@ -918,16 +1061,18 @@ inline bool try_start_replay(TileQueue &q, const void *desc, const WorkItem &w, 
   }
   S.seen[item] = S.round;
   q.ensure_slot();
+  S.ensure_list();
   q.kind = *(const int *)desc;
   q.desc = desc;
   q.stream = stream;
   q.vec_ok = S.vec_ok;
   q.out_ok = S.out_ok;
-  q.pinned[q.slot][q.n++] = w;
+  q.n = 1; // members are marked and counted, not copied: the work list is S.list (all of them) or is gathered at the flush
   q.replay = idx;
   q.rpos = (size_t)item + 1;
   S.last_use = ++q.use_clock;
   bump(g_q_replayed);
+  q.open_window(idx); // from here on the other members may arrive without the lock
   return true;
 }
 // bookkeeping of one queued invoke: footprints from the descriptor, allocation bases ("anchors" of the 2-D planes) from
@@ -979,19 +1124,20 @@ inline void submit_item(TileQueue &q, DeviceRanges &devmem, const void *desc, co
     int idx = -1;
     if (q.rpos < S.items.size() && S.items[q.rpos].same(desc, w, stream)) idx = (int)q.rpos;
     else idx = S.index_of(desc, w, stream);
-    if (idx >= 0 && S.seen[idx] != S.round) {
-      S.seen[idx] = S.round;
-      q.pinned[q.slot][q.n++] = w;
+    if (idx >= 0 && S.mark(idx)) {
+      ++q.n;
       q.rpos = (size_t)idx + 1;
       bump(g_q_replayed);
       return;
     }
     if (idx < 0 && S.is_terminator(desc, w, stream)) {
       bump(g_q_terminated);
-      q.flush();          // as seen before: this invoke conflicts with the group (replay ends, the queue is empty)
-      q.backoff_next = 2; // a whole group replayed: the caller is repeating itself
+      q.flush(nullptr, true); // as seen before: this invoke conflicts with the group (replay ends, the queue is empty; the launch is
+      q.backoff_next = 2;     // issued once the next group is open). A whole group replayed: the caller is repeating itself
     } else { // neither a member nor a known terminator: make the bookkeeping catch up with what has been queued
       bump(g_q_abandoned);
+      q.close_window();
+      q.materialize();
       q.learn = q.replay;
       q.learn_n = (size_t)q.n;
       q.replay = -1;
@@ -1001,7 +1147,11 @@ inline void submit_item(TileQueue &q, DeviceRanges &devmem, const void *desc, co
       q.rec_open = true;
     }
   }
-  if (q.n == 0 && try_start_replay(q, desc, w, stream)) return;
+  if (q.n == 0 && try_start_replay(q, desc, w, stream)) {
+    q.issue_pending();
+    return;
+  }
+  q.issue_pending();
   process_item(q, devmem, desc, w, stream);
 }
 
@@ -1406,26 +1556,33 @@ Scheduler &sched() {
   }
   return *p;
 }
-// Two ways into the queue state. INLINE (the default): the caller does the bookkeeping itself under a spin
-// lock - the cheapest path for one caller (45 ns per invoke; handing entries to another core costs several
-// cache-line transfers each). SCHEDULED: as soon as a second thread shows up inside one epoch (the reference's
-// OpenMP workers), the process switches - once, for good - to the ring + scheduler thread above.
+// Three ways into the queue state. DIRECT: a member of the recorded group that is being replayed is marked by its caller without
+// any lock (DirectWindow) - the steady state of compiled code that repeats itself, from one thread or from the reference's OpenMP
+// team alike. INLINE: everything else takes a spin lock and does the bookkeeping itself (45 ns per invoke for one caller).
+// SCHEDULED: if several threads keep arriving on the locked path - a program the trace cache does not help, where one lock
+// around the bookkeeping serialises the callers - the process switches, once and for good, to the rings + scheduler thread above
+// (xsmm_hip_set_tile_queue(2) / TPP_HIP_TILE_QUEUE=2: as soon as a second thread shows up, the round-2 behaviour).
 struct SpinLock {
-  std::atomic_flag f = ATOMIC_FLAG_INIT;
+  std::atomic<int> f{0};
   void lock() {
-    for (unsigned spins = 0; f.test_and_set(std::memory_order_acquire); ++spins) {
-      if (spins < 2000) cpu_relax();
+    for (unsigned spins = 0;; ++spins) {
+      if (f.load(std::memory_order_relaxed) == 0 && f.exchange(1, std::memory_order_acquire) == 0) return; // (waiters spin on a shared line)
+      if (spins < 4000) cpu_relax();
       else sched_yield();
     }
   }
-  void unlock() { f.clear(std::memory_order_release); }
+  void unlock() { f.store(0, std::memory_order_release); }
 };
 struct InlineQueue {
   SpinLock mu;
   TileQueue q;
+  DirectWindow dw;
   std::atomic<bool> scheduled{false}; // one-way switch, flipped under mu after q has been flushed
   uint64_t owner = 0;                 // thread that queued last (under mu)
-  int foreign = 0;                    // arrivals of other threads since the last flush point
+  int foreign = 0;                    // arrivals of other threads since the last flush point (tile-queue mode 2)
+  bool multi = false;                 // more than one thread has queued
+  int64_t slow = 0, groups_at = 0;    // locked arrivals since a group was last replayed through the window / q.direct_groups then
+  InlineQueue() { q.dw = &dw; }
 };
 InlineQueue &inl() {
   static InlineQueue i;
@@ -1470,19 +1627,48 @@ bool enqueue_item(const void *desc, const WorkItem &item, const void *const *ptr
   for (int i = 0; i < n_ptrs; ++i)
     if (!devmem.is_device(ptrs[i], i)) return false;
   InlineQueue &iq = inl();
+  // DIRECT: the invoke is a member of the recorded group being replayed
+  if (const uint64_t c = iq.dw.cur.load(std::memory_order_acquire)) {
+    if (DirectWindow::Caller *me = iq.dw.mine()) {
+      me->busy.store(c, std::memory_order_seq_cst);
+      bool joined = false;
+      if (iq.dw.cur.load(std::memory_order_seq_cst) == c) {
+        Segment &S = iq.q.segs[(c & 127) - 1];
+        if (me->tag != c) {
+          me->tag = c;
+          me->count = 0;
+        }
+        int idx = -1;
+        if (me->hint < S.items.size() && S.items[me->hint].same(desc, item, s)) idx = (int)me->hint;
+        else idx = S.index_of(desc, item, s);
+        if (idx >= 0 && S.mark(idx)) {
+          ++me->count;
+          me->hint = (uint32_t)idx + 1;
+          joined = true;
+        }
+      }
+      me->busy.store(0, std::memory_order_release);
+      if (joined) return true;
+    }
+  }
   if (!iq.scheduled.load(std::memory_order_acquire)) {
     std::lock_guard<SpinLock> lk(iq.mu);
     if (!iq.scheduled.load(std::memory_order_relaxed)) {
       const uint64_t me = (uint64_t)(uintptr_t)&devmem; // the address of this thread's cache identifies the thread (one TLS lookup per invoke, not two)
       if (iq.owner != me) {
-        if (iq.owner != 0 && ++iq.foreign > 4) { // several threads are queueing concurrently: hand over to the scheduler
-          iq.q.flush();
-          (void)sched(); // create it (its worker thread starts with the first entry)
-          iq.scheduled.store(true, std::memory_order_release);
-        }
+        if (iq.owner != 0) iq.multi = true;
+        if (iq.owner != 0 && cfg().tile_queue.load(std::memory_order_relaxed) == 2 && ++iq.foreign > 4) iq.slow = 1 << 30;
         iq.owner = me;
       }
-      if (!iq.scheduled.load(std::memory_order_relaxed)) {
+      if (iq.q.direct_groups != iq.groups_at) { // a group went through the window since the last look: the cache is working
+        iq.groups_at = iq.q.direct_groups;
+        iq.slow = 0;
+      }
+      if (iq.multi && ++iq.slow > 8192) { // several threads, and the locked path is where they meet: hand over to the scheduler
+        iq.q.flush();
+        (void)sched(); // create it (its worker thread starts with the first entry)
+        iq.scheduled.store(true, std::memory_order_release);
+      } else {
         submit_item(iq.q, devmem, desc, item, s);
         return true;
       }
@@ -1925,7 +2111,7 @@ extern "C" void xsmm_hip_set_stream(void *s) {
 }
 extern "C" int xsmm_hip_set_tile_queue(int enable) {
   flush_tile_queue();
-  return cfg().tile_queue.exchange(enable != 0);
+  return cfg().tile_queue.exchange(enable < 0 ? 0 : enable > 2 ? 2 : enable); // 2: several callers always go through the scheduler thread
 }
 extern "C" void xsmm_hip_flush(void) { flush_tile_queue(); }
 // n fused_brgemm invokes in one call: exactly the effect of xsmm_fused_brgemm_invoke(dtype, handles[i], ...) for i = 0 .. n-1 in
