@@ -152,7 +152,12 @@ TPP_XSMM_EXPORT int xsmm_hip_set_async(int enable);
  * xsmm_hip_flush / xsmm_hip_synchronize / perf_stop_timer). Program order is preserved. Operands
  * of queued invokes must stay valid until the flush. Returns the previous setting. Also env
  * TPP_HIP_TILE_QUEUE=1. The queue serves ONE device per process (the device current on the first
- * queued invoke): a queued invoke from a thread whose current device differs is a fatal error. */
+ * queued invoke): a queued invoke from a thread whose current device differs is a fatal error.
+ * Several calling threads (the reference's OpenMP team over a layer's tile grid): a group that was collected once is
+ * REPLAYED when its invokes come again - each caller marks its own invokes in the recorded group without taking a lock, and
+ * the complete group launches from a work list that already sits in device memory. Programs that do not repeat themselves
+ * are handed to a scheduler thread after a few thousand locked arrivals; enable = 2 (TPP_HIP_TILE_QUEUE=2) does that as soon
+ * as a second thread shows up (the round-2 behaviour, kept for comparison runs). */
 TPP_XSMM_EXPORT int xsmm_hip_set_tile_queue(int enable);
 TPP_XSMM_EXPORT void xsmm_hip_flush(void);
 /* n fused_brgemm invokes in ONE call (arrays of length n, one entry per call): exactly the effect of

@@ -704,20 +704,25 @@ struct Segment {
   uint64_t last_use = 0;
   // The group's work list as the grouped kernels read it: items[i].w in recorded order, in pinned host memory, written once when
   // the group is first replayed. A replay in which EVERY member arrives launches straight from it - nobody copies a work item.
-  WorkItem *list = nullptr;
+  WorkItem *list = nullptr, *list_dev = nullptr; // ... and its copy in device memory (what the launches read: no PCIe round trip at the head of every workgroup)
   size_t list_cap = 0;
   bool list_valid = false, list_used = false; // holds items[] of THIS recording / a launch may still be reading it
   hipStream_t list_stream = nullptr;           // ... on this stream
-  void ensure_list() {
+  void ensure_list(hipStream_t stream) { // (the group's stream: every launch from the list goes there, behind the copy)
     if (list_valid) return;
-    if (list_used) HIP_OK(hipStreamSynchronize(list_stream)); // the buffer carried another recording's items: its last launch must be done
+    if (list_used) HIP_OK(hipStreamSynchronize(list_stream)); // the buffers carried another recording's items: its last launch must be done
     list_used = false;
     if (list_cap < items.size()) {
       if (list) HIP_OK(hipHostFree(list));
+      if (list_dev) HIP_OK(hipFree(list_dev));
       list_cap = items.size() < 64 ? 64 : items.size();
       HIP_OK(hipHostMalloc((void **)&list, sizeof(WorkItem) * list_cap, hipHostMallocDefault));
+      HIP_OK(hipMalloc((void **)&list_dev, sizeof(WorkItem) * list_cap));
     }
     for (size_t i = 0; i < items.size(); ++i) list[i] = items[i].w;
+    HIP_OK(hipMemcpyAsync(list_dev, list, sizeof(WorkItem) * items.size(), hipMemcpyHostToDevice, stream));
+    list_used = true; // (the copy reads `list`)
+    list_stream = stream;
     list_valid = true;
   }
   bool mark(int idx) { return __atomic_exchange_n(&seen[idx], round, __ATOMIC_RELAXED) != round; } // false: joined this round already
@@ -728,6 +733,10 @@ struct Segment {
     return (size_t)(h ^ (h >> 29));
   }
   void build() {
+    // by output address: membership is all a replay needs, and with the reference's static schedules a caller's invokes then sit
+    // next to each other - its arrival marks in `seen` share cache lines with its own marks only, and "the one after my last" is
+    // usually the next invoke (DirectWindow::Caller::hint) without a hash lookup
+    std::stable_sort(items.begin(), items.end(), [](const TraceItem &a, const TraceItem &b) { return (uintptr_t)a.w.C < (uintptr_t)b.w.C; });
     size_t cap = 16;
     while (cap < 2 * items.size()) cap *= 2;
     table.assign(cap, -1);
@@ -905,9 +914,9 @@ struct TileQueue {
     if (!pending.armed) return;
     pending.armed = false;
     Segment &S = segs[pending.seg];
-    if (pending.kind == KIND_GEMM) HIP_OK(launch_gemm_grouped(*(const GemmDesc *)pending.desc, S.list, pending.n, pending.vec_ok, pending.out_ok, pending.stream));
-    else if (pending.kind == KIND_UNARY) HIP_OK(launch_unary_grouped(*(const UnaryDesc *)pending.desc, S.list, pending.n, pending.stream));
-    else HIP_OK(launch_binary_grouped(*(const BinaryDesc *)pending.desc, S.list, pending.n, pending.stream));
+    if (pending.kind == KIND_GEMM) HIP_OK(launch_gemm_grouped(*(const GemmDesc *)pending.desc, S.list_dev, pending.n, pending.vec_ok, pending.out_ok, pending.stream));
+    else if (pending.kind == KIND_UNARY) HIP_OK(launch_unary_grouped(*(const UnaryDesc *)pending.desc, S.list_dev, pending.n, pending.stream));
+    else HIP_OK(launch_binary_grouped(*(const BinaryDesc *)pending.desc, S.list_dev, pending.n, pending.stream));
     S.list_used = true;
     S.list_stream = pending.stream;
   }
@@ -1061,7 +1070,7 @@ inline bool try_start_replay(TileQueue &q, const void *desc, const WorkItem &w, 
   }
   S.seen[item] = S.round;
   q.ensure_slot();
-  S.ensure_list();
+  S.ensure_list(stream);
   q.kind = *(const int *)desc;
   q.desc = desc;
   q.stream = stream;
