@@ -82,6 +82,65 @@ def test_mid_size_layers_pick_the_loader_wave_tiles(rt):
         assert tag in rt.kernel_name(h), (m, rt.kernel_name(h))
 
 
+# ---------------------------------------------------------------- the same tiles on a FLAT bf16 B operand (variants 24 .. 27)
+FLAT_CASES = [(v + 4, m, n, k, br, kw) for (v, m, n, k, br, kw) in LW_CASES if br >= 1] + [
+    (24, 32, 64, 64, 8, dict(beta0=True)),                      # ring of 8 exactly / SUP = 2 intervals
+    (24, 64, 64, 64, 7, dict(beta0=True, bias=True)),           # odd chunk count: one chunk per barrier
+    (25, 64, 64, 64, 10, dict(beta0=True, relu=True)),
+    (25, 64, 64, 64, 2, dict(beta0=True)),                      # two chunks = one SUP = 2 interval
+    (26, 64, 128, 192, 3, dict(beta0=True, ldb=136, sb=192 * 136)),
+    (27, 128, 128, 64, 2, dict(beta0=True, sb=0)),              # the same B block twice
+    (27, 256, 256, 64, 11, dict(lda=1024, sa=64, ldb=264, sb=64 * 264, beta0=True, bias=True, relu=True)),
+]
+
+
+@pytest.mark.parametrize("case", FLAT_CASES, ids=lambda c: "v%d_m%d_n%d_k%d_br%d" % c[:5])
+def test_brgemm_bf16_flat_b_tiles(rt, case):
+    """flat B ([k][ldb], no VNNI flag): the pair-row interleave happens in the B loader (VNNIUtils.cpp:75-77 defines the
+    layout) - parity against the oracle's flat-B arithmetic, every tile"""
+    v, m, n, k, br, kw = case
+    kw = dict(kw)
+    if "sb" in kw and kw["sb"] == 64 * kw.get("ldb", n) and k != 64:
+        kw["sb"] = k * kw.get("ldb", n)
+    name = gemm_case(rt, BF16, m, n, k, br, vnni=False, seed=v * 1000 + m + n + br, force=v, **kw)
+    assert "lw_flatb<%dx%d" % TILES[v - 4] in name, name
+
+
+def test_flat_b_is_bit_identical_to_the_vnni_kernel_on_the_packed_operand(rt):
+    """the flat-B kernel computes what xsmm.unary pack + the VNNI-2 kernel compute, bit for bit (same tiles, same MFMA order):
+    C5's pack launch is not needed for a flat operand. 2048^3 is BASELINE config 5's shape."""
+    for (m, n, k, br, v) in ((512, 1024, 64, 16, 20), (1024, 1024, 64, 16, 21), (2048, 2048, 128, 16, 23)):
+        rng = np.random.default_rng(m + n)
+        K = k * br
+        A, Bf, D = rand(rng, m * K, BF16), rand(rng, K * n, BF16), rand(rng, n, BF16)
+        Bv = Bf.reshape(K // 2, 2, n).transpose(0, 2, 1).reshape(-1).copy()  # VNNI-2: [K/2][n][2]
+        dA, dBf, dBv, dD = dev(A), dev(Bf), dev(Bv), dev(D)
+        outs = []
+        for (flags, dB, force) in ((4, dBf, v + 4), (4 | VB, dBv, v)):
+            rt.force_variant(force)
+            try:
+                h = rt.fused_brgemm_dispatch(BF16, m, n, k, K, n, n, k, k * n, flags, 0, 5, 4, 1)
+            finally:
+                rt.force_variant(-1)
+            C = np.zeros(m * n, dtype=A.dtype)
+            dC = dev(C)
+            rt.fused_brgemm(BF16, h, dA, 0, dB, 0, dC, 0, dD, 0, br)
+            outs.append((rt.kernel_name(h), host(dC, C)))
+        assert "flatb" in outs[0][0] and "flatb" not in outs[1][0], [o[0] for o in outs]
+        assert np.array_equal(outs[0][1], outs[1][1]), "flat-B %s differs from %s" % (outs[0][0], outs[1][0])
+
+
+def test_flat_b_default_dispatch(rt):
+    """without forcing: an aligned flat-B bf16 dispatch gets a loader-wave tile, a ragged one stays on the generic kernel"""
+    h = rt.brgemm_dispatch(BF16, 2048, 2048, 128, 2048, 2048, 2048, 128, 128 * 2048, 4)
+    assert "lw_flatb<128x128>" in rt.kernel_name(h), rt.kernel_name(h)
+    h = rt.brgemm_dispatch(BF16, 512, 1024, 64, 1024, 1024, 1024, 64, 64 * 1024, 4)
+    assert "lw_flatb<32x64" in rt.kernel_name(h), rt.kernel_name(h)
+    h = rt.brgemm_dispatch(BF16, 48, 40, 24, 24, 40, 40, 48 * 24, 24 * 40, 0)
+    assert "flatb" not in rt.kernel_name(h), rt.kernel_name(h)
+
+
+
 # ---------------------------------------------------------------- chains
 class Chain:
     """a chain of whole-layer fused BRGEMMs on `m` rows: dims = [k0, n, n, ...] (every layer n columns)"""

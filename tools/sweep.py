@@ -66,6 +66,32 @@ def bf16_case(m, n, k, br, tag="", force=None):
         m, n, k, br, rt.kernel_name(h), t * 1e6, fl / t / 1e12, fl / t / 25e12, tag), flush=True)
 
 
+def bf16_flat_case(m, n, k, br, tag="", force=None):
+    """flat B ([K][n] row-major, no VNNI flag): the interleave happens in the B loader of the loader-wave tiles"""
+    K = k * br
+    A = (torch.rand(m, K, device="cuda") * 2 - 1).to(torch.bfloat16)
+    B = (torch.rand(K, n, device="cuda") * 2 - 1).to(torch.bfloat16)
+    C = torch.zeros(m, n, device="cuda", dtype=torch.bfloat16)
+    if force is not None:
+        rt.force_variant(force)
+    h = rt.brgemm_dispatch(BF16, m, n, k, K, n, n, k, k * n, 4)
+    rt.force_variant(-1)
+    t = time_it(lambda: rt.brgemm(BF16, h, A, 0, B, 0, C, 0, br))
+    fl = 2.0 * m * n * K
+    print("bf16 m%-5d n%-5d k%-5d br%-3d %-32s %8.2f us %8.1f TF  %5.1f%% %s" % (
+        m, n, k, br, rt.kernel_name(h), t * 1e6, fl / t / 1e12, fl / t / 25e12, tag), flush=True)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "flatb":
+    # flat-B bf16 against the VNNI-2 kernels on the same shapes (same run): C5, the C4 layer and its shards, 4096^3
+    for (m, n, k, br, tag) in ((2048, 2048, 128, 16, "C5"), (4096, 1024, 64, 16, "C4 layer"), (2048, 1024, 64, 16, ""),
+                               (1024, 1024, 64, 16, ""), (512, 1024, 64, 16, ""), (4096, 4096, 64, 64, "4096^3")):
+        bf16_case(m, n, k, br, tag + " VNNI-2 B")
+        if m * n >= 128 * 128 * 192:
+            bf16_case(m, n, k, br, tag + " VNNI-2 B, 128x128 loader-wave tile", force=23)
+        bf16_flat_case(m, n, k, br, tag + " flat B")
+    sys.exit(0)
+
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "f32lw":
     # loader-wave f32 kernels (5 64x64, 6 64x64+K2, 7 64x32+K2, 9 32x32+K4) against the round-1 kernels (0, 1, 2, 3, 4)
     for (m, n, k, br, tag) in ((1024, 1024, 64, 16, "C2"), (512, 1024, 64, 16, "C3 shape"), (256, 1024, 64, 16, "bs=256 layer"),

@@ -647,6 +647,10 @@ enum GemmVariant : int {
   V_BF16_LW_64x64 = 21,
   V_BF16_LW_64x128 = 22,
   V_BF16_LW_128x128 = 23,
+  V_BF16_LWF_32x64 = 24,  // the same tiles for a FLAT bf16 B operand (no VNNI flag): the pair-row interleave happens in the B loader
+  V_BF16_LWF_64x64 = 25,
+  V_BF16_LWF_64x128 = 26,
+  V_BF16_LWF_128x128 = 27,
 };
 
 template <int WM, int WN, int WK, int NACC, bool DMA>
@@ -716,6 +720,11 @@ static hipError_t launch_grouped_t(const GemmArgs &a, const WorkItem *items, int
 
 hipError_t launch_bf16_grouped64(const GemmArgs &a, const WorkItem *items, int n_items, hipStream_t s); // brgemm_bf16.hip
 hipError_t launch_bf16_small32(const GemmArgs &a, const WorkItem *items, int n_items, hipStream_t s); // brgemm_bf16_small.hip
+// flat-B bf16 for the loader-wave tiles: 16-byte row pieces of A, B and C, 64-k chunks, 32-bit lane offsets
+static bool bf16_flat_eligible(const GemmDesc &d) {
+  return d.dtype == DT_BF16 && !d.vnni_b && !d.vnni_c && d.k > 0 && d.k % 64 == 0 && d.m % 32 == 0 && d.n % 64 == 0 &&
+         !((d.lda | d.ldb | d.ldc | d.stride_a | d.stride_b) & 7) && d.lda < (1 << 22) && d.ldb < (1 << 21) && d.ldc < (1 << 22);
+}
 static bool bf16_small_eligible(const GemmDesc &d) {
   return d.dtype == DT_BF16 && d.vnni_b && d.m % 32 == 0 && d.n % 32 == 0 && d.k > 0 && d.k % 16 == 0 && !(d.lda & 7) &&
          !(d.stride_a & 7) && !(d.stride_b & 1) && !(d.ldc & 3);
@@ -820,6 +829,10 @@ static const char *variant_name(int v) {
   case V_BF16_LW_64x64: return "brgemm_bf16_lw<64x64>";
   case V_BF16_LW_64x128: return "brgemm_bf16_lw<64x128>";
   case V_BF16_LW_128x128: return "brgemm_bf16_lw<128x128>";
+  case V_BF16_LWF_32x64: return "brgemm_bf16_lw_flatb<32x64,k2>";
+  case V_BF16_LWF_64x64: return "brgemm_bf16_lw_flatb<64x64>";
+  case V_BF16_LWF_64x128: return "brgemm_bf16_lw_flatb<64x128>";
+  case V_BF16_LWF_128x128: return "brgemm_bf16_lw_flatb<128x128>";
   case V_F32_64x64: return "brgemm_f32_fast<64x64,k1>";
   case V_F32_64x32K2: return "brgemm_f32_fast<64x32,k2>";
   case V_F32_32x32K4: return "brgemm_f32_fast<32x32,k4>";
@@ -861,6 +874,22 @@ bool plan_gemm(GemmDesc &d, int forced_variant) {
       blw_tile_dims(forced_variant - V_BF16_LW_32x64, &bm, &bn);
       if (d.m % bm == 0 && d.n % bn == 0) v = forced_variant;
     }
+  } else if (d.dtype == DT_BF16 && bf16_flat_eligible(d)) {
+    // flat B ([k][n] row-major, what xsmm.unary pack would have turned into VNNI-2): the loader-wave tiles with the interleave
+    // in the B loader. The largest tile that still gives 3/4 of the CUs a workgroup, else the smallest the shape divides
+    // (launch_gemm falls back to the generic kernel when an operand is not 16-byte aligned).
+    int t = pick_bf16_lw_tile(d);
+    for (int c = 0; t < 0 && c < 4; ++c) {
+      int bm, bn;
+      blw_tile_dims(c, &bm, &bn);
+      if (d.m % bm == 0 && d.n % bn == 0) t = c;
+    }
+    if (t >= 0) v = V_BF16_LWF_32x64 + t;
+    if (forced_variant >= V_BF16_LWF_32x64 && forced_variant <= V_BF16_LWF_128x128) {
+      int bm, bn;
+      blw_tile_dims(forced_variant - V_BF16_LWF_32x64, &bm, &bn);
+      if (d.m % bm == 0 && d.n % bn == 0) v = forced_variant;
+    }
   } else if (d.dtype == DT_BF16 && bf16_small_eligible(d)) {
     v = V_BF16_SMALL32; // k a multiple of 16 only (e.g. the compiler-native 32x32x32 tile), m or n a multiple of 32 only
     if (forced_variant == V_BF16_LW_32x64) { // the 32x64 loader-wave tile needs m % 32 only (bf16_fast_eligible asks for 64)
@@ -899,7 +928,7 @@ hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C,
   // the bf16 kernel stores 16-byte row pieces and reads the bias 8 bytes at a time
   if (v >= V_BF16_FAST && v != V_BF16_SMALL32 && ((((uintptr_t)C) & 15) || (d.bias && (((uintptr_t)D) & 7)))) v = V_GENERIC;
   if (v == V_BF16_SMALL32 && ((((uintptr_t)C) & 7) || (d.bias && (((uintptr_t)D) & 7)))) v = V_GENERIC;
-  if (v >= V_BF16_LW_32x64 && v <= V_BF16_LW_128x128 && a.br < 1) v = V_GENERIC; // empty batch (C = epilogue of nothing): the loader-wave kernels assume a chunk
+  if (v >= V_BF16_LW_32x64 && v <= V_BF16_LWF_128x128 && a.br < 1) v = V_GENERIC; // empty batch (C = epilogue of nothing): the loader-wave kernels assume a chunk
   switch (v) {
   // LDS-DMA panels for every tile but the smallest: measured C2 +3 %, C3 +8 %, 4096^3 +3 %, 3 x 1024 MLP
   // at batch 512 / 1024 +5 % / +3 % over register staging. 32x32 tiles with 4 K-split waves have
@@ -933,6 +962,21 @@ hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C,
     c.dbg = lw_dbg;
     c.L[0] = ChainLayer{a.B, a.D, a.C, a.ldb, a.ldc, a.stride_a, a.stride_b, a.k, a.br, a.ep, 0};
     return launch_bf16_lw(v - V_BF16_LW_32x64, c, stream);
+  }
+  case V_BF16_LWF_32x64:
+  case V_BF16_LWF_64x64:
+  case V_BF16_LWF_64x128:
+  case V_BF16_LWF_128x128: {
+    ChainArgs c;
+    c.A = a.A; c.lda = a.lda; c.cnt = nullptr; c.err = nullptr; c.target = 0;
+    c.m = a.m; c.n = a.n; c.nlayers = 1; c.tiles_m = c.tiles_n = 0; c.xm = 0; c.stamps = nullptr;
+    static const int lwf_dbg = [] {
+      const char *e = getenv("TPP_HIP_CHAIN_DBG"); // timing experiments only
+      return e ? atoi(e) : 0;
+    }();
+    c.dbg = lwf_dbg;
+    c.L[0] = ChainLayer{a.B, a.D, a.C, a.ldb, a.ldc, a.stride_a, a.stride_b, a.k, a.br, a.ep, 0};
+    return launch_bf16_lw_flatb(v - V_BF16_LWF_32x64, c, stream);
   }
   default: break;
   }

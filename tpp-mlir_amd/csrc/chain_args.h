@@ -37,6 +37,7 @@ struct ChainArgs {
 // tile: 0 = 32x64 (K split over two wave groups), 1 = 64x64, 2 = 64x128, 3 = 128x128
 void blw_tile_dims(int tile, int *bm, int *bn);
 hipError_t launch_bf16_lw(int tile, const ChainArgs &a, hipStream_t s);
+hipError_t launch_bf16_lw_flatb(int tile, const ChainArgs &a, hipStream_t s); // the same tiles, B operand flat [k][ldb] (no VNNI flag)
 hipError_t launch_bf16_chain(int tile, const ChainArgs &a, hipStream_t s);
 
 } // namespace tpp
