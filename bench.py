@@ -646,6 +646,27 @@ def main():
         others.append({"workload": "C5 bf16 BRGEMM 2048^3 VNNI_B (k=128, br=16)", "kernel": rt.kernel_name(h5),
                        "value": round(2.0 * M5 ** 3 * Ko / wg / 1e9, 1), "unit": "GFLOP/s", "us_per_step": round(wg / Ko * 1e6, 2),
                        "frac_of_bf16_mfma_peak": round(2.0 * M5 ** 3 * Ko / wg / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)})
+        # C5 end to end, both ways: pack launch + VNNI-2 BRGEMM (what the reference's pipeline emits), and ONE BRGEMM on the flat
+        # operand (no VNNI flag: the interleave happens in the B loader of the loader-wave tiles)
+
+        def c5_both():
+            rt.unary(BF16, hp5, B5, 0, B5v, 0)
+            rt.brgemm(BF16, h5, A5, 0, B5v, 0, C5, 0, 16)
+        h5f = rt.brgemm_dispatch(BF16, M5, M5, 128, M5, M5, M5, 128, 128 * M5, 4)
+        C5f = torch.empty_like(C5)
+
+        def c5_flat():
+            rt.brgemm(BF16, h5f, A5, 0, B5, 0, C5f, 0, 16)
+        warm(c5_both, Wo, sync)
+        wb, _ = timed(c5_both, Ko, sync, barrier)
+        warm(c5_flat, Wo, sync)
+        wf, _ = timed(c5_flat, Ko, sync, barrier)
+        sync()
+        others.append({"workload": "C5 end to end: VNNI-2 pack launch + bf16 BRGEMM 2048^3", "kernel": rt.kernel_name(h5),
+                       "value": round(2.0 * M5 ** 3 * Ko / wb / 1e9, 1), "unit": "GFLOP/s", "us_per_step": round(wb / Ko * 1e6, 2)})
+        others.append({"workload": "C5 end to end on the FLAT B operand (one launch, interleave in the B loader)", "kernel": rt.kernel_name(h5f),
+                       "value": round(2.0 * M5 ** 3 * Ko / wf / 1e9, 1), "unit": "GFLOP/s", "us_per_step": round(wf / Ko * 1e6, 2),
+                       "bit_identical_to_pack_plus_vnni": bool(torch.equal(C5f, C5))})
 
         # a large bf16 output (one 256x256 tile per CU): the shape class the 256-tile kernel exists for
         ML = 4096
@@ -685,6 +706,7 @@ def main():
         if os.path.exists(replay):
             for label, extra in (("tile queue, tiles 32,32,32", ["--tiles", "32", "--queue", "1", "-n", "200"]),
                                  ("tile queue, tiles 32,32,32, 2 OpenMP callers", ["--tiles", "32", "--queue", "1", "-n", "200", "--threads", "2"]),
+                                 ("tile queue, tiles 32,32,32, 8 OpenMP callers", ["--tiles", "32", "--queue", "1", "-n", "200", "--threads", "8"]),
                                  ("tile queue, tiles 64,64,64", ["--tiles", "64", "--queue", "1", "-n", "200"]),
                                  ("tile queue, tiles 32,32,32, bf16 + VNNI-2 W", ["--tiles", "32", "--queue", "1", "-n", "200", "--bf16"]),
                                  ("tile queue, tiles 64,64,64, bf16 + VNNI-2 W", ["--tiles", "64", "--queue", "1", "-n", "200", "--bf16"]),
