@@ -78,7 +78,7 @@ template <int PPL> __device__ __forceinline__ void blw_wait_younger(int younger)
 // The steady-state loop is a literal s_waitcnt + s_barrier + the DMA instructions + ~10 scalar instructions: measured on the
 // first version of this function (one general loop with a switch over the wait count, the layer bookkeeping and an argument load
 // inside), a 16-chunk layer took 5.7 us with NO loads and NO MFMAs at all - the loader's own instruction stream set the pace.
-template <bool IS_A, int NL, int NLA, int NSLOT_C, int SUP, int BM, int BN, int WK, bool MULTI>
+template <bool IS_A, int NL, int NLA, int NSLOT_C, int SUP, int BM, int BN, int WK, bool MULTI, int FB = 0>
 __device__ __forceinline__ void blw_loader(chain_kernarg_t *pp, unsigned char *smem, int lane, int m0, int n0, int tm, int L, int part) {
   chain_kernarg_t &p = *pp;
   constexpr int A_SLOT = BM * 128, SLOT = (BM + BN) * 128;
@@ -125,6 +125,18 @@ __device__ __forceinline__ void blw_loader(chain_kernarg_t *pp, unsigned char *s
       vo1 = NL == 1 ? rowoff_ + (unsigned)(((lane & 7) ^ (4 + (lane >> 4))) << 4) : vo0;                               \
       step = (unsigned)(NL * 8 * (int)lda_ * 2);                                                                       \
       sc1 = MULTI && (l) > 0 && !(dbg & 1); /* written by other workgroups in THIS launch: sc1 loads (L1 bypassed) */  \
+    } else if (FB == 2) {                                                                                              \
+      /* FLAT B ([k][ldb]), image = the chunk's 64 rows as they are, for the transpose reads of the MFMA waves: instruction v */ \
+      /* covers rows (512/BN)*v ..: lane -> row lane / (BN/8), 16-byte piece lane % (BN/8); the 64-byte blocks of a row are */ \
+      /* XOR-swizzled with the row (BN = 128: row & 3, BN = 64: (row >> 1) & 1) on the SOURCE side, like the A panel */ \
+      constexpr int RPT_ = 512 / BN, PPR_ = BN / 8;                                                                    \
+      g = (const unsigned short *)p.L[l].B + n0 + (int64_t)part * RPT_ * p.L[l].ldb;                                   \
+      d_in = (int64_t)BLW_BK * p.L[l].ldb;                                                                             \
+      d_wrap = p.L[l].stride_b - (int64_t)(kchunks - 1) * d_in;                                                        \
+      const int row_ = lane / PPR_, piece_ = lane % PPR_;                                                              \
+      const int swz_ = BN == 128 ? (row_ & 3) << 2 : ((row_ >> 1) & 1) << 2;                                           \
+      vo0 = vo1 = (unsigned)(row_ * (int)p.L[l].ldb * 2 + ((piece_ ^ swz_) << 4));                                     \
+      step = (unsigned)(NL * RPT_ * (int)p.L[l].ldb * 2);                                                              \
     } else {                                                                                                           \
       g = (const unsigned short *)p.L[l].B + 2 * (int64_t)n0 + (int64_t)part * RPI * 2 * p.L[l].ldb;                   \
       d_in = (int64_t)(BLW_BK / 2) * 2 * p.L[l].ldb;                                                                   \
@@ -233,116 +245,7 @@ __device__ __forceinline__ void blw_loader(chain_kernarg_t *pp, unsigned char *s
 #undef BLW_LOAD_STATE
 }
 
-// The B loader for a FLAT bf16 operand ([k][ldb] row-major, no VNNI flag on the dispatch): the VNNI-2 interleave the MFMA
-// fragments want (lib/TPP/Transforms/Utils/VNNIUtils.cpp:75-77: element (k, n) at [k / 2][n][k % 2]) is done on the way into
-// LDS, so a flat B needs no pack launch in front of the GEMM. LDS-DMA moves dwords as they are, so this panel goes through
-// registers: a lane loads the same 8 columns of rows 2r and 2r + 1 (16 bytes each, a whole tile row per BN / 8 lanes), merges
-// them with 8 v_perm_b32 into the two 16-byte pieces of pair-row r and writes them where the DMA loader would have put them -
-// the MFMA waves and the A loader do not know the difference. (tools/ubench/fillmix.hip: L2 -> registers -> LDS fills a CU's
-// LDS as fast as LDS-DMA does, ~59 B/clk.) Two barrier intervals of loads are in flight in two register sets; loads of chunks
-// past the end are issued switched off (num_records = 0), so one counted s_waitcnt serves every iteration. Single layer only.
-// Barrier schedule as blw_loader: P, then one per further chunk.
-template <int NL, int NSLOT_C, int SUP, int BM, int BN>
-__device__ __forceinline__ void blw_loader_flatb(chain_kernarg_t *pp, unsigned char *smem, int lane, int n0, int part) {
-  chain_kernarg_t &p = *pp;
-  constexpr int A_SLOT = BM * 128, SLOT = (BM + BN) * 128;
-  constexpr int NSLOT = NSLOT_C / SUP;
-  constexpr int U = (BN / 16) / NL; // 2 KiB units (512 / BN pair-rows) of a chunk's B image per wave
-  constexpr int RPU = 512 / BN;
-  constexpr int UPL = U * SUP;      // units per barrier interval
-  static_assert(U >= 1 && (BN / 16) % NL == 0 && 4 * UPL <= 63 && NSLOT >= 3, "two intervals of loads in flight");
-  const int kchunks = p.L[0].k / BLW_BK;
-  const int T = p.L[0].br * kchunks / SUP;
-  const int ldb = (int)p.L[0].ldb;
-  const unsigned short *g = (const unsigned short *)p.L[0].B + n0 + (int64_t)part * RPU * 2 * ldb;
-  const int64_t d_in = (int64_t)BLW_BK * ldb, d_wrap = p.L[0].stride_b - (int64_t)(kchunks - 1) * d_in;
-  int kc = 0;
-  const int prl = lane / (BN / 8), g8 = lane % (BN / 8);       // pair-row inside the unit, 8-column group
-  const unsigned vo = (unsigned)(2 * prl * ldb * 2 + g8 * 16); // row 2 prl, columns 8 g8 ..
-  const unsigned rowb = (unsigned)(ldb * 2), step = (unsigned)(NL * RPU * 2 * ldb * 2);
-  const unsigned lds_lane = (unsigned)(A_SLOT + part * 2048 + prl * BN * 4 + g8 * 32);
-  u32x4 r[2][UPL][2];
-  auto issue = [&](int set, bool live) __attribute__((always_inline)) {
-#pragma unroll
-    for (int sub = 0; sub < SUP; ++sub) {
-      const int nrec = __builtin_amdgcn_readfirstlane(live ? 0x7fffffff : 0);
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)g, 0, nrec, 0x00020000);
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        r[set][sub * U + u][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, u * step, 0);
-        r[set][sub * U + u][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo + rowb, u * step, 0);
-      }
-      if (live) {
-        if (++kc == kchunks) {
-          kc = 0;
-          g += d_wrap;
-        } else {
-          g += d_in;
-        }
-      }
-    }
-  };
-  auto write = [&](int set, int slot) __attribute__((always_inline)) {
-#pragma unroll
-    for (int sub = 0; sub < SUP; ++sub)
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const u32x4 e = r[set][sub * U + u][0], o = r[set][sub * U + u][1]; // rows 2r (even k) and 2r + 1 (odd k)
-        u32x4 lo, hi; // columns 8 g8 .. + 3 and + 4 .. + 7: dword n = { even k in the low half, odd k in the high half }
-        lo[0] = __builtin_amdgcn_perm(o[0], e[0], 0x05040100u);
-        lo[1] = __builtin_amdgcn_perm(o[0], e[0], 0x07060302u);
-        lo[2] = __builtin_amdgcn_perm(o[1], e[1], 0x05040100u);
-        lo[3] = __builtin_amdgcn_perm(o[1], e[1], 0x07060302u);
-        hi[0] = __builtin_amdgcn_perm(o[2], e[2], 0x05040100u);
-        hi[1] = __builtin_amdgcn_perm(o[2], e[2], 0x07060302u);
-        hi[2] = __builtin_amdgcn_perm(o[3], e[3], 0x05040100u);
-        hi[3] = __builtin_amdgcn_perm(o[3], e[3], 0x07060302u);
-        // (a lane owns 32 contiguous bytes: sixteen lanes' first halves hit every bank twice. Swapping the halves of lanes 8 .. 15
-        // removes the conflict for 8 v_cndmask per unit - measured 2-9 % slower than living with it.)
-        unsigned char *d = smem + (slot * SUP + sub) * SLOT + lds_lane + u * (NL * 2048);
-        *(u32x4 *)d = lo;
-        *(u32x4 *)(d + 16) = hi;
-      }
-  };
-  // Interval c + LEAD has landed in register set `set`: into its ring slot with it (published by the barrier), the set takes
-  // interval c + LEAD + 2. LEAD = 2 when the ring has a fourth slot: the LDS image is then a whole interval ahead of what the MFMA
-  // waves need next, and the v_perm / ds_write work of this wave is off their critical path (with LEAD = 1 they waited at every
-  // barrier for it: measured 27.4 -> 23.8 us on 2048^3 together with the second loader wave).
-  constexpr int LEAD = NSLOT >= 4 ? 2 : 1;
-  auto stepf = [&](int set, int slot, bool have, bool more) __attribute__((always_inline)) {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * UPL) : "memory"); // all but the younger interval's loads
-    if (have) write(set, slot);
-    issue(set, more);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  };
-  issue(0, T > 0);
-  issue(1, T > 1);
-  int slot = 0;
-  stepf(0, 0, T > 0, T > 2);
-  slot = 1;
-  if (LEAD == 2) {
-    stepf(1, 1, T > 1, T > 3);
-    slot = 2 == NSLOT ? 0 : 2;
-  }
-  __builtin_amdgcn_s_barrier(); // P: chunk 0 (and 1) published
-  // barrier i + 1 publishes interval i + LEAD, held by set (i + LEAD) & 1
-  const int steps = T - 1;
-  int i = 0;
-  for (; i + 1 < steps; i += 2) {
-    stepf(LEAD & 1, slot, i + LEAD < T, i + LEAD + 2 < T);
-    __builtin_amdgcn_s_barrier();
-    slot = slot + 1 == NSLOT ? 0 : slot + 1;
-    stepf((LEAD + 1) & 1, slot, i + 1 + LEAD < T, i + 1 + LEAD + 2 < T);
-    __builtin_amdgcn_s_barrier();
-    slot = slot + 1 == NSLOT ? 0 : slot + 1;
-  }
-  if (i < steps) {
-    stepf(LEAD & 1, slot, i + LEAD < T, false);
-    __builtin_amdgcn_s_barrier();
-  }
-}
-
-template <int WM, int WN, int WK, int TM, int TN, int NSLOT, int NLA, int NLB, int SUP, bool MULTI, bool FLATB = false>
+template <int WM, int WN, int WK, int TM, int TN, int NSLOT, int NLA, int NLB, int SUP, bool MULTI, int FLATB = 0>
 __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_lw(ChainArgs p_by_value) {
   chain_kernarg_t *pp = (chain_kernarg_t *)__builtin_amdgcn_kernarg_segment_ptr(); // = &p_by_value (the only explicit argument)
   chain_kernarg_t &p = *pp;
@@ -364,7 +267,8 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
   static_assert(SUP == 1 || ((SUP == 2 || SUP == 4) && TM * TN <= 2 && NSLOT % SUP == 0 && NSLOT % 2 == 0),
                 "several chunks per barrier: the tiles that read a whole chunk of fragments ahead");
   constexpr int NLW = NLA + NLB; // loader waves
-  static_assert(!FLATB || !MULTI, "the flat-B loader serves single layers");
+  static_assert(FLATB == 0 || FLATB == 2, "0: VNNI-2 B image, 2: flat B image + transpose reads");
+  static_assert(FLATB != 2 || BN >= 64, "transpose-read image: 64-byte blocks swizzled inside rows of >= 128 bytes");
   static_assert(BN == 32 || BN == 64 || BN == 128, "B pair-rows per DMA instruction");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_c[];
 
@@ -393,8 +297,7 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
   if (wave >= NMW) {
     // ---- loader waves (blw_loader above) ---------------------------------------------------------------------------
     if (wave < NMW + NLA) blw_loader<true, NLA, NLA, NSLOT, SUP, BM, BN, WK, MULTI>(pp, smem_c, lane, m0, n0, tm, L, wave - NMW);
-    else if constexpr (FLATB) blw_loader_flatb<NLB, NSLOT, SUP, BM, BN>(pp, smem_c, lane, n0, wave - NMW - NLA);
-    else blw_loader<false, NLB, NLA, NSLOT, SUP, BM, BN, WK, MULTI>(pp, smem_c, lane, m0, n0, tm, L, wave - NMW - NLA);
+    else blw_loader<false, NLB, NLA, NSLOT, SUP, BM, BN, WK, MULTI, FLATB>(pp, smem_c, lane, m0, n0, tm, L, wave - NMW - NLA);
     return; // ended waves do not take part in later barriers
   }
 
@@ -415,6 +318,14 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     b_lane[j] = (4 * lh) * BN + (wn * TN + j) * 32 + li;
+    if constexpr (FLATB == 2) {
+      // flat image [64 k][BN] (blw_loader FB = 2), fragments by ds_read_b64_tr_b16: in every 16 lanes, lane p names the 8-byte
+      // piece (row p / 4, columns 4 (p % 4) ..) of a [4 k][16 n] block and receives COLUMN p of it - four consecutive k of
+      // its own column (tools/ubench/tr16_probe.hip pins that). Byte offset of this lane's piece for k = 8 lh + p / 4:
+      const int pp16 = lane & 15, blk = wn * TN + j, rowl = pp16 >> 2;
+      const int swz = BN == 128 ? rowl : (rowl >> 1) & 1;
+      b_lane[j] = (8 * lh + rowl) * (BN * 2) + ((blk ^ swz) << 6) + ((lane >> 4) & 1) * 32 + (pp16 & 3) * 8;
+    }
     asm volatile("" : "+v"(b_lane[j])); // one base VGPR per column tile: rows r, r+1 pair up as ds_read2(st64)_b32
   }
   auto frag_load = [&](int buf, int slot, int ks) __attribute__((always_inline)) {
@@ -427,9 +338,19 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const unsigned int *bp = bs + b_lane[j] + (8 * ks) * BN;
+      if constexpr (FLATB == 2) {
+        typedef short s16x4_lw __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) s16x4_lw lds_s16x4_lw;
+        typedef __attribute__((address_space(3))) unsigned char lds_u8_lw;
+        lds_u8_lw *bb = (lds_u8_lw *)(as + A_SLOT) + b_lane[j] + (16 * ks) * (BN * 2);
+        const u32x2_lw q0 = __builtin_bit_cast(u32x2_lw, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_lw *)bb));
+        const u32x2_lw q1 = __builtin_bit_cast(u32x2_lw, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_lw *)(bb + 4 * (BN * 2))));
+        bw[buf][j] = u32x4{q0[0], q0[1], q1[0], q1[1]};
+      } else {
+        const unsigned int *bp = bs + b_lane[j] + (8 * ks) * BN;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) bw[buf][j][r] = bp[r * BN];
+        for (int r = 0; r < 4; ++r) bw[buf][j][r] = bp[r * BN];
+      }
     }
   };
   const int dbg = p.dbg;
@@ -648,7 +569,7 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
   }
 }
 
-template <int WM, int WN, int WK, int TM, int TN, int NSLOT, int NLA, int NLB, int SUP, bool MULTI, bool FLATB = false>
+template <int WM, int WN, int WK, int TM, int TN, int NSLOT, int NLA, int NLB, int SUP, bool MULTI, int FLATB = 0>
 static hipError_t launch_blw_t(const ChainArgs &a, hipStream_t s) {
   constexpr int NOUT = WM * WN, BM = 32 * WM * TM, BN = 32 * WN * TN, NT = 64 * (WM * WN * WK + NLA + NLB);
   constexpr size_t lds = (size_t)NSLOT * (BM + BN) * 128 + (WK > 1 ? (size_t)NOUT * 4096 : 0);
@@ -724,19 +645,25 @@ hipError_t launch_bf16_lw(int tile, const ChainArgs &a, hipStream_t s) {
   BLW_DISPATCH(false)
 }
 
-// one layer whose B operand is FLAT ([k][ldb] bf16): the same tiles, B through blw_loader_flatb
+// One layer whose B operand is FLAT ([k][ldb] bf16, no VNNI flag on the dispatch - what xsmm.unary pack would have turned into
+// VNNI-2, lib/TPP/Transforms/Utils/VNNIUtils.cpp:75-77): the VNNI kernels' configurations with the B image and the fragment
+// reads swapped (FLATB = 2): the chunk's 64 rows go into LDS as they are (LDS-DMA, 64-byte blocks swizzled on the source side)
+// and a B fragment is two ds_read_b64_tr_b16 - the hardware transpose hands every lane four consecutive k of its own column.
+// No pack launch, no VALU, and the reads run at the LDS's full 256 B/clk where the VNNI image needs 4-byte reads (128 B/clk):
+// bit-identical to pack + VNNI kernel and as fast or faster on every tile (profiles/r03_flat_b_bf16.txt). A first version
+// interleaved the pair-rows in a register-staging B loader (buffer_load_dwordx4 x 2 -> 8 v_perm_b32 -> 2 ds_write_b128): correct,
+// 15-28 % slower (the ds_write path: ~79 B/clk and 2-way conflicts), removed.
 hipError_t launch_bf16_lw_flatb(int tile, const ChainArgs &a, hipStream_t s) {
   if (a.L[0].br < 1 || a.L[0].k < BLW_BK || tile < 0 || tile > 3) return hipErrorInvalidValue;
   switch (tile * 2 + (blw_sup2(a) ? 1 : 0)) {
-  case 0: return launch_blw_t<1, 2, 2, 1, 1, 8, 1, 2, 1, false, true>(a, s);
-  case 1: return launch_blw_t<1, 2, 2, 1, 1, 8, 1, 2, 2, false, true>(a, s);
-  // (two B loader waves for every tile: one wave moves ~24 B/clk through its registers, a 128-wide panel needs 32)
-  case 2: return launch_blw_t<2, 2, 1, 1, 1, 8, 1, 2, 1, false, true>(a, s);
-  case 3: return launch_blw_t<2, 2, 1, 1, 1, 8, 1, 2, 2, false, true>(a, s);
+  case 0: return launch_blw_t<1, 2, 2, 1, 1, 8, 1, 2, 1, false, 2>(a, s);
+  case 1: return launch_blw_t<1, 2, 2, 1, 1, 8, 1, 2, 2, false, 2>(a, s);
+  case 2: return launch_blw_t<2, 2, 1, 1, 1, 8, 1, 1, 1, false, 2>(a, s);
+  case 3: return launch_blw_t<2, 2, 1, 1, 1, 8, 1, 1, 2, false, 2>(a, s);
   case 4:
-  case 5: return launch_blw_t<2, 2, 1, 1, 2, 6, 1, 2, 1, false, true>(a, s);
+  case 5: return launch_blw_t<2, 2, 1, 1, 2, 6, 1, 2, 1, false, 2>(a, s);
   case 6:
-  case 7: return launch_blw_t<2, 2, 1, 2, 2, 4, 1, 2, 1, false, true>(a, s);
+  case 7: return launch_blw_t<2, 2, 1, 2, 2, 4, 1, 1, 1, false, 2>(a, s);
   default: return hipErrorInvalidValue;
   }
 }
