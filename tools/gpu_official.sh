@@ -42,6 +42,10 @@ python tools/sweep.py 2>/dev/null | grep -E "^(f32|bf16)" > $OUT/sweep.txt
 python tools/sweep.py big 2>/dev/null | grep -E "^(f32|bf16)" >> $OUT/sweep.txt
 python tools/sweep.py shards 2>/dev/null | grep -E "^bf16" >> $OUT/sweep.txt
 python tools/sweep.py small 2>/dev/null | grep -E "^bf16" >> $OUT/sweep.txt
+python tools/sweep.py flatb 2>/dev/null | grep -E "^bf16" > $OUT/flatb.txt
+tools/ubench/fillmix.out > $OUT/fill_paths.txt 2>&1
+tools/ubench/tr16_probe.out > $OUT/tr16_probe.txt 2>&1
+timeout 200 python tools/queue_fuzz.py 45 5 2>&1 | tail -1 > $OUT/queue_fuzz.txt
 bash tools/gpu_replay.sh $TAG > /dev/null 2>&1
 python tools/eltwise_bw.py > $OUT/eltwise_bw.txt 2>/dev/null
 python tools/vendor_compare.py > $OUT/vendor_compare.txt 2>/dev/null
