@@ -786,12 +786,6 @@ struct DirectWindow {
   alignas(64) std::atomic<uint64_t> cur{0};
   alignas(64) std::atomic<int> ncallers{0}; // high-water mark of claimed caller slots
   Caller callers[MAXC];
-  struct Lease {
-    Caller *c = nullptr;
-    ~Lease() {
-      if (c) c->owned.store(0, std::memory_order_release);
-    }
-  };
   Caller *claim() {
     const int n = ncallers.load(std::memory_order_acquire);
     for (int i = 0; i < MAXC; ++i) {
@@ -804,15 +798,6 @@ struct DirectWindow {
       }
     }
     return nullptr; // more caller threads than slots: this one always takes the locked path
-  }
-  Caller *mine() {
-    thread_local Lease lease;
-    thread_local bool tried = false;
-    if (!tried) {
-      tried = true;
-      lease.c = claim();
-    }
-    return lease.c;
   }
 };
 
@@ -1639,15 +1624,31 @@ void check_queue_device() {
         "turn the queue off (xsmm_hip_set_tile_queue(0)) for multi-device processes", expect, dev);
 }
 
+// everything a calling thread keeps for the enqueue path, behind ONE thread-local lookup per invoke (in a shared library every
+// thread_local access is a call into the dynamic TLS resolver)
+struct CallerState {
+  DeviceRanges devmem; // per caller: no sharing, no lock
+  DirectWindow::Caller *me = nullptr;
+  bool claimed = false;
+  ~CallerState() {
+    if (me) me->owned.store(0, std::memory_order_release);
+  }
+};
+
 bool enqueue_item(const void *desc, const WorkItem &item, const void *const *ptrs, int n_ptrs, hipStream_t s) {
-  thread_local DeviceRanges devmem; // per caller: no sharing, no lock
+  thread_local CallerState tl;
+  DeviceRanges &devmem = tl.devmem;
   if (devmem.refresh()) check_queue_device();
   for (int i = 0; i < n_ptrs; ++i)
     if (!devmem.is_device(ptrs[i], i)) return false;
-  InlineQueue &iq = inl();
+  static InlineQueue &iq = inl();
   // DIRECT: the invoke is a member of the recorded group being replayed
   if (const uint64_t c = iq.dw.cur.load(std::memory_order_acquire)) {
-    if (DirectWindow::Caller *me = iq.dw.mine()) {
+    if (!tl.claimed) {
+      tl.claimed = true;
+      tl.me = iq.dw.claim();
+    }
+    if (DirectWindow::Caller *me = tl.me) {
       me->busy.store(c, std::memory_order_seq_cst);
       bool joined = false;
       if (iq.dw.cur.load(std::memory_order_seq_cst) == c) {
