@@ -354,7 +354,14 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
     }
   };
   const int dbg = p.dbg;
-  const bool skip_math = (dbg & 32) != 0; // timing experiments: barriers only
+  // Timing experiment "no fragment reads / MFMAs" (dbg & 32) is a COMPILE-TIME switch: as a run-time branch around every group of
+  // reads and MFMAs it split the chunk body into basic blocks, the compiler's wait-count insertion lost track of which LDS reads
+  // were outstanding across them and put s_waitcnt lgkmcnt(0..2) in front of the MFMAs - each k-step waited for the fragment reads
+  // issued just before it (274 cycles per k-step of 128 cycles of MFMA on the 128x128 tile).
+  // (The chain and flat-B instances keep the run-time flag for now: without those block boundaries hipcc renames their accumulators
+  // from chunk body to chunk body - v_mfma D != C at every exit of the ring loop - and spills 150 .. 1500 bytes per lane.)
+  constexpr bool RT_SKIP = MULTI || FLATB != 0;
+  const bool skip_math = RT_SKIP && (dbg & 32) != 0;
   // one chunk in ring slot S: step q multiplies fragment buffer q while the fragments of step q + PD are read (the last PD
   // steps read the first steps of chunk t+1, published by the mid-chunk barrier; after the last chunk of a layer they
   // read a slot nobody uses - the values are dropped)
