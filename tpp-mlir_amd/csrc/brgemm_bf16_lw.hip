@@ -312,6 +312,7 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
   constexpr bool FULLPF = TM * TN <= 2;
   constexpr int NFB = FULLPF ? 2 * KS : KS;
   static_assert(!FULLPF || NSLOT % 2 == 0, "chunk parity from the ring slot");
+  static_assert(SUP == 1 || FULLPF, "two chunks per barrier: the tiles with two fragment sets");
   bf16x8_lw af[NFB][TM];
   u32x4 bw[NFB][TN]; // B fragments as dwords
   int b_lane[TN];   // dword index of this lane's column of tile j in pair-row 4*lh of a k-step
@@ -354,25 +355,35 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
     }
   };
   const int dbg = p.dbg;
-  // Timing experiment "no fragment reads / MFMAs" (dbg & 32) is a COMPILE-TIME switch: as a run-time branch around every group of
-  // reads and MFMAs it split the chunk body into basic blocks, the compiler's wait-count insertion lost track of which LDS reads
-  // were outstanding across them and put s_waitcnt lgkmcnt(0..2) in front of the MFMAs - each k-step waited for the fragment reads
-  // issued just before it (274 cycles per k-step of 128 cycles of MFMA on the 128x128 tile).
-  // (The chain and flat-B instances keep the run-time flag for now: without those block boundaries hipcc renames their accumulators
-  // from chunk body to chunk body - v_mfma D != C at every exit of the ring loop - and spills 150 .. 1500 bytes per lane.)
-  constexpr bool RT_SKIP = MULTI || FLATB != 0;
-  const bool skip_math = RT_SKIP && (dbg & 32) != 0;
-  // one chunk in ring slot S: step q multiplies fragment buffer q while the fragments of step q + PD are read (the last PD
-  // steps read the first steps of chunk t+1, published by the mid-chunk barrier; after the last chunk of a layer they
-  // read a slot nobody uses - the values are dropped)
-  // t, T: this chunk's index and the layer's chunk count. The workgroup barrier sits in the middle of every SUP-th chunk (S a
-  // multiple of SUP: layers start at slot 0) when another barrier interval follows: it publishes the next SUP chunks and retires
-  // the previous SUP slots. (With SUP = 2 the fragments of the odd chunk are read during the even chunk's second half - the same
-  // interval, already published - and those of the next even chunk during the odd chunk's, behind the barrier.)
-  auto chunk = [&](auto slot_c, int t, int T) __attribute__((always_inline)) {
-    constexpr int S = decltype(slot_c)::value, NS = (S + 1) % NSLOT;
-    const bool has_next = (S % SUP == 0) && t + SUP < T;
-    constexpr int CUR = FULLPF ? (S & 1) * KS : 0, NXT = FULLPF ? ((S & 1) ^ 1) * KS : 0; // fragment sets of chunk t / t+1
+  // Timing experiment "no fragment reads / MFMAs" (dbg & 32) is a COMPILE-TIME switch (-DTPP_BLW_SKIP_MATH): as a run-time branch
+  // around every group of reads and MFMAs it split the chunk body into basic blocks, the compiler's wait-count insertion lost track
+  // of which LDS reads were outstanding across them and put s_waitcnt lgkmcnt(0..2) in front of the MFMAs - each k-step waited for
+  // the fragment reads issued just before it (274 cycles per k-step of 128 cycles of MFMA on the 128x128 tile).
+#ifdef TPP_BLW_SKIP_MATH
+  const bool skip_math = (dbg & 32) != 0;
+#else
+  constexpr bool skip_math = false;
+  (void)dbg;
+#endif
+  // One chunk in ring slot `slot` (a run-time value: ONE body - two for the tiles that alternate fragment sets - instead of one per
+  // ring slot entered through a switch; the slot's LDS offset costs TM + TN vector adds per k-step. The per-slot bodies with their
+  // exit after every chunk made hipcc rename the accumulators from body to body - v_mfma D != C - in the chain and flat-B
+  // instances, which then spilled 150 .. 1500 bytes per lane). Step q multiplies fragment buffer q while the fragments of step
+  // q + PD are read (the last PD steps read the first steps of chunk t+1, published by the mid-chunk barrier; after the last chunk
+  // of a layer they read a slot nobody uses - the values are dropped).
+  // t, T: this chunk's index and the layer's chunk count. The workgroup barrier sits in the middle of every SUP-th chunk (slot a
+  // multiple of SUP: layers start at such a slot) when another barrier interval follows: it publishes the next SUP chunks and
+  // retires the previous SUP slots. (With SUP = 2 the fragments of the odd chunk are read during the even chunk's second half - the
+  // same interval, already published - and those of the next even chunk during the odd chunk's, behind the barrier.)
+  // PAR (tiles with two fragment sets): parity of the slot = which set holds this chunk's fragments.
+  // HN: does this chunk carry the barrier? 1 yes / 0 no as compile-time facts (the steady-state loop bodies are then single basic
+  // blocks: a conditional barrier - or the loop's exit test - in the middle of a body is a block boundary at which the compiler
+  // waits for every LDS read in flight), 2 = decided at run time (the odd first chunk).
+  auto chunk = [&](auto par_c, auto hn_c, int slot, int t, int T) __attribute__((always_inline)) {
+    constexpr int PAR = decltype(par_c)::value, HN = decltype(hn_c)::value;
+    const int ns = slot + 1 == NSLOT ? 0 : slot + 1;
+    const bool has_next = HN == 2 ? (SUP == 1 || PAR == 0) && t + SUP < T : HN == 1;
+    constexpr int CUR = FULLPF ? PAR * KS : 0, NXT = FULLPF ? (PAR ^ 1) * KS : 0; // fragment sets of chunk t / t+1
 #pragma unroll
     for (int q = 0; q < KS; ++q) {
       if (!skip_math) {
@@ -380,12 +391,12 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
           // second half of the chunk (chunk t+1 is published): two of its k-steps per step
           if (q >= KS / 2) {
             const int r = 2 * (q - KS / 2);
-            frag_load(NXT + r, NS, wk * KS + r);
-            if (r + 1 < KS) frag_load(NXT + r + 1, NS, wk * KS + r + 1);
+            frag_load(NXT + r, ns, wk * KS + r);
+            if (r + 1 < KS) frag_load(NXT + r + 1, ns, wk * KS + r + 1);
           }
         } else {
-          if (q + PD < KS) frag_load(q + PD, S, wk * KS + q + PD);
-          else frag_load(q + PD - KS, NS, wk * KS + q + PD - KS);
+          if (q + PD < KS) frag_load(q + PD, slot, wk * KS + q + PD);
+          else frag_load(q + PD - KS, ns, wk * KS + q + PD - KS);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -397,12 +408,14 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_lw, bw[CUR + q][j]), af[CUR + q][i], acc[i][j], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (q == KS / 2 - 1 && (S % SUP == 0) && has_next) {
+      if (q == KS / 2 - 1 && has_next) {
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
       }
     }
   };
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
 
   int s0 = 0; // ring slot of the current layer's chunk 0
   for (int l = 0; l < L; ++l) {
@@ -443,24 +456,45 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
       for (int s = 0; s < KS; ++s) frag_load(FULLPF ? KS + s : s, s0, wk * KS + s);
     }
     {
-      int t = 0;
-      [&]() __attribute__((always_inline)) {
-#define BLW_RING_CASE(S)                                           \
-  case S:                                                          \
-    if constexpr (S < NSLOT) {                                     \
-      chunk(std::integral_constant<int, S>{}, t, T);               \
-      if (++t == T) return;                                        \
-    }                                                              \
-    [[fallthrough]];
-        for (int first = s0;; first = 0) { // one body per ring slot (literal LDS offsets), entered at the layer's first slot
-          switch (first) {
-            BLW_RING_CASE(0) BLW_RING_CASE(1) BLW_RING_CASE(2) BLW_RING_CASE(3) BLW_RING_CASE(4) BLW_RING_CASE(5)
-            BLW_RING_CASE(6) BLW_RING_CASE(7) BLW_RING_CASE(8) BLW_RING_CASE(9) BLW_RING_CASE(10) BLW_RING_CASE(11)
-          default: break;
-          }
+      int t = 0, slot = s0;
+      auto next = [&](int x) __attribute__((always_inline)) { return x + 1 == NSLOT ? 0 : x + 1; };
+      using Y = std::integral_constant<int, 1>;
+      using N = std::integral_constant<int, 0>;
+      using R = std::integral_constant<int, 2>;
+      if constexpr (!FULLPF) { // (SUP = 1) every chunk but the last carries the barrier; T >= 1
+        for (; t + 1 < T; ++t) {
+          chunk(P0{}, Y{}, slot, t, T);
+          slot = next(slot);
         }
-#undef BLW_RING_CASE
-      }();
+        chunk(P0{}, N{}, slot, t, T);
+      } else if constexpr (SUP == 2) { // (T even, s0 even) the barrier sits in the even chunk of every pair but the last
+        for (; t + 2 < T; t += 2) {
+          chunk(P0{}, Y{}, slot, t, T);
+          slot = next(slot);
+          chunk(P1{}, N{}, slot, t + 1, T);
+          slot = next(slot);
+        }
+        chunk(P0{}, N{}, slot, t, T);
+        chunk(P1{}, N{}, next(slot), t + 1, T);
+      } else {
+        if (slot & 1) { // (an odd first slot: after a layer with an odd chunk count)
+          chunk(P1{}, R{}, slot, t, T);
+          slot = next(slot);
+          ++t;
+        }
+        for (; t + 2 < T; t += 2) {
+          chunk(P0{}, Y{}, slot, t, T);
+          slot = next(slot);
+          chunk(P1{}, Y{}, slot, t + 1, T);
+          slot = next(slot);
+        }
+        if (t + 1 < T) {
+          chunk(P0{}, Y{}, slot, t, T);
+          chunk(P1{}, N{}, next(slot), t + 1, T);
+        } else if (t < T) {
+          chunk(P0{}, N{}, slot, t, T);
+        }
+      }
     }
     s0 = (s0 + T) % NSLOT;
     // the fragments prefetched past the end of the layer are dead: without this the compiler sinks their reads
