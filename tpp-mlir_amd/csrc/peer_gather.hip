@@ -104,8 +104,25 @@ __global__ __launch_bounds__(64) void peer_wait_kernel(unsigned *my_flags, int w
 extern "C" void *xsmm_hip_get_stream(void);
 
 // a dedicated, zeroed device allocation (IPC handles name whole allocations: nothing here is carved out of a caching allocator)
+// Small allocations (<= 64 KiB: the flag / ready / ticket / err words that peers on OTHER devices write and this device polls) are
+// taken FINE-GRAINED when the runtime offers it: such memory is not held in this device's L2, so a poll cannot be served a stale line
+// that a remote store never touched. The data buffers stay ordinary device memory: they are read by kernels launched AFTER the wait
+// kernel has seen the flags (a launch boundary invalidates the L2).
 extern "C" void *xsmm_hip_peer_alloc(int64_t bytes) {
   void *p = nullptr;
+  if (bytes <= 65536 && hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocFinegrained) == hipSuccess && p) {
+    hipIpcMemHandle_t probe;
+    if (hipIpcGetMemHandle(&probe, p) == hipSuccess) { // (only if it can be shared like the others)
+      PG_OK(hipMemset(p, 0, (size_t)bytes));
+      PG_OK(hipDeviceSynchronize());
+      return p;
+    }
+    (void)hipGetLastError();
+    (void)hipFree(p);
+    p = nullptr;
+  } else {
+    (void)hipGetLastError();
+  }
   PG_OK(hipMalloc(&p, (size_t)bytes));
   PG_OK(hipMemset(p, 0, (size_t)bytes));
   PG_OK(hipDeviceSynchronize());

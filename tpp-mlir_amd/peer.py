@@ -73,12 +73,61 @@ class PeerGather:
     @classmethod
     def create(cls, rt, rank, world, total_bytes, group=None):
         """the gather object, or None when the buffers cannot be shared (then use RCCL: mlp.all_gather_rows)"""
+        import sys
         try:
-            return cls(rt, rank, world, total_bytes, group)
+            obj = cls(rt, rank, world, total_bytes, group)
         except Exception as ex:  # a mapping problem must not cost the run: RCCL is the fallback
-            import sys
             sys.stderr.write("[tpp-mlir_amd.peer] peer-store gather unavailable (%s): falling back to RCCL\n" % ex)
-            return None
+            obj = None
+        # every rank or none - and only if three known patterns come out right on EVERY rank (both buffer parities and a re-use):
+        # a mapping that "works" but is not coherent between these devices must cost a fallback, not a wrong output or a hung step
+        ok = obj is not None
+        if world > 1:
+            import torch.distributed as dist
+            votes = [None] * world
+            dist.all_gather_object(votes, ok, group=group)
+            if not all(votes):
+                if obj is not None:
+                    obj.close()
+                return None
+            ok = obj.selftest()
+            dist.all_gather_object(votes, ok, group=group)
+            if not all(votes):
+                if rank == 0:
+                    sys.stderr.write("[tpp-mlir_amd.peer] peer-store gather failed its self-test on ranks %s: falling back to RCCL\n"
+                                     % [w for w, v in enumerate(votes) if not v])
+                obj.close()
+                return None
+        return obj
+
+    def selftest(self):
+        """three gathers of a pattern every rank can compute for every other rank; True if this rank's copies are exact and no
+        wait timed out"""
+        import torch
+        per = (self.total // self.world) // 16 * 16
+        n16 = per // 2
+        base = torch.arange(n16, device="cuda", dtype=torch.int32)
+
+        def pattern(w, step):
+            return ((base * 31 + 7919 * (w + 1) + 104729 * step) % 32749).to(torch.int16)
+        ok = True
+        try:
+            for step in range(3):
+                src = pattern(self.rank, step)
+                torch.cuda.synchronize()  # (the runtime's stream need not be torch's)
+                out = self.gather(src, per, self.rank * per)
+                self.rt.synchronize()
+                torch.cuda.synchronize()
+                if int(self._err_view.cpu()[0]) != 0:
+                    self._err_view.zero_()
+                    ok = False
+                    break
+                for w in range(self.world):
+                    if not torch.equal(out[w * n16:(w + 1) * n16], pattern(w, step)):
+                        ok = False
+        except Exception:
+            ok = False
+        return ok
 
     def gather(self, src, nbytes, dst_offset):
         """enqueue one step on the runtime's stream: this rank's `nbytes` at `src` go to offset `dst_offset` of every rank's
