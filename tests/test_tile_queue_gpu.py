@@ -15,12 +15,14 @@ pkg = importlib.import_module("tpp-mlir_amd")
 F32, BF16 = 1, 2
 
 
-@pytest.fixture()
-def rtq():
+@pytest.fixture(params=[1, 2], ids=["direct", "scheduler"])
+def rtq(request):
+    """the tile queue in both multi-caller modes: 1 = replayed groups are joined lock-free by every caller (direct window), the rest
+    under the queue's lock; 2 = several callers hand their invokes to the scheduler thread (per-caller rings)"""
     rt = pkg.get_runtime()
     assert rt.device_count() >= 1
     prev_async = rt.set_async(True)
-    prev_q = rt.set_tile_queue(True)
+    prev_q = rt.set_tile_queue(request.param)
     yield rt
     rt.synchronize()
     rt.set_tile_queue(prev_q)

@@ -2130,7 +2130,20 @@ extern "C" void xsmm_hip_set_stream(void *s) {
 }
 extern "C" int xsmm_hip_set_tile_queue(int enable) {
   flush_tile_queue();
-  return cfg().tile_queue.exchange(enable < 0 ? 0 : enable > 2 ? 2 : enable); // 2: several callers always go through the scheduler thread
+  const int mode = enable < 0 ? 0 : enable > 2 ? 2 : enable; // 2: several callers always go through the scheduler thread
+  const int prev = cfg().tile_queue.exchange(mode);
+  if (prev == 2 && mode != 2) {
+    // leaving mode 2: back to the inline / direct path (a mode switch happens between bursts - no invoke is in flight - and the
+    // flush above has drained the scheduler's rings)
+    InlineQueue &iq = inl();
+    std::lock_guard<SpinLock> lk(iq.mu);
+    iq.scheduled.store(false, std::memory_order_release);
+    iq.owner = 0;
+    iq.foreign = 0;
+    iq.multi = false;
+    iq.slow = 0;
+  }
+  return prev;
 }
 extern "C" void xsmm_hip_flush(void) { flush_tile_queue(); }
 // n fused_brgemm invokes in one call: exactly the effect of xsmm_fused_brgemm_invoke(dtype, handles[i], ...) for i = 0 .. n-1 in

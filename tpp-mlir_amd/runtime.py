@@ -207,7 +207,7 @@ class XsmmRuntime:
         self.lib.xsmm_hip_set_stream(getattr(stream, "cuda_stream", stream) or None)
 
     def set_tile_queue(self, enable):
-        return bool(self.lib.xsmm_hip_set_tile_queue(int(enable)))  # 0 off, 1 on, 2 on + scheduler thread for several callers
+        return int(self.lib.xsmm_hip_set_tile_queue(int(enable)))  # 0 off, 1 on, 2 on + scheduler thread for several callers; returns the previous mode
 
     def flush(self):
         self.lib.xsmm_hip_flush()
