@@ -973,6 +973,7 @@ struct TileQueue {
     const int rp = replay;
     if (rp >= 0 && n > 0 && (size_t)n != segs[rp].items.size()) materialize();
     const bool whole = rp >= 0 && n > 0 && (size_t)n == segs[rp].items.size(); // the recorded group, complete: launch from its own list
+    // (counts are exact: an arrival is counted by whoever's atomic exchange on the item's mark saw it unmarked - once per round)
     store_recording(next); // (never touches segs[rp] during a replay: nothing is being recorded)
     replay = -1;
     if (n == 0) return;
