@@ -501,6 +501,34 @@ def test_conv_as_gemm_invokes_strided_rows(rt):
         assert np.abs(got.reshape(P, Q, K) - want).max() <= 1e-4 * max(1.0, np.abs(want).max())
 
 
+@pytest.mark.parametrize("k", [4, 36, 100, 1000])
+def test_brgemm_f32_generic_k_multiple_of_4(rt, k):
+    """the generic kernel's 16-byte operand path with a ragged last chunk (k a multiple of 4, not of 32): the pieces at or beyond k
+    are requested past the descriptor's end and must read as zeros - whatever lies behind the operands in memory (NaN here)"""
+    m, n, br = 96, 72, 3
+    lda, ldb = k + 8, n + 4
+    rng = np.random.default_rng(k)
+    A = np.full(br * m * lda + 64, np.nan, dtype=np.float32)
+    B = np.full(br * k * ldb + 64, np.nan, dtype=np.float32)
+    for b in range(br):
+        A[b * m * lda:(b + 1) * m * lda].reshape(m, lda)[:, :k] = rng.uniform(-1, 1, (m, k))
+        B[b * k * ldb:(b + 1) * k * ldb].reshape(k, ldb)[:, :n] = rng.uniform(-1, 1, (k, n))
+    C = rng.uniform(-1, 1, m * n).astype(np.float32)
+    Cref = C.copy()
+    An, Bn = np.nan_to_num(A), np.nan_to_num(B)
+    orc.brgemm(F32, m, n, k, lda, ldb, n, m * lda, k * ldb, 0, An, 0, Bn, 0, Cref, 0, br)
+    rt.force_variant(8)
+    try:
+        h = rt.brgemm_dispatch(F32, m, n, k, lda, ldb, n, m * lda, k * ldb, 0)
+    finally:
+        rt.force_variant(-1)
+    dC = dev(C)
+    rt.brgemm(F32, h, dev(A), 0, dev(B), 0, dC, 0, br)
+    got = host(dC, C)
+    assert np.isfinite(got).all(), "a tail piece beyond k was read"
+    check_close(got, Cref, F32, "generic f32 k=%d [%s]" % (k, rt.kernel_name(h)), None, k * br)
+
+
 def test_brgemm_bf16_flat_b_generic(rt):
     gemm_case(rt, BF16, 48, 40, 24, 3, vnni=False, seed=3, bias=True)
 

@@ -82,6 +82,13 @@ def bf16_flat_case(m, n, k, br, tag="", force=None):
         m, n, k, br, rt.kernel_name(h), t * 1e6, fl / t / 1e12, fl / t / 25e12, tag), flush=True)
 
 
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "generic":
+    # the generic kernel (variant 8) on its operand paths: k a multiple of 32 / of 4 only (16-byte loads, ragged last chunk) / odd (element loads)
+    for (m, n, k, br, tag) in ((1024, 1024, 64, 16, "k % 32 == 0"), (1024, 1024, 100, 10, "k = 100: 16-byte loads, ragged last chunk"),
+                               (1024, 1024, 1000, 1, "k = 1000"), (1000, 1000, 1000, 1, "m, n ragged too"), (1024, 1024, 101, 10, "k = 101: element loads")):
+        f32_case(m, n, k, br, force=8, tag=tag)
+    sys.exit(0)
+
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "flatb":
     # flat-B bf16 against the VNNI-2 kernels on the same shapes (same run): C5, the C4 layer and its shards, 4096^3
     for (m, n, k, br, tag) in ((2048, 2048, 128, 16, "C5"), (4096, 1024, 64, 16, "C4 layer"), (2048, 1024, 64, 16, ""),

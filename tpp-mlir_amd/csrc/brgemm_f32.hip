@@ -440,10 +440,15 @@ __global__ __launch_bounds__(256) void brgemm_grouped(GemmArgs p, const WorkItem
           __builtin_amdgcn_make_buffer_rsrc((void *)((const float *)it.A + abase + (int64_t)m0 * p.lda + kk0), 0, nrec, 0x00020000);
       const __amdgpu_buffer_rsrc_t rB =
           __builtin_amdgcn_make_buffer_rsrc((void *)((const float *)it.B + bbase + (int64_t)kk0 * p.ldb + n0), 0, nrec, 0x00020000);
+      // k need only be a multiple of 4: in the last chunk of a batch element the 16-byte pieces at or beyond k (A: k piece c4, B: k
+      // row) are requested at an offset past the descriptor's end and come back as zeros - no branch, no select on loaded data
+      const int klim = p.k - kk0; // >= 32 in every chunk but a ragged last one
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        ra[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, voffA[u], 0, 0));
-        rb[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rB, voffB[u], 0, 0));
+        const int q = lane + 64 * u;
+        const unsigned oa = 4 * (q & 7) < klim ? voffA[u] : 0x80000000u, ob = (q >> 3) < klim ? voffB[u] : 0x80000000u;
+        ra[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, oa, 0, 0));
+        rb[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rB, ob, 0, 0));
       }
       return;
     }
@@ -740,7 +745,7 @@ hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_i
   a.ep = (d.beta0 ? EP_BETA0 : 0) | (d.bias ? EP_BIAS : 0) | (d.relu ? EP_RELU : 0) | (d.vnni_c ? EP_VNNI_C : 0);
   a.tiles_m = a.tiles_n = 0;
   const bool tiles_ok = vec_ok && d.n % 4 == 0 && d.k % GK == 0; // 16-byte pieces; ragged m / n edges are predicated
-  const bool vec = tiles_ok && d.dtype == DT_F32 && !d.vnni_b && !((d.lda | d.ldb | d.stride_a | d.stride_b) & 3) &&
+  const bool vec = vec_ok && d.n % 4 == 0 && d.k % 4 == 0 && d.dtype == DT_F32 && !d.vnni_b && !((d.lda | d.ldb | d.stride_a | d.stride_b) & 3) &&
                    d.lda < (1 << 24) && d.ldb < (1 << 24); // (32-bit tile-relative lane offsets: 32 rows x ld x 4 B < 2^31)
   // f32 tiles with k a multiple of 64 (mlir-gen --tiles=64,64,64, the most common setting of the reference's
   // benchmark configs): the fast tile families in grouped mode, the largest tile that still yields about one
@@ -982,7 +987,7 @@ hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C,
   }
   // everything else: the grouped kernel with a single, inline work item
   const bool tiles_ok = aligned16 && d.n % 4 == 0 && d.k % GK == 0; // ragged m / n edges are predicated
-  const bool vec = tiles_ok && d.dtype == DT_F32 && !d.vnni_b && !((d.lda | d.ldb | d.stride_a | d.stride_b) & 3) &&
+  const bool vec = aligned16 && d.n % 4 == 0 && d.k % 4 == 0 && d.dtype == DT_F32 && !d.vnni_b && !((d.lda | d.ldb | d.stride_a | d.stride_b) & 3) &&
                    d.lda < (1 << 24) && d.ldb < (1 << 24); // (32-bit tile-relative lane offsets)
   const bool vec16 = tiles_ok && d.dtype == DT_BF16 && d.vnni_b && !((d.lda | d.stride_a | d.stride_b) & 7) && !(d.ldb & 3) &&
                      d.lda < (1 << 21) && d.ldb < (1 << 21); // (32-bit lane offsets)
