@@ -462,6 +462,24 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
       using N = std::integral_constant<int, 0>;
       using R = std::integral_constant<int, 2>;
       if constexpr (!FULLPF) { // (SUP = 1) every chunk but the last carries the barrier; T >= 1
+        if constexpr (NSLOT == 4) {
+          // whole laps of the ring with LITERAL slots (LDS offsets are immediates: no address adds, and the four bodies of a lap
+          // are one basic block): 4096^3 on the 128x128 tile 139 -> 131 us, 2048^3 on a flat B 20.6 -> 19.05, the 4096-row chain
+          // 34 -> 33 us (same-box A/B). A single layer starts
+          // at slot 0; a layer of a chain first walks to slot 0.
+          if constexpr (MULTI) {
+            for (; slot != 0 && t + 1 < T; ++t) {
+              chunk(P0{}, Y{}, slot, t, T);
+              slot = next(slot);
+            }
+          }
+          for (; t + 4 < T; t += 4) {
+            chunk(P0{}, Y{}, 0, t, T);
+            chunk(P0{}, Y{}, 1, t + 1, T);
+            chunk(P0{}, Y{}, 2, t + 2, T);
+            chunk(P0{}, Y{}, 3, t + 3, T);
+          }
+        }
         for (; t + 1 < T; ++t) {
           chunk(P0{}, Y{}, slot, t, T);
           slot = next(slot);
