@@ -501,7 +501,10 @@ def main():
                 dist.all_reduce(ok_, op=dist.ReduceOp.MIN)  # every rank or none
                 if int(ok_[0]) == 0:
                     pg_ = None
-            gather_used.append("peer-store (IPC-mapped peer buffers, 2 launches per step)" if pg_ is not None else
+                if pg_ is not None:
+                    pg_.overlap(True)  # the wait for the peers' blocks on a side stream: the next step computes meanwhile
+            gather_used.append("peer-store (IPC-mapped peer buffers, 2 launches per step, the wait kernel on a side stream: it overlaps "
+                               "the next step's compute; the timed region ends with a device-wide synchronize)" if pg_ is not None else
                                "rccl all_gather_into_tensor" if use_dist else "none (one rank)")
             sync()
 

@@ -191,6 +191,13 @@ TPP_XSMM_EXPORT int xsmm_hip_ipc_close(void *ptr);
 TPP_XSMM_EXPORT void xsmm_hip_peer_gather(const void *src, int64_t bytes, int64_t dst_offset, int64_t world, int64_t rank,
                                           void *const *dst, void *const *flags, void *const *ready, void *my_flags, void *my_ready,
                                           void *ticket, void *err, int64_t epoch);
+/* OVERLAP mode of the peer gather (0 / 1, returns the previous setting): the wait kernel goes to a side stream, so the transfer
+ * time of a step's blocks no longer sits between this step's kernels and the next step's on the runtime's stream. The gathered
+ * output of a step is then complete when the SIDE stream has passed that step's wait kernel: xsmm_hip_peer_drain() blocks the
+ * host until it has; xsmm_hip_peer_wait_stream() returns the stream (hipStream_t) for an event-based dependence. */
+TPP_XSMM_EXPORT int xsmm_hip_peer_overlap(int enable);
+TPP_XSMM_EXPORT void *xsmm_hip_peer_wait_stream(void);
+TPP_XSMM_EXPORT void xsmm_hip_peer_drain(void);
 /* counters of the tile queue since process start: out[0] grouped launches, out[1] invokes queued with the full
  * dependence bookkeeping, out[2] invokes queued by replay of a recorded group (trace cache), out[3] groups ended by
  * a remembered terminator, out[4] replays abandoned (the caller left the recorded group) */

@@ -49,6 +49,39 @@ def main():
         parts = [torch.empty(mine.rows * N // 2, dtype=torch.int32) for _ in range(world)]  # (gloo has no int16: pairs as int32)
         dist.all_gather(parts, out.cpu().view(torch.int32))
         assert torch.equal(full.cpu().view(torch.int32), torch.cat(parts)), "step %d rank %d: gathered output differs from the gloo all_gather" % (step, rank)
+    # OVERLAP mode: the wait kernels on a side stream. (a) step by step; (b) a pipelined burst - no host synchronisation between
+    # the steps, output e is consumed (cloned on the compute stream behind an event of the side stream) after step e+1 has been
+    # computed and before it is gathered, which is the ordering the mode asks of a consumer
+    pg.overlap(True)
+    side = torch.cuda.ExternalStream(rt.lib.xsmm_hip_peer_wait_stream())
+    for step in range(6, 9):
+        X = dev(orc.f32_to_bf16(np.random.default_rng(100 + step).uniform(-1, 1, batch * N).astype(np.float32)))
+        out = mine.forward(X[mine.row0 * N:(mine.row0 + mine.rows) * N], W, B, acts)
+        full = pg.gather(out, mine.rows * N * 2, mine.row0 * N * 2)
+        ref = whole.forward(X, W, B, wacts)
+        rt.synchronize()
+        pg.check()
+        assert torch.equal(full, ref), "overlap step %d rank %d: gathered output differs from the unsharded result" % (step, rank)
+    Xs = [dev(orc.f32_to_bf16(np.random.default_rng(200 + i).uniform(-1, 1, batch * N).astype(np.float32))) for i in range(7)]
+    torch.cuda.synchronize()
+    got, prev_full = [], None
+    for i in range(7):
+        out = mine.forward(Xs[i][mine.row0 * N:(mine.row0 + mine.rows) * N], W, B, acts)
+        if prev_full is not None:
+            ev = torch.cuda.Event()
+            ev.record(side)
+            torch.cuda.current_stream().wait_event(ev)
+            got.append(prev_full.clone())
+        prev_full = pg.gather(out, mine.rows * N * 2, mine.row0 * N * 2)
+    rt.synchronize()
+    pg.check()
+    got.append(prev_full.clone())
+    torch.cuda.synchronize()
+    for i in range(7):
+        ref = whole.forward(Xs[i], W, B, wacts)
+        rt.synchronize()
+        assert torch.equal(got[i], ref), "pipelined step %d rank %d: gathered output differs from the unsharded result" % (i, rank)
+    pg.overlap(False)
     # the price of the gather itself: 200 steps of a 1 MiB block per rank, nothing else on the stream
     blk = torch.zeros(512 * 1024, dtype=torch.int16, device="cuda")
     pg2 = pkg.PeerGather.create(rt, rank, world, world * blk.numel() * 2)

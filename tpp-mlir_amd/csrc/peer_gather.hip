@@ -18,6 +18,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
+#include <mutex>
 
 namespace {
 
@@ -102,6 +104,38 @@ __global__ __launch_bounds__(64) void peer_wait_kernel(unsigned *my_flags, int w
 } // namespace
 
 extern "C" void *xsmm_hip_get_stream(void);
+
+namespace {
+// OVERLAP mode: the wait kernel of a gather goes to a side stream. The scatter stays on the runtime's stream (it reads the rank's
+// fresh output), but waiting for the PEERS' blocks to land - the xGMI transfer time of the step - no longer sits between this
+// step's kernels and the next step's: the next step's compute starts right behind the scatter. The wait kernel needs no stream
+// order to be correct (it polls the flags of ITS epoch; this rank's own flag is raised by its own scatter), it is one wave without
+// LDS (it fits beside a chain kernel that fills every CU), and buffer re-use across steps is guarded by the ready words as before.
+// What changes for the caller: "the gathered output of step e is complete" is the side stream's business - xsmm_hip_peer_drain()
+// (host) or an event on xsmm_hip_peer_wait_stream() before consuming it.
+std::atomic<int> g_overlap{0};
+hipStream_t g_wait_stream = nullptr;
+std::mutex g_wait_mu;
+hipStream_t wait_stream() {
+  std::lock_guard<std::mutex> lk(g_wait_mu);
+  if (!g_wait_stream) PG_OK(hipStreamCreateWithFlags(&g_wait_stream, hipStreamNonBlocking));
+  return g_wait_stream;
+}
+} // namespace
+
+extern "C" int xsmm_hip_peer_overlap(int enable) {
+  if (enable) (void)wait_stream();
+  return g_overlap.exchange(enable != 0);
+}
+extern "C" void *xsmm_hip_peer_wait_stream(void) { return (void *)wait_stream(); }
+extern "C" void xsmm_hip_peer_drain(void) {
+  hipStream_t s = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_wait_mu);
+    s = g_wait_stream;
+  }
+  if (s) PG_OK(hipStreamSynchronize(s));
+}
 
 // a dedicated, zeroed device allocation (IPC handles name whole allocations: nothing here is carved out of a caching allocator)
 // Small allocations (<= 64 KiB: the flag / ready / ticket / err words that peers on OTHER devices write and this device polls) are
@@ -191,6 +225,7 @@ extern "C" void xsmm_hip_peer_gather(const void *src, int64_t bytes, int64_t dst
   hipStream_t s = (hipStream_t)xsmm_hip_get_stream();
   hipLaunchKernelGGL(peer_scatter_kernel, dim3((unsigned)a.chunks, (unsigned)world), dim3(256), 0, s, a);
   PG_OK(hipGetLastError());
-  hipLaunchKernelGGL(peer_wait_kernel, dim3(1), dim3(64), 0, s, (unsigned *)my_flags, (int)world, (unsigned)epoch, (unsigned *)err);
+  hipStream_t ws = g_overlap.load(std::memory_order_relaxed) ? wait_stream() : s;
+  hipLaunchKernelGGL(peer_wait_kernel, dim3(1), dim3(64), 0, ws, (unsigned *)my_flags, (int)world, (unsigned)epoch, (unsigned *)err);
   PG_OK(hipGetLastError());
 }

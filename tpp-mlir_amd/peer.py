@@ -139,8 +139,18 @@ class PeerGather:
                                          self._ready, self._my_flags, self._my_ready, self._ticket, self._err, self.epoch)
         return self.full[par]
 
+    def overlap(self, enable=True):
+        """the wait kernels on a side stream (csrc/peer_gather.hip): the next step's compute starts behind the scatter instead of
+        behind the arrival of every peer's block. Process-wide switch; call drain() (or synchronize the device) before reading a
+        gathered output."""
+        return bool(self.rt.lib.xsmm_hip_peer_overlap(1 if enable else 0))
+
+    def drain(self):
+        self.rt.lib.xsmm_hip_peer_drain()
+
     def check(self):
         """after a synchronize: did a wait time out (a peer died / never arrived)?"""
+        self.drain()
         e = int(self._err_view.cpu()[0])
         if e:
             raise RuntimeError("peer-store gather timed out (code 0x%x): a peer never arrived" % e)

@@ -87,6 +87,9 @@ _SIGNATURES = {
     "xsmm_hip_ipc_open": (VP, [VP]),
     "xsmm_hip_ipc_close": (ctypes.c_int, [VP]),
     "xsmm_hip_peer_gather": (None, [VP, I64, I64, I64, I64, ctypes.POINTER(VP), ctypes.POINTER(VP), ctypes.POINTER(VP), VP, VP, VP, VP, I64]),
+    "xsmm_hip_peer_overlap": (ctypes.c_int, [ctypes.c_int]),
+    "xsmm_hip_peer_wait_stream": (VP, []),
+    "xsmm_hip_peer_drain": (None, []),
     "xsmm_hip_tile_queue_stats": (None, [ctypes.POINTER(ctypes.c_int64)]),
     "xsmm_hip_get_stream": (VP, []),
     "xsmm_hip_synchronize": (None, []),
