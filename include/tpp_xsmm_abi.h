@@ -194,7 +194,9 @@ TPP_XSMM_EXPORT void xsmm_hip_peer_gather(const void *src, int64_t bytes, int64_
 /* OVERLAP mode of the peer gather (0 / 1, returns the previous setting): the wait kernel goes to a side stream, so the transfer
  * time of a step's blocks no longer sits between this step's kernels and the next step's on the runtime's stream. The gathered
  * output of a step is then complete when the SIDE stream has passed that step's wait kernel: xsmm_hip_peer_drain() blocks the
- * host until it has; xsmm_hip_peer_wait_stream() returns the stream (hipStream_t) for an event-based dependence. */
+ * host until it has; xsmm_hip_peer_wait_stream() returns the stream (hipStream_t) for an event-based dependence. A consumer of
+ * the output of step e must run before this rank enqueues the gather of step e+1 on the runtime's stream (the peers take "rank r
+ * has entered gather e+1" as the licence to overwrite the buffer of step e at step e+2, exactly as without the overlap). */
 TPP_XSMM_EXPORT int xsmm_hip_peer_overlap(int enable);
 TPP_XSMM_EXPORT void *xsmm_hip_peer_wait_stream(void);
 TPP_XSMM_EXPORT void xsmm_hip_peer_drain(void);
