@@ -27,8 +27,8 @@ constexpr int LW_NSLOT = 4; // LDS ring slots
 
 typedef __attribute__((address_space(3))) void lds_void_lw;
 
-template <int WM, int WN, int WK, bool GROUPED>
-__global__ __launch_bounds__(64 * (WM * WN * WK + 2)) void brgemm_f32_lw(GemmArgs p, const WorkItem *__restrict__ items) {
+template <int WM, int WN, int WK, bool GROUPED, int NL = 1>
+__global__ __launch_bounds__(64 * (WM * WN * WK + 2 * NL)) void brgemm_f32_lw(GemmArgs p, const WorkItem *__restrict__ items) {
   constexpr int NMW = WM * WN * WK; // MFMA waves
   constexpr int BM = 32 * WM, BN = 32 * WN;
   constexpr int A_STAGE = BM * LW_BK, B_STAGE = LW_BK * BN, SLOT = A_STAGE + B_STAGE; // floats
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + 2)) void brgemm_f32_lw(GemmArg
   // the two loader waves are the FIRST two hardware waves of the workgroup (waves start in order: the panels' first
   // chunks are requested before the MFMA waves have been launched); `wave` is the role index: MFMA waves 0 .. NMW-1, loaders NMW, NMW+1
   const int hw_wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wave = TPP_LW_LOADERS_FIRST ? (hw_wave < 2 ? NMW + hw_wave : hw_wave - 2) : hw_wave;
+  const int wave = TPP_LW_LOADERS_FIRST ? (hw_wave < 2 * NL ? NMW + hw_wave : hw_wave - 2 * NL) : hw_wave;
   // XCD-blocked (8, bn, bm) or plain (1, tiles_n, tiles_m) grid: see brgemm_f32.hip. GROUPED (tile queue): grid (items,
   // tiles_n, tiles_m), workgroup = one tile of one queued invoke, operands and batch count from its item. A template
   // parameter, not a run-time test: the plain kernel is the headline kernel and must not carry a second mode (measured: 0.6 %).
@@ -63,7 +63,9 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + 2)) void brgemm_f32_lw(GemmArg
 
   if (wave >= NMW) {
     // ---- loader waves --------------------------------------------------------------------
-    const bool isA = wave == NMW;
+    const bool isA = (wave - NMW) < NL; // NL loader waves per panel: wave `part` issues the instructions part, part + NL, ...
+    const int part = (wave - NMW) % NL;
+    static_assert(NA % NL == 0 && NB % NL == 0, "panel instructions divide over the loader waves");
     // per-lane source offsets, constant for the whole kernel. A instruction v covers rows 4v .. 4v+3
     // (lane -> row 4v + lane/16, 16-byte piece lane%16, XOR-ed with row&15 = 4(v&3) + lane/16: the
     // fragment read applies the same XOR); the 16-row group v>>2 goes into the scalar offset.
@@ -72,6 +74,12 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + 2)) void brgemm_f32_lw(GemmArg
     for (int j = 0; j < 4; ++j) {
       const int r = 4 * j + (lane >> 4);
       voA[j] = (unsigned)((r * (int)p.lda + 4 * ((lane & 15) ^ r)) * 4);
+    }
+    unsigned voA2[2]; // NL = 2: this wave's instructions have v & 3 = part and part + 2
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = 4 * (part + 2 * j) + (lane >> 4);
+      voA2[j] = (unsigned)((r * (int)p.lda + 4 * ((lane & 15) ^ r)) * 4);
     }
     const unsigned voB = (unsigned)(((lane / (BN / 4)) * (int)p.ldb + 4 * (lane % (BN / 4))) * 4);
     const unsigned stepA = (unsigned)(16 * (int)p.lda * 4), stepB = (unsigned)(RPI * (int)p.ldb * 4);
@@ -84,12 +92,17 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + 2)) void brgemm_f32_lw(GemmArg
       const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)g, 0, 0x7fffffff, 0x00020000);
       if (isA) {
 #pragma unroll
-        for (int v = 0; v < NA; ++v)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_lw *)(base + v * 256), 16, voA[v & 3], (v >> 2) * stepA, 0, 0);
+        for (int i = 0; i < NA / NL; ++i) {
+          const int v = part + NL * i; // (NL = 2: v & 3 is part or part + 2 - both live in voA)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_lw *)(base + v * 256), 16, NL == 1 ? voA[i & 3] : voA2[i & 1],
+                                                   (unsigned)(v >> 2) * stepA, 0, 0);
+        }
       } else {
 #pragma unroll
-        for (int v = 0; v < NB; ++v)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_lw *)(base + v * 256), 16, voB, v * stepB, 0, 0);
+        for (int i = 0; i < NB / NL; ++i) {
+          const int v = part + NL * i;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_lw *)(base + v * 256), 16, voB, (unsigned)v * stepB, 0, 0);
+        }
       }
       if (++kc == kchunks) {
         kc = 0;
@@ -102,11 +115,11 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + 2)) void brgemm_f32_lw(GemmArg
     auto wait_left = [&](int chunks) __attribute__((always_inline)) {
       if (chunks == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else if (isA) {
-        if (chunks == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NA) : "memory");
+        if (chunks == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA / NL) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NA / NL) : "memory");
       } else {
-        if (chunks == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NB) : "memory");
+        if (chunks == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB / NL) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NB / NL) : "memory");
       }
     };
     // Prologue: chunks 0 and 1 are requested, chunk 0 is PUBLISHED as soon as it has landed, chunk 2 follows behind the barrier.
@@ -252,11 +265,11 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + 2)) void brgemm_f32_lw(GemmArg
   }
 }
 
-template <int WM, int WN, int WK> static hipError_t launch_lw_t(const GemmArgs &a, hipStream_t s) {
-  constexpr int BM = 32 * WM, BN = 32 * WN, NT = 64 * (WM * WN * WK + 2);
+template <int WM, int WN, int WK, int NL = 1> static hipError_t launch_lw_t(const GemmArgs &a, hipStream_t s) {
+  constexpr int BM = 32 * WM, BN = 32 * WN, NT = 64 * (WM * WN * WK + 2 * NL);
   constexpr size_t lds = (size_t)LW_NSLOT * (BM * LW_BK + LW_BK * BN) * sizeof(float);
   static std::atomic<unsigned long long> lds_set{0};
-  if (hipError_t e = ensure_dynamic_lds((const void *)brgemm_f32_lw<WM, WN, WK, false>, (int)lds, lds_set); e != hipSuccess) return e;
+  if (hipError_t e = ensure_dynamic_lds((const void *)brgemm_f32_lw<WM, WN, WK, false, NL>, (int)lds, lds_set); e != hipSuccess) return e;
   GemmArgs args = a;
   const int tiles_m = a.m / BM, tiles_n = a.n / BN;
   dim3 grid;
@@ -269,7 +282,7 @@ template <int WM, int WN, int WK> static hipError_t launch_lw_t(const GemmArgs &
     if (tiles_m > 65535 || tiles_n > 65535) return hipErrorInvalidValue;
     grid = dim3(1, tiles_n, tiles_m);
   }
-  hipLaunchKernelGGL((brgemm_f32_lw<WM, WN, WK, false>), grid, dim3(NT), lds, s, args, (const WorkItem *)nullptr);
+  hipLaunchKernelGGL((brgemm_f32_lw<WM, WN, WK, false, NL>), grid, dim3(NT), lds, s, args, (const WorkItem *)nullptr);
   return hipGetLastError();
 }
 
@@ -302,7 +315,9 @@ hipError_t launch_f32_lw_grouped(int tile, const GemmArgs &a, const WorkItem *it
 hipError_t launch_f32_lw(int tile, const GemmArgs &a, hipStream_t s) {
   switch (tile) {
   case 0: return launch_lw_t<2, 2, 1>(a, s);
-  case 1: return launch_lw_t<2, 2, 2>(a, s);
+  // two loader waves per panel for the 8-wave tile (C2): the 16 + 16 requests of a chunk - above all of chunk 0, which every MFMA
+  // wave waits for - go out in half the time; same-box A/B 18.10 -> 17.97 us. The 64x32 tile (C3) measured 1 % slower with them.
+  case 1: return launch_lw_t<2, 2, 2, 2>(a, s);
   case 2: return launch_lw_t<2, 1, 2>(a, s);
   case 3: return launch_lw_t<1, 1, 4>(a, s);
   default: return hipErrorInvalidValue;
