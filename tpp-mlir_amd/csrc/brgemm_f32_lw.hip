@@ -75,7 +75,7 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + 2 * NL)) void brgemm_f32_lw(Ge
       const int r = 4 * j + (lane >> 4);
       voA[j] = (unsigned)((r * (int)p.lda + 4 * ((lane & 15) ^ r)) * 4);
     }
-    unsigned voA2[2]; // NL = 2: this wave's instructions have v & 3 = part and part + 2
+    unsigned voA2[2]; // NL = 2: this wave's instructions have v & 3 = part and part + 2 (NL = 4: always part)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int r = 4 * (part + 2 * j) + (lane >> 4);
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + 2 * NL)) void brgemm_f32_lw(Ge
 #pragma unroll
         for (int i = 0; i < NA / NL; ++i) {
           const int v = part + NL * i; // (NL = 2: v & 3 is part or part + 2 - both live in voA)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_lw *)(base + v * 256), 16, NL == 1 ? voA[i & 3] : voA2[i & 1],
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_lw *)(base + v * 256), 16, NL == 1 ? voA[i & 3] : NL == 2 ? voA2[i & 1] : voA2[0],
                                                    (unsigned)(v >> 2) * stepA, 0, 0);
         }
       } else {
@@ -317,7 +317,7 @@ hipError_t launch_f32_lw(int tile, const GemmArgs &a, hipStream_t s) {
   case 0: return launch_lw_t<2, 2, 1>(a, s);
   // two loader waves per panel for the 8-wave tile (C2): the 16 + 16 requests of a chunk - above all of chunk 0, which every MFMA
   // wave waits for - go out in half the time; same-box A/B 18.10 -> 17.97 us. The 64x32 tile (C3) measured 1 % slower with them.
-  case 1: return launch_lw_t<2, 2, 2, 2>(a, s);
+  case 1: return launch_lw_t<2, 2, 2, 2>(a, s); // (four per panel: 18.25 us)
   case 2: return launch_lw_t<2, 1, 2>(a, s);
   case 3: return launch_lw_t<1, 1, 4>(a, s);
   default: return hipErrorInvalidValue;
