@@ -508,4 +508,7 @@ def test_trace_cache_with_several_callers(rtq):
     for layer in range(3):
         close(host(acts[layer], X), ref2[layer], F32)
     launches, checked, replayed, terminated, abandoned = (b - a for a, b in zip(stats0, rt.tile_queue_stats()))
-    assert replayed > 0 and abandoned > 0, (launches, checked, replayed, terminated, abandoned)
+    # (how a divergence ends a replay depends on the interleaving: an unknown invoke abandons it, an invoke of another recorded
+    # group that arrives at a complete group just terminates it - the results above are the check, the counters only say that
+    # the cache was in use)
+    assert replayed > 0 and abandoned + terminated > 0, (launches, checked, replayed, terminated, abandoned)

@@ -641,7 +641,7 @@ enum GemmVariant : int {
   V_F32_64x64K2 = 4, // 8 waves 2x2x2 (two waves per SIMD share every K chunk)
   V_F32_LW_64x64 = 5,     // brgemm_f32_lw.hip: 4 MFMA waves 2x2x1 + 2 loader waves
   V_F32_LW_64x64K2 = 6,   // 8 MFMA waves 2x2x2 + 2 loader waves
-  V_F32_LW_64x32K2 = 7,   // 4 MFMA waves 2x1x2 + 2 loader waves
+  V_F32_LW_64x32K2 = 7,   // 8 MFMA waves 2x1x4 + 2 loader waves (K split over four groups since round 3; the name of the constant stayed)
   V_GENERIC = 8,     // chosen per invoke when the fast preconditions fail
   V_F32_LW_32x32K4 = 9,   // 4 MFMA waves 1x1x4 + 2 loader waves
   V_BF16_FAST = 16,  // brgemm_bf16.hip: 64x64 register-staged
@@ -845,7 +845,7 @@ static const char *variant_name(int v) {
   case V_F32_64x64K2: return "brgemm_f32_fast<64x64,k2>";
   case V_F32_LW_64x64: return "brgemm_f32_fast_lw<64x64,k1>";
   case V_F32_LW_64x64K2: return "brgemm_f32_fast_lw<64x64,k2>";
-  case V_F32_LW_64x32K2: return "brgemm_f32_fast_lw<64x32,k2>";
+  case V_F32_LW_64x32K2: return "brgemm_f32_fast_lw<64x32,k4>";
   case V_F32_LW_32x32K4: return "brgemm_f32_fast_lw<32x32,k4>";
   case V_BF16_FAST: return "brgemm_bf16_fast<64x64>";
   case V_BF16_DMA128: return "brgemm_bf16_dma<128x128>";

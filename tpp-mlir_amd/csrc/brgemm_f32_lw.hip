@@ -304,21 +304,23 @@ hipError_t launch_f32_lw_grouped(int tile, const GemmArgs &a, const WorkItem *it
   switch (tile) {
   case 0: return launch_lw_grouped_t<2, 2, 1>(a, items, n_items, s);
   case 1: return launch_lw_grouped_t<2, 2, 2>(a, items, n_items, s);
-  case 2: return launch_lw_grouped_t<2, 1, 2>(a, items, n_items, s);
+  case 2: return launch_lw_grouped_t<2, 1, 4>(a, items, n_items, s);
   case 3: return launch_lw_grouped_t<1, 1, 4>(a, items, n_items, s);
   default: return hipErrorInvalidValue;
   }
 }
 
 // tile: 0 = 64x64 (4 MFMA waves), 1 = 64x64 with K split over 2 wave groups (8 MFMA waves, two per
-// SIMD), 2 = 64x32 with K split over 2 (4 MFMA waves), 3 = 32x32 with K split over 4 (4 MFMA waves)
+// SIMD), 2 = 64x32 with K split over 4 (8 MFMA waves), 3 = 32x32 with K split over 4 (4 MFMA waves)
 hipError_t launch_f32_lw(int tile, const GemmArgs &a, hipStream_t s) {
   switch (tile) {
   case 0: return launch_lw_t<2, 2, 1>(a, s);
   // two loader waves per panel for the 8-wave tile (C2): the 16 + 16 requests of a chunk - above all of chunk 0, which every MFMA
   // wave waits for - go out in half the time; same-box A/B 18.10 -> 17.97 us. The 64x32 tile (C3) measured 1 % slower with them.
   case 1: return launch_lw_t<2, 2, 2, 2>(a, s); // (four per panel: 18.25 us)
-  case 2: return launch_lw_t<2, 1, 2>(a, s);
+  // 64x32 with K split over FOUR wave groups: 8 MFMA waves = two per SIMD, like the 64x64 k2 tile - one wave's fragment reads and
+  // barrier waits hide behind the other's MFMAs. C3 (512 x 1024 x 1024): 10.52 -> 10.21 us same-box against the K2 split (4 waves).
+  case 2: return launch_lw_t<2, 1, 4>(a, s);
   case 3: return launch_lw_t<1, 1, 4>(a, s);
   default: return hipErrorInvalidValue;
   }
