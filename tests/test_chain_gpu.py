@@ -347,3 +347,44 @@ def test_sharded_mlp_forward_uses_the_chain(rt):
             assert np.abs(a - c).max() <= 0.02 * max(1.0, np.abs(c).max()), "ShardedMlp layer %d" % l
     finally:
         rt.set_async(was_async)
+
+
+def test_chain_call_captured_into_a_graph_runs_as_separate_launches(rt):
+    """a launch's hand-off target is baked into its arguments, so a CAPTURED chain call must not become the one-launch kernel: replayed
+    from the graph its consumers would not wait. Inside a capture the call falls back to the separate launches (return value False);
+    the graph is replayed three times on fresh inputs and must match the un-captured chain bit for bit every time."""
+    import torch
+    ch = Chain(rt, 256, [256, 256, 256, 256], seed=21, force=20)
+    was_async = rt.set_async(True)
+    try:
+        dx = dev(ch.new_input())
+        acts_g = [dev(np.zeros(256 * 256, np.uint16)) for _ in range(3)]
+        acts_r = [dev(np.zeros(256 * 256, np.uint16)) for _ in range(3)]
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        fused_in_capture = []
+        with torch.cuda.stream(s):
+            rt.set_stream(s)
+            rt.fused_brgemm_chain(BF16, ch.calls(dx, acts_g))  # warm up outside the capture
+            s.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s, capture_error_mode="relaxed"):
+                fused_in_capture.append(rt.fused_brgemm_chain(BF16, ch.calls(dx, acts_g)))
+        rt.set_stream(None)
+        torch.cuda.synchronize()
+        assert fused_in_capture == [False], "a captured chain call must not use the one-launch kernel"
+        for rep in range(3):
+            dx.copy_(dev(ch.new_input()))
+            for a in acts_g:
+                a.fill_(0x7fc0)
+            torch.cuda.synchronize()
+            g.replay()
+            assert rt.fused_brgemm_chain(BF16, ch.calls(dx, acts_r))
+            rt.synchronize()
+            torch.cuda.synchronize()
+            for l in range(3):
+                assert torch.equal(acts_g[l], acts_r[l]), "replay %d layer %d differs from the un-captured chain" % (rep, l)
+    finally:
+        rt.set_stream(None)
+        rt.synchronize()
+        rt.set_async(was_async)

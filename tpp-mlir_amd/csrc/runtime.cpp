@@ -1831,6 +1831,13 @@ bool try_chain_launch(int n, const GemmDesc *const *d, void *const *pa, void *co
   } while (0)
   if (n < 2 || n > CH_MAXL) NOCHAIN("fewer than 2 or more than 8 calls");
   if (!cfg().async.load(std::memory_order_relaxed)) NOCHAIN("synchronous mode");
+  {
+    // a launch's hand-off target (epoch x tiles per row block) is baked into its arguments: replayed from a graph it would be
+    // stale - the consumers would not wait. Captured streams get the separate launches.
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(cfg().stream.load(std::memory_order_relaxed), &cs) != hipSuccess) (void)hipGetLastError();
+    else if (cs != hipStreamCaptureStatusNone) NOCHAIN("the stream is being captured into a graph");
+  }
   static const int enabled = [] {
     const char *e = getenv("TPP_HIP_CHAIN");
     return e ? atoi(e) : 1;
