@@ -223,6 +223,15 @@ extern "C" void xsmm_hip_peer_gather(const void *src, int64_t bytes, int64_t dst
   const long long cap = 1024 / world > 1 ? 1024 / world : 1;
   a.chunks = (int)(chunks < 1 ? 1 : chunks > cap ? cap : chunks);
   hipStream_t s = (hipStream_t)xsmm_hip_get_stream();
+  {
+    // the epoch is an argument of both kernels: replayed from a graph the flags would never reach it again
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+      fprintf(stderr, "tpp-xsmm-hip: xsmm_hip_peer_gather cannot be captured into a graph (its epoch is per call)\n");
+      exit(-1);
+    }
+    (void)hipGetLastError();
+  }
   hipLaunchKernelGGL(peer_scatter_kernel, dim3((unsigned)a.chunks, (unsigned)world), dim3(256), 0, s, a);
   PG_OK(hipGetLastError());
   hipStream_t ws = g_overlap.load(std::memory_order_relaxed) ? wait_stream() : s;
