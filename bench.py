@@ -548,11 +548,12 @@ def main():
         if world == 1:
             # what every rank of a world of 2 / 4 / 8 GPUs would run per step (its row share, no collective), measured on THIS GPU:
             # the one-launch chain and the same share as three launches; python path (this harness) and native (tools/mlp_probe)
-            _, _, _, t3 = run_mlp(4096, K, W, chain=False)
+            Ks = max(K, 200)  # (short steps: the synchronizes around a 20-step region would be 5-10 % of it)
+            _, _, _, t3 = run_mlp(4096, Ks, W, chain=False)
             shares = {"1": {"rows": 4096, "chain_us": round(mcompute * 1e6, 2), "three_launches_us": round(t3 * 1e6, 2)}}
             for w_ in (2, 4, 8):
-                _, sh_c, _, tc_ = run_mlp(4096, K, W, chain=True, as_world=w_, as_rank=w_ - 1)
-                _, sh_l, _, tl_ = run_mlp(4096, K, W, chain=False, as_world=w_, as_rank=w_ - 1)
+                _, sh_c, _, tc_ = run_mlp(4096, Ks, W, chain=True, as_world=w_, as_rank=w_ - 1)
+                _, sh_l, _, tl_ = run_mlp(4096, Ks, W, chain=False, as_world=w_, as_rank=w_ - 1)
                 shares[str(w_)] = {"rows": sh_c.rows, "chain_us": round(tc_ * 1e6, 2), "three_launches_us": round(tl_ * 1e6, 2),
                                    "one_launch": bool(sh_c.last_step_fused), "kernel": rt.kernel_name(sh_l.handles[0][0])}
             mlp["per_rank_step_us"] = shares
