@@ -138,13 +138,18 @@ extern "C" void xsmm_hip_peer_drain(void) {
 }
 
 // a dedicated, zeroed device allocation (IPC handles name whole allocations: nothing here is carved out of a caching allocator)
-// Small allocations (<= 64 KiB: the flag / ready / ticket / err words that peers on OTHER devices write and this device polls) are
-// taken FINE-GRAINED when the runtime offers it: such memory is not held in this device's L2, so a poll cannot be served a stale line
-// that a remote store never touched. The data buffers stay ordinary device memory: they are read by kernels launched AFTER the wait
-// kernel has seen the flags (a launch boundary invalidates the L2).
+// Peer-visible allocations - the flag / ready words that peers on OTHER devices write and this device polls, and the output
+// buffers they store their row blocks into - are taken FINE-GRAINED when the runtime offers it: such memory is not held in this
+// device's L2, so neither a poll nor a later read of a gathered output can be served a stale line that a remote store never
+// touched (a remote write reaches the memory, not this device's cache). Ordinary device memory is the fallback; PeerGather's
+// self-test (peer.py: three gathers incl. a re-use of a buffer this device has read before) decides whether the result can be used.
 extern "C" void *xsmm_hip_peer_alloc(int64_t bytes) {
   void *p = nullptr;
-  if (bytes <= 65536 && hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocFinegrained) == hipSuccess && p) {
+  static const bool fine = [] {
+    const char *e = getenv("TPP_HIP_PEER_FINEGRAINED"); // 0: plain hipMalloc (A/B runs)
+    return !e || atoi(e) != 0;
+  }();
+  if (fine && hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocFinegrained) == hipSuccess && p) {
     hipIpcMemHandle_t probe;
     if (hipIpcGetMemHandle(&probe, p) == hipSuccess) { // (only if it can be shared like the others)
       PG_OK(hipMemset(p, 0, (size_t)bytes));
