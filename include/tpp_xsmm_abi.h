@@ -222,7 +222,7 @@ TPP_XSMM_EXPORT int xsmm_hip_device_count(void);
 /* Name of the HIP kernel variant a GEMM-like handle selected, for profiles. */
 TPP_XSMM_EXPORT const char *xsmm_hip_kernel_name(int64_t handle);
 /* Force a GEMM tile variant for A/B benchmarking and tests (-1 = automatic): f32 0..4 (64x64,
- * 64x32+K2, 32x32+K4, 128x64, 64x64+K2), 5..7 the loader-wave kernels (64x64, 64x64+K2, 64x32+K4), 8 generic, bf16 16 / 17 / 18 / 19 (64x64, 128x128, 256x256, 32x32 + K split),
+ * 64x32+K2, 32x32+K4, 128x64, 64x64+K2), 5..7 the loader-wave kernels (64x64, 64x64+K2, 64x32+K4), 8 generic, 9 / 10 loader-wave 32x32+K4 / 128x64, bf16 16 / 17 / 18 / 19 (64x64, 128x128, 256x256, 32x32 + K split),
  * 20 .. 23 the bf16 loader-wave tiles for mid-size outputs (32x64 + K split, 64x64, 64x128, 128x128).
  * Honoured at dispatch when the shape divides the tile. */
 TPP_XSMM_EXPORT void xsmm_hip_force_variant(int variant);

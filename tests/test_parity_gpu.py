@@ -212,18 +212,18 @@ def test_brgemm_f32_fast_variants(rt, case):
 
 
 @pytest.mark.parametrize("variant,m,n", [(0, 128, 128), (1, 128, 96), (2, 96, 96), (3, 256, 128), (4, 128, 128),
-                                         (5, 128, 128), (6, 128, 192), (7, 128, 96), (9, 96, 96)])
+                                         (5, 128, 128), (6, 128, 192), (7, 128, 96), (9, 96, 96), (10, 256, 128)])
 def test_brgemm_f32_forced_tile_variants(rt, variant, m, n):
     gemm_case(rt, F32, m, n, 64, 4, sa=64, lda=256, sb=64 * n, beta0=False, bias=True, relu=True,
               seed=variant, force=variant)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 9])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 9, 10])
 @pytest.mark.parametrize("k,br", [(64, 0), (64, 1), (64, 2), (64, 3), (64, 4), (64, 5), (64, 7), (128, 3), (192, 2), (64, 16)])
 def test_brgemm_f32_chunk_stream_lengths(rt, variant, k, br):
     """every ring position of the uniform chunk loops (1 .. 16 chunks, chunk streams that wrap inside a batch
     element), for every fast f32 tile family incl. the loader-wave kernels, both accumulator starts"""
-    m, n = (256, 128) if variant == 3 else (128, 128)
+    m, n = (256, 128) if variant in (3, 10) else (128, 128)
     for beta0 in (True, False):
         name = gemm_case(rt, F32, m, n, k, br, lda=k * max(br, 1) + 8, ldb=n + 4, ldc=n + 4, sa=k, sb=k * (n + 4),
                          beta0=beta0, bias=not beta0, relu=beta0, seed=variant * 100 + k + br, force=variant,

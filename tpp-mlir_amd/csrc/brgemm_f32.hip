@@ -644,6 +644,7 @@ enum GemmVariant : int {
   V_F32_LW_64x32K2 = 7,   // 8 MFMA waves 2x1x4 + 2 loader waves (K split over four groups since round 3; the name of the constant stayed)
   V_GENERIC = 8,     // chosen per invoke when the fast preconditions fail
   V_F32_LW_32x32K4 = 9,   // 4 MFMA waves 1x1x4 + 2 loader waves
+  V_F32_LW_128x64 = 10,   // 8 MFMA waves 4x2x1 + 2 x 2 loader waves, 3-slot ring (large outputs)
   V_BF16_FAST = 16,  // brgemm_bf16.hip: 64x64 register-staged
   V_BF16_DMA128 = 17, // brgemm_bf16.hip: 128x128, LDS-DMA + loader waves
   V_BF16_DMA256 = 18, // brgemm_bf16_dma256.hip: 256x256, LDS-DMA
@@ -700,7 +701,7 @@ static hipError_t launch_fast(const GemmArgs &a, hipStream_t s) {
 }
 
 hipError_t launch_gemm_bf16_fast(int tile, const GemmArgs &a, hipStream_t s); // brgemm_bf16.hip
-hipError_t launch_f32_lw(int tile, const GemmArgs &a, hipStream_t s);         // brgemm_f32_lw.hip
+hipError_t launch_f32_lw(int tile, const GemmArgs &a, hipStream_t s);         // brgemm_f32_lw.hip (tile 4: 128x64, forced variant 10 only - it measures within 2 % of brgemm_f32_fast<128x64>)
 hipError_t launch_f32_lw_grouped(int tile, const GemmArgs &a, const WorkItem *items, int n_items, hipStream_t s);
 int pick_bf16_tile(const GemmDesc &d);
 bool bf16_fast_eligible(const GemmDesc &d);
@@ -847,6 +848,7 @@ static const char *variant_name(int v) {
   case V_F32_LW_64x64K2: return "brgemm_f32_fast_lw<64x64,k2>";
   case V_F32_LW_64x32K2: return "brgemm_f32_fast_lw<64x32,k4>";
   case V_F32_LW_32x32K4: return "brgemm_f32_fast_lw<32x32,k4>";
+  case V_F32_LW_128x64: return "brgemm_f32_fast_lw<128x64,k1>";
   case V_BF16_FAST: return "brgemm_bf16_fast<64x64>";
   case V_BF16_DMA128: return "brgemm_bf16_dma<128x128>";
   case V_BF16_DMA256: return "brgemm_bf16_dma<256x256>";
@@ -908,6 +910,7 @@ bool plan_gemm(GemmDesc &d, int forced_variant) {
     const int bm[] = {64, 64, 32, 128, 64, 64, 64, 64}, bn[] = {64, 32, 32, 64, 64, 64, 64, 32};
     if (forced_variant <= 7 && d.m % bm[forced_variant] == 0 && d.n % bn[forced_variant] == 0) v = forced_variant;
     if (forced_variant == V_F32_LW_32x32K4 && d.m % 32 == 0 && d.n % 32 == 0) v = forced_variant;
+    if (forced_variant == V_F32_LW_128x64 && d.m % 128 == 0 && d.n % 64 == 0) v = forced_variant;
     if (forced_variant == V_GENERIC) v = V_GENERIC;
   } else if (forced_variant == V_GENERIC) {
     v = V_GENERIC;
@@ -949,6 +952,7 @@ hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C,
   case V_F32_LW_64x64K2:
   case V_F32_LW_64x32K2: return launch_f32_lw(v - V_F32_LW_64x64, a, stream);
   case V_F32_LW_32x32K4: return launch_f32_lw(3, a, stream);
+  case V_F32_LW_128x64: return launch_f32_lw(4, a, stream);
   case V_BF16_FAST:
   case V_BF16_DMA128:
   case V_BF16_DMA256: return launch_gemm_bf16_fast(v - V_BF16_FAST, a, stream);

@@ -27,7 +27,8 @@ constexpr int LW_NSLOT = 4; // LDS ring slots
 
 typedef __attribute__((address_space(3))) void lds_void_lw;
 
-template <int WM, int WN, int WK, bool GROUPED, int NL = 1>
+// NSLOT: ring depth (4; 3 for the 128x64 tile, whose 48 KiB slots would not fit four times)
+template <int WM, int WN, int WK, bool GROUPED, int NL = 1, int NSLOT = LW_NSLOT>
 __global__ __launch_bounds__(64 * (WM * WN * WK + 2 * NL)) void brgemm_f32_lw(GemmArgs p, const WorkItem *__restrict__ items) {
   constexpr int NMW = WM * WN * WK; // MFMA waves
   constexpr int BM = 32 * WM, BN = 32 * WN;
@@ -36,7 +37,8 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + 2 * NL)) void brgemm_f32_lw(Ge
   constexpr int RPI = 256 / BN;    // B rows per DMA instruction
   constexpr int NB = LW_BK / RPI;  // DMA instructions per chunk of B
   constexpr int KB_PER_WAVE = 8 / WK, KB_HALF = KB_PER_WAVE / 2;
-  static_assert(KB_HALF >= 1 && NA <= 31 && NB <= 31, "tile outside the schedule's limits (vmcnt is 6 bits)");
+  static_assert(KB_HALF >= 1 && NA / NL <= 31 && NB / NL <= 31, "tile outside the schedule's limits (vmcnt is 6 bits)");
+  static_assert(NSLOT == 3 || NSLOT == 4, "ring depth");
   extern __shared__ __attribute__((aligned(16))) float smem_lw[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -130,11 +132,11 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + 2 * NL)) void brgemm_f32_lw(Ge
     if (T > 1) issue(1);
     wait_left(T > 1 ? 1 : 0);
     __builtin_amdgcn_s_barrier(); // chunk 0 published
-    if (T > 2) issue(2);
+    if (NSLOT > 3 && T > 2) issue(2); // (a 3-slot ring holds chunks t, t+1, t+2: nothing more before chunk 0 has been retired)
     for (int t = 0; t + 1 < T; ++t) {
-      wait_left(t + 2 < T ? 1 : 0); // chunk t+1 has landed (chunk t+2 may still fly)
-      __builtin_amdgcn_s_barrier();  // = the MFMA waves' mid-chunk barrier of chunk t
-      if (t + 3 < T) issue((t + 3) & (LW_NSLOT - 1)); // the slot of chunk t-1: every MFMA wave is past it
+      wait_left(NSLOT > 3 && t + 2 < T ? 1 : 0); // chunk t+1 has landed (4 slots: chunk t+2 may still fly)
+      __builtin_amdgcn_s_barrier();               // = the MFMA waves' mid-chunk barrier of chunk t
+      if (t + NSLOT - 1 < T) issue((t + NSLOT - 1) % NSLOT); // the slot of chunk t-1: every MFMA wave is past it
     }
     return; // ended waves do not take part in later barriers
   }
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + 2 * NL)) void brgemm_f32_lw(Ge
   };
   const int kbw = wk * KB_PER_WAVE;
   auto chunk = [&](auto slot_c, bool has_next) __attribute__((always_inline)) {
-    constexpr int S = decltype(slot_c)::value, NS = (S + 1) & (LW_NSLOT - 1);
+    constexpr int S = decltype(slot_c)::value, NS = (S + 1) % NSLOT;
 #pragma unroll
     for (int q = 0; q < KB_PER_WAVE; ++q) {
       const int cur = q & 1, nxt = cur ^ 1;
@@ -214,8 +216,10 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + 2 * NL)) void brgemm_f32_lw(Ge
       if (++t == T) break;
       chunk(S2{}, t + 1 < T);
       if (++t == T) break;
-      chunk(S3{}, t + 1 < T);
-      if (++t == T) break;
+      if constexpr (NSLOT > 3) {
+        chunk(S3{}, t + 1 < T);
+        if (++t == T) break;
+      }
     }
   }
 
@@ -265,11 +269,12 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + 2 * NL)) void brgemm_f32_lw(Ge
   }
 }
 
-template <int WM, int WN, int WK, int NL = 1> static hipError_t launch_lw_t(const GemmArgs &a, hipStream_t s) {
+template <int WM, int WN, int WK, int NL = 1, int NSLOT = LW_NSLOT> static hipError_t launch_lw_t(const GemmArgs &a, hipStream_t s) {
   constexpr int BM = 32 * WM, BN = 32 * WN, NT = 64 * (WM * WN * WK + 2 * NL);
-  constexpr size_t lds = (size_t)LW_NSLOT * (BM * LW_BK + LW_BK * BN) * sizeof(float);
+  constexpr size_t lds = (size_t)NSLOT * (BM * LW_BK + LW_BK * BN) * sizeof(float);
+  static_assert(lds <= 160 * 1024, "LDS budget");
   static std::atomic<unsigned long long> lds_set{0};
-  if (hipError_t e = ensure_dynamic_lds((const void *)brgemm_f32_lw<WM, WN, WK, false, NL>, (int)lds, lds_set); e != hipSuccess) return e;
+  if (hipError_t e = ensure_dynamic_lds((const void *)brgemm_f32_lw<WM, WN, WK, false, NL, NSLOT>, (int)lds, lds_set); e != hipSuccess) return e;
   GemmArgs args = a;
   const int tiles_m = a.m / BM, tiles_n = a.n / BN;
   dim3 grid;
@@ -282,7 +287,7 @@ template <int WM, int WN, int WK, int NL = 1> static hipError_t launch_lw_t(cons
     if (tiles_m > 65535 || tiles_n > 65535) return hipErrorInvalidValue;
     grid = dim3(1, tiles_n, tiles_m);
   }
-  hipLaunchKernelGGL((brgemm_f32_lw<WM, WN, WK, false, NL>), grid, dim3(NT), lds, s, args, (const WorkItem *)nullptr);
+  hipLaunchKernelGGL((brgemm_f32_lw<WM, WN, WK, false, NL, NSLOT>), grid, dim3(NT), lds, s, args, (const WorkItem *)nullptr);
   return hipGetLastError();
 }
 
@@ -322,6 +327,8 @@ hipError_t launch_f32_lw(int tile, const GemmArgs &a, hipStream_t s) {
   // barrier waits hide behind the other's MFMAs. C3 (512 x 1024 x 1024): 10.52 -> 10.21 us same-box against the K2 split (4 waves).
   case 2: return launch_lw_t<2, 1, 4>(a, s);
   case 3: return launch_lw_t<1, 1, 4>(a, s);
+  // 128x64 for large outputs: 8 MFMA waves (4 x 2 tiles of 32x32), two loader waves per panel, a 3-slot ring (48 KiB per slot)
+  case 4: return launch_lw_t<4, 2, 1, 2, 3>(a, s);
   default: return hipErrorInvalidValue;
   }
 }
