@@ -353,34 +353,37 @@ static inline bool aligned(const void *p, size_t a) { return (((uintptr_t)p) & (
 // read with 16-byte row pieces into LDS (row pitch 64+PAD elements), then every lane gathers
 // VEC elements of one input column (VEC small LDS reads) and stores them as 16 contiguous bytes
 // of an output row; consecutive lanes cover one contiguous output row segment.
-template <typename T, int TS>
+template <typename T, int TSR, int TSC>
 __global__ __launch_bounds__(256) void transpose_vec_kernel(int64_t m, int64_t n, int64_t ldi, int64_t ldo,
                                                             const T *__restrict__ in, T *__restrict__ out) {
-  // TS x TS tile; TS = 64 (f32) or 128 (bf16, when the shape allows): every row piece is then 256 bytes on both
-  // global sides (bf16 with 64-wide tiles moved 128-byte pieces 32 KiB apart: 4.3 TB/s at 16384^2)
-  constexpr int VEC = 16 / sizeof(T), TPR = TS / VEC, RPP = 256 / TPR; // threads per row, rows per pass
-  constexpr int PITCH = TS + (sizeof(T) == 4 ? 1 : 2);
-  __shared__ T tile[TS * PITCH];
+  // TSR x TSC tile of the INPUT (rows x columns): row pieces of TSC elements are read, row pieces of TSR elements are written.
+  // 128 x 128 when the shape allows (bf16 with 64-wide tiles moved 128-byte pieces 32 KiB apart: 4.3 TB/s at 16384^2; f32: see the
+  // launcher), else 64 x 64.
+  constexpr int VEC = 16 / sizeof(T), TPR = TSC / VEC, RPP = 256 / TPR; // threads per input row piece, input rows per pass
+  constexpr int TPO = TSR / VEC;                                        // threads per output row piece
+  constexpr int PITCH = TSC + (sizeof(T) == 4 ? 1 : 2);
+  extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[]; // TSR * PITCH elements (dynamic: 128 x 128 f32 is 64.5 KiB)
+  T *tile = (T *)tile_raw;
   // (a G x G super-block tile order was measured for DRAM page / TLB locality at 16384^2: no effect)
-  const int64_t tiles_n = n / TS;
+  const int64_t tiles_n = n / TSC;
   // DIAGONAL tile order: blocks that run at the same time (consecutive ids) then write to different column offsets
   // of the output AND different row groups - with the row-major order they all wrote row segments a whole number of
   // tile rows (a power of two of bytes for the usual shapes) apart, i.e. into the same memory channels. Measured
   // (profiles/r02_eltwise_bw.txt): f32 8192^2 4.33 -> 4.97 TB/s, 16384^2 4.53 -> 4.98, bf16 16384^2 4.14 -> 4.60.
   const int64_t ti = blockIdx.x / tiles_n, tj = (blockIdx.x % tiles_n + ti) % tiles_n;
-  const int64_t i0 = ti * TS, j0 = tj * TS;
+  const int64_t i0 = ti * TSR, j0 = tj * TSC;
   const int t = threadIdx.x;
 #pragma unroll
-  for (int r = t / TPR; r < TS; r += RPP) {
+  for (int r = t / TPR; r < TSR; r += RPP) {
     const Pack<T, VEC> v = *(const Pack<T, VEC> *)(in + (i0 + r) * ldi + j0 + (t % TPR) * VEC);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) tile[r * PITCH + (t % TPR) * VEC + e] = v.v[e];
   }
   __syncthreads();
-  // output row = input column c (TS of them), VEC consecutive output columns = input rows r0..r0+VEC-1
+  // output row = input column c (TSC of them), VEC consecutive output columns = input rows r0..r0+VEC-1
 #pragma unroll
-  for (int q = t; q < TS * TPR; q += 256) {
-    const int c = q / TPR, r0 = (q % TPR) * VEC; // TPR consecutive lanes = one contiguous output row segment
+  for (int q = t; q < TSC * TPO; q += 256) {
+    const int c = q / TPO, r0 = (q % TPO) * VEC; // TPO consecutive lanes = one contiguous output row segment
     Pack<T, VEC> v;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) v.v[e] = tile[(r0 + e) * PITCH + c];
@@ -400,12 +403,21 @@ static hipError_t launch_unary_t(const UnaryDesc &d, const void *in, float scala
   if (op == (int)U_TRANSPOSE) {
     const int64_t tiles = ((d.m + 63) / 64) * ((d.n + 63) / 64);
     const bool vec_ok = d.ldi % V == 0 && d.ldo % V == 0 && aligned(in, 16) && aligned(out, 16);
-    if (vec_ok && sizeof(T) == 2 && d.m % 128 == 0 && d.n % 128 == 0)
-      hipLaunchKernelGGL((transpose_vec_kernel<T, 128>), dim3((unsigned)((d.m / 128) * (d.n / 128))), dim3(256), 0, s, d.m, d.n,
-                         d.ldi, d.ldo, (const T *)in, (T *)out);
-    else if (vec_ok && d.m % 64 == 0 && d.n % 64 == 0)
-      hipLaunchKernelGGL((transpose_vec_kernel<T, 64>), dim3((unsigned)tiles), dim3(256), 0, s, d.m, d.n, d.ldi, d.ldo,
-                         (const T *)in, (T *)out);
+    static const int alt = [] { const char *e = getenv("TPP_HIP_TRANSPOSE_TILE"); return e ? atoi(e) : 0; }(); // A/B runs
+#define TPP_TRANSPOSE_LAUNCH(R, C)                                                                                        \
+  do {                                                                                                                    \
+    constexpr int lds_ = (R) * ((C) + (sizeof(T) == 4 ? 1 : 2)) * (int)sizeof(T);                                         \
+    static std::atomic<unsigned long long> set_{0};                                                                       \
+    if (hipError_t e_ = ensure_dynamic_lds((const void *)transpose_vec_kernel<T, R, C>, lds_, set_); e_ != hipSuccess) return e_; \
+    hipLaunchKernelGGL((transpose_vec_kernel<T, R, C>), dim3((unsigned)((d.m / (R)) * (d.n / (C)))), dim3(256), lds_, s, d.m, d.n, d.ldi, \
+                       d.ldo, (const T *)in, (T *)out);                                                                   \
+  } while (0)
+    // 128 x 128 tiles when the shape allows (f32: 512-byte row pieces on both sides, 64.5 KiB of LDS, two workgroups per CU - 8192^2
+    // 4.9 -> 5.4 TB/s, 16384^2 5.2 -> 5.4 against 64 x 64; 64 x 128 / 128 x 64 landed in between; bf16 tiles of 256 x 128, 128 x 256
+    // and 256 x 256 measured 5-35 % SLOWER than 128 x 128). TPP_HIP_TRANSPOSE_TILE=64 forces the small tile for A/B runs.
+    if (vec_ok && alt != 64 && d.m % 128 == 0 && d.n % 128 == 0) TPP_TRANSPOSE_LAUNCH(128, 128);
+    else if (vec_ok && d.m % 64 == 0 && d.n % 64 == 0) TPP_TRANSPOSE_LAUNCH(64, 64);
+#undef TPP_TRANSPOSE_LAUNCH
     else
       hipLaunchKernelGGL((transpose_kernel<T>), dim3((unsigned)tiles), dim3(256), 0, s, d.m, d.n, d.ldi, d.ldo,
                          (const T *)in, (T *)out);
