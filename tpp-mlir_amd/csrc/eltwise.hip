@@ -78,11 +78,12 @@ __global__ __launch_bounds__(256) void unary_kernel(int op, int bc, int64_t m, i
                                                     const T *in, T *out, float scalar,
                                                     int use_scalar) {
   const int64_t nv = n / VEC, total = m * nv;
+  const bool small = total < ((int64_t)1 << 31); // 32-bit index division (a 64-bit one is ~100 instructions per element)
   const T sc = use_scalar ? Bits<T>::from_f32(scalar) : T(0);
   const bool stream_in = bc == BC_NONE && op != (int)U_ZERO && !use_scalar;
   auto fetch = [&](int64_t idx, int64_t &o) __attribute__((always_inline)) {
     // (m == 1: the launcher flattened a contiguous operand - no division)
-    const int64_t i = m == 1 ? 0 : idx / nv, j = (idx - i * nv) * VEC;
+    const int64_t i = m == 1 ? 0 : small ? (int64_t)((unsigned)idx / (unsigned)nv) : idx / nv, j = (idx - i * nv) * VEC;
     o = i * ldo + j;
     Pack<T, VEC> x;
     if (op == (int)U_ZERO) {
@@ -131,8 +132,9 @@ template <typename T, int VEC>
 __global__ __launch_bounds__(256) void binary_kernel(int op, int bc0, int bc1, int64_t m, int64_t n, int64_t ldl,
                                                      int64_t ldr, int64_t ldo, const T *lhs, const T *rhs, T *out) {
   const int64_t nv = n / VEC, total = m * nv;
+  const bool small = total < ((int64_t)1 << 31); // 32-bit index division
   auto fetch = [&](int64_t idx, Pack<T, VEC> &l, Pack<T, VEC> &r, int64_t &o) __attribute__((always_inline)) {
-    const int64_t i = m == 1 ? 0 : idx / nv, j = (idx - i * nv) * VEC;
+    const int64_t i = m == 1 ? 0 : small ? (int64_t)((unsigned)idx / (unsigned)nv) : idx / nv, j = (idx - i * nv) * VEC;
     o = i * ldo + j;
     l = bc0 == BC_NONE ? load_stream<T, VEC>(lhs + i * ldl + j) : load_operand<T, VEC>(lhs, bc0, i, j, ldl);
     r = bc1 == BC_NONE ? load_stream<T, VEC>(rhs + i * ldr + j) : load_operand<T, VEC>(rhs, bc1, i, j, ldr);
