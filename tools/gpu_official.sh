@@ -37,7 +37,12 @@ for v in 16 17 19 20 21 22 23; do timeout 60 tools/mlp_probe --variant $v --only
 for rows in 512 1024 2048 4096; do
   TPP_HIP_CHAIN_STAMPS=$OUT/stamps_${rows}.txt timeout 60 tools/mlp_probe --only chain --rows $rows --iters 50 > /dev/null 2>&1
   echo "== rows $rows"; python tools/stamps_report.py $OUT/stamps_${rows}.txt; done > $OUT/chain_anatomy.txt 2>&1
-for dbg in 0 16 32 48 2 6 7; do echo "dbg=$dbg"; TPP_HIP_CHAIN_DBG=$dbg timeout 100 tools/mlp_probe 2>&1; done > $OUT/chain_ablation.txt
+# timing with parts of the chain kernel switched off: side builds only (python tpp-mlir_amd/build.py --ablation BEFORE the gpurun call;
+# the shipped library has no such switch). 32 / 48 need the build with the fragment reads and MFMAs compiled out as well.
+if [ -f tools/_abl/libtpp_xsmm_runner_utils.so ]; then
+for dbg in 0 16 32 48 2 6 7; do echo "dbg=$dbg"; lib=tools/_abl; [ $((dbg & 32)) -ne 0 ] && lib=tools/_abl_nomath
+  LD_LIBRARY_PATH=$lib TPP_HIP_CHAIN_DBG=$dbg timeout 100 tools/mlp_probe 2>&1; done > $OUT/chain_ablation.txt
+fi
 python tools/sweep.py 2>/dev/null | grep -E "^(f32|bf16)" > $OUT/sweep.txt
 python tools/sweep.py big 2>/dev/null | grep -E "^(f32|bf16)" >> $OUT/sweep.txt
 python tools/sweep.py shards 2>/dev/null | grep -E "^bf16" >> $OUT/sweep.txt

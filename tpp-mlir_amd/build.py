@@ -62,6 +62,44 @@ def build(force=False, verbose=False):
     return SO_PATH
 
 
+ABLATION_SOURCES = ["runtime.cpp", "brgemm_f32.hip", "brgemm_bf16_lw.hip"]  # the translation units that look at TPP_HIP_ABLATION
+
+
+def build_ablation(skip_math=False, verbose=False):
+    """Side build for timing experiments: the same library with -DTPP_HIP_ABLATION (then, and only then, the loader-wave
+    bf16 kernels obey TPP_HIP_CHAIN_DBG - chain_args.h; several of its bits give wrong results by design) into
+    tools/_abl/ (skip_math: also -DTPP_BLW_SKIP_MATH, into tools/_abl_nomath/). Use it through
+    `LD_LIBRARY_PATH=tools/_abl tools/mlp_probe ...`; nothing in the package, the tests or bench.py loads it."""
+    build()
+    cc = hipcc()
+    root = os.path.dirname(HERE)
+    name = "_abl_nomath" if skip_math else "_abl"
+    outdir = os.path.join(root, "tools", name)
+    objdir = os.path.join(HERE, "build", name)
+    os.makedirs(outdir, exist_ok=True)
+    os.makedirs(objdir, exist_ok=True)
+    defs = ["-DTPP_HIP_ABLATION"] + (["-DTPP_BLW_SKIP_MATH"] if skip_math else [])
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        cmd = [cc] + FLAGS + defs + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed on %s:\n%s" % (src, r.stderr))
+        return obj
+
+    with ThreadPoolExecutor(max_workers=len(ABLATION_SOURCES)) as ex:
+        objs = list(ex.map(compile_one, ABLATION_SOURCES))
+    objs += [os.path.join(HERE, "build", os.path.splitext(f)[0] + ".o") for f in SOURCES if f not in ABLATION_SOURCES]
+    out = os.path.join(outdir, SO_NAME)
+    r = subprocess.run([cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-pthread", "-o", out] + objs, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n" + r.stderr)
+    return out
+
+
 def build_tools(verbose=False):
     """native harness tools that link the .so: tools/tpp_replay (the stand-in for tpp-run's timing loop on
     this path) and tools/c2_probe (per-launch timing of C2 + the target of bench.py's rocprofv3 PMC passes)"""
@@ -87,3 +125,6 @@ def build_tools(verbose=False):
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
     print(build_tools(verbose=True))
+    if "--ablation" in sys.argv:
+        print(build_ablation(verbose=True))
+        print(build_ablation(skip_math=True, verbose=True))

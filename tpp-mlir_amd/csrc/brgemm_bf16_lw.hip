@@ -91,7 +91,11 @@ __device__ __forceinline__ void blw_loader(chain_kernarg_t *pp, unsigned char *s
   [[maybe_unused]] constexpr int RPI = 256 / BN;     // VNNI pair-rows per B instruction
   static_assert(PPC >= 1 && (IS_A ? BM / 8 : BN / 8) % NL == 0 && (!IS_A || NL == 1 || NL % 2 == 0), "panel instructions divide over the loader waves");
   static_assert(NSLOT >= 3 && NSLOT_C % SUP == 0 && (NSLOT - 1) * PPL <= 63, "ring depth / vmcnt is 6 bits");
+#ifdef TPP_HIP_ABLATION
   const int dbg = p.dbg;
+#else
+  constexpr int dbg = 0; // the timing switches exist in ablation builds only (chain_args.h)
+#endif
   const bool no_dma = (dbg & (16 | (IS_A ? 128 : 64))) != 0; // timing experiments: this panel is not fetched
   bool ahead = false;
   if (MULTI && !IS_A) {
@@ -310,6 +314,7 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
   // second half of chunk t (measured on the 64x64 tile with a two-step lookahead: 420 cycles per chunk for 128 cycles of MFMA).
   // The 128x128 tile (four accumulators, 128 cycles per k-step) reads two k-steps ahead out of one set.
   constexpr bool FULLPF = TM * TN <= 2;
+  constexpr int BLW_RD = 3; // SUP = 2: k-steps the fragment reads run ahead of their MFMA
   constexpr int NFB = FULLPF ? 2 * KS : KS;
   static_assert(!FULLPF || NSLOT % 2 == 0, "chunk parity from the ring slot");
   static_assert(SUP == 1 || FULLPF, "two chunks per barrier: the tiles with two fragment sets");
@@ -354,7 +359,11 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
       }
     }
   };
+#ifdef TPP_HIP_ABLATION
   const int dbg = p.dbg;
+#else
+  constexpr int dbg = 0; // the timing switches exist in ablation builds only (chain_args.h)
+#endif
   // Timing experiment "no fragment reads / MFMAs" (dbg & 32) is a COMPILE-TIME switch (-DTPP_BLW_SKIP_MATH): as a run-time branch
   // around every group of reads and MFMAs it split the chunk body into basic blocks, the compiler's wait-count insertion lost track
   // of which LDS reads were outstanding across them and put s_waitcnt lgkmcnt(0..2) in front of the MFMAs - each k-step waited for
@@ -387,7 +396,16 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
 #pragma unroll
     for (int q = 0; q < KS; ++q) {
       if (!skip_math) {
-        if constexpr (FULLPF) {
+        if constexpr (FULLPF && SUP == 2) {
+          // two chunks per barrier: everything up to the end of chunk t+1 was published before chunk t began (the odd chunk with
+          // its pair, the next even one by the barrier in the middle of the even chunk before it) and the step after the barrier
+          // may read one chunk further. So the fragments are read ONE k-step per step, BLW_RD steps ahead of their MFMA, through
+          // the 2 * KS buffers as a ring: the LDS pipe works all the time instead of in the second halves of the chunks, and the
+          // wait in front of an MFMA is for reads issued three MFMAs earlier (3 * BLW_RD + 3 reads in flight: lgkmcnt has 4 bits).
+          const int tg = q + BLW_RD, ch = tg / KS;
+          const int nns = ns + 1 == NSLOT ? 0 : ns + 1;
+          frag_load((PAR * KS + tg) % NFB, ch == 0 ? slot : ch == 1 ? ns : nns, wk * KS + tg % KS);
+        } else if constexpr (FULLPF) {
           // second half of the chunk (chunk t+1 is published): two of its k-steps per step
           if (q >= KS / 2) {
             const int r = 2 * (q - KS / 2);
@@ -448,7 +466,10 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
     // a second copy of the accumulators and 250 spilled registers)
     // the layers follow each other through the ring: this one starts at slot s0 (the loaders count the same way)
     const int last_slot = (s0 + T - 1) % NSLOT;
-    if (!FULLPF || !(s0 & 1)) {
+    if constexpr (FULLPF && SUP == 2) { // (s0 even; the first barrier interval = chunks 0 and 1 is published)
+#pragma unroll
+      for (int s = 0; s < BLW_RD; ++s) frag_load(s, s0 + s / KS, wk * KS + s % KS);
+    } else if (!FULLPF || !(s0 & 1)) {
 #pragma unroll
       for (int s = 0; s < (FULLPF ? KS : PD); ++s) frag_load(s, s0, wk * KS + s);
     } else { // (chunk parity = slot parity selects the fragment set)

@@ -964,11 +964,7 @@ hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C,
     ChainArgs c;
     c.A = a.A; c.lda = a.lda; c.cnt = nullptr; c.err = nullptr; c.target = 0;
     c.m = a.m; c.n = a.n; c.nlayers = 1; c.tiles_m = c.tiles_n = 0; c.xm = 0; c.stamps = nullptr;
-    static const int lw_dbg = [] {
-      const char *e = getenv("TPP_HIP_CHAIN_DBG"); // timing experiments only (brgemm_bf16_lw.hip): results may be wrong
-      return e ? atoi(e) : 0;
-    }();
-    c.dbg = lw_dbg;
+    c.dbg = chain_ablation_bits();
     c.L[0] = ChainLayer{a.B, a.D, a.C, a.ldb, a.ldc, a.stride_a, a.stride_b, a.k, a.br, a.ep, 0};
     return launch_bf16_lw(v - V_BF16_LW_32x64, c, stream);
   }
@@ -979,11 +975,7 @@ hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C,
     ChainArgs c;
     c.A = a.A; c.lda = a.lda; c.cnt = nullptr; c.err = nullptr; c.target = 0;
     c.m = a.m; c.n = a.n; c.nlayers = 1; c.tiles_m = c.tiles_n = 0; c.xm = 0; c.stamps = nullptr;
-    static const int lwf_dbg = [] {
-      const char *e = getenv("TPP_HIP_CHAIN_DBG"); // timing experiments only
-      return e ? atoi(e) : 0;
-    }();
-    c.dbg = lwf_dbg;
+    c.dbg = chain_ablation_bits();
     c.L[0] = ChainLayer{a.B, a.D, a.C, a.ldb, a.ldc, a.stride_a, a.stride_b, a.k, a.br, a.ep, 0};
     return launch_bf16_lw_flatb(v - V_BF16_LWF_32x64, c, stream);
   }

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace tpp {
 
@@ -28,11 +29,26 @@ struct ChainArgs {
   int nlayers;
   int tiles_m, tiles_n; // filled by the launcher
   int xm;               // filled by the launcher: XCD grid xm x (8 / xm) over the tile grid, 0 = linear tile order
-  int dbg;              // timing experiments only (TPP_HIP_CHAIN_DBG): 1 plain A loads, 2 no wait at the seams, 4 plain stores,
-                        // 16 no DMA, 32 no fragment reads / MFMAs, 64 no B DMA, 128 no A DMA
+  int dbg;              // timing experiments, ABLATION BUILDS ONLY (-DTPP_HIP_ABLATION, then TPP_HIP_CHAIN_DBG): 1 plain A loads,
+                        // 2 no wait at the seams, 4 plain stores, 16 no DMA, 32 no fragment reads / MFMAs, 64 no B DMA, 128 no A DMA,
+                        // 256 whole prologue before the first barrier. The shipped library compiles the kernels with dbg == 0 and
+                        // never reads the variable: several of these switches give wrong results by design.
   unsigned long long *stamps; // profiling (TPP_HIP_CHAIN_STAMPS=file): [workgroup][layer][8] s_memrealtime stamps, else nullptr
   ChainLayer L[CH_MAXL];
 };
+
+// the value of ChainArgs::dbg on the host side
+static inline int chain_ablation_bits() {
+#ifdef TPP_HIP_ABLATION
+  static const int v = [] {
+    const char *e = getenv("TPP_HIP_CHAIN_DBG");
+    return e ? atoi(e) : 0;
+  }();
+  return v;
+#else
+  return 0;
+#endif
+}
 
 // tile: 0 = 32x64 (K split over two wave groups), 1 = 64x64, 2 = 64x128, 3 = 128x128
 void blw_tile_dims(int tile, int *bm, int *bn);

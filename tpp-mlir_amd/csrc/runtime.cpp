@@ -1900,11 +1900,7 @@ bool try_chain_launch(int n, const GemmDesc *const *d, void *const *pa, void *co
   c.m = (int)m;
   c.n = (int)nn;
   c.nlayers = n;
-  static const int dbg = [] {
-    const char *e = getenv("TPP_HIP_CHAIN_DBG"); // timing experiments only: results may be wrong
-    return e ? atoi(e) : 0;
-  }();
-  c.dbg = dbg;
+  c.dbg = chain_ablation_bits();
   for (int i = 0; i < n; ++i)
     c.L[i] = ChainLayer{pb[i], pd[i], pc[i], d[i]->ldb, d[i]->ldc, d[i]->stride_a, d[i]->stride_b, (int)d[i]->k, (int)br[i],
                         EP_BETA0 | (d[i]->bias ? EP_BIAS : 0) | (d[i]->relu ? EP_RELU : 0), 0};
