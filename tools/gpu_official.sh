@@ -34,8 +34,8 @@ done )
 # the per-rank step of the row-sharded C4 MLP (one chain launch vs three launches), forced tiles, and the chain kernel's phases
 for i in 1 2 3; do timeout 100 tools/mlp_probe; done > $OUT/mlp_probe.txt 2>&1
 for v in 16 17 19 20 21 22 23; do timeout 60 tools/mlp_probe --variant $v --only layers --rows 256,512,1024,2048,4096; done > $OUT/mlp_probe_forced.txt 2>&1
-for rows in 512 1024 2048 4096; do
-  TPP_HIP_CHAIN_STAMPS=$OUT/stamps_${rows}.txt timeout 60 tools/mlp_probe --only chain --rows $rows --iters 50 > /dev/null 2>&1
+[ -f tools/_abl/libtpp_xsmm_runner_utils.so ] && for rows in 512 1024 2048 4096; do
+  LD_LIBRARY_PATH=tools/_abl TPP_HIP_CHAIN_STAMPS=$OUT/stamps_${rows}.txt timeout 60 tools/mlp_probe --only chain --rows $rows --iters 50 > /dev/null 2>&1
   echo "== rows $rows"; python tools/stamps_report.py $OUT/stamps_${rows}.txt; done > $OUT/chain_anatomy.txt 2>&1
 # timing with parts of the chain kernel switched off: side builds only (python tpp-mlir_amd/build.py --ablation BEFORE the gpurun call;
 # the shipped library has no such switch). 32 / 48 need the build with the fragment reads and MFMAs compiled out as well.

@@ -50,10 +50,14 @@ constexpr int BLW_BK = 64; // k per chunk
 // run time, and a by-value / by-reference copy of the struct would be spilled to scratch (640 bytes per lane) for that.
 typedef const __attribute__((address_space(4))) ChainArgs chain_kernarg_t;
 
-// profiling stamps (chain mode, TPP_HIP_CHAIN_STAMPS): slot of (workgroup, layer): 0 layer start, 1 chunk 0 published, 2 K loop done,
-// 3 tile stores issued, 4 stores drained + S1 (MFMA wave 0); 5 A loader starts waiting, 6 producers have arrived, 7 first chunks requested
+// profiling stamps (chain mode, TPP_HIP_CHAIN_STAMPS, ABLATION BUILDS ONLY - in the shipped kernels this is empty: each stamp was a
+// scalar load of p.stamps + a wait + a branch on the path of MFMA wave 0 and of the polling loader, five and three times per layer):
+// slot of (workgroup, layer): 0 layer start, 1 chunk 0 published, 2 K loop done, 3 tile stores issued, 4 stores drained + S1 (MFMA
+// wave 0); 5 A loader starts waiting, 6 producers have arrived, 7 first chunks requested
 __device__ __forceinline__ void blw_stamp(chain_kernarg_t &p, int layer, int slot, int lane) {
+#ifdef TPP_HIP_ABLATION
   if (p.stamps && lane == 0) p.stamps[((size_t)blockIdx.x * CH_MAXL + layer) * 8 + slot] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // s_waitcnt vmcnt(younger * PPL): this wave's DMA of all but the `younger` most recent chunks has landed

@@ -33,7 +33,7 @@ struct ChainArgs {
                         // 2 no wait at the seams, 4 plain stores, 16 no DMA, 32 no fragment reads / MFMAs, 64 no B DMA, 128 no A DMA,
                         // 256 whole prologue before the first barrier. The shipped library compiles the kernels with dbg == 0 and
                         // never reads the variable: several of these switches give wrong results by design.
-  unsigned long long *stamps; // profiling (TPP_HIP_CHAIN_STAMPS=file): [workgroup][layer][8] s_memrealtime stamps, else nullptr
+  unsigned long long *stamps; // profiling (ablation builds, TPP_HIP_CHAIN_STAMPS=file): [workgroup][layer][8] s_memrealtime stamps, else nullptr
   ChainLayer L[CH_MAXL];
 };
 

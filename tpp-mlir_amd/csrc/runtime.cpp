@@ -1788,11 +1788,14 @@ int chip_cus() { // compute units of the current device (0: unknown)
   return n;
 }
 
-// profiling: TPP_HIP_CHAIN_STAMPS=<file> makes every chain launch record s_memrealtime stamps (100 MHz) per workgroup and layer
+// profiling (-DTPP_HIP_ABLATION side builds only, build.py --ablation): TPP_HIP_CHAIN_STAMPS=<file> makes every chain launch record s_memrealtime stamps (100 MHz) per workgroup and layer
 // (see blw_stamp in brgemm_bf16_lw.hip) into pinned host memory; the LAST launch's stamps are written to the file at every sync point.
 unsigned long long *g_stamps = nullptr;
 size_t g_stamps_wgs = 0;
 unsigned long long *chain_stamps(size_t wgs) { // under g_chain_mu
+#ifndef TPP_HIP_ABLATION
+  return nullptr;
+#endif
   static const char *path = getenv("TPP_HIP_CHAIN_STAMPS");
   if (!path) return nullptr;
   if (!g_stamps) HIP_OK(hipHostMalloc((void **)&g_stamps, sizeof(unsigned long long) * 8 * CH_MAXL * 1024, hipHostMallocDefault));
