@@ -82,3 +82,14 @@ def test_bf16_loader_wave_kernels_do_not_spill():
     assert len(names) == len(scratch) >= 18, (len(names), len(scratch))
     bad = [(n, s) for n, s in zip(names, scratch) if s != 0]
     assert not bad, "spilling kernels: %s" % bad
+
+
+def test_shipped_library_has_no_measurement_switches():
+    """the switches that take work out of the chain kernel (TPP_HIP_CHAIN_DBG, results wrong by design) and the in-kernel stamps
+    (TPP_HIP_CHAIN_STAMPS) exist in -DTPP_HIP_ABLATION side builds only (tpp-mlir_amd/build.py --ablation): the shipped library
+    must not even contain the variable names"""
+    import importlib
+    build = importlib.import_module("tpp-mlir_amd.build")
+    blob = open(build.build(), "rb").read()
+    for name in (b"TPP_HIP_CHAIN_DBG", b"TPP_HIP_CHAIN_STAMPS"):
+        assert name not in blob, name

@@ -1793,18 +1793,24 @@ int chip_cus() { // compute units of the current device (0: unknown)
 unsigned long long *g_stamps = nullptr;
 size_t g_stamps_wgs = 0;
 unsigned long long *chain_stamps(size_t wgs) { // under g_chain_mu
-#ifndef TPP_HIP_ABLATION
-  return nullptr;
-#endif
+#ifdef TPP_HIP_ABLATION
   static const char *path = getenv("TPP_HIP_CHAIN_STAMPS");
   if (!path) return nullptr;
   if (!g_stamps) HIP_OK(hipHostMalloc((void **)&g_stamps, sizeof(unsigned long long) * 8 * CH_MAXL * 1024, hipHostMallocDefault));
   if (wgs > 1024) return nullptr;
   g_stamps_wgs = wgs;
   return g_stamps;
+#else
+  (void)wgs;
+  return nullptr; // the shipped kernels carry no stamp code (brgemm_bf16_lw.hip: blw_stamp)
+#endif
 }
 void dump_chain_stamps() {
+#ifdef TPP_HIP_ABLATION
   const char *path = getenv("TPP_HIP_CHAIN_STAMPS");
+#else
+  const char *path = nullptr;
+#endif
   if (!path || !g_stamps || !g_stamps_wgs) return;
   if (FILE *f = fopen(path, "w")) {
     for (size_t w = 0; w < g_stamps_wgs; ++w)
