@@ -178,8 +178,12 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + 2 * NL)) void brgemm_f32_lw(Ge
     for (int s = 0; s < 4; ++s) fb[buf][s] = bs[(8 * kb + 4 * lh + s) * BN];
   };
   const int kbw = wk * KB_PER_WAVE;
-  auto chunk = [&](auto slot_c, bool has_next) __attribute__((always_inline)) {
+  // hn_c: does another chunk follow (= does this chunk carry the barrier)? 1: yes, a compile-time fact - the steady-state lap below
+  // is then ONE basic block (a conditional barrier or an exit test between two chunks is a block boundary: a branch, and a point
+  // where the compiler waits for every LDS read in flight); 2: decided at run time (the last lap)
+  auto chunk = [&](auto slot_c, auto hn_c, bool has_next_rt) __attribute__((always_inline)) {
     constexpr int S = decltype(slot_c)::value, NS = (S + 1) % NSLOT;
+    const bool has_next = decltype(hn_c)::value == 1 ? true : has_next_rt;
 #pragma unroll
     for (int q = 0; q < KB_PER_WAVE; ++q) {
       const int cur = q & 1, nxt = cur ^ 1;
@@ -197,8 +201,11 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + 2 * NL)) void brgemm_f32_lw(Ge
     // the prefetched fragments of chunk t+1 are dead on the loop's exit path: without this the compiler sinks
     // their reads into the next chunk's head, where the first MFMA then waits for them (the wait this
     // implies sits behind the last step's four MFMAs: the reads are long back)
+    // (not inside the steady-state laps: there the next chunk follows in the same basic block, the sched_barriers keep the order,
+    // and the pin would only make the compiler wait for the prefetched fragments at the end of every chunk)
     constexpr int PF = KB_PER_WAVE & 1;
-    asm volatile("" : "+v"(fa[PF]), "+v"(fb[PF][0]), "+v"(fb[PF][1]), "+v"(fb[PF][2]), "+v"(fb[PF][3]));
+    if constexpr (decltype(hn_c)::value != 1)
+      asm volatile("" : "+v"(fa[PF]), "+v"(fb[PF][0]), "+v"(fb[PF][1]), "+v"(fb[PF][2]), "+v"(fb[PF][3]));
   };
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
@@ -209,15 +216,24 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + 2 * NL)) void brgemm_f32_lw(Ge
   __builtin_amdgcn_sched_barrier(0);
   if (T > 0) {
     frag_load(0, 0, kbw);
-    for (int t = 0;;) {
-      chunk(S0{}, t + 1 < T);
+    using HY = std::integral_constant<int, 1>;
+    using HR = std::integral_constant<int, 2>;
+    int t = 0;
+    for (; t + NSLOT < T; t += NSLOT) { // whole laps of the ring that are followed by at least one more chunk
+      chunk(S0{}, HY{}, true);
+      chunk(S1{}, HY{}, true);
+      chunk(S2{}, HY{}, true);
+      if constexpr (NSLOT > 3) chunk(S3{}, HY{}, true);
+    }
+    for (;;) { // the last lap: 1 .. NSLOT chunks
+      chunk(S0{}, HR{}, t + 1 < T);
       if (++t == T) break;
-      chunk(S1{}, t + 1 < T);
+      chunk(S1{}, HR{}, t + 1 < T);
       if (++t == T) break;
-      chunk(S2{}, t + 1 < T);
+      chunk(S2{}, HR{}, t + 1 < T);
       if (++t == T) break;
       if constexpr (NSLOT > 3) {
-        chunk(S3{}, t + 1 < T);
+        chunk(S3{}, HR{}, t + 1 < T);
         if (++t == T) break;
       }
     }
