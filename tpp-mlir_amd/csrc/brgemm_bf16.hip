@@ -329,7 +329,7 @@ __global__ __launch_bounds__(64 * WM * WN) void brgemm_bf16_fast(GemmArgs p, con
         const u32x4 out = {s0[0], s1[0], s0[1], s1[1]};
         // lower half: columns 32j + 8g .. +7 ; upper half: columns 32j + 8(g+1) .. +7
         const unsigned colb = (unsigned)((32 * j + 8 * g) * 2) + (lh ? 16u - 8u : 0u);
-        __builtin_amdgcn_raw_buffer_store_b128(out, rsrcC, voffC + colb, (unsigned)(32 * i) * ldcb, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(out, rsrcC, voffC + colb, (unsigned)(32 * i) * ldcb, C_STORE_AUX);
       }
     }
   }
@@ -740,7 +740,7 @@ __global__ __launch_bounds__(256 + 64 * NLW) void brgemm_bf16_dma128(GemmArgs p)
     const int row = it * 8 + (lane >> 3), ch = lane & 7;
     const u32x4 v = *(const u32x4 *)(ot + row * ES + ch * 16);
     __builtin_amdgcn_raw_buffer_store_b128(v, rsrcC, (unsigned)(lane >> 3) * ldcb + (unsigned)(ch * 16),
-                                           (unsigned)(it * 8) * ldcb, 0);
+                                           (unsigned)(it * 8) * ldcb, C_STORE_AUX);
   }
 }
 

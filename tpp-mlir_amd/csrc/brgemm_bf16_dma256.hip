@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) void brgemm_bf16_dma256(GemmArgs p) {
       const int row = it * 4 + (lane >> 4), ch = lane & 15;
       const u32x4 v = *(const u32x4 *)(ot + row * ES + ch * 16);
       __builtin_amdgcn_raw_buffer_store_b128(v, rsrcC, (unsigned)(lane >> 4) * ldcb + (unsigned)(ch * 16),
-                                             (unsigned)(ih * 64 + it * 4) * ldcb, 0);
+                                             (unsigned)(ih * 64 + it * 4) * ldcb, C_STORE_AUX);
     }
   }
 }

@@ -635,7 +635,7 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
           const u32x4 v = *(const u32x4 *)(ot + row * ES + ch * 16);
           const unsigned voff = (unsigned)(32 * i + row) * ldcb + (unsigned)(ch * 16);
           if (MULTI && l + 1 < L && !(dbg & 4)) __builtin_amdgcn_raw_buffer_store_b128(v, rsrcC, voff, 0, 16); // sc1: write-through (hand-off)
-          else __builtin_amdgcn_raw_buffer_store_b128(v, rsrcC, voff, 0, 0);
+          else __builtin_amdgcn_raw_buffer_store_b128(v, rsrcC, voff, 0, C_STORE_AUX); // (last layer / single layer: gemm_common.h)
         }
       }
     }

@@ -365,7 +365,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void brgemm_f32_fast(GemmArgs p,
     float v = acc[0][r] + bias;
     if (p.ep & EP_RELU) v = v > 0.0f ? v : 0.0f;
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrcC, voffC,
-                                          (unsigned)((r & 3) + 8 * (r >> 2)) * ldcb, 0);
+                                          (unsigned)((r & 3) + 8 * (r >> 2)) * ldcb, C_STORE_AUX);
   }
 }
 

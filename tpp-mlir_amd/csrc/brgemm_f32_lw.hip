@@ -24,6 +24,7 @@ namespace tpp {
 
 constexpr int LW_BK = 64;   // k per chunk
 constexpr int LW_NSLOT = 4; // LDS ring slots
+constexpr int LW_C_AUX = C_STORE_AUX; // write-through C stores (gemm_common.h)
 
 typedef __attribute__((address_space(3))) void lds_void_lw;
 
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + 2 * NL)) void brgemm_f32_lw(Ge
         for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
       }
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrcC,
-                                             (unsigned)(((wm * 32 + q) * (int)p.ldc + wn * 32 + 4 * c4) * 4), 0, 0);
+                                             (unsigned)(((wm * 32 + q) * (int)p.ldc + wn * 32 + 4 * c4) * 4), 0, LW_C_AUX);
     }
     return;
   }
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + 2 * NL)) void brgemm_f32_lw(Ge
     float v = acc[r] + bias;
     if (p.ep & EP_RELU) v = v > 0.0f ? v : 0.0f;
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrcC, voffC,
-                                          (unsigned)((r & 3) + 8 * (r >> 2)) * ldcb, 0);
+                                          (unsigned)((r & 3) + 8 * (r >> 2)) * ldcb, LW_C_AUX);
   }
 }
 

@@ -79,6 +79,16 @@ static inline hipError_t ensure_dynamic_lds(const void *kernel, int bytes, std::
   if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
   return e;
 }
+// Cache policy (buffer-instruction aux bits) of the stores of an output tile that this launch does not read again: 16 = sc1,
+// write-through. A line that is already in memory when the kernel ends is one the end-of-kernel write-back of the L2s does not have
+// to move, and the launch boundary behind a kernel that leaves B dirty bytes costs ~B / 6 TB/s (0.7 us for the 4 MiB of C2).
+// Same box, C2 17.57 -> 17.34 us, C3 9.94 -> 9.85 (profiles/r03_f32_lw_laps_ab.txt); sc0+sc1, sc1+nt measured the same, nt alone
+// helps C2 but not C3. -DTPP_C_STORE_AUX=n: side builds for A/B runs.
+#ifndef TPP_C_STORE_AUX
+#define TPP_C_STORE_AUX 16
+#endif
+constexpr int C_STORE_AUX = TPP_C_STORE_AUX;
+
 // compute units of the current device (queried once per process; tile heuristics use it)
 static inline int device_cu_count() {
   static std::atomic<int> cus{0};
