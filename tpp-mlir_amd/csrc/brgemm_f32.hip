@@ -869,9 +869,15 @@ bool plan_gemm(GemmDesc &d, int forced_variant) {
     if (v == V_BF16_FAST && bf16_small_eligible(d) && (d.m / 64) * (d.n / 64) < (3 * g_num_cus) / 4) v = V_BF16_SMALL32;
     // mid-size outputs (the 64x64 / 32x32 families, or 128x128 tiles for fewer than 3/4 of the CUs): one loader-wave workgroup
     // per CU. Measured (profiles/r03_sweep_shapes.txt, 1024-wide layer, K = 1024): see DESIGN.md 4.2.
-    if (v == V_BF16_FAST || v == V_BF16_SMALL32 || (v == V_BF16_DMA128 && (d.m / 128) * (d.n / 128) * 4 < 3 * (int64_t)g_num_cus)) {
+    const int64_t t128 = (d.m / 128) * (d.n / 128);
+    if (v == V_BF16_FAST || v == V_BF16_SMALL32 || (v == V_BF16_DMA128 && t128 * 4 < 3 * (int64_t)g_num_cus)) {
       const int lw = pick_bf16_lw_tile(d);
       if (lw >= 0 && !(lw == 3 && v == V_BF16_DMA128)) v = V_BF16_LW_32x64 + lw;
+    } else if (v == V_BF16_DMA128 && t128 <= (int64_t)g_num_cus && pick_bf16_lw_tile(d) == 3) {
+      // ONE round of 128x128 tiles (the C4 layer 4096 x 1024, C5 2048 x 2048): since the end of round 3 the loader-wave tile is
+      // at least as fast as brgemm_bf16_dma128 there (same box, profiles/r03_write_through_c_stores.txt: C5 18.2 against 18.7 us,
+      // the C4 layer 10.4 against 10.6-11.5) - and it is the tile the 4096-row chain runs on. Several rounds: dma128 (not re-measured).
+      v = V_BF16_LW_128x128;
     }
     const int tile = forced_variant - V_BF16_FAST; // a forced bf16 tile is honoured if the shape divides it
     if (tile >= 0 && tile <= 2 && d.m % (64 << tile) == 0 && d.n % (64 << tile) == 0) v = forced_variant;
