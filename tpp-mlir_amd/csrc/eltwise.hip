@@ -56,8 +56,21 @@ template <typename T, int VEC> __device__ __forceinline__ Pack<T, VEC> load_stre
   if constexpr (sizeof(Pack<T, VEC>) == 16) return __builtin_bit_cast(Pack<T, VEC>, __builtin_nontemporal_load((const u32x4_e *)p));
   else return *(const Pack<T, VEC> *)p;
 }
-template <typename T, int VEC> __device__ __forceinline__ void store_stream(T *p, const Pack<T, VEC> &v) {
-  if constexpr (sizeof(Pack<T, VEC>) == 16) __builtin_nontemporal_store(__builtin_bit_cast(u32x4_e, v), (u32x4_e *)p);
+// 16-byte WRITE-THROUGH store (sc1): the line is in memory when the store retires instead of sitting dirty in the L2 until it is
+// evicted or until the end-of-kernel write-back. Measured by size (profiles/r03_eltwise_store_policy.txt, 2048^2 .. 16384^2, same
+// box, GB/s against the nontemporal / plain stores used before): transposes f32 +0..31 %, bf16 +0..49 %, binary add +0..14 % (one
+// size -3 %), relu f32 +1..23 %; relu bf16 is mixed (-7 % at 8192^2, +16 % at 2048^2): the bf16 unary streams keep nontemporal
+// stores. (sc1 nt is better still for f32 transposes up to 8192^2 and worse beyond: the repeated benchmark input then stays in the
+// 256 MiB Infinity Cache - not a property a single transpose has, so it is not used.) Inline asm: the builtins reach sc1 only
+// through buffer stores, whose 32-bit offsets do not span these operands.
+template <typename T, int VEC> __device__ __forceinline__ void store_wt(T *p, const Pack<T, VEC> &v) {
+  static_assert(sizeof(Pack<T, VEC>) == 16, "16-byte packs");
+  const u32x4_e x = __builtin_bit_cast(u32x4_e, v);
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
+}
+template <typename T, int VEC, bool WT = false> __device__ __forceinline__ void store_stream(T *p, const Pack<T, VEC> &v) {
+  if constexpr (sizeof(Pack<T, VEC>) == 16 && WT) store_wt<T, VEC>(p, v);
+  else if constexpr (sizeof(Pack<T, VEC>) == 16) __builtin_nontemporal_store(__builtin_bit_cast(u32x4_e, v), (u32x4_e *)p);
   else *(Pack<T, VEC> *)p = v;
 }
 // Work distribution of the eltwise kernels: block b owns ONE contiguous span of the index space (rounded to whole rounds of 256
@@ -109,7 +122,7 @@ __global__ __launch_bounds__(256) void unary_kernel(int op, int bc, int64_t m, i
     }
     // (a pure fill - zero / scalar broadcast - keeps plain stores: nontemporal ones measured 7.4 -> 5.8 TB/s on a 256 MiB fill)
     if (op == (int)U_ZERO || use_scalar) *(Pack<T, VEC> *)(out + o) = x;
-    else store_stream<T, VEC>(out + o, x);
+    else store_stream<T, VEC, sizeof(T) == 4>(out + o, x);
   };
   int64_t idx, end;
   span_of_block(total, idx, end);
@@ -153,7 +166,7 @@ __global__ __launch_bounds__(256) void binary_kernel(int op, int bc0, int bc1, i
       }
       x.v[e] = Bits<T>::from_f32(c);
     }
-    store_stream<T, VEC>(out + o, x);
+    store_stream<T, VEC, true>(out + o, x);
   };
   int64_t idx, end;
   span_of_block(total, idx, end);
@@ -389,7 +402,7 @@ __global__ __launch_bounds__(256) void transpose_vec_kernel(int64_t m, int64_t n
     Pack<T, VEC> v;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) v.v[e] = tile[(r0 + e) * PITCH + c];
-    *(Pack<T, VEC> *)(out + (j0 + c) * ldo + i0 + r0) = v; // (plain accesses: nontemporal ones measured 4.8 -> 4.3 TB/s here, bf16 6.5 -> 4.8)
+    store_wt<T, VEC>(out + (j0 + c) * ldo + i0 + r0, v); // (write-through: see store_wt; nontemporal stores measured 4.8 -> 4.3 TB/s here)
   }
 }
 
