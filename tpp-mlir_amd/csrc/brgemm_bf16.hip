@@ -329,7 +329,9 @@ __global__ __launch_bounds__(64 * WM * WN) void brgemm_bf16_fast(GemmArgs p, con
         const u32x4 out = {s0[0], s1[0], s0[1], s1[1]};
         // lower half: columns 32j + 8g .. +7 ; upper half: columns 32j + 8(g+1) .. +7
         const unsigned colb = (unsigned)((32 * j + 8 * g) * 2) + (lh ? 16u - 8u : 0u);
-        __builtin_amdgcn_raw_buffer_store_b128(out, rsrcC, voffC + colb, (unsigned)(32 * i) * ldcb, C_STORE_AUX);
+        // (plain stores here: two lanes cover 32 contiguous bytes of a row per instruction, and write-through of PARTIAL lines is slow -
+        // this kernel measured 4-7 % slower with sc1, the VNNI-2 pack kernel, 32 bytes per lane, 40 %: gemm_common.h)
+        __builtin_amdgcn_raw_buffer_store_b128(out, rsrcC, voffC + colb, (unsigned)(32 * i) * ldcb, 0);
       }
     }
   }

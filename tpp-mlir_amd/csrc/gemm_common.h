@@ -83,7 +83,10 @@ static inline hipError_t ensure_dynamic_lds(const void *kernel, int bytes, std::
 // write-through. A line that is already in memory when the kernel ends is one the end-of-kernel write-back of the L2s does not have
 // to move, and the launch boundary behind a kernel that leaves B dirty bytes costs ~B / 6 TB/s (0.7 us for the 4 MiB of C2).
 // Same box, C2 17.57 -> 17.34 us, C3 9.94 -> 9.85 (profiles/r03_f32_lw_laps_ab.txt); sc0+sc1, sc1+nt measured the same, nt alone
-// helps C2 but not C3. -DTPP_C_STORE_AUX=n: side builds for A/B runs.
+// helps C2 but not C3. ONLY where one store instruction writes whole 128-byte lines (8 lanes x 16 bytes or 32 lanes x 4 bytes of
+// one row): write-through of partial lines costs - the reg-staged 64x64 bf16 kernel (32 contiguous bytes per row and instruction)
+// measured 4-7 % slower with sc1, the VNNI-2 pack kernel (two 16-byte stores per lane) 6.5 -> 3.8 TB/s; both keep plain stores.
+// -DTPP_C_STORE_AUX=n: side builds for A/B runs.
 #ifndef TPP_C_STORE_AUX
 #define TPP_C_STORE_AUX 16
 #endif
