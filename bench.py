@@ -5,11 +5,14 @@ Step = one pass of the hot path over one batch of synthetic input:
   primary workload (value/metric): BASELINE config[1] "BRGEMM 1024x1024x1024 fp32,
     batch-reduce=16": ONE xsmm_brgemm_invoke, C[1024x1024] += sum_{b<16} A_b[1024x64] B_b[64x1024]
     (dispatch m=n=1024 k=64 lda=ldb=ldc=1024 stride_a=64 stride_b=65536).
-    With --gpus N every rank runs its own independent BRGEMM (weak scaling, no collective:
-    the reference has no exchange step on this path).
   secondary ("mlp" object in the same JSON line): BASELINE config[3] 3-layer MLP
-    1024->1024->1024->1024 bf16 bs=4096 (bias+relu fused), tile rows sharded across the
-    ranks with ONE RCCL all-gather of the output (strong scaling).
+    1024->1024->1024->1024 bf16 bs=4096 (bias+relu fused).
+  With --gpus N > 1 the roles swap: the headline (`value`) is the STRONG-scaled MLP - tile rows sharded across the
+    ranks, the all-gather of the output INSIDE the timed step, both gather paths (peer-store over IPC-mapped buffers
+    and RCCL all_gather_into_tensor) timed in the same run, the gathered output compared bit for bit with the
+    unsharded result on every rank (`mlp.gathered_bit_identical`; the run exits 3 if it is false), the one-GPU step of
+    the same run next to it (`mlp.one_gpu_same_run`). The weak-scaled C2 (one independent BRGEMM per GPU, no collective:
+    the reference has no exchange step on this path) is reported under `c2_weak`.
 Timing: inputs resident in HBM, W warm-up steps, then exactly K steps between
 barrier+synchronize pairs, max over ranks (nothing but the K invokes inside the wall-clock region); the
 HIP-event pair for the kernel-side time brackets an immediate repeat of the same K steps (see timed()). FLOPs are the reference's BENCH_TOTAL_FLOPS
@@ -391,14 +394,25 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no HIP device visible); there is no CPU fallback")
+    # TEST SWITCH (tests/test_bench_multi_gpu.py): TPP_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and runs the process group on
+    # gloo (RCCL cannot place two ranks on one device) - the whole N > 1 code path of this file, the peer-store gather over real IPC
+    # handles included, on a one-GPU box. The numbers of such a run are meaningless (the ranks time-slice one GPU) and say so.
+    one_device = os.environ.get("TPP_BENCH_ONE_DEVICE", "0") == "1"
+    if one_device:
+        local = 0
     torch.cuda.set_device(local)
     use_dist = world > 1 or args.force_dist
+    backend = "gloo" if one_device else "nccl"
+    ctl_group = None
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("NCCL_DEBUG", "WARN")  # no version banner on stdout
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local))
+        if one_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            ctl_group = dist.new_group(backend="gloo")  # host objects (IPC handles, votes) travel over gloo, not over the GPUs
 
     def barrier():
         if use_dist:
@@ -484,76 +498,134 @@ def main():
             rt.unary(BF16, hp, wf, 0, wv, 0)  # C5 prologue: weights packed to VNNI-2 by the runtime's own op
             Wv.append(wv)
             Bs.append(torch.from_numpy(bf_.view(np.int16)).cuda())
-        x_gen = orc.TensorInit("normal", 123 + rank)
+        x_all = {}  # the kernel input, the SAME on every rank (tpp-run's normal stream, seed 123): a rank uses its own rows of it
 
-        def run_mlp(batch, steps, warmup, chain=True, as_world=None, as_rank=None):
-            """row-sharded MLP on `batch` rows: (spec, sharded object, step seconds with the gather, without it).
+        def x_rows(batch, row0, rows):
+            if batch not in x_all:
+                x_all[batch] = torch.from_numpy(orc.TensorInit("normal", 123).fill(batch * N, BF16).view(np.int16)).cuda()
+            return x_all[batch][row0 * N:(row0 + max(rows, 1)) * N]
+
+        peer_objs = {}  # batch -> PeerGather or None (created once per batch size: 2 x batch x N x 2 bytes of mapped buffers each)
+
+        def peer_for(batch):
+            if batch not in peer_objs:
+                pg_ = None
+                if use_dist and batch % (128 * world) == 0:
+                    pg_ = pkg.PeerGather.create(rt, rank, world, batch * N * 2, group=ctl_group)  # every rank or none (it votes)
+                    if pg_ is not None:
+                        pg_.overlap(True)  # the wait for the peers' blocks on a side stream: the next step computes meanwhile
+                peer_objs[batch] = pg_
+            return peer_objs[batch]
+
+        def run_mlp(batch, steps, warmup, chain=True, as_world=None, as_rank=None, gather=None):
+            """row-sharded MLP on `batch` rows; gather: None (this rank's share only), "peer" (peer-store all-gather) or "rccl"
+            (dist.all_gather_into_tensor) INSIDE the timed step. Returns (spec, sharded object, seconds per step, gathered output).
             as_world / as_rank: time the share rank as_rank would have in a world of as_world GPUs, on THIS GPU"""
             spec_ = pkg.MlpSpec(batch=batch)
             sh_ = pkg.ShardedMlp(spec_, rank if as_rank is None else as_rank, world if as_world is None else as_world, rt, chain=chain)
-            X_ = torch.from_numpy(x_gen.fill(max(sh_.rows, 1) * N, BF16).view(np.int16)).cuda()
+            X_ = x_rows(batch, sh_.row0, sh_.rows)
             acts_ = [torch.empty(max(sh_.rows, 1), N, dtype=torch.bfloat16, device="cuda") for _ in range(3)]
-            full_ = torch.empty(batch, N, dtype=torch.bfloat16, device="cuda")
-            pg_ = None
-            if use_dist and args.gather == "peer" and as_world is None and batch % (128 * world) == 0:
-                pg_ = pkg.PeerGather.create(rt, rank, world, batch * N * 2)
-                ok_ = torch.tensor([1 if pg_ is not None else 0], device="cuda")
-                dist.all_reduce(ok_, op=dist.ReduceOp.MIN)  # every rank or none
-                if int(ok_[0]) == 0:
-                    pg_ = None
-                if pg_ is not None:
-                    pg_.overlap(True)  # the wait for the peers' blocks on a side stream: the next step computes meanwhile
-            gather_used.append("peer-store (IPC-mapped peer buffers, 2 launches per step, the wait kernel on a side stream: it overlaps "
-                               "the next step's compute; the timed region ends with a device-wide synchronize)" if pg_ is not None else
-                               "rccl all_gather_into_tensor" if use_dist else "none (one rank)")
+            full_ = torch.empty(batch, N, dtype=torch.bfloat16, device="cuda") if gather == "rccl" else None
+            pg_ = peer_for(batch) if gather == "peer" else None
+            last = [None]
             sync()
 
-            def compute_only():
-                sh_.forward(X_, Wv, Bs, acts_)
-
-            def with_gather():
+            def step_():
                 out = sh_.forward(X_, Wv, Bs, acts_)
-                if pg_ is not None:
-                    pg_.gather(out, sh_.rows * N * 2, sh_.row0 * N * 2)
-                elif use_dist and as_world is None:
+                if gather == "peer":
+                    last[0] = pg_.gather(out, sh_.rows * N * 2, sh_.row0 * N * 2)
+                elif gather == "rccl":
                     pkg.all_gather_rows(out, full_, spec_, world)
+                    last[0] = full_
+                else:
+                    last[0] = out
 
-            res = []
-            for fn in (compute_only, with_gather):
-                spin_up(fn, sync, 0.03)
-                warm(fn, warmup, sync)
-                w_, _ = timed(fn, steps, sync, barrier)
-                tw = torch.tensor([w_], dtype=torch.float64, device="cuda")
-                if use_dist:
-                    dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-                res.append(float(tw[0]) / steps)
+            spin_up(step_, sync, 0.03)
+            warm(step_, warmup, sync)
+            w_, _ = timed(step_, steps, sync, barrier)
+            tw = torch.tensor([w_], dtype=torch.float64, device="cuda")
+            if use_dist:
+                dist.all_reduce(tw, op=dist.ReduceOp.MAX)
             if pg_ is not None:
                 pg_.check()
-            return spec_, sh_, res[1], res[0]
+            return spec_, sh_, float(tw[0]) / steps, last[0]
 
-        gather_used = []
-        spec, sh, mstep, mcompute = run_mlp(4096, K, W)
+        def unsharded_on_the_shards_tile(batch, sh_):
+            """the full batch on THIS GPU with the tile the rank shares ran on (three launches: more tiles than CUs is fine there) -
+            the same arithmetic per element as the sharded run, so the gathered output must equal it bit for bit"""
+            name = rt.kernel_name(sh_.handles[0][0])
+            forced = {"brgemm_bf16_lw<32x64,k2>": 20, "brgemm_bf16_lw<64x64>": 21, "brgemm_bf16_lw<64x128>": 22, "brgemm_bf16_lw<128x128>": 23,
+                      "brgemm_bf16_fast<64x64>": 16, "brgemm_bf16_dma<128x128>": 17, "brgemm_bf16_dma<256x256>": 18,
+                      "brgemm_bf16_small<32x32,k4>": 19}.get(name, -1)
+            rt.force_variant(forced)
+            try:
+                whole = pkg.ShardedMlp(pkg.MlpSpec(batch=batch), 0, 1, rt, chain=False)
+            finally:
+                rt.force_variant(-1)
+            acts_ = [torch.empty(batch, N, dtype=torch.bfloat16, device="cuda") for _ in range(3)]
+            ref = whole.forward(x_rows(batch, 0, batch), Wv, Bs, acts_)
+            sync()
+            return ref, rt.kernel_name(whole.handles[0][0]), name
+
+        if not use_dist:
+            spec, sh, mstep, _ = run_mlp(4096, K, W)
+            mcompute = mstep
+            gathers = None
+        else:
+            # N > 1: the strong-scaled step with the all-gather INSIDE the timed region, BOTH gather paths in the same run, then the
+            # check: every rank recomputes the full batch unsharded and compares the gathered output bit for bit (VERDICT r3 item 2)
+            spec, sh, mcompute, _ = run_mlp(4096, K, W)
+            gathers = {}
+            ref, ref_kernel, shard_kernel = unsharded_on_the_shards_tile(4096, sh)
+            for path in (["peer"] if peer_for(4096) is not None else []) + ["rccl"]:
+                _, _, t_, full_ = run_mlp(4096, K, W, gather=path)
+                sync()
+                if path == "peer":
+                    peer_for(4096).drain()
+                same = torch.equal(full_.view(torch.int16).reshape(-1), ref.view(torch.int16).reshape(-1))
+                ok_ = torch.tensor([1 if same else 0], device="cuda")
+                dist.all_reduce(ok_, op=dist.ReduceOp.MIN)
+                gathers[path] = {"ms_per_step": round(t_ * 1e3, 5), "value": round(spec.flops() / t_ / 1e9, 1), "unit": "GFLOP/s",
+                                 "gathered_bit_identical": bool(int(ok_[0]))}
+            best = min(gathers, key=lambda p_: gathers[p_]["ms_per_step"])
+            mstep = gathers[best]["ms_per_step"] * 1e-3
+            if peer_for(4096) is None:
+                gathers["peer"] = {"unavailable": "the peer buffers could not be mapped or the self-test failed on a rank: RCCL only"}
+            # the same step on ONE GPU in the same run (rank 0's device, the others wait): the denominator of the speed-up
+            _, sh1, t1_, _ = run_mlp(4096, K, W, as_world=1, as_rank=0)
+            mlp_n1 = {"ms_per_step": round(t1_ * 1e3, 5), "value": round(spec.flops() / t1_ / 1e9, 1), "kernel": rt.kernel_name(sh1.handles[0][0]),
+                      "one_chain_launch": bool(sh1.last_step_fused)}
         fused_flag = bool(sh.last_step_fused)
         mlp = {"workload": "3-layer MLP 1024x3 bf16 bs=4096 bias+relu, rows sharded over %d GPU(s)%s" % (
-                   world, " + RCCL all-gather of the output" if use_dist else ""),
+                   world, " + all-gather of the output inside the timed step" if use_dist else ""),
                "value": round(spec.flops() / mstep / 1e9, 1), "unit": "GFLOP/s", "scaling": "strong",
                "ms_per_step": round(mstep * 1e3, 5), "ms_per_step_compute_only": round(mcompute * 1e3, 5),
                "flops_per_step": spec.flops(),
                "frac_of_bf16_mfma_peak": round(spec.flops() / mstep / 1e12 / (PEAK_BF16_MFMA_TFLOPS * world), 4),
                "kernel": rt.kernel_name(sh.handles[0][0]) if sh.rows else "",
-               "step_is_one_chain_launch": fused_flag, "gather": gather_used[0],
-               "inputs": "weights / biases: mlir-gen --seed 123 dense constants (seed chain 123, rand(), ...), input: tpp-run normal init seed 123",
+               "step_is_one_chain_launch": fused_flag,
+               "inputs": "weights / biases: mlir-gen --seed 123 dense constants (seed chain 123, rand(), ...), input: tpp-run normal init seed 123 "
+                         "(one stream over the whole batch; a rank takes its rows)",
                "note": "25.8 GFLOP per step; a rank's three layers run as ONE persistent launch (xsmm_hip_fused_brgemm_chain_invoke) "
                        "when the chain fits the chip, see DESIGN.md sections 4.2 / 5"}
+        if use_dist:
+            mlp["gather"] = best
+            mlp["gathers"] = gathers
+            mlp["gathered_bit_identical"] = all(g.get("gathered_bit_identical", True) for g in gathers.values())
+            mlp["gathered_check"] = ("after the timed regions every rank recomputed the full batch unsharded on its own GPU (kernel %s, forced to "
+                                     "the tile the %d-row shares run on: %s) and compared the gathered [4096][1024] output of each gather path "
+                                     "bit for bit; AND over the ranks" % (ref_kernel, sh.rows, shard_kernel))
+            mlp["one_gpu_same_run"] = mlp_n1
+            mlp["speedup_vs_one_gpu_same_run"] = round(mlp_n1["ms_per_step"] * 1e-3 / mstep, 3)
         if world == 1:
             # what every rank of a world of 2 / 4 / 8 GPUs would run per step (its row share, no collective), measured on THIS GPU:
             # the one-launch chain and the same share as three launches; python path (this harness) and native (tools/mlp_probe)
             Ks = max(K, 200)  # (short steps: the synchronizes around a 20-step region would be 5-10 % of it)
-            _, _, _, t3 = run_mlp(4096, Ks, W, chain=False)
+            _, _, t3, _ = run_mlp(4096, Ks, W, chain=False)
             shares = {"1": {"rows": 4096, "chain_us": round(mcompute * 1e6, 2), "three_launches_us": round(t3 * 1e6, 2)}}
             for w_ in (2, 4, 8):
-                _, sh_c, _, tc_ = run_mlp(4096, Ks, W, chain=True, as_world=w_, as_rank=w_ - 1)
-                _, sh_l, _, tl_ = run_mlp(4096, Ks, W, chain=False, as_world=w_, as_rank=w_ - 1)
+                _, sh_c, tc_, _ = run_mlp(4096, Ks, W, chain=True, as_world=w_, as_rank=w_ - 1)
+                _, sh_l, tl_, _ = run_mlp(4096, Ks, W, chain=False, as_world=w_, as_rank=w_ - 1)
                 shares[str(w_)] = {"rows": sh_c.rows, "chain_us": round(tc_ * 1e6, 2), "three_launches_us": round(tl_ * 1e6, 2),
                                    "one_launch": bool(sh_c.last_step_fused), "kernel": rt.kernel_name(sh_l.handles[0][0])}
             mlp["per_rank_step_us"] = shares
@@ -573,9 +645,12 @@ def main():
                                          "chain_us[1] / chain_us[N])")
         if use_dist:
             # the same MLP at a batch where compute dominates (8 x 4096 rows): what the sharding itself scales like
-            spec_l, sh_l, lstep, lcompute = run_mlp(32768, max(20, K // 10), max(5, W // 10))
+            Kl, Wl = max(20, K // 10), max(5, W // 10)
+            spec_l, sh_l, lcompute, _ = run_mlp(32768, Kl, Wl)
+            lpath = "peer" if peer_for(32768) is not None else "rccl"
+            _, _, lstep, _ = run_mlp(32768, Kl, Wl, gather=lpath)
             mlp["large_batch_variant"] = {
-                "workload": "same MLP, bs=32768, rows sharded over %d GPU(s) + RCCL all-gather of the output (64 MiB)" % world,
+                "workload": "same MLP, bs=32768, rows sharded over %d GPU(s) + all-gather of the output (64 MiB, %s)" % (world, lpath),
                 "value": round(spec_l.flops() / lstep / 1e9, 1), "unit": "GFLOP/s", "scaling": "strong",
                 "ms_per_step": round(lstep * 1e3, 5), "ms_per_step_compute_only": round(lcompute * 1e3, 5),
                 "kernel": rt.kernel_name(sh_l.handles[0][0]) if sh_l.rows else ""}
@@ -740,6 +815,21 @@ def main():
             hA, hB, hC = inputs(args.init)
             cpu = cpu_baseline(args.cpu_seconds, hA, hB, hC)
 
+    # who took part: the process group's own count and every rank's device (N distinct GPUs, or the one-device test rig)
+    group_info = None
+    if use_dist:
+        pr = torch.cuda.get_device_properties(local)
+        me = {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "device_index": local, "device": pr.name,
+              "pci_bus_id": getattr(pr, "pci_bus_id", None), "uuid": str(getattr(pr, "uuid", "")) or None,
+              "visible": os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")}
+        everyone = [None] * world
+        dist.all_gather_object(everyone, me, group=ctl_group)
+        group_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks": everyone,
+                      "distinct_devices": len({(e["device_index"], e["pci_bus_id"], e["uuid"]) for e in everyone}),
+                      "one_device_test_rig": one_device}
+        for pg_ in list((peer_objs if not args.no_mlp else {}).values()):
+            if pg_ is not None:
+                pg_.close()  # (collective: every rank reaches this point)
     # RCCL writes its version banner to the C stdout buffer: shut the process group down and flush C
     # stdio first, so that the JSON line is the LAST thing on stdout
     if use_dist:
@@ -776,7 +866,32 @@ def main():
             line["mlp"] = mlp
         if others:
             line["other_configs"] = others
+        if group_info is not None:
+            line["process_group"] = group_info
+        if world > 1 and mlp is not None:
+            # N > 1: the headline of the line is BASELINE's multi-GPU workload - the strong-scaled bs = 4096 MLP with the all-gather of
+            # the output inside the timed step (north_star: "tile-sharded across the GPUs with a RCCL all-gather").
+            # The weak-scaled C2 (one independent BRGEMM per GPU, no communication: N x by construction) moves to `c2_weak`.
+            line["c2_weak"] = {k_: line[k_] for k_ in ("metric", "value", "unit", "ms_per_step", "scaling", "dtype", "config", "roofline")}
+            line.update({"metric": "GFLOP/s on the 3-layer MLP 1024x3 bf16 bs=4096 (bias+relu), rows sharded over the GPUs, all-gather of the "
+                                   "output inside the timed step",
+                         "value": mlp["value"], "unit": "GFLOP/s", "ms_per_step": mlp["ms_per_step"], "scaling": "strong", "dtype": "bf16",
+                         "config": {"workload": "BASELINE config 4: 3-layer MLP 1024->1024->1024->1024 bf16, bs=4096, %d rows per GPU, "
+                                                "gather: %s" % (4096 // world, mlp["gather"]),
+                                    "kernel": mlp["kernel"], "flops_per_step": mlp["flops_per_step"],
+                                    "one_gpu_same_run_ms_per_step": mlp["one_gpu_same_run"]["ms_per_step"],
+                                    "speedup_vs_one_gpu_same_run": mlp["speedup_vs_one_gpu_same_run"],
+                                    "gathered_bit_identical": mlp["gathered_bit_identical"]},
+                         "roofline": {"bound": "mfma", "achieved": round(mlp["value"] / 1e3, 2), "peak": PEAK_BF16_MFMA_TFLOPS * world,
+                                      "unit": "TFLOP/s", "frac": mlp["frac_of_bf16_mfma_peak"], "traffic": None,
+                                      "note": "whole-job flops / step wall time (gather included) against N x the dense bf16 MFMA peak; the "
+                                              "per-kernel roofline of the shard kernels is in the N = 1 line (mlp.per_rank_step_us)"}})
+            if one_device:
+                line["data"] = "synthetic (TEST RIG: all ranks on ONE device - the timings of this line are meaningless)"
         print(json.dumps(line), flush=True)
+        if mlp is not None and mlp.get("gathered_bit_identical") is False:
+            sys.stderr.write("[bench] the gathered MLP output differs from the unsharded result: this run is INVALID\n")
+            sys.exit(3)
 
 
 if __name__ == "__main__":

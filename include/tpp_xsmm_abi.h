@@ -224,8 +224,18 @@ TPP_XSMM_EXPORT const char *xsmm_hip_kernel_name(int64_t handle);
 /* Force a GEMM tile variant for A/B benchmarking and tests (-1 = automatic): f32 0..4 (64x64,
  * 64x32+K2, 32x32+K4, 128x64, 64x64+K2), 5..7 the loader-wave kernels (64x64, 64x64+K2, 64x32+K4), 8 generic, 9 / 10 loader-wave 32x32+K4 / 128x64, bf16 16 / 17 / 18 / 19 (64x64, 128x128, 256x256, 32x32 + K split),
  * 20 .. 23 the bf16 loader-wave tiles for mid-size outputs (32x64 + K split, 64x64, 64x128, 128x128).
- * Honoured at dispatch when the shape divides the tile. */
+ * Honoured at dispatch when the shape divides the tile;
+ * 24 .. 27 the same tiles for a flat bf16 B operand, 28 .. 31 for a VNNI-4 B operand. */
 TPP_XSMM_EXPORT void xsmm_hip_force_variant(int variant);
+/* The VNNI blocking factor v of bf16 B operands ([k/v][ldb][v]) of gemm / brgemm / fused_brgemm handles dispatched FROM NOW ON with
+ * the VNNI_B wire flag: 2 (default) or 4; also TPP_HIP_VNNI_FACTOR. The factor is not on the wire - the reference's compiler and its
+ * runtime library both ask libxsmm_cpuid_dot_pack_factor(LIBXSMM_DATATYPE_BF16) (lib/TPP/Transforms/Utils/VNNIUtils.cpp:25-45; the
+ * `--vnni=4` rows of benchmarks/config/omp/mlir-bf16.json:68-100): a harness that lowers with vnni = 4 sets 4 here before it
+ * dispatches. k must then be a multiple of 4 (dispatch dies otherwise); ldb is the k-group row stride / v as the compiler passes it
+ * (ConvertLinalgToXsmm.cpp:1144). xsmm.unary VNNI2 (kind 28) always packs pairs - there is no VNNI-4 pack kind at this revision
+ * (XsmmEnum.td:34-45). set returns the previous factor, -1 for an invalid one. */
+TPP_XSMM_EXPORT int xsmm_hip_set_vnni_factor(int factor);
+TPP_XSMM_EXPORT int xsmm_hip_get_vnni_factor(void);
 /* Library version string. */
 TPP_XSMM_EXPORT const char *xsmm_hip_version(void);
 

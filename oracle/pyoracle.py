@@ -84,8 +84,11 @@ def lib():
     global _LIB
     if _LIB is None:
         so = os.path.join(_HERE, "liboracle.so")
-        if not os.path.exists(so):
-            build()
+        try:
+            build()  # (a no-op unless a source is newer than the library)
+        except Exception:
+            if not os.path.exists(so):
+                raise
         try:
             L = ctypes.CDLL(so)
         except OSError:
@@ -159,6 +162,21 @@ def fused_brgemm(dt, m, n, k, lda, ldb, ldc, sa, sb, gflags, uflags, ukind, bfla
     rc = lib().oracle_fused_brgemm(dt, m, n, k, lda, ldb, ldc, sa, sb, gflags, uflags, ukind, bflags, bkind,
                                    _p(A, offA), _p(B, offB), _p(C, offC), _p(D, offD), br)
     assert rc == 0, "oracle_fused_brgemm: unsupported arguments"
+
+
+def set_vnni_factor(v):
+    """the oracle's stand-in for libxsmm_cpuid_dot_pack_factor(BF16) (VNNIUtils.cpp:25-45): 2 (default) or 4; returns the old one"""
+    L = lib()
+    L.oracle_set_vnni_factor.argtypes = [ctypes.c_int]
+    old = L.oracle_get_vnni_factor()
+    assert L.oracle_set_vnni_factor(int(v)) == 0, "VNNI factor must be 2 or 4"
+    return old
+
+
+def pack_vnni(w, k, n, v):
+    """row-major bf16 bits [k][n] -> VNNI-v [k/v][n][v] (MLIRGen.cpp:657-664 / VNNIUtils.cpp:75-77); a pure index move"""
+    w = np.asarray(w).reshape(k, n)
+    return np.ascontiguousarray(w.reshape(k // v, v, n).transpose(0, 2, 1)).reshape(-1)
 
 
 def unary(kind, dt, m, n, ldi, ldo, flags, inp, offIn, out, offOut):

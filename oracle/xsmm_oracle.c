@@ -65,10 +65,25 @@ static inline void st(void *p, int64_t i, int dt, float v) {
   else ((uint16_t *)p)[i] = oracle_f32_to_bf16(v);
 }
 
-/* B element (kk, j) of one batch: flat row-major, or VNNI-2 [K/2][N][2] with the
- * row stride ldb already divided by 2 by the compiler (ConvertLinalgToXsmm.cpp:1144). */
+/* The VNNI blocking factor v of bf16 operands is NOT on the wire: the reference asks libxsmm,
+ * `libxsmm_cpuid_dot_pack_factor(LIBXSMM_DATATYPE_BF16)` (lib/TPP/Transforms/Utils/VNNIUtils.cpp:25-45: 2 on x86, 4 where the
+ * dot-product instruction takes four - the `--vnni=4` rows of benchmarks/config/omp/mlir-bf16.json:68-100, extension "svebf16"),
+ * or a DLTI hint, and compiler and runtime library agree because they share that one call. Here: a process-wide setting
+ * (default 2) with the same role; the product's twin is xsmm_hip_set_vnni_factor / TPP_HIP_VNNI_FACTOR. */
+static int g_vnni_factor = 2;
+int oracle_set_vnni_factor(int v) {
+  if (v != 2 && v != 4) return -1;
+  g_vnni_factor = v;
+  return 0;
+}
+int oracle_get_vnni_factor(void) { return g_vnni_factor; }
+
+/* B element (kk, j) of one batch: flat row-major, or VNNI-v [K/v][N][v] (matrix B - [...][K/vnniFactor][N][vnniFactor],
+ * VNNIUtils.cpp:75-77; mlir-gen's packed weights MLIRGen.cpp:657-664) with the row stride ldb already divided by v by the
+ * compiler (ConvertLinalgToXsmm.cpp:1144: ldb = stride / vnniFactor). */
 static inline int64_t b_index(int64_t kk, int64_t j, int64_t ldb, int vnni) {
-  return vnni ? (kk / 2) * (2 * ldb) + j * 2 + (kk % 2) : kk * ldb + j;
+  const int64_t v = g_vnni_factor;
+  return vnni ? (kk / v) * (v * ldb) + j * v + (kk % v) : kk * ldb + j;
 }
 
 /* C element (i, j): row-major, or - wire flag VNNI_C = 8192 - "post-packed" VNNI-2 [m/2][n][2]: the rows pair up
@@ -100,6 +115,7 @@ int oracle_fused_brgemm(int64_t dt, int64_t m, int64_t n, int64_t k, int64_t lda
   const int vnni_c = (gemm_flags & G_VNNI_C) != 0;
   if ((gemm_flags & (G_VNNI_B_WIRE | G_VNNI_A_WIRE | G_VNNI_C)) && dt != BF16) return -1;
   if (vnni_c && (m & 1)) return -1;
+  if (vnni && (k % g_vnni_factor)) return -1;
   if (binary_kind != 0 && !(binary_kind == B_ADD && binary_flags == BF_COL0)) return -1;
   if (unary_kind != 0 && unary_kind != U_RELU) return -1;
   (void)unary_flags;

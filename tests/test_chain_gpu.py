@@ -320,6 +320,40 @@ def test_chain_falls_back_when_it_must(rt):
         rt.set_async(was_async)
 
 
+def test_chain_with_row_striding_batches_runs_call_by_call(rt):
+    """the chain kernel hands an output over per ROW BLOCK, so a later layer whose batch elements stride over ROWS
+    (stride_a >= lda: batch element b reads rows shifted by stride_a / lda) must not run inside it - it would read rows other
+    workgroups have not stored yet. Layer 1 here: A_b = rows [b*64, b*64 + 64) ... of layer 0's [128 + 64][128] output viewed
+    with stride_a = 64 * lda, br = 2, k = 128. The call must return False and equal the two invokes issued one by one."""
+    import torch
+    rng = np.random.default_rng(21)
+    m, n, k0 = 64, 128, 128
+    rows0 = 128  # layer 0 writes 128 rows; layer 1 reads them as 2 batch elements of 64 rows x 128 k
+    W0 = dev(rand(rng, (k0 // 2) * 2 * n, BF16, -0.25, 0.25))
+    W1 = dev(rand(rng, 2 * (n // 2) * 2 * n, BF16, -0.25, 0.25))
+    b0, b1 = dev(rand(rng, n, BF16)), dev(rand(rng, n, BF16))
+    x = dev(rand(rng, rows0 * k0, BF16))
+    h0 = rt.fused_brgemm_dispatch(BF16, m, n, 64, k0, n, n, 64, 64 * n, 4 | VB, 0, 5, 4, 1)
+    # same m / n as layer 0 (a chain needs that), A strides over rows: stride_a = 64 rows
+    h1 = rt.fused_brgemm_dispatch(BF16, m, n, 128, n, n, n, 64 * n, 128 * n, 4 | VB, 0, 5, 4, 1)
+    act0 = dev(np.zeros(rows0 * n, np.uint16))
+    # layer 0 fills all 128 rows first (two invokes), so that layer 1's row-striding read is well defined
+    out_f, out_s = dev(np.zeros(m * n, np.uint16)), dev(np.zeros(m * n, np.uint16))
+    was_async = rt.set_async(True)
+    try:
+        rt.fused_brgemm(BF16, h0, x, 64 * k0, W0, 0, act0, 64 * n, b0, 0, k0 // 64)  # rows 64..127
+        calls = [(h0, x, 0, W0, 0, act0, 0, b0, 0, k0 // 64), (h1, act0, 0, W1, 0, out_f, 0, b1, 0, 2)]
+        assert not rt.fused_brgemm_chain(BF16, calls), "a row-striding later layer must not run inside the chain kernel"
+        rt.synchronize()
+        rt.fused_brgemm(BF16, h0, x, 0, W0, 0, act0, 0, b0, 0, k0 // 64)
+        rt.fused_brgemm(BF16, h1, act0, 0, W1, 0, out_s, 0, b1, 0, 2)
+        rt.synchronize()
+        assert torch.equal(out_f, out_s)
+    finally:
+        rt.synchronize()
+        rt.set_async(was_async)
+
+
 def test_sharded_mlp_forward_uses_the_chain(rt):
     """tpp-mlir_amd.mlp.ShardedMlp.forward hands the rank's step over in one call"""
     import torch

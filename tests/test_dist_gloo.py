@@ -148,3 +148,79 @@ def test_column_sharded_mlp_gather_per_layer_world2(batch, dtype):
         assert p.exitcode == 0
     assert all(ok for (_, ok, _, _) in res), res
     assert all(nl == 3 and br == world for (_, _, nl, br) in res)
+
+
+# ---- PeerGather.create: the fallback protocol (a rank that failed before the barrier left the others hanging) ------
+class _FakePeerLib:
+    """the five entry points PeerGather's set-up calls, with a fault injected on one rank (no GPU involved)"""
+
+    def __init__(self, rank, fail_rank, fail_at):
+        self.rank, self.fail_rank, self.fail_at = rank, fail_rank, fail_at
+        self.next, self.freed, self.closed = 0x1000, [], []
+
+    def xsmm_hip_peer_alloc(self, nbytes):
+        if self.rank == self.fail_rank and self.fail_at == "alloc":
+            return 0
+        self.next += 0x100000
+        return self.next
+
+    def xsmm_hip_ipc_export(self, ptr, out):
+        return -1 if (self.rank == self.fail_rank and self.fail_at == "export") else 0
+
+    def xsmm_hip_ipc_open(self, handle):
+        if self.rank == self.fail_rank and self.fail_at == "open":
+            return 0
+        self.next += 0x100000
+        return self.next
+
+    def xsmm_hip_ipc_close(self, ptr):
+        self.closed.append(ptr)
+        return 0
+
+    def xsmm_hip_peer_free(self, ptr):
+        self.freed.append(ptr)
+
+
+class _FakePeerRt:
+    def __init__(self, lib):
+        self.lib = lib
+
+    def synchronize(self):
+        pass
+
+
+def run_rank_peer_fallback(rank, world, port, fail_at, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lib = _FakePeerLib(rank, 1, fail_at)
+        pg = pkg.PeerGather.create(_FakePeerRt(lib), rank, world, 1 << 20)
+        # the collectives of both ranks still pair up: this all_reduce would hang or mismatch otherwise
+        t = torch.tensor([rank + 1])
+        dist.all_reduce(t)
+        out_q.put((rank, pg is None, int(t[0]), len(lib.freed), len(lib.closed)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_at", ["alloc", "export", "open"])
+def test_peer_gather_falls_back_on_every_rank_when_one_rank_fails(fail_at):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=run_rank_peer_fallback, args=(r, world, port, fail_at, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for (rank, none, total, freed, closed) in res:
+        assert none, "rank %d kept a peer-gather object although rank 1 failed (%s)" % (rank, fail_at)
+        assert total == 3, "the collectives after the fallback did not pair up"
+    # whatever a rank did allocate or map has been released again (ADVICE r3: close() leaked the rank's own buffers)
+    assert res[0][3] == 3  # rank 0: its three allocations freed
+    if fail_at == "open":
+        assert res[1][3] == 3

@@ -61,3 +61,36 @@ def test_mlir_gen_flops_formula():
         for k, n in zip(c["layers"][:-1], c["layers"][1:]):
             total += 2 * m * n * k + (m * n if c["bias"] else 0) + (m * n if c["relu"] else 0)
         assert total == c["flops"], c
+
+
+def test_oracle_vnni_factor_4_equals_the_flat_operand():
+    """B as VNNI-4 [k/4][n][4] (MLIRGen.cpp:657-664; the factor comes from libxsmm_cpuid_dot_pack_factor in the
+    reference, VNNIUtils.cpp:25-45 - here oracle_set_vnni_factor). The contraction walks k in order whatever the packing, so the
+    result on the packed operand is the result on the flat operand bit for bit; factor 2 stays the default."""
+    import numpy as np
+    from oracle import pyoracle as orc
+    rng = np.random.default_rng(0)
+    m, n, k, br = 5, 6, 8, 3
+    A = orc.f32_to_bf16(rng.uniform(-1, 1, br * m * k).astype(np.float32))
+    Bf = orc.f32_to_bf16(rng.uniform(-1, 1, br * k * n).astype(np.float32))
+    outs = {}
+    for v in (0, 2, 4):
+        if v:
+            old = orc.set_vnni_factor(v)
+            B = np.concatenate([orc.pack_vnni(Bf[b * k * n:(b + 1) * k * n], k, n, v) for b in range(br)])
+        else:
+            B = Bf
+        C = np.zeros(m * n, np.uint16)
+        orc.brgemm(2, m, n, k, k, n, n, m * k, k * n, 4 | (2048 if v else 0), A, 0, B, 0, C, 0, br)
+        if v:
+            orc.set_vnni_factor(old)
+        outs[v] = C
+    assert np.array_equal(outs[0], outs[2]) and np.array_equal(outs[0], outs[4])
+    assert orc.set_vnni_factor(2) == 2
+    # k must be a multiple of the factor
+    old = orc.set_vnni_factor(4)
+    try:
+        rc = orc.lib().oracle_fused_brgemm(2, 2, 2, 6, 6, 2, 2, 12, 12, 4 | 2048, 0, 0, 0, 0, A.ctypes.data, Bf.ctypes.data, C.ctypes.data, None, 1)
+        assert rc != 0
+    finally:
+        orc.set_vnni_factor(old)

@@ -1,0 +1,166 @@
+"""VNNI-4 bf16 B operands ([k/4][n][4]; `--vnni=4` in benchmarks/config/omp/mlir-bf16.json:68-100, layout
+MLIRGen.cpp:657-664 / VNNIUtils.cpp:75-77). The factor is not on the wire - the reference asks libxsmm_cpuid_dot_pack_factor
+(VNNIUtils.cpp:25-45) - so the runtime takes it from xsmm_hip_set_vnni_factor / TPP_HIP_VNNI_FACTOR at dispatch time.
+Parity: the HIP result on the VNNI-4 operand against the oracle (a) run on the same packed operand with its own factor set to 4 and
+(b) fed the FLAT operand (as test_c5 does for VNNI-2) - the two oracle runs are bit-identical by construction (same k order)."""
+import importlib
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as orc
+from test_parity_gpu import BF16, VB, check_close, dev, host, rand
+
+pytestmark = pytest.mark.gpu
+pkg = importlib.import_module("tpp-mlir_amd")
+
+
+@pytest.fixture(scope="module")
+def rt():
+    r = pkg.get_runtime()
+    assert r.device_count() >= 1, "no HIP device visible: the gpu tests need an MI355X"
+    return r
+
+
+@pytest.fixture()
+def vnni4(rt):
+    old = rt.set_vnni_factor(4)
+    old_o = orc.set_vnni_factor(4)
+    yield 4
+    rt.set_vnni_factor(old)
+    orc.set_vnni_factor(old_o)
+
+
+def pack(Bf, K, n, ldb, v, br=1, sb=None):
+    """flat [br][K][n] -> VNNI-v [br][K/v][ldb][v] (batch stride sb elements)"""
+    sb = K * ldb if sb is None else sb
+    out = np.zeros((br - 1) * sb + (K // v) * ldb * v, np.uint16)
+    for b in range(br):
+        blk = Bf[b * K * n:(b + 1) * K * n].reshape(K // v, v, n).transpose(0, 2, 1)  # [K/v][n][v]
+        dst = out[b * sb:b * sb + (K // v) * ldb * v].reshape(K // v, ldb, v)
+        dst[:, :n, :] = blk
+    return out
+
+
+def run_case(rt, m, n, k, br, force=None, bias=True, relu=True, beta0=True, ldb=None, lda=None, ldc=None, mode="device", seed=0,
+             expect=None):
+    rng = np.random.default_rng(seed)
+    ldb, lda, ldc = ldb or n, lda or k * br, ldc or n
+    sa, sb = k, k * ldb
+    A = rand(rng, (m - 1) * lda + k * br + 8, BF16)
+    Bf = rand(rng, br * k * n, BF16, -0.5, 0.5)
+    B4 = pack(Bf, k, n, ldb, 4, br, sb)
+    D = rand(rng, n, BF16)
+    C0 = rand(rng, m * ldc, BF16)
+    flags = (4 if beta0 else 0) | VB
+    fused = bias or relu
+    # oracle on the packed operand (factor 4) and on the flat one: bit-identical
+    ref = C0.copy()
+    ref_flat = C0.copy()
+    if fused:
+        orc.fused_brgemm(BF16, m, n, k, lda, ldb, ldc, sa, sb, flags, 0, 5 if relu else 0, 4 if bias else 0, 1 if bias else 0,
+                         A, 0, B4, 0, ref, 0, D, 0, br)
+        orc.fused_brgemm(BF16, m, n, k, lda, n, ldc, sa, k * n, flags & ~VB, 0, 5 if relu else 0, 4 if bias else 0, 1 if bias else 0,
+                         A, 0, Bf, 0, ref_flat, 0, D, 0, br)
+    else:
+        orc.brgemm(BF16, m, n, k, lda, ldb, ldc, sa, sb, flags, A, 0, B4, 0, ref, 0, br)
+        orc.brgemm(BF16, m, n, k, lda, n, ldc, sa, k * n, flags & ~VB, A, 0, Bf, 0, ref_flat, 0, br)
+    assert np.array_equal(ref, ref_flat), "the oracle on the VNNI-4 operand differs from the oracle on the flat operand"
+    if force is not None:
+        rt.force_variant(force)
+    try:
+        if fused:
+            h = rt.fused_brgemm_dispatch(BF16, m, n, k, lda, ldb, ldc, sa, sb, flags, 0, 5 if relu else 0, 4 if bias else 0, 1 if bias else 0)
+        else:
+            h = rt.brgemm_dispatch(BF16, m, n, k, lda, ldb, ldc, sa, sb, flags)
+    finally:
+        if force is not None:
+            rt.force_variant(-1)
+    name = rt.kernel_name(h)
+    if expect:
+        assert expect in name, name
+    if mode == "device":
+        dA, dB, dC, dD = dev(A), dev(B4), dev(C0), dev(D)
+        if fused:
+            rt.fused_brgemm(BF16, h, dA, 0, dB, 0, dC, 0, dD, 0, br)
+        else:
+            rt.brgemm(BF16, h, dA, 0, dB, 0, dC, 0, br)
+        got = host(dC, C0)
+    else:
+        got = C0.copy()
+        if fused:
+            rt.fused_brgemm(BF16, h, A, 0, B4, 0, got, 0, D, 0, br)
+        else:
+            rt.brgemm(BF16, h, A, 0, B4, 0, got, 0, br)
+    sel = np.concatenate([np.arange(r * ldc, r * ldc + n) for r in range(m)])
+    check_close(got[sel], ref[sel], BF16, "vnni4[%s] m%d n%d k%d br%d" % (name, m, n, k, br))
+    if ldc > n:  # the gap columns between the rows belong to somebody else
+        gap = np.setdiff1d(np.arange(m * ldc), sel)
+        assert np.array_equal(got[gap], C0[gap])
+    return name, got
+
+
+@pytest.mark.parametrize("variant,m,n", [(28, 64, 128), (29, 128, 128), (30, 128, 256), (31, 256, 256)])
+@pytest.mark.parametrize("k,br", [(64, 1), (64, 5), (128, 3), (64, 16)])
+def test_vnni4_loader_wave_tiles(rt, vnni4, variant, m, n, k, br):
+    """every loader-wave tile with the VNNI-4 B image (two 8-byte fragment reads), chunk streams around the ring depths, padded
+    leading dimensions, both accumulator starts"""
+    for (beta0, bias, relu) in ((True, True, True), (False, False, False)):
+        run_case(rt, m, n, k, br, force=variant, bias=bias, relu=relu, beta0=beta0, ldb=n + 2, lda=k * br + 8, ldc=n + 8,
+                 seed=variant * 100 + k + br, expect="vnni4")
+
+
+def test_vnni4_shapes_of_the_reference_benchmark_config(rt, vnni4):
+    """benchmarks/config/omp/mlir-bf16.json:68-100: mlir-gen --batch=256 --layers=1024,1024,1024,1024 --tiles=32,32,32 --vnni=4,
+    bias + relu: (a) the compiler-native tile invoke [32,32,32,32,32,32,1024,1024] br = 32 (k = 32: the generic kernel's element
+    path), (b) the same layer as one whole-layer dispatch (256 x 1024, k = 64, br = 16) and (c) a bs = 4096 layer"""
+    name, _ = run_case(rt, 32, 32, 32, 32, seed=1)
+    assert "generic" in name or "grouped" in name, name
+    name, _ = run_case(rt, 256, 1024, 64, 16, seed=2, expect="vnni4")
+    name, _ = run_case(rt, 4096, 1024, 64, 16, seed=3, expect="vnni4<128x128>")
+
+
+def test_vnni4_is_bit_identical_to_the_vnni2_kernel_on_the_same_matrix(rt):
+    """the same logical B packed with factor 2 and with factor 4: same tile, same MFMA k order -> the same bits"""
+    for (m, n, k, br, tile) in ((512, 1024, 64, 16, 0), (1024, 1024, 64, 16, 1), (2048, 2048, 128, 16, 3)):
+        rng = np.random.default_rng(m)
+        K = k * br
+        A, Bf, D = rand(rng, m * K, BF16), rand(rng, K * n, BF16), rand(rng, n, BF16)
+        outs = []
+        for v in (2, 4):
+            old = rt.set_vnni_factor(v)
+            rt.force_variant((20 if v == 2 else 28) + tile)
+            try:
+                h = rt.fused_brgemm_dispatch(BF16, m, n, k, K, n, n, k, k * n, 4 | VB, 0, 5, 4, 1)
+            finally:
+                rt.force_variant(-1)
+                rt.set_vnni_factor(old)
+            Bp = pack(Bf, K, n, n, v)
+            C = np.zeros(m * n, np.uint16)
+            dC = dev(C)
+            rt.fused_brgemm(BF16, h, dev(A), 0, dev(Bp), 0, dC, 0, dev(D), 0, br)
+            outs.append((rt.kernel_name(h), host(dC, C)))
+        assert "vnni4" in outs[1][0] and "vnni4" not in outs[0][0], [o[0] for o in outs]
+        assert np.array_equal(outs[0][1], outs[1][1]), "%s differs from %s" % (outs[1][0], outs[0][0])
+
+
+def test_vnni4_ragged_and_host_pointers(rt, vnni4):
+    """ragged shapes (generic kernel) and the host-memory mirror (the B span follows the factor)"""
+    run_case(rt, 6, 6, 8, 2, bias=False, relu=False, beta0=False, seed=4)
+    run_case(rt, 13, 10, 12, 3, seed=5, ldb=12, ldc=16)
+    run_case(rt, 64, 64, 64, 2, seed=6, mode="host", expect="vnni4")
+    run_case(rt, 13, 10, 12, 3, seed=7, mode="host")
+
+
+def test_vnni4_handles_do_not_alias_vnni2_handles(rt):
+    """the factor is part of the descriptor: the same tuple dispatched under factor 2 and under factor 4 gives two handles"""
+    old = rt.set_vnni_factor(2)
+    try:
+        h2 = rt.brgemm_dispatch(BF16, 64, 64, 64, 64, 64, 64, 4096, 4096, 4 | VB)
+        rt.set_vnni_factor(4)
+        h4 = rt.brgemm_dispatch(BF16, 64, 64, 64, 64, 64, 64, 4096, 4096, 4 | VB)
+        rt.set_vnni_factor(2)
+        assert h2 != h4 and rt.brgemm_dispatch(BF16, 64, 64, 64, 64, 64, 64, 4096, 4096, 4 | VB) == h2
+        assert "vnni4" in rt.kernel_name(h4) and "vnni4" not in rt.kernel_name(h2)
+    finally:
+        rt.set_vnni_factor(old)

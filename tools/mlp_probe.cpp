@@ -29,7 +29,7 @@ static unsigned short f2bf(float f) {
 }
 
 int main(int argc, char **argv) {
-  int iters = 400, layers = 3, width = 1024, variant = -1;
+  int iters = 400, layers = 3, width = 1024, variant = -1, pad = 0;
   std::string rows_arg = "512,1024,2048,4096", only = "all";
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
@@ -39,6 +39,7 @@ int main(int argc, char **argv) {
     else if (a == "--width" && i + 1 < argc) width = atoi(argv[++i]);
     else if (a == "--variant" && i + 1 < argc) variant = atoi(argv[++i]);
     else if (a == "--only" && i + 1 < argc) only = argv[++i];
+    else if (a == "--pad" && i + 1 < argc) pad = atoi(argv[++i]); // extra elements per row of the input / the activations (leading dimensions K + pad)
     else { fprintf(stderr, "unknown flag %s\n", a.c_str()); return 2; }
   }
   if (xsmm_hip_device_count() < 1) { fprintf(stderr, "mlp_probe: no HIP device (there is no CPU fallback)\n"); return 1; }
@@ -71,15 +72,16 @@ int main(int argc, char **argv) {
   CHECK(hipEventCreate(&e0));
   CHECK(hipEventCreate(&e1));
   for (int rows : rows_list) {
-    std::vector<unsigned short> hx((size_t)rows * K);
+    const int64_t LD = K + pad;
+    std::vector<unsigned short> hx((size_t)rows * LD);
     for (auto &v : hx) v = f2bf(du(eng));
     unsigned short *x;
     std::vector<unsigned short *> act(layers);
     CHECK(hipMalloc((void **)&x, hx.size() * 2));
     CHECK(hipMemcpy(x, hx.data(), hx.size() * 2, hipMemcpyHostToDevice));
-    for (int l = 0; l < layers; ++l) CHECK(hipMalloc((void **)&act[l], (size_t)rows * N * 2));
+    for (int l = 0; l < layers; ++l) CHECK(hipMalloc((void **)&act[l], (size_t)rows * (N + pad) * 2));
     if (variant >= 0) xsmm_hip_force_variant(variant);
-    const int64_t h = xsmm_fused_brgemm_dispatch(2, rows, N, 64, K, N, N, 64, 64 * N, XSMM_GEMM_FLAG_BETA_0 | XSMM_GEMM_WIRE_VNNI_B, 0,
+    const int64_t h = xsmm_fused_brgemm_dispatch(2, rows, N, 64, LD, N, N + pad, 64, 64 * N, XSMM_GEMM_FLAG_BETA_0 | XSMM_GEMM_WIRE_VNNI_B, 0,
                                                  XSMM_UNARY_RELU, XSMM_BINARY_FLAG_BCAST_COL_IN_0, XSMM_BINARY_ADD);
     xsmm_hip_force_variant(-1);
     std::vector<int64_t> hs(layers, h), zero(layers, 0), brs(layers, br);
@@ -125,9 +127,9 @@ int main(int argc, char **argv) {
     if (only != "layers") t_chain = time_it(step_chain);
     xsmm_hip_synchronize();
     const double flops = 2.0 * rows * N * K * layers;
-    printf("{\"rows\": %d, \"layers\": %d, \"width\": %d, \"kernel\": \"%s\", \"one_layer_us\": %.3f, \"per_layer_launches_us\": %.3f, "
+    printf("{\"rows\": %d, \"layers\": %d, \"width\": %d, \"pad\": %d, \"kernel\": \"%s\", \"one_layer_us\": %.3f, \"per_layer_launches_us\": %.3f, "
            "\"chain_us\": %.3f, \"chain_one_launch\": %s, \"chain_tflops\": %.1f, \"layers_tflops\": %.1f}\n",
-           rows, layers, width, xsmm_hip_kernel_name(h), t_one, t_layers, t_chain, fused ? "true" : "false",
+           rows, layers, width, pad, xsmm_hip_kernel_name(h), t_one, t_layers, t_chain, fused ? "true" : "false",
            t_chain > 0 ? flops / t_chain * 1e-6 : 0.0, t_layers > 0 ? flops / t_layers * 1e-6 : 0.0);
     fflush(stdout);
     CHECK(hipFree(x));

@@ -117,6 +117,44 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "bf16":
     bf16_case(4096, 4096, 64, 64, force=17, tag="4096^3 forced 128x128")
     sys.exit(0)
 
+def bf16_vnni4_case(m, n, k, br, tag="", force=None):
+    """VNNI-4 B ([K/4][n][4], xsmm_hip_set_vnni_factor(4)): the loader-wave tiles with 8-byte fragment reads"""
+    K = k * br
+    A = (torch.rand(m, K, device="cuda") * 2 - 1).to(torch.bfloat16)
+    B = (torch.rand(K // 4, n, 4, device="cuda") * 2 - 1).to(torch.bfloat16)
+    C = torch.zeros(m, n, device="cuda", dtype=torch.bfloat16)
+    old = rt.set_vnni_factor(4)
+    if force is not None:
+        rt.force_variant(force)
+    h = rt.brgemm_dispatch(BF16, m, n, k, K, n, n, k, k * n, 4 | 2048)
+    rt.force_variant(-1)
+    rt.set_vnni_factor(old)
+    t = time_it(lambda: rt.brgemm(BF16, h, A, 0, B, 0, C, 0, br))
+    fl = 2.0 * m * n * K
+    print("bf16 m%-5d n%-5d k%-5d br%-3d %-32s %8.2f us %8.1f TF  %5.1f%% %s" % (
+        m, n, k, br, rt.kernel_name(h), t * 1e6, fl / t / 1e12, fl / t / 25e12, tag), flush=True)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "vnni4":
+    # VNNI-4 against VNNI-2 and flat B on the same tiles (same run): the B fragment reads are 8-byte / 4-byte / transpose reads
+    for (m, n, k, br, what) in ((4096, 1024, 64, 16, "C4 layer"), (4096, 1024, 64, 128, "C4 output, K=8192"), (2048, 2048, 128, 16, "C5"),
+                                (2048, 1024, 64, 16, "2048 rows"), (1024, 1024, 64, 16, "1024 rows"), (512, 1024, 64, 16, "512 rows"),
+                                (256, 1024, 64, 16, "256 rows")):
+        bf16_case(m, n, k, br, tag=what + " VNNI-2")
+        bf16_vnni4_case(m, n, k, br, tag=what + " VNNI-4")
+        bf16_flat_case(m, n, k, br, tag=what + " flat B")
+    sys.exit(0)
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "lw128":
+    # the 128x128 loader-wave tile (forced 23 / flat B 27) under TPP_HIP_BLW_MODE: C4 layer, the same output at K = 8192 (time per
+    # chunk = the difference / 112), C5, two rounds of tiles, 4096^3
+    tag = "MODE=%s" % os.environ.get("TPP_HIP_BLW_MODE", "0")
+    for (m, n, k, br, what) in ((4096, 1024, 64, 16, "C4 layer"), (4096, 1024, 64, 128, "C4 output, K=8192"), (2048, 2048, 128, 16, "C5"),
+                                (4096, 2048, 64, 32, "512 tiles"), (4096, 4096, 64, 64, "4096^3")):
+        bf16_case(m, n, k, br, force=23, tag=what + " " + tag)
+        bf16_flat_case(m, n, k, br, force=27, tag=what + " flat B " + tag)
+    sys.exit(0)
+
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "small":
     # small bf16 outputs: the reference's --batch=256 layers and the per-rank shards of the MLP, tile families 16 / 19
     for m in (128, 256, 512, 1024, 2048):

@@ -65,24 +65,23 @@ def build(force=False, verbose=False):
 ABLATION_SOURCES = ["runtime.cpp", "brgemm_f32.hip", "brgemm_bf16_lw.hip"]  # the translation units that look at TPP_HIP_ABLATION
 
 
-def build_ablation(skip_math=False, verbose=False):
-    """Side build for timing experiments: the same library with -DTPP_HIP_ABLATION (then, and only then, the loader-wave
-    bf16 kernels obey TPP_HIP_CHAIN_DBG - chain_args.h; several of its bits give wrong results by design) into
-    tools/_abl/ (skip_math: also -DTPP_BLW_SKIP_MATH, into tools/_abl_nomath/). Use it through
-    `LD_LIBRARY_PATH=tools/_abl tools/mlp_probe ...`; nothing in the package, the tests or bench.py loads it."""
+def build_side(name, defs, sources=None, verbose=False):
+    """A side build of the library into tools/<name>/ with extra -D switches on the translation units `sources` (default: the ones
+    that look at TPP_HIP_ABLATION); every other object comes from the product build. For A/B and timing experiments only: use it
+    through `LD_LIBRARY_PATH=tools/<name> tools/mlp_probe ...` or `TPP_XSMM_LIBRARY=tools/<name>/libtpp_xsmm_runner_utils.so
+    python ...`; nothing in the package, the tests or bench.py loads it."""
     build()
     cc = hipcc()
     root = os.path.dirname(HERE)
-    name = "_abl_nomath" if skip_math else "_abl"
+    sources = list(sources or ABLATION_SOURCES)
     outdir = os.path.join(root, "tools", name)
     objdir = os.path.join(HERE, "build", name)
     os.makedirs(outdir, exist_ok=True)
     os.makedirs(objdir, exist_ok=True)
-    defs = ["-DTPP_HIP_ABLATION"] + (["-DTPP_BLW_SKIP_MATH"] if skip_math else [])
 
     def compile_one(src):
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
-        cmd = [cc] + FLAGS + defs + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [cc] + FLAGS + list(defs) + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -90,14 +89,22 @@ def build_ablation(skip_math=False, verbose=False):
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, r.stderr))
         return obj
 
-    with ThreadPoolExecutor(max_workers=len(ABLATION_SOURCES)) as ex:
-        objs = list(ex.map(compile_one, ABLATION_SOURCES))
-    objs += [os.path.join(HERE, "build", os.path.splitext(f)[0] + ".o") for f in SOURCES if f not in ABLATION_SOURCES]
+    with ThreadPoolExecutor(max_workers=len(sources)) as ex:
+        objs = list(ex.map(compile_one, sources))
+    objs += [os.path.join(HERE, "build", os.path.splitext(f)[0] + ".o") for f in SOURCES if f not in sources]
     out = os.path.join(outdir, SO_NAME)
     r = subprocess.run([cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-pthread", "-o", out] + objs, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stderr)
     return out
+
+
+def build_ablation(skip_math=False, verbose=False):
+    """Side build for timing experiments: the same library with -DTPP_HIP_ABLATION (then, and only then, the loader-wave
+    bf16 kernels obey TPP_HIP_CHAIN_DBG - chain_args.h; several of its bits give wrong results by design) into
+    tools/_abl/ (skip_math: also -DTPP_BLW_SKIP_MATH, into tools/_abl_nomath/)."""
+    defs = ["-DTPP_HIP_ABLATION"] + (["-DTPP_BLW_SKIP_MATH"] if skip_math else [])
+    return build_side("_abl_nomath" if skip_math else "_abl", defs, verbose=verbose)
 
 
 def build_tools(verbose=False):
@@ -128,3 +135,7 @@ if __name__ == "__main__":
     if "--ablation" in sys.argv:
         print(build_ablation(verbose=True))
         print(build_ablation(skip_math=True, verbose=True))
+    for a in sys.argv[1:]:  # --side=name:-DX=1,-DY  (any number of them)
+        if a.startswith("--side="):
+            nm, _, ds = a[len("--side="):].partition(":")
+            print(build_side(nm, [d for d in ds.split(",") if d], sources=["brgemm_bf16_lw.hip"], verbose=True))

@@ -767,7 +767,7 @@ template <int LW> static hipError_t launch_bf16_dma128(const GemmArgs &a, hipStr
 }
 
 bool bf16_fast_eligible(const GemmDesc &d) {
-  if (d.dtype != DT_BF16 || !d.vnni_b) return false;
+  if (d.dtype != DT_BF16 || !d.vnni_b || d.vnni_factor != 2) return false; // (VNNI-4 operands: bf16_vnni4_eligible, brgemm_f32.hip)
   if (d.k <= 0 || d.k % BKH) return false;
   if (d.m % 64 || d.n % 64) return false;
   if ((d.lda & 7) || (d.ldb & 3) || (d.ldc & 7) || (d.stride_a & 7) || (d.stride_b & 7)) return false;

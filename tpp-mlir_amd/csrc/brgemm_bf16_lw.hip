@@ -145,6 +145,15 @@ __device__ __forceinline__ void blw_loader(chain_kernarg_t *pp, unsigned char *s
       const int swz_ = BN == 128 ? (row_ & 3) << 2 : ((row_ >> 1) & 1) << 2;                                           \
       vo0 = vo1 = (unsigned)(row_ * (int)p.L[l].ldb * 2 + ((piece_ ^ swz_) << 4));                                     \
       step = (unsigned)(NL * RPT_ * (int)p.L[l].ldb * 2);                                                              \
+    } else if (FB == 4) {                                                                                              \
+      /* VNNI-4 B ([k/4][ldb][4]): image = the chunk's 16 k-group rows of BN * 8 bytes as they are; instruction v covers */ \
+      /* k-group rows (128/BN)*v ..: lane -> row lane / (BN/2), 16-byte piece lane % (BN/2). A fragment is two 8-byte reads. */ \
+      constexpr int RPI4_ = 128 / BN, PPR4_ = BN / 2;                                                                  \
+      g = (const unsigned short *)p.L[l].B + 4 * (int64_t)n0 + (int64_t)part * RPI4_ * 4 * p.L[l].ldb;                 \
+      d_in = (int64_t)BLW_BK * p.L[l].ldb;                                                                             \
+      d_wrap = p.L[l].stride_b - (int64_t)(kchunks - 1) * d_in;                                                        \
+      vo0 = vo1 = (unsigned)((lane / PPR4_) * (int)p.L[l].ldb * 8 + ((lane % PPR4_) << 4));                            \
+      step = (unsigned)(NL * RPI4_ * (int)p.L[l].ldb * 8);                                                             \
     } else {                                                                                                           \
       g = (const unsigned short *)p.L[l].B + 2 * (int64_t)n0 + (int64_t)part * RPI * 2 * p.L[l].ldb;                   \
       d_in = (int64_t)(BLW_BK / 2) * 2 * p.L[l].ldb;                                                                   \
@@ -275,7 +284,8 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
   static_assert(SUP == 1 || ((SUP == 2 || SUP == 4) && TM * TN <= 2 && NSLOT % SUP == 0 && NSLOT % 2 == 0),
                 "several chunks per barrier: the tiles that read a whole chunk of fragments ahead");
   constexpr int NLW = NLA + NLB; // loader waves
-  static_assert(FLATB == 0 || FLATB == 2, "0: VNNI-2 B image, 2: flat B image + transpose reads");
+  static_assert(FLATB == 0 || FLATB == 2 || FLATB == 4, "0: VNNI-2 B image, 2: flat B image + transpose reads, 4: VNNI-4 B image + 8-byte reads");
+  static_assert(FLATB != 4 || BN >= 64, "VNNI-4 image: whole k-group rows per DMA instruction");
   static_assert(FLATB != 2 || BN >= 64, "transpose-read image: 64-byte blocks swizzled inside rows of >= 128 bytes");
   static_assert(BN == 32 || BN == 64 || BN == 128, "B pair-rows per DMA instruction");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_c[];
@@ -299,13 +309,20 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
     tm = b / p.tiles_n;
     tn = b - tm * p.tiles_n;
   }
-  const int m0 = tm * BM, n0 = tn * BN;
+#ifdef TPP_HIP_ABLATION
+  // timing experiment (dbg & 512): every workgroup LOADS the panels of tile (0, 0) - 100 % L2 hits after the first touch, no fabric
+  // traffic - and stores its own tile: what the K loop costs when no byte comes from beyond the L2
+  const bool alias_ = (p.dbg & 512) != 0;
+  const int m0 = tm * BM, n0 = tn * BN, m0_ld = alias_ ? 0 : m0, n0_ld = alias_ ? 0 : n0;
+#else
+  const int m0 = tm * BM, n0 = tn * BN, m0_ld = m0, n0_ld = n0;
+#endif
   const int L = MULTI ? p.nlayers : 1;
 
   if (wave >= NMW) {
     // ---- loader waves (blw_loader above) ---------------------------------------------------------------------------
-    if (wave < NMW + NLA) blw_loader<true, NLA, NLA, NSLOT, SUP, BM, BN, WK, MULTI>(pp, smem_c, lane, m0, n0, tm, L, wave - NMW);
-    else blw_loader<false, NLB, NLA, NSLOT, SUP, BM, BN, WK, MULTI, FLATB>(pp, smem_c, lane, m0, n0, tm, L, wave - NMW - NLA);
+    if (wave < NMW + NLA) blw_loader<true, NLA, NLA, NSLOT, SUP, BM, BN, WK, MULTI>(pp, smem_c, lane, m0_ld, n0_ld, tm, L, wave - NMW);
+    else blw_loader<false, NLB, NLA, NSLOT, SUP, BM, BN, WK, MULTI, FLATB>(pp, smem_c, lane, m0_ld, n0_ld, tm, L, wave - NMW - NLA);
     return; // ended waves do not take part in later barriers
   }
 
@@ -336,6 +353,10 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
       const int swz = BN == 128 ? rowl : (rowl >> 1) & 1;
       b_lane[j] = (8 * lh + rowl) * (BN * 2) + ((blk ^ swz) << 6) + ((lane >> 4) & 1) * 32 + (pp16 & 3) * 8;
     }
+    if constexpr (FLATB == 4) {
+      // VNNI-4 image [16 k-groups][BN][4] (blw_loader FB = 4): this lane's column, k-group 2 lh of a k-step (bytes)
+      b_lane[j] = (2 * lh) * (BN * 8) + ((wn * TN + j) * 32 + li) * 8;
+    }
     asm volatile("" : "+v"(b_lane[j])); // one base VGPR per column tile: rows r, r+1 pair up as ds_read2(st64)_b32
   }
   auto frag_load = [&](int buf, int slot, int ks) __attribute__((always_inline)) {
@@ -355,6 +376,11 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
         lds_u8_lw *bb = (lds_u8_lw *)(as + A_SLOT) + b_lane[j] + (16 * ks) * (BN * 2);
         const u32x2_lw q0 = __builtin_bit_cast(u32x2_lw, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_lw *)bb));
         const u32x2_lw q1 = __builtin_bit_cast(u32x2_lw, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_lw *)(bb + 4 * (BN * 2))));
+        bw[buf][j] = u32x4{q0[0], q0[1], q1[0], q1[1]};
+      } else if constexpr (FLATB == 4) {
+        // four consecutive k of a column are 8 contiguous bytes: k-groups 4 ks + 2 lh and + 1 = the lane's eight k of this step
+        const unsigned char *bb = as + A_SLOT + b_lane[j] + (4 * ks) * (BN * 8);
+        const u32x2_lw q0 = *(const u32x2_lw *)bb, q1 = *(const u32x2_lw *)(bb + BN * 8);
         bw[buf][j] = u32x4{q0[0], q0[1], q1[0], q1[1]};
       } else {
         const unsigned int *bp = bs + b_lane[j] + (8 * ks) * BN;
@@ -748,6 +774,25 @@ hipError_t launch_bf16_lw_flatb(int tile, const ChainArgs &a, hipStream_t s) {
   case 5: return launch_blw_t<2, 2, 1, 1, 2, 6, 1, 2, 1, false, 2>(a, s);
   case 6:
   case 7: return launch_blw_t<2, 2, 1, 2, 2, 4, 1, 1, 1, false, 2>(a, s);
+  default: return hipErrorInvalidValue;
+  }
+}
+
+// One layer whose B operand is VNNI-4 ([k/4][ldb][4] bf16: the dispatch carries the VNNI flag, the factor is the runtime's setting,
+// xsmm_hip_set_vnni_factor - lib/TPP/Transforms/Utils/VNNIUtils.cpp:25-45, benchmarks/config/omp/mlir-bf16.json:68-100): the same
+// configurations with the B image and the fragment reads of FLATB = 4 - the chunk's 16 k-group rows go into the LDS as they are and a
+// fragment is two 8-byte reads (256 B/clk against the 128 B/clk of the VNNI-2 image's 4-byte reads).
+hipError_t launch_bf16_lw_vnni4(int tile, const ChainArgs &a, hipStream_t s) {
+  if (a.L[0].br < 1 || a.L[0].k < BLW_BK || tile < 0 || tile > 3) return hipErrorInvalidValue;
+  switch (tile * 2 + (blw_sup2(a) ? 1 : 0)) {
+  case 0: return launch_blw_t<1, 2, 2, 1, 1, 8, 1, 2, 1, false, 4>(a, s);
+  case 1: return launch_blw_t<1, 2, 2, 1, 1, 8, 1, 2, 2, false, 4>(a, s);
+  case 2: return launch_blw_t<2, 2, 1, 1, 1, 8, 1, 1, 1, false, 4>(a, s);
+  case 3: return launch_blw_t<2, 2, 1, 1, 1, 8, 1, 1, 2, false, 4>(a, s);
+  case 4:
+  case 5: return launch_blw_t<2, 2, 1, 1, 2, 6, 1, 2, 1, false, 4>(a, s);
+  case 6:
+  case 7: return launch_blw_t<2, 2, 1, 2, 2, 4, 1, 1, 1, false, 4>(a, s);
   default: return hipErrorInvalidValue;
   }
 }

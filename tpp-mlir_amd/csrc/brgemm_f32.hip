@@ -464,7 +464,8 @@ __global__ __launch_bounds__(256) void brgemm_grouped(GemmArgs p, const WorkItem
           const int bk = kk0 + row, bj = n0 + 4 * c4 + e;
           float v = 0.0f;
           if (bk < p.k && bj < p.n) {
-            const int64_t idx = VNNI ? (int64_t)(bk >> 1) * (2 * p.ldb) + 2 * (int64_t)bj + (bk & 1)
+            // VNNI-v B [k/v][ldb][v] (v = p.vf: 2 or 4; the oracle's b_index)
+            const int64_t idx = VNNI ? (int64_t)(bk / p.vf) * (p.vf * p.ldb) + p.vf * (int64_t)bj + (bk % p.vf)
                                      : (int64_t)bk * p.ldb + bj;
             v = Elem<T>::load(gB, bbase + idx);
           }
@@ -657,6 +658,10 @@ enum GemmVariant : int {
   V_BF16_LWF_64x64 = 25,
   V_BF16_LWF_64x128 = 26,
   V_BF16_LWF_128x128 = 27,
+  V_BF16_LW4_32x64 = 28,  // the same tiles for a VNNI-4 B operand [k/4][n][4] (xsmm_hip_set_vnni_factor(4)): a fragment is two 8-byte reads
+  V_BF16_LW4_64x64 = 29,
+  V_BF16_LW4_64x128 = 30,
+  V_BF16_LW4_128x128 = 31,
 };
 
 template <int WM, int WN, int WK, int NACC, bool DMA>
@@ -731,8 +736,13 @@ static bool bf16_flat_eligible(const GemmDesc &d) {
   return d.dtype == DT_BF16 && !d.vnni_b && !d.vnni_c && d.k > 0 && d.k % 64 == 0 && d.m % 32 == 0 && d.n % 64 == 0 &&
          !((d.lda | d.ldb | d.ldc | d.stride_a | d.stride_b) & 7) && d.lda < (1 << 22) && d.ldb < (1 << 21) && d.ldc < (1 << 22);
 }
+// VNNI-4 B for the loader-wave tiles: k-group rows of 8 * ldb bytes in 16-byte pieces, 64-k chunks, 32-bit lane offsets
+static bool bf16_vnni4_eligible(const GemmDesc &d) {
+  return d.dtype == DT_BF16 && d.vnni_b && d.vnni_factor == 4 && !d.vnni_c && d.k > 0 && d.k % 64 == 0 && d.m % 32 == 0 && d.n % 64 == 0 &&
+         !((d.lda | d.ldc | d.stride_a | d.stride_b) & 7) && !(d.ldb & 1) && d.lda < (1 << 22) && d.ldb < (1 << 20) && d.ldc < (1 << 22);
+}
 static bool bf16_small_eligible(const GemmDesc &d) {
-  return d.dtype == DT_BF16 && d.vnni_b && d.m % 32 == 0 && d.n % 32 == 0 && d.k > 0 && d.k % 16 == 0 && !(d.lda & 7) &&
+  return d.dtype == DT_BF16 && d.vnni_b && d.vnni_factor == 2 && d.m % 32 == 0 && d.n % 32 == 0 && d.k > 0 && d.k % 16 == 0 && !(d.lda & 7) &&
          !(d.stride_a & 7) && !(d.stride_b & 1) && !(d.ldc & 3);
 }
 
@@ -745,6 +755,7 @@ hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_i
   a.m = (int)d.m; a.n = (int)d.n; a.k = (int)d.k; a.br = 0;
   a.ep = (d.beta0 ? EP_BETA0 : 0) | (d.bias ? EP_BIAS : 0) | (d.relu ? EP_RELU : 0) | (d.vnni_c ? EP_VNNI_C : 0);
   a.tiles_m = a.tiles_n = 0;
+  a.vf = d.vnni_factor ? d.vnni_factor : 2;
   const bool tiles_ok = vec_ok && d.n % 4 == 0 && d.k % GK == 0; // 16-byte pieces; ragged m / n edges are predicated
   const bool vec = vec_ok && d.n % 4 == 0 && d.k % 4 == 0 && d.dtype == DT_F32 && !d.vnni_b && !((d.lda | d.ldb | d.stride_a | d.stride_b) & 3) &&
                    d.lda < (1 << 24) && d.ldb < (1 << 24); // (32-bit tile-relative lane offsets: 32 rows x ld x 4 B < 2^31)
@@ -768,7 +779,7 @@ hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_i
     }
   }
   // bf16 + VNNI-2 B with 16-byte loads: 8-element A pieces, pair-rows of B 16-byte aligned
-  const bool vec16 = tiles_ok && d.dtype == DT_BF16 && d.vnni_b && !((d.lda | d.stride_a | d.stride_b) & 7) && !(d.ldb & 3) &&
+  const bool vec16 = tiles_ok && d.dtype == DT_BF16 && d.vnni_b && d.vnni_factor == 2 && !((d.lda | d.stride_a | d.stride_b) & 7) && !(d.ldb & 3) &&
                      d.lda < (1 << 21) && d.ldb < (1 << 21); // (32-bit lane offsets)
   // bf16 tiles of 64x64 with k a multiple of 64: the 64x64 bf16 family in grouped mode (it stores 16-byte
   // row pieces and reads the bias 8 bytes at a time: checked per item by the queue through out_ok)
@@ -839,6 +850,10 @@ static const char *variant_name(int v) {
   case V_BF16_LWF_64x64: return "brgemm_bf16_lw_flatb<64x64>";
   case V_BF16_LWF_64x128: return "brgemm_bf16_lw_flatb<64x128>";
   case V_BF16_LWF_128x128: return "brgemm_bf16_lw_flatb<128x128>";
+  case V_BF16_LW4_32x64: return "brgemm_bf16_lw_vnni4<32x64,k2>";
+  case V_BF16_LW4_64x64: return "brgemm_bf16_lw_vnni4<64x64>";
+  case V_BF16_LW4_64x128: return "brgemm_bf16_lw_vnni4<64x128>";
+  case V_BF16_LW4_128x128: return "brgemm_bf16_lw_vnni4<128x128>";
   case V_F32_64x64: return "brgemm_f32_fast<64x64,k1>";
   case V_F32_64x32K2: return "brgemm_f32_fast<64x32,k2>";
   case V_F32_32x32K4: return "brgemm_f32_fast<32x32,k4>";
@@ -861,7 +876,25 @@ bool plan_gemm(GemmDesc &d, int forced_variant) {
   int v = V_GENERIC;
   if (d.vnni_c) forced_variant = V_GENERIC; // VNNI-2 C store: the generic kernel's epilogue only
   if (d.dtype == DT_F32 && !d.vnni_b) v = pick_f32_variant(d);
-  else if (d.dtype == DT_BF16 && bf16_fast_eligible(d)) {
+  else if (d.dtype == DT_BF16 && d.vnni_b && d.vnni_factor == 4) {
+    // VNNI-4 B ([k/4][n][4]: benchmarks/config/omp/mlir-bf16.json:68-100 `--vnni=4`): the loader-wave tiles with the VNNI-4 image
+    // (the largest tile that still gives 3/4 of the CUs a workgroup, else the smallest the shape divides); everything else - ragged
+    // shapes, k not a multiple of 64 (the compiler-native 32x32x32 tiles) - on the generic kernel's element path
+    if (bf16_vnni4_eligible(d)) {
+      int t = pick_bf16_lw_tile(d);
+      for (int c = 0; t < 0 && c < 4; ++c) {
+        int bm, bn;
+        blw_tile_dims(c, &bm, &bn);
+        if (d.m % bm == 0 && d.n % bn == 0) t = c;
+      }
+      if (t >= 0) v = V_BF16_LW4_32x64 + t;
+      if (forced_variant >= V_BF16_LW4_32x64 && forced_variant <= V_BF16_LW4_128x128) {
+        int bm, bn;
+        blw_tile_dims(forced_variant - V_BF16_LW4_32x64, &bm, &bn);
+        if (d.m % bm == 0 && d.n % bn == 0) v = forced_variant;
+      }
+    }
+  } else if (d.dtype == DT_BF16 && bf16_fast_eligible(d)) {
     v = V_BF16_FAST + pick_bf16_tile(d);
     // small outputs (e.g. the reference's --batch=256 layers): 32x32 tiles with K split over the waves give
     // every CU a workgroup. Measured crossover with the 64x64 family (n = 1024, K = 1024): 5.1 vs 8.4 us at 64
@@ -936,13 +969,14 @@ hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C,
   a.m = (int)d.m; a.n = (int)d.n; a.k = (int)d.k; a.br = (int)(br < 0 ? 0 : br);
   a.ep = (d.beta0 ? EP_BETA0 : 0) | (d.bias ? EP_BIAS : 0) | (d.relu ? EP_RELU : 0) | (d.vnni_c ? EP_VNNI_C : 0);
   a.tiles_m = a.tiles_n = 0;
+  a.vf = d.vnni_factor ? d.vnni_factor : 2;
   int v = d.variant;
   const bool aligned16 = ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0;
   if (v != V_GENERIC && !aligned16) v = V_GENERIC;
   // the bf16 kernel stores 16-byte row pieces and reads the bias 8 bytes at a time
   if (v >= V_BF16_FAST && v != V_BF16_SMALL32 && ((((uintptr_t)C) & 15) || (d.bias && (((uintptr_t)D) & 7)))) v = V_GENERIC;
   if (v == V_BF16_SMALL32 && ((((uintptr_t)C) & 7) || (d.bias && (((uintptr_t)D) & 7)))) v = V_GENERIC;
-  if (v >= V_BF16_LW_32x64 && v <= V_BF16_LWF_128x128 && a.br < 1) v = V_GENERIC; // empty batch (C = epilogue of nothing): the loader-wave kernels assume a chunk
+  if (v >= V_BF16_LW_32x64 && v <= V_BF16_LW4_128x128 && a.br < 1) v = V_GENERIC; // empty batch (C = epilogue of nothing): the loader-wave kernels assume a chunk
   switch (v) {
   // LDS-DMA panels for every tile but the smallest: measured C2 +3 %, C3 +8 %, 4096^3 +3 %, 3 x 1024 MLP
   // at batch 512 / 1024 +5 % / +3 % over register staging. 32x32 tiles with 4 K-split waves have
@@ -974,6 +1008,17 @@ hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C,
     c.L[0] = ChainLayer{a.B, a.D, a.C, a.ldb, a.ldc, a.stride_a, a.stride_b, a.k, a.br, a.ep, 0};
     return launch_bf16_lw(v - V_BF16_LW_32x64, c, stream);
   }
+  case V_BF16_LW4_32x64:
+  case V_BF16_LW4_64x64:
+  case V_BF16_LW4_64x128:
+  case V_BF16_LW4_128x128: {
+    ChainArgs c;
+    c.A = a.A; c.lda = a.lda; c.cnt = nullptr; c.err = nullptr; c.target = 0;
+    c.m = a.m; c.n = a.n; c.nlayers = 1; c.tiles_m = c.tiles_n = 0; c.xm = 0; c.stamps = nullptr;
+    c.dbg = chain_ablation_bits();
+    c.L[0] = ChainLayer{a.B, a.D, a.C, a.ldb, a.ldc, a.stride_a, a.stride_b, a.k, a.br, a.ep, 0};
+    return launch_bf16_lw_vnni4(v - V_BF16_LW4_32x64, c, stream);
+  }
   case V_BF16_LWF_32x64:
   case V_BF16_LWF_64x64:
   case V_BF16_LWF_64x128:
@@ -991,7 +1036,7 @@ hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C,
   const bool tiles_ok = aligned16 && d.n % 4 == 0 && d.k % GK == 0; // ragged m / n edges are predicated
   const bool vec = aligned16 && d.n % 4 == 0 && d.k % 4 == 0 && d.dtype == DT_F32 && !d.vnni_b && !((d.lda | d.ldb | d.stride_a | d.stride_b) & 3) &&
                    d.lda < (1 << 24) && d.ldb < (1 << 24); // (32-bit tile-relative lane offsets)
-  const bool vec16 = tiles_ok && d.dtype == DT_BF16 && d.vnni_b && !((d.lda | d.stride_a | d.stride_b) & 7) && !(d.ldb & 3) &&
+  const bool vec16 = tiles_ok && d.dtype == DT_BF16 && d.vnni_b && d.vnni_factor == 2 && !((d.lda | d.stride_a | d.stride_b) & 7) && !(d.ldb & 3) &&
                      d.lda < (1 << 21) && d.ldb < (1 << 21); // (32-bit lane offsets)
   if (d.dtype == DT_F32) return vec ? launch_grouped_t<float, false, true>(a, nullptr, 1, stream)
                                     : launch_grouped_t<float, false, false>(a, nullptr, 1, stream);

@@ -31,7 +31,8 @@ struct ChainArgs {
   int xm;               // filled by the launcher: XCD grid xm x (8 / xm) over the tile grid, 0 = linear tile order
   int dbg;              // timing experiments, ABLATION BUILDS ONLY (-DTPP_HIP_ABLATION, then TPP_HIP_CHAIN_DBG): 1 plain A loads,
                         // 2 no wait at the seams, 4 plain stores, 16 no DMA, 32 no fragment reads / MFMAs, 64 no B DMA, 128 no A DMA,
-                        // 256 whole prologue before the first barrier. The shipped library compiles the kernels with dbg == 0 and
+                        // 256 whole prologue before the first barrier, 512 every workgroup loads the panels of tile (0, 0) (no fabric
+                        // traffic: the K loop on L2 hits only). The shipped library compiles the kernels with dbg == 0 and
                         // never reads the variable: several of these switches give wrong results by design.
   unsigned long long *stamps; // profiling (ablation builds, TPP_HIP_CHAIN_STAMPS=file): [workgroup][layer][8] s_memrealtime stamps, else nullptr
   ChainLayer L[CH_MAXL];
@@ -54,6 +55,7 @@ static inline int chain_ablation_bits() {
 void blw_tile_dims(int tile, int *bm, int *bn);
 hipError_t launch_bf16_lw(int tile, const ChainArgs &a, hipStream_t s);
 hipError_t launch_bf16_lw_flatb(int tile, const ChainArgs &a, hipStream_t s); // the same tiles, B operand flat [k][ldb] (no VNNI flag)
+hipError_t launch_bf16_lw_vnni4(int tile, const ChainArgs &a, hipStream_t s); // the same tiles, B operand VNNI-4 [k/4][ldb][4]
 hipError_t launch_bf16_chain(int tile, const ChainArgs &a, hipStream_t s);
 
 } // namespace tpp

@@ -22,6 +22,7 @@ struct GemmArgs {
   int m, n, k, br;
   int ep;              // EP_* bits
   int tiles_m, tiles_n;
+  int vf;              // VNNI blocking factor of B (2 or 4) when the operand is VNNI-packed
 };
 
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short h) {

@@ -66,12 +66,17 @@ struct Config {
   std::atomic<hipStream_t> stream{nullptr};
   std::atomic<int> forced_variant{-1};
   std::atomic<int> tile_queue{0};
+  std::atomic<int> vnni_factor{2}; // blocking factor of VNNI B operands dispatched from now on (xsmm_hip_set_vnni_factor / TPP_HIP_VNNI_FACTOR)
   int trace = 0; // TPP_HIP_TRACE: 1 = one stderr line per dispatch + a roctx range per invoke, 2 = also one stderr line per invoke
   Config() {
     if (const char *e = getenv("TPP_HIP_ASYNC")) async = atoi(e) != 0;
     if (const char *e = getenv("TPP_HIP_TRACE")) trace = atoi(e);
     if (const char *e = getenv("TPP_HIP_VARIANT")) forced_variant = atoi(e);
     if (const char *e = getenv("TPP_HIP_TILE_QUEUE")) tile_queue = atoi(e) < 0 ? 0 : atoi(e) > 2 ? 2 : atoi(e);
+    if (const char *e = getenv("TPP_HIP_VNNI_FACTOR")) {
+      if (atoi(e) == 2 || atoi(e) == 4) vnni_factor = atoi(e);
+      else fprintf(stderr, "[tpp-xsmm-hip] TPP_HIP_VNNI_FACTOR=%s ignored: the factor is 2 or 4\n", e);
+    }
   }
 };
 Config &cfg() {
@@ -406,7 +411,11 @@ int64_t gemm_dispatch_common(const char *who, int has_batch, int fused, int64_t 
   const bool vnni_c = (flags & XSMM_GEMM_FLAG_VNNI_C) != 0;
   if ((flags & (XSMM_GEMM_WIRE_VNNI_B | XSMM_GEMM_WIRE_VNNI_A | XSMM_GEMM_FLAG_VNNI_C)) && dtype != DT_BF16)
     die("%s: VNNI flags require bf16 (XsmmOps.cpp:292-298)", who);
-  if (vnni_b && (k & 1)) die("%s: VNNI-2 B operand needs an even k, got %ld", who, (long)k);
+  // The blocking factor of a VNNI B operand is not on the wire: the reference's compiler and its runtime library both ask
+  // libxsmm_cpuid_dot_pack_factor (VNNIUtils.cpp:25-45; `--vnni=4` in benchmarks/config/omp/mlir-bf16.json:68-100). Its stand-in
+  // here is a process-wide setting read at dispatch time (xsmm_hip_set_vnni_factor / TPP_HIP_VNNI_FACTOR, default 2).
+  const int vf = vnni_b ? cfg().vnni_factor.load(std::memory_order_relaxed) : 2;
+  if (vnni_b && (k % vf)) die("%s: VNNI-%d B operand needs k to be a multiple of %d, got %ld", who, vf, vf, (long)k);
   if ((flags & XSMM_GEMM_WIRE_VNNI_A) && (k & 1)) die("%s: VNNI-2 A operand needs an even k, got %ld", who, (long)k);
   if (vnni_c && (m & 1)) die("%s: VNNI-2 C operand needs an even m, got %ld", who, (long)m);
   if (fused) {
@@ -423,7 +432,7 @@ int64_t gemm_dispatch_common(const char *who, int has_batch, int fused, int64_t 
   }
   std::vector<int64_t> key = {KIND_GEMM, has_batch, fused, dtype, m, n, k, lda, ldb, ldc, stride_a, stride_b,
                               flags & (XSMM_GEMM_FLAG_BETA_0 | XSMM_GEMM_WIRE_VNNI_B | XSMM_GEMM_FLAG_VNNI_C), unary_kind, binary_kind,
-                              cfg().forced_variant.load()};
+                              cfg().forced_variant.load(), vf};
   void *h = intern(key, [&]() {
     GemmDesc *d = new GemmDesc();
     memset(d, 0, sizeof(*d));
@@ -435,6 +444,7 @@ int64_t gemm_dispatch_common(const char *who, int has_batch, int fused, int64_t 
     d->beta0 = (flags & XSMM_GEMM_FLAG_BETA_0) != 0;
     d->vnni_b = vnni_b;
     d->vnni_c = vnni_c;
+    d->vnni_factor = vf;
     d->bias = fused && binary_kind == XSMM_BINARY_ADD;
     d->relu = fused && unary_kind == XSMM_UNARY_RELU;
     plan_gemm(*d, cfg().forced_variant.load());
@@ -482,7 +492,8 @@ __attribute__((always_inline)) inline void gemm_operands(const GemmDesc *d, void
   else C.shape(d->m, (size_t)d->n * es, (size_t)d->ldc * es);
   if (br > 0 && d->k > 0) {
     A.bytes = ((size_t)(br - 1) * d->stride_a + span(d->m, d->lda, d->k)) * es;
-    const size_t bspan = d->vnni_b ? span((d->k + 1) / 2, 2 * d->ldb, 2 * d->n) : span(d->k, d->ldb, d->n);
+    const int64_t vf = d->vnni_factor;
+    const size_t bspan = d->vnni_b ? span((d->k + vf - 1) / vf, vf * d->ldb, vf * d->n) : span(d->k, d->ldb, d->n);
     B.bytes = ((size_t)(br - 1) * d->stride_b + bspan) * es;
   }
 }
@@ -1863,6 +1874,10 @@ bool try_chain_launch(int n, const GemmDesc *const *d, void *const *pa, void *co
     if (((uintptr_t)pa[i] | (uintptr_t)pb[i] | (uintptr_t)pc[i]) & 15) NOCHAIN("an operand is not 16-byte aligned");
     if (g.bias && (!pd[i] || ((uintptr_t)pd[i] & 7))) NOCHAIN("a bias operand is not 8-byte aligned");
     if (i > 0 && (pa[i] != pc[i - 1] || g.lda != d[i - 1]->ldc)) NOCHAIN("not a chain: a call does not read its predecessor's output");
+    // The kernel hands layer i-1's output over row block by row block (a consumer waits for the producers of ITS rows only): every
+    // batch element of layer i must stay inside its own rows, i.e. the batch strides walk along k within one leading dimension.
+    // (A row-striding stride_a would read rows that other workgroups may not have stored yet.)
+    if (i > 0 && (br[i] - 1) * g.stride_a + g.k > g.lda) NOCHAIN("a later call's batch elements leave the rows of its predecessor's output");
     if (!devmem.is_device(pa[i], 0) || !devmem.is_device(pb[i], 1) || !devmem.is_device(pc[i], 2) || (g.bias && !devmem.is_device(pd[i], 3)))
       NOCHAIN("a host operand");
   }
@@ -1886,11 +1901,12 @@ bool try_chain_launch(int n, const GemmDesc *const *d, void *const *pa, void *co
   // no operand of the launch may overlap an output (a layer's input rows are read by other workgroups while later layers store)
   Operand A, B, C, D;
   struct Span { const void *p; size_t n; };
-  Span outs[CH_MAXL], ins[2 * CH_MAXL + 1];
+  Span outs[CH_MAXL], ins[2 * CH_MAXL + 1], a_in[CH_MAXL];
   int n_ins = 0;
   for (int i = 0; i < n; ++i) {
     gemm_operands(d[i], pa[i], pb[i], pc[i], pd[i], br[i], A, B, C, D);
     outs[i] = Span{C.ptr, C.bytes};
+    a_in[i] = Span{A.ptr, A.bytes};
     ins[n_ins++] = Span{B.ptr, B.bytes};
     if (d[i]->bias) ins[n_ins++] = Span{D.ptr, D.bytes};
     if (i == 0) ins[n_ins++] = Span{A.ptr, A.bytes};
@@ -1900,6 +1916,10 @@ bool try_chain_launch(int n, const GemmDesc *const *d, void *const *pa, void *co
       if (ranges_overlap(outs[i].p, outs[i].n, outs[j].p, outs[j].n)) NOCHAIN("two outputs overlap");
     for (int j = 0; j < n_ins; ++j)
       if (ranges_overlap(outs[i].p, outs[i].n, ins[j].p, ins[j].n)) NOCHAIN("an output overlaps an input");
+    // the A operand of a later layer is its predecessor's output by construction; what it reads (k may be wider than the
+    // predecessor's n: the gap columns of the rows) may overlap no OTHER output of the launch
+    for (int j = 1; j < n; ++j)
+      if (j != i + 1 && ranges_overlap(outs[i].p, outs[i].n, a_in[j].p, a_in[j].n)) NOCHAIN("an output overlaps a later call's input");
   }
 #undef NOCHAIN
   ChainArgs c;
@@ -2260,4 +2280,10 @@ extern "C" const char *xsmm_hip_kernel_name(int64_t handle) {
   return (d && d->kind == KIND_GEMM) ? d->name : "";
 }
 extern "C" void xsmm_hip_force_variant(int v) { cfg().forced_variant.store(v); }
+// the VNNI blocking factor of bf16 B operands dispatched from now on (2 or 4); returns the previous one, -1 for an invalid factor
+extern "C" int xsmm_hip_set_vnni_factor(int v) {
+  if (v != 2 && v != 4) return -1;
+  return cfg().vnni_factor.exchange(v);
+}
+extern "C" int xsmm_hip_get_vnni_factor(void) { return cfg().vnni_factor.load(); }
 extern "C" const char *xsmm_hip_version(void) { return "tpp-xsmm-hip 0.1 (gfx950)"; }

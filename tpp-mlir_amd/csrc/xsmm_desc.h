@@ -22,6 +22,8 @@ struct GemmDesc {
   int64_t wire_flags;   // as received (BETA_0 = 4, VNNI_B wire = 2048, ...)
   int beta0, vnni_b, bias, relu;
   int vnni_c;           // C stored / read as VNNI-2 [m/2][n][2] (wire flag 8192): generic kernel only
+  int vnni_factor;      // blocking factor v of a VNNI B operand [k/v][n][v]: 2, or 4 (xsmm_hip_set_vnni_factor at dispatch time; the
+                        // factor is not on the wire - the reference asks libxsmm_cpuid_dot_pack_factor, VNNIUtils.cpp:25-45)
   int variant;          // kernel variant chosen at dispatch (see gemm_variants.h), -1 = by invoke
   char name[64];        // kernel name for profiles
   char trace[160];      // dispatch tuple + kernel name as text (trace ranges)
@@ -65,6 +67,7 @@ hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_i
 // fills d.variant / d.name; returns false if no kernel can run the descriptor
 bool plan_gemm(GemmDesc &d, int forced_variant);
 constexpr int GEMM_VARIANT_BF16_LW0 = 20; // = V_BF16_LW_32x64: first of the four loader-wave bf16 tiles (brgemm_bf16_lw.hip)
+constexpr int GEMM_VARIANT_BF16_LW4_0 = 28; // = V_BF16_LW4_32x64: the same four tiles for a VNNI-4 B operand
 constexpr int GEMM_VARIANT_GENERIC = 8; // = V_GENERIC of brgemm_f32.hip: the generic kernel was chosen (or forced) at dispatch
 // bf16 + VNNI-2 B, k a multiple of 64, m and n of 64, 16-byte-aligned leading dimensions within the 32-bit lane offsets: what the
 // LDS-DMA bf16 tile families (brgemm_bf16.hip, brgemm_bf16_lw.hip) need

@@ -25,79 +25,105 @@ class PeerGather:
     tensor holding the gathered output of THIS step (double-buffered: valid until the step after next)."""
 
     def __init__(self, rt, rank, world, total_bytes, group=None):
-        import torch
-        import torch.distributed as dist
+        """Local part only (allocate + export the IPC handles). No collective runs here and nothing raises: a failure is recorded
+        in self.ok and voted on in create(), so that every rank issues the same collectives in the same order whatever happens on
+        one of them (a rank that raised before the barrier left the others hanging in it)."""
         self.rt, self.rank, self.world, self.total = rt, rank, world, int(total_bytes)
+        self.group = group
+        self._own, self._mapped, self.handles = [], [], None
+        self.ok, self.why = True, ""
+        self.epoch = 0
         lib = rt.lib
         ctl_bytes = 4096  # flags[world] at 0, ready[world] at 1024, ticket at 2048, err at 2112
-        self._own = [lib.xsmm_hip_peer_alloc(self.total), lib.xsmm_hip_peer_alloc(self.total), lib.xsmm_hip_peer_alloc(ctl_bytes)]
-        handles = []
-        for p in self._own:
-            h = (ctypes.c_ubyte * 64)()
-            if lib.xsmm_hip_ipc_export(p, h) != 0:
-                raise RuntimeError("hipIpcGetMemHandle failed")
-            handles.append(bytes(h))
-        everyone = [None] * world
-        if world > 1:
-            dist.all_gather_object(everyone, handles, group=group)
-        else:
-            everyone[0] = handles
-        self._mapped = []
-        self.full_ptr = [[None] * world, [None] * world]  # [parity][peer]
-        self.ctl_ptr = [None] * world
-        for w in range(world):
-            if w == rank:
-                ptrs = self._own
-            else:
-                ptrs = []
-                for hb in everyone[w]:
-                    buf = (ctypes.c_ubyte * 64).from_buffer_copy(hb)
-                    q = lib.xsmm_hip_ipc_open(buf)
-                    if not q:
-                        raise RuntimeError("hipIpcOpenMemHandle failed for peer %d" % w)
-                    ptrs.append(q)
-                    self._mapped.append(q)
-            self.full_ptr[0][w], self.full_ptr[1][w], self.ctl_ptr[w] = ptrs
-        arr = lambda v: (VP * world)(*[VP(int(x)) for x in v])  # noqa: E731
-        self._dst = [arr(self.full_ptr[0]), arr(self.full_ptr[1])]
-        self._flags = arr(self.ctl_ptr)
-        self._ready = arr([int(c) + 1024 for c in self.ctl_ptr])
-        me = int(self.ctl_ptr[rank])
-        self._my_flags, self._my_ready, self._ticket, self._err = VP(me), VP(me + 1024), VP(me + 2048), VP(me + 2112)
-        self.epoch = 0
-        self.full = [torch.as_tensor(_RawDevice(self._own[i], self.total, "<i2", 2), device="cuda") for i in (0, 1)]
-        self._err_view = torch.as_tensor(_RawDevice(me + 2112, 4, "<i4", 4), device="cuda")
-        if world > 1:
-            dist.barrier(group=group)  # every rank has mapped every buffer before anybody writes
+        try:
+            for nbytes in (self.total, self.total, ctl_bytes):
+                q = lib.xsmm_hip_peer_alloc(nbytes)
+                if not q:
+                    raise RuntimeError("device allocation of %d bytes failed" % nbytes)
+                self._own.append(q)
+            handles = []
+            for q in self._own:
+                h = (ctypes.c_ubyte * 64)()
+                if lib.xsmm_hip_ipc_export(q, h) != 0:
+                    raise RuntimeError("hipIpcGetMemHandle failed")
+                handles.append(bytes(h))
+            self.handles = handles
+        except Exception as ex:
+            self.ok, self.why = False, str(ex)
+
+    def _map(self, everyone):
+        """open every peer's handles (local; failures are recorded, not raised) and build the pointer tables"""
+        import torch
+        lib, world, rank = self.rt.lib, self.world, self.rank
+        try:
+            if not self.ok:
+                raise RuntimeError(self.why)
+            if any(h is None for h in everyone):
+                raise RuntimeError("rank(s) %s could not export their buffers" % [w for w, h in enumerate(everyone) if h is None])
+            self.full_ptr = [[None] * world, [None] * world]  # [parity][peer]
+            self.ctl_ptr = [None] * world
+            for w in range(world):
+                if w == rank:
+                    ptrs = self._own
+                else:
+                    ptrs = []
+                    for hb in everyone[w]:
+                        buf = (ctypes.c_ubyte * 64).from_buffer_copy(hb)
+                        q = lib.xsmm_hip_ipc_open(buf)
+                        if not q:
+                            raise RuntimeError("hipIpcOpenMemHandle failed for peer %d" % w)
+                        ptrs.append(q)
+                        self._mapped.append(q)
+                self.full_ptr[0][w], self.full_ptr[1][w], self.ctl_ptr[w] = ptrs
+            arr = lambda v: (VP * world)(*[VP(int(x)) for x in v])  # noqa: E731
+            self._dst = [arr(self.full_ptr[0]), arr(self.full_ptr[1])]
+            self._flags = arr(self.ctl_ptr)
+            self._ready = arr([int(c) + 1024 for c in self.ctl_ptr])
+            me = int(self.ctl_ptr[rank])
+            self._my_flags, self._my_ready, self._ticket, self._err = VP(me), VP(me + 1024), VP(me + 2048), VP(me + 2112)
+            self.full = [torch.as_tensor(_RawDevice(self._own[i], self.total, "<i2", 2), device="cuda") for i in (0, 1)]
+            self._err_view = torch.as_tensor(_RawDevice(me + 2112, 4, "<i4", 4), device="cuda")
+        except Exception as ex:
+            self.ok, self.why = False, str(ex)
 
     @classmethod
     def create(cls, rt, rank, world, total_bytes, group=None):
-        """the gather object, or None when the buffers cannot be shared (then use RCCL: mlp.all_gather_rows)"""
+        """The gather object, or None - on EVERY rank or on none - when the buffers cannot be shared or the self-test fails
+        somewhere (then use RCCL: mlp.all_gather_rows). Collectives, identical on every rank regardless of local failures:
+        all_gather_object(handles) -> [local mapping] -> all_gather_object(ok) -> [self-test: three gathers] ->
+        all_gather_object(ok). The second vote also orders "every rank has mapped every buffer" before anybody's first store."""
         import sys
-        try:
-            obj = cls(rt, rank, world, total_bytes, group)
-        except Exception as ex:  # a mapping problem must not cost the run: RCCL is the fallback
-            sys.stderr.write("[tpp-mlir_amd.peer] peer-store gather unavailable (%s): falling back to RCCL\n" % ex)
-            obj = None
-        # every rank or none - and only if three known patterns come out right on EVERY rank (both buffer parities and a re-use):
-        # a mapping that "works" but is not coherent between these devices must cost a fallback, not a wrong output or a hung step
-        ok = obj is not None
+        obj = cls(rt, rank, world, total_bytes, group)
         if world > 1:
             import torch.distributed as dist
+            everyone = [None] * world
+            dist.all_gather_object(everyone, obj.handles, group=group)
+        else:
+            everyone = [obj.handles]
+        obj._map(everyone)
+        votes = [obj.ok]
+        if world > 1:
+            votes = [None] * world
+            dist.all_gather_object(votes, obj.ok, group=group)
+        if not all(votes):
+            sys.stderr.write("[tpp-mlir_amd.peer] rank %d: peer-store gather unavailable (%s; ranks that failed: %s): falling back to RCCL\n"
+                             % (rank, obj.why or "a peer failed", [w for w, v in enumerate(votes) if not v]))
+            obj.close(collective=False)  # (nobody has stored anything: no barrier needed, and every rank is on this path)
+            return None
+        # only if three known patterns come out right on EVERY rank (both buffer parities and a re-use): a mapping that "works" but
+        # is not coherent between these devices must cost a fallback, not a wrong output or a hung step. (world == 1 too: the
+        # kernels and the flag protocol run the same way against the rank's own buffers.)
+        ok = obj.selftest()
+        votes = [ok]
+        if world > 1:
             votes = [None] * world
             dist.all_gather_object(votes, ok, group=group)
-            if not all(votes):
-                if obj is not None:
-                    obj.close()
-                return None
-            ok = obj.selftest()
-            dist.all_gather_object(votes, ok, group=group)
-            if not all(votes):
-                if rank == 0:
-                    sys.stderr.write("[tpp-mlir_amd.peer] peer-store gather failed its self-test on ranks %s: falling back to RCCL\n"
-                                     % [w for w, v in enumerate(votes) if not v])
-                obj.close()
-                return None
+        if not all(votes):
+            if rank == 0:
+                sys.stderr.write("[tpp-mlir_amd.peer] peer-store gather failed its self-test on ranks %s: falling back to RCCL\n"
+                                 % [w for w, v in enumerate(votes) if not v])
+            obj.close()
+            return None
         return obj
 
     def selftest(self):
@@ -155,7 +181,26 @@ class PeerGather:
         if e:
             raise RuntimeError("peer-store gather timed out (code 0x%x): a peer never arrived" % e)
 
-    def close(self):
+    def close(self, collective=True):
+        """unmap the peers' buffers and free this rank's own (2 x total_bytes + the control block). Collective by default: the
+        owners free only after every rank has drained its stream and unmapped (a peer may still be storing into this rank's
+        buffers, or polling its flags). collective=False: only where no gather has run and every rank takes the same path."""
+        lib = self.rt.lib
+        if collective and self.world > 1:
+            import torch.distributed as dist
+            try:
+                self.rt.synchronize()
+                self.drain()
+            except Exception:
+                pass
+            dist.barrier(group=self.group)  # nobody stores into anybody's buffers any more
         for q in self._mapped:
-            self.rt.lib.xsmm_hip_ipc_close(q)
+            lib.xsmm_hip_ipc_close(q)
         self._mapped = []
+        if collective and self.world > 1:
+            import torch.distributed as dist
+            dist.barrier(group=self.group)  # every peer has unmapped: the owners may free
+        self.full, self._err_view = [], None
+        for q in self._own:
+            lib.xsmm_hip_peer_free(q)
+        self._own = []

@@ -99,6 +99,8 @@ _SIGNATURES = {
     "xsmm_hip_device_count": (ctypes.c_int, []),
     "xsmm_hip_kernel_name": (ctypes.c_char_p, [I64]),
     "xsmm_hip_force_variant": (None, [ctypes.c_int]),
+    "xsmm_hip_set_vnni_factor": (ctypes.c_int, [ctypes.c_int]),
+    "xsmm_hip_get_vnni_factor": (ctypes.c_int, []),
     "xsmm_hip_version": (ctypes.c_char_p, []),
 }
 
@@ -257,6 +259,13 @@ class XsmmRuntime:
 
     def force_variant(self, v):
         self.lib.xsmm_hip_force_variant(v)
+
+    def set_vnni_factor(self, v):
+        """VNNI blocking factor (2 / 4) of bf16 B operands dispatched from now on; returns the previous one"""
+        old = self.lib.xsmm_hip_set_vnni_factor(int(v))
+        if old < 0:
+            raise ValueError("the VNNI factor is 2 or 4")
+        return old
 
     def version(self):
         return self.lib.xsmm_hip_version().decode()
