@@ -400,6 +400,9 @@ def main():
     one_device = os.environ.get("TPP_BENCH_ONE_DEVICE", "0") == "1"
     if one_device:
         local = 0
+        # the persistent chain kernel needs every workgroup of ITS launch resident at once (one per CU): two processes that time-slice
+        # one GPU starve each other's hand-offs (50 ms timeouts, the runtime dies loudly). On the rig the layers run as separate launches.
+        os.environ["TPP_HIP_CHAIN"] = "0"
     torch.cuda.set_device(local)
     use_dist = world > 1 or args.force_dist
     backend = "gloo" if one_device else "nccl"

@@ -1,0 +1,53 @@
+"""bench.py --gpus N on the one-device multi-process rig: two ranks, BOTH on cuda:0 (the switch
+TPP_BENCH_ONE_DEVICE=1: process group on gloo, the peer-store gather over real hipIpcMemHandles exactly as between two GPUs of a
+node), launched the way the driver launches it. The line must say: 2 ranks, the strong-scaled MLP as the headline with the gather
+inside the timed step, BOTH gather paths timed in the same run, and the gathered output bit-identical to the unsharded result.
+(The timings of such a run are meaningless - the ranks time-slice one GPU - and the line says so.)"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_bench_two_ranks_on_one_device_reports_verified_strong_scaling():
+    env = dict(os.environ, TPP_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "3",
+           "--no-cpu-baseline", "--no-pmc"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    if r.returncode != 0:
+        pytest.fail("bench.py --gpus 2 exited %d\n--- stdout (tail)\n%s\n--- stderr (tail)\n%s" % (r.returncode, r.stdout[-1500:], r.stderr[-6000:]), pytrace=False)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 3
+    pgp = d["process_group"]
+    assert pgp["world_size"] == 2 and len(pgp["ranks"]) == 2 and pgp["one_device_test_rig"] is True
+    # the headline at N > 1: the strong-scaled MLP, gather inside the timed step; C2 (weak, no communication) is secondary
+    assert d["scaling"] == "strong" and d["dtype"] == "bf16" and "MLP" in d["metric"]
+    assert d["c2_weak"]["scaling"] == "weak" and d["c2_weak"]["dtype"] == "f32" and d["c2_weak"]["value"] > 0
+    mlp = d["mlp"]
+    assert d["value"] == mlp["value"] and abs(d["ms_per_step"] - mlp["ms_per_step"]) < 1e-9
+    # both gather paths were timed in this run and both were checked against the unsharded result
+    g = mlp["gathers"]
+    assert set(g) == {"peer", "rccl"}, g
+    for path in ("peer", "rccl"):
+        assert g[path]["ms_per_step"] > 0 and g[path]["gathered_bit_identical"] is True, g
+    assert mlp["gathered_bit_identical"] is True and d["config"]["gathered_bit_identical"] is True
+    assert mlp["gather"] in ("peer", "rccl") and mlp["one_gpu_same_run"]["ms_per_step"] > 0
+    assert mlp["speedup_vs_one_gpu_same_run"] > 0
+    assert "TEST RIG" in d["data"]
