@@ -172,6 +172,13 @@ TPP_XSMM_EXPORT void xsmm_hip_flush(void);
  * Same arithmetic as the separate launches (f32 accumulation in k order, one rounding per layer); bit-identical to them when
  * they run on the same tile, which is the case whenever dispatch planned the layers with a loader-wave tile (variants 20 .. 23)
  * that fits the chip. Returns 1 if the chain ran as one launch, 0 if it ran call by call.
+ * Call i > 0 must keep every batch element inside its predecessor's rows ((br - 1) * stride_a + k <= lda): the hand-off is per row
+ * block; a row-striding later call runs call by call.
+ * RESIDENCY: the single launch needs every workgroup of its grid on a compute unit at the same time (one per CU). The grid is
+ * checked against the CUs the stream may use (a CU mask is honoured); what cannot be checked is another process - or another
+ * stream's LDS-heavy kernel - occupying CUs at that moment: the single-launch path needs the device to itself. Every wait inside
+ * the kernel is bounded (50 ms): a starved launch is REPORTED at the next xsmm_hip_synchronize / perf_stop_timer (the runtime dies
+ * loudly, its results are invalid), never hung. A harness that shares the GPU sets TPP_HIP_CHAIN=0.
  * TPP_HIP_CHAIN=0 disables the single-launch path. */
 TPP_XSMM_EXPORT int xsmm_hip_fused_brgemm_chain_invoke(int64_t dtype, int64_t n, const int64_t *handles, void *const *a,
                                                        const int64_t *off_a, void *const *b, const int64_t *off_b,

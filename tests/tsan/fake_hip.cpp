@@ -89,6 +89,7 @@ hipError_t hipMemcpy2DAsync(void *dst, size_t dpitch, const void *src, size_t sp
 }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 hipError_t hipStreamIsCapturing(hipStream_t, hipStreamCaptureStatus *s) { *s = hipStreamCaptureStatusNone; return hipSuccess; }
+hipError_t hipExtStreamGetCUMask(hipStream_t, uint32_t n, uint32_t *m) { for (uint32_t i = 0; i < n; ++i) m[i] = i < 8 ? 0xffffffffu : 0u; return hipSuccess; }
 hipError_t hipMemset(void *p, int v, size_t bytes) { memset(p, v, bytes); return hipSuccess; }
 hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int) { *v = 256; return hipSuccess; }
 hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = nullptr; return hipSuccess; }

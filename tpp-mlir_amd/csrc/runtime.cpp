@@ -719,14 +719,23 @@ struct Segment {
   size_t list_cap = 0;
   bool list_valid = false, list_used = false; // holds items[] of THIS recording / a launch may still be reading it
   hipStream_t list_stream = nullptr;           // ... on this stream
-  void ensure_list(hipStream_t stream) { // (the group's stream: every launch from the list goes there, behind the copy)
-    if (list_valid) return;
+  // Called with the inline queue's lock held, once per RECORDING (a steady-state replay never comes here). The buffers are sized
+  // for the largest group (TileQueue::CAP) the first time a segment needs them and then travel with it (store_recording swaps
+  // segments, so at most NSEG + 1 sets exist per queue: allocation is a start-up cost, not a per-recording one); they live as long
+  // as the process (like the pinned work-list slots: no HIP call at exit). While the stream is being CAPTURED into a graph no list
+  // is built (allocation / synchronisation are not legal there): the replay then gathers its members into a pinned slot at the
+  // flush like an incomplete group (TileQueue::flush) - returns false.
+  bool ensure_list(hipStream_t stream, size_t cap) {
+    if (list_valid) return true;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess) (void)hipGetLastError();
+    else if (cs != hipStreamCaptureStatusNone) return false;
     if (list_used) HIP_OK(hipStreamSynchronize(list_stream)); // the buffers carried another recording's items: its last launch must be done
     list_used = false;
     if (list_cap < items.size()) {
       if (list) HIP_OK(hipHostFree(list));
       if (list_dev) HIP_OK(hipFree(list_dev));
-      list_cap = items.size() < 64 ? 64 : items.size();
+      list_cap = items.size() < cap ? cap : items.size();
       HIP_OK(hipHostMalloc((void **)&list, sizeof(WorkItem) * list_cap, hipHostMallocDefault));
       HIP_OK(hipMalloc((void **)&list_dev, sizeof(WorkItem) * list_cap));
     }
@@ -735,6 +744,7 @@ struct Segment {
     list_used = true; // (the copy reads `list`)
     list_stream = stream;
     list_valid = true;
+    return true;
   }
   bool mark(int idx) { return __atomic_exchange_n(&seen[idx], round, __ATOMIC_RELAXED) != round; } // false: joined this round already
   static size_t hash(const WorkItem &w) {
@@ -982,8 +992,9 @@ struct TileQueue {
     issue_pending();
     close_window();
     const int rp = replay;
-    if (rp >= 0 && n > 0 && (size_t)n != segs[rp].items.size()) materialize();
-    const bool whole = rp >= 0 && n > 0 && (size_t)n == segs[rp].items.size(); // the recorded group, complete: launch from its own list
+    // the recorded group, complete, and its device-resident list exists (not while capturing): launch from its own list
+    const bool whole = rp >= 0 && n > 0 && (size_t)n == segs[rp].items.size() && segs[rp].list_valid;
+    if (rp >= 0 && n > 0 && !whole) materialize();
     // (counts are exact: an arrival is counted by whoever's atomic exchange on the item's mark saw it unmarked - once per round)
     store_recording(next); // (never touches segs[rp] during a replay: nothing is being recorded)
     replay = -1;
@@ -1067,7 +1078,7 @@ inline bool try_start_replay(TileQueue &q, const void *desc, const WorkItem &w, 
   }
   S.seen[item] = S.round;
   q.ensure_slot();
-  S.ensure_list(stream);
+  (void)S.ensure_list(stream, (size_t)TileQueue::CAP); // (false while the stream is being captured: the flush gathers the members instead)
   q.kind = *(const int *)desc;
   q.desc = desc;
   q.stream = stream;
@@ -1798,6 +1809,22 @@ int chip_cus() { // compute units of the current device (0: unknown)
   }
   return n;
 }
+// Compute units a launch on `s` can actually use: the device's, restricted by the stream's CU mask (hipExtStreamCreateWithCUMask,
+// or the process-wide ROC_GLOBAL_CU_MASK / HSA_CU_MASK the runtime folds into every stream's mask). The persistent chain kernel
+// needs all of its workgroups resident at once - one per CU - so its grid is checked against THIS number. What no query
+// can see is another PROCESS (or another stream's LDS-heavy kernel) holding CUs at launch time: the chain launch needs the device
+// to itself (include/tpp_xsmm_abi.h says so); every spin in the kernel is bounded and a starved launch is reported, not hung.
+int stream_cus(hipStream_t s) {
+  const int all = chip_cus();
+  uint32_t mask[16] = {};
+  if (all <= 0 || hipExtStreamGetCUMask(s, 16, mask) != hipSuccess) {
+    (void)hipGetLastError();
+    return all;
+  }
+  int bits = 0;
+  for (uint32_t w : mask) bits += __builtin_popcount(w);
+  return bits > 0 && bits < all ? bits : all;
+}
 
 // profiling (-DTPP_HIP_ABLATION side builds only, build.py --ablation): TPP_HIP_CHAIN_STAMPS=<file> makes every chain launch record s_memrealtime stamps (100 MHz) per workgroup and layer
 // (see blw_stamp in brgemm_bf16_lw.hip) into pinned host memory; the LAST launch's stamps are written to the file at every sync point.
@@ -1885,7 +1912,7 @@ bool try_chain_launch(int n, const GemmDesc *const *d, void *const *pa, void *co
   // with the same loader-wave tile and that tile fits, use it - the launch is then bit-identical to the separate launches; else
   // the smallest tile that fits (most CUs busy).
   int tile = -1, bm = 0, bn = 0;
-  const int64_t cus = chip_cus();
+  const int64_t cus = stream_cus(cfg().stream.load(std::memory_order_relaxed));
   auto fits = [&](int t) {
     blw_tile_dims(t, &bm, &bn);
     return m % bm == 0 && nn % bn == 0 && (m / bm) * (nn / bn) <= cus;
