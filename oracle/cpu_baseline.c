@@ -101,3 +101,9 @@ int cpu_baseline_threads(void) {
   extern int omp_get_max_threads(void);
   return omp_get_max_threads();
 }
+/* threads of the following runs (bench.py sizes the team to the CPUs the container may really use: affinity mask AND cgroup quota -
+ * a 128-thread team under a 16-CPU quota is throttled to a fraction of what 16 threads deliver) */
+void cpu_baseline_set_threads(int n) {
+  extern void omp_set_num_threads(int);
+  if (n > 0) omp_set_num_threads(n);
+}

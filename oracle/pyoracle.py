@@ -19,6 +19,31 @@ I64 = ctypes.c_int64
 VP = ctypes.c_void_p
 
 
+def usable_cpus():
+    """CPUs this process may really keep busy: the affinity mask AND the cgroup CPU quota (cgroup v2 cpu.max / v1 cfs_quota_us).
+    Returns (cpus, detail dict). A container with nproc = 256 and a quota of 16 CPUs can SUSTAIN 16 threads; larger teams are
+    throttled by the scheduler and run far slower than 16 threads do."""
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except Exception:
+        aff = os.cpu_count() or 1
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    cpus = aff if quota is None else max(1, min(aff, int(quota)))
+    return cpus, {"affinity_cpus": aff, "cgroup_cpu_quota": quota}
+
+
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
     srcs = [os.path.join(_HERE, f) for f in ("xsmm_oracle.c", "tensor_init.cpp", "Makefile")]
@@ -61,6 +86,11 @@ class CpuBaseline:
 
     def threads(self):
         return self.L.cpu_baseline_threads()
+
+    def set_threads(self, n):
+        self.L.cpu_baseline_set_threads.argtypes = [ctypes.c_int]
+        self.L.cpu_baseline_set_threads(int(n))
+        return self.threads()
 
     def pack(self, A, B, C, m, n, k):
         """row-major A [m][k], B [k][n], C [m][n] -> the packed block buffers the tile loop runs on"""

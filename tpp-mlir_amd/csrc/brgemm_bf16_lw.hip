@@ -46,6 +46,9 @@ typedef unsigned int u32x2_lw __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(1))) unsigned int g_u32_lw;
 
 constexpr int BLW_BK = 64; // k per chunk
+#ifndef TPP_BLW_INTERLEAVE
+#define TPP_BLW_INTERLEAVE 2 // fragment reads dealt between the MFMAs of a k-step: 1 = the four-accumulator tile (128x128), 2 = + 64x128; 0 = in front (A/B)
+#endif
 // The kernel's argument block, read where it lies (kernarg segment, constant address space): the layer table is indexed at
 // run time, and a by-value / by-reference copy of the struct would be spilled to scratch (640 bytes per lane) for that.
 typedef const __attribute__((address_space(4))) ChainArgs chain_kernarg_t;
@@ -447,13 +450,36 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
           else frag_load(q + PD - KS, ns, wk * KS + q + PD - KS);
         }
       }
-      __builtin_amdgcn_sched_barrier(0);
+      // The step's fragment reads (for MFMAs two steps / half a chunk ahead) are dealt BETWEEN the step's MFMAs, not in front of them:
+      // a 32x32x16 bf16 MFMA holds the matrix pipe for 32 cycles, six DS instructions take the wave longer than that to issue - in
+      // front of the MFMAs the pipe ran dry once per k-step (same-box A/B, profiles/r04_bf16_lw_read_interleave.txt: the 4096-row
+      // layer 10.02 -> 9.45 us, its chain 30.5 -> 29.4, C5 17.6 -> 17.0, 4096^3 on this tile 128.2 -> 122.3).
+      constexpr bool IL = TPP_BLW_INTERLEAVE >= 1 && (!FULLPF || (TPP_BLW_INTERLEAVE >= 2 && SUP == 1 && TM * TN >= 2));
+      if constexpr (!IL) __builtin_amdgcn_sched_barrier(0);
       if (!skip_math) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_lw, bw[CUR + q][j]), af[CUR + q][i], acc[i][j], 0, 0, 0);
+      }
+      if constexpr (IL && !FULLPF) {
+        constexpr int NRD = TM + (FLATB == 4 ? TN : 2 * TN); // DS read instructions of a step (VNNI-4: one ds_read2_b64 per column tile)
+        constexpr int PER = (NRD + TM * TN - 2) / (TM * TN - 1);
+#pragma unroll
+        for (int g_ = 0; g_ < TM * TN - 1; ++g_) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x100, PER, 0); // then a share of the DS reads
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      } else if constexpr (IL) {
+        // two fragment sets (64x128): the second half of a chunk reads TWO k-steps of the next chunk per step, behind every MFMA a share
+        constexpr int NRD = 2 * (TM + (FLATB == 4 ? TN : 2 * TN)), PER = (NRD + TM * TN - 1) / (TM * TN);
+#pragma unroll
+        for (int g_ = 0; g_ < TM * TN; ++g_) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, PER, 0);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
       if (q == KS / 2 - 1 && has_next) {
@@ -513,7 +539,7 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
       using N = std::integral_constant<int, 0>;
       using R = std::integral_constant<int, 2>;
       if constexpr (!FULLPF) { // (SUP = 1) every chunk but the last carries the barrier; T >= 1
-        if constexpr (NSLOT == 4) {
+        if constexpr (NSLOT == 4 || NSLOT == 5) {
           // whole laps of the ring with LITERAL slots (LDS offsets are immediates: no address adds, and the four bodies of a lap
           // are one basic block): 4096^3 on the 128x128 tile 139 -> 131 us, 2048^3 on a flat B 20.6 -> 19.05, the 4096-row chain
           // 34 -> 33 us (same-box A/B). A single layer starts
@@ -524,11 +550,9 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
               slot = next(slot);
             }
           }
-          for (; t + 4 < T; t += 4) {
-            chunk(P0{}, Y{}, 0, t, T);
-            chunk(P0{}, Y{}, 1, t + 1, T);
-            chunk(P0{}, Y{}, 2, t + 2, T);
-            chunk(P0{}, Y{}, 3, t + 3, T);
+          for (; t + NSLOT < T; t += NSLOT) {
+#pragma unroll
+            for (int s_ = 0; s_ < NSLOT; ++s_) chunk(P0{}, Y{}, s_, t + s_, T);
           }
         }
         for (; t + 1 < T; ++t) {
