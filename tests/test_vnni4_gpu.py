@@ -164,3 +164,49 @@ def test_vnni4_handles_do_not_alias_vnni2_handles(rt):
         assert "vnni4" in rt.kernel_name(h4) and "vnni4" not in rt.kernel_name(h2)
     finally:
         rt.set_vnni_factor(old)
+
+
+@pytest.mark.parametrize("queue", [0, 1])
+def test_vnni4_compiler_native_tile_invokes_of_a_layer(rt, vnni4, queue):
+    """the call pattern of `mlir-gen --tiles=32,32,32 --vnni=4` (benchmarks/config/omp/mlir-bf16.json:68-100): packed A [MB][KB][32][32],
+    W [NB][KB][32/4][32][4], C [MB][NB][32][32], ONE fused dispatch (32,32,32,32,32,32,1024,1024) and MB x NB invokes with batch KB -
+    unqueued (one launch per invoke: the bf16 MFMA path of the generic kernel on the VNNI-4 image) and through the tile queue (one
+    grouped launch per layer); two chained layers against the oracle's replay of the same invokes"""
+    MB, NB, KB = 4, 8, 8
+    rng = np.random.default_rng(11 + queue)
+    X = rand(rng, MB * KB * 1024, BF16)
+    Ws = [rand(rng, NB * KB * 1024, BF16, -0.3, 0.3) for _ in range(2)]
+    bs = [rand(rng, NB * 32, BF16) for _ in range(2)]
+    disp = (BF16, 32, 32, 32, 32, 32, 32, 1024, 1024, 4 | VB, 0, 5, 4, 1)
+    refs, cur = [], X
+    for l in range(2):
+        out = np.zeros(MB * NB * 1024, np.uint16)
+        for i in range(MB):
+            for j in range(NB):
+                orc.fused_brgemm(*disp, cur, i * KB * 1024, Ws[l], j * KB * 1024, out, (i * NB + j) * 1024, bs[l], j * 32, KB)
+        refs.append(out)
+        cur = out
+    h = rt.fused_brgemm_dispatch(*disp)
+    prev_async, prev_q = rt.set_async(True), rt.set_tile_queue(queue)
+    try:
+        dX, dW, db = dev(X), [dev(w) for w in Ws], [dev(b) for b in bs]
+        dA = [dev(np.zeros(MB * NB * 1024, np.uint16)) for _ in range(2)]
+        for rep in range(3):  # (the third pass replays the recorded groups)
+            cur = dX
+            for l in range(2):
+                for i in range(MB):
+                    for j in range(NB):
+                        rt.fused_brgemm(BF16, h, cur, i * KB * 1024, dW[l], j * KB * 1024, dA[l], (i * NB + j) * 1024, db[l], j * 32, KB)
+                cur = dA[l]
+            rt.synchronize()
+        for l in range(2):
+            prev = X if l == 0 else host(dA[0], X)
+            one = np.zeros(MB * NB * 1024, np.uint16)  # layer l from the GPU's own layer l-1: one layer's error at a time
+            for i in range(MB):
+                for j in range(NB):
+                    orc.fused_brgemm(*disp, prev, i * KB * 1024, Ws[l], j * KB * 1024, one, (i * NB + j) * 1024, bs[l], j * 32, KB)
+            check_close(host(dA[l], X), one, BF16, "vnni4 tile invokes layer %d queue %d" % (l, queue))
+    finally:
+        rt.synchronize()
+        rt.set_tile_queue(prev_q)
+        rt.set_async(prev_async)

@@ -385,7 +385,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void brgemm_f32_fast(GemmArgs p,
 // VEC selects 16-byte loads when shape, strides and pointers allow.
 constexpr int GK = 32; // k per chunk of the grouped kernel
 
-template <typename T, bool VNNI, bool VEC>
+template <typename T, bool VNNI, bool VEC, int VF = 2>
 __global__ __launch_bounds__(256) void brgemm_grouped(GemmArgs p, const WorkItem *__restrict__ items) {
   extern __shared__ __attribute__((aligned(16))) float smem_g[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -537,9 +537,11 @@ __global__ __launch_bounds__(256) void brgemm_grouped(GemmArgs p, const WorkItem
     for (int v = 0; v < 2; ++v) {
       const int q = lane + 64 * v;
       // tile-relative (see the f32 path): the descriptor base carries m0 * lda and 2 * n0
-      const int a_row = m0 + (q >> 2) < p.m ? (q >> 2) : p.m - 1 - m0, b_col = n0 + 4 * (q & 7) < p.n ? 4 * (q & 7) : 0;
+      // B: a 16-byte piece = 4 columns x 2 k (VNNI-2: 16 pair-rows of 128 B) or 2 columns x 4 k (VNNI-4: 8 k-group rows of 256 B)
+      constexpr int CPP = 8 / VF, PPR = 32 / CPP; // columns per piece, pieces per row of the 32-column panel
+      const int a_row = m0 + (q >> 2) < p.m ? (q >> 2) : p.m - 1 - m0, b_col = n0 + CPP * (q % PPR) < p.n ? CPP * (q % PPR) : 0;
       vA[v] = (unsigned)((a_row * (int)p.lda + 8 * (q & 3)) * 2);
-      vB[v] = (unsigned)(((q >> 3) * 2 * (int)p.ldb + 2 * b_col) * 2);
+      vB[v] = (unsigned)(((q / PPR) * VF * (int)p.ldb + VF * b_col) * 2);
     }
     u32x4 sa[2][2], sb[2][2];
     auto gload_bf = [&](int cc, int set, bool live) __attribute__((always_inline)) {
@@ -548,7 +550,7 @@ __global__ __launch_bounds__(256) void brgemm_grouped(GemmArgs p, const WorkItem
       const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
           (void *)((const unsigned short *)it.A + (int64_t)b * p.stride_a + (int64_t)m0 * p.lda + kk0), 0, nrec, 0x00020000);
       const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(
-          (void *)((const unsigned short *)it.B + (int64_t)b * p.stride_b + (int64_t)(kk0 >> 1) * (2 * p.ldb) + 2 * (int64_t)n0), 0, nrec, 0x00020000);
+          (void *)((const unsigned short *)it.B + (int64_t)b * p.stride_b + (int64_t)(kk0 / VF) * (VF * p.ldb) + VF * (int64_t)n0), 0, nrec, 0x00020000);
 #pragma unroll
       for (int v = 0; v < 2; ++v) {
         sa[set][v] = __builtin_amdgcn_raw_buffer_load_b128(rA, vA[v], 0, 0);
@@ -559,7 +561,7 @@ __global__ __launch_bounds__(256) void brgemm_grouped(GemmArgs p, const WorkItem
       const int q = lane + 64 * v;
       unsigned char *ab = wlb + buf * BUFB;
       *(u32x4 *)(ab + (q >> 2) * APITCH + (q & 3) * 16) = sa[set][v];
-      *(u32x4 *)(ab + ABYTES + (q >> 3) * 128 + (q & 7) * 16) = sb[set][v];
+      *(u32x4 *)(ab + ABYTES + q * 16) = sb[set][v]; // (the rows follow each other: [16][128 B] or [8][256 B], both = piece q at 16 q)
     };
     auto compute_bf = [&](int buf, bool stage, int set) __attribute__((always_inline)) {
       const unsigned char *ab = wlb + buf * BUFB;
@@ -568,8 +570,15 @@ __global__ __launch_bounds__(256) void brgemm_grouped(GemmArgs p, const WorkItem
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         af[ks] = *(const bf16x8_g *)(ab + li * APITCH + (2 * ks + lh) * 16);
+        if constexpr (VF == 4) { // k-groups 4 ks + 2 lh and + 1 of this lane's column: two 8-byte pieces
+          typedef unsigned int u32x2_g __attribute__((ext_vector_type(2)));
+          const u32x2_g q0 = *(const u32x2_g *)(ab + ABYTES + (4 * ks + 2 * lh) * 256 + li * 8);
+          const u32x2_g q1 = *(const u32x2_g *)(ab + ABYTES + (4 * ks + 2 * lh + 1) * 256 + li * 8);
+          bfr[ks] = u32x4{q0[0], q0[1], q1[0], q1[1]};
+        } else {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) bfr[ks][t] = *(const unsigned int *)(ab + ABYTES + (8 * ks + 4 * lh + t) * 128 + li * 4);
+          for (int t = 0; t < 4; ++t) bfr[ks][t] = *(const unsigned int *)(ab + ABYTES + (8 * ks + 4 * lh + t) * 128 + li * 4);
+        }
       }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -711,10 +720,10 @@ hipError_t launch_f32_lw_grouped(int tile, const GemmArgs &a, const WorkItem *it
 int pick_bf16_tile(const GemmDesc &d);
 bool bf16_fast_eligible(const GemmDesc &d);
 
-template <typename T, bool VNNI, bool VEC>
+template <typename T, bool VNNI, bool VEC, int VF = 2>
 static hipError_t launch_grouped_t(const GemmArgs &a, const WorkItem *items, int n_items, hipStream_t s) {
   constexpr size_t lds = 4 * 2 * 2 * 32 * GK * sizeof(float); // 64 KiB: 4 waves x 2 buffers x (A + B)
-  auto kern = brgemm_grouped<T, VNNI, VEC>;
+  auto kern = brgemm_grouped<T, VNNI, VEC, VF>;
   static std::atomic<unsigned long long> lds_set{0};
   if (hipError_t e = ensure_dynamic_lds((const void *)kern, (int)lds, lds_set); e != hipSuccess) return e;
   GemmArgs args = a;
@@ -779,6 +788,8 @@ hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_i
     }
   }
   // bf16 + VNNI-2 B with 16-byte loads: 8-element A pieces, pair-rows of B 16-byte aligned
+  const bool vec16x = d.dtype == DT_BF16 && d.vnni_b && !((d.lda | d.stride_a | d.stride_b) & 7) && d.lda < (1 << 21) && d.ldb < (1 << 21);
+  const bool vec16_4 = vec16x && d.vnni_factor == 4 && vec_ok && d.n % 2 == 0 && d.k % GK == 0 && !(d.ldb & 1); // VNNI-4: 16-byte pieces of 2 columns
   const bool vec16 = tiles_ok && d.dtype == DT_BF16 && d.vnni_b && d.vnni_factor == 2 && !((d.lda | d.stride_a | d.stride_b) & 7) && !(d.ldb & 3) &&
                      d.lda < (1 << 21) && d.ldb < (1 << 21); // (32-bit lane offsets)
   // bf16 tiles of 64x64 with k a multiple of 64: the 64x64 bf16 family in grouped mode (it stores 16-byte
@@ -789,6 +800,7 @@ hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_i
   if (vec_ok && out_ok && d.variant != V_GENERIC && bf16_small_eligible(d)) return launch_bf16_small32(a, items, n_items, stream);
   if (d.dtype == DT_F32) return vec ? launch_grouped_t<float, false, true>(a, items, n_items, stream)
                                     : launch_grouped_t<float, false, false>(a, items, n_items, stream);
+  if (d.vnni_b && vec16_4) return launch_grouped_t<unsigned short, true, true, 4>(a, items, n_items, stream); // VNNI-4 on the bf16 MFMA path
   if (d.vnni_b) return vec16 ? launch_grouped_t<unsigned short, true, true>(a, items, n_items, stream)
                              : launch_grouped_t<unsigned short, true, false>(a, items, n_items, stream);
   return launch_grouped_t<unsigned short, false, false>(a, items, n_items, stream);
@@ -1036,10 +1048,13 @@ hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C,
   const bool tiles_ok = aligned16 && d.n % 4 == 0 && d.k % GK == 0; // ragged m / n edges are predicated
   const bool vec = aligned16 && d.n % 4 == 0 && d.k % 4 == 0 && d.dtype == DT_F32 && !d.vnni_b && !((d.lda | d.ldb | d.stride_a | d.stride_b) & 3) &&
                    d.lda < (1 << 24) && d.ldb < (1 << 24); // (32-bit tile-relative lane offsets)
+  const bool vec16x = d.dtype == DT_BF16 && d.vnni_b && !((d.lda | d.stride_a | d.stride_b) & 7) && d.lda < (1 << 21) && d.ldb < (1 << 21);
+  const bool vec16_4 = vec16x && d.vnni_factor == 4 && aligned16 && d.n % 2 == 0 && d.k % GK == 0 && !(d.ldb & 1); // VNNI-4: 16-byte pieces of 2 columns
   const bool vec16 = tiles_ok && d.dtype == DT_BF16 && d.vnni_b && d.vnni_factor == 2 && !((d.lda | d.stride_a | d.stride_b) & 7) && !(d.ldb & 3) &&
                      d.lda < (1 << 21) && d.ldb < (1 << 21); // (32-bit lane offsets)
   if (d.dtype == DT_F32) return vec ? launch_grouped_t<float, false, true>(a, nullptr, 1, stream)
                                     : launch_grouped_t<float, false, false>(a, nullptr, 1, stream);
+  if (d.vnni_b && vec16_4) return launch_grouped_t<unsigned short, true, true, 4>(a, nullptr, 1, stream);
   if (d.vnni_b) return vec16 ? launch_grouped_t<unsigned short, true, true>(a, nullptr, 1, stream)
                              : launch_grouped_t<unsigned short, true, false>(a, nullptr, 1, stream);
   return launch_grouped_t<unsigned short, false, false>(a, nullptr, 1, stream);
