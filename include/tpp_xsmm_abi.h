@@ -165,7 +165,7 @@ TPP_XSMM_EXPORT void xsmm_hip_flush(void);
  *                                                    d[i], off_d[i], num_batches[i]);
  * (XsmmRunnerUtils.cpp:363-457 per call). This is how a harness hands over a rank's MLP step (mlir-gen's layer chain,
  * MLIRGen.cpp:632-681: every layer one whole-layer fused_brgemm): when the calls form a CHAIN - call i+1 reads call i's
- * output as its A operand (same pointer, lda = ldc), bf16 with a VNNI-2 B, beta 0, equal m and n, device pointers,
+ * output as its A operand (same pointer, lda = ldc), bf16 with ONE kind of B operand (VNNI-2, flat or VNNI-4), beta 0, equal m and n, device pointers,
  * asynchronous mode, the outputs overlap no other operand, and one of the 32x64 .. 128x128 tiles covers m x n with at most
  * one workgroup per compute unit - the whole chain runs as ONE persistent kernel (rows of layer i+1 start as soon as the
  * same rows of layer i are stored: no kernel boundary, the next layer's weight panels are prefetched under the epilogue).

@@ -210,3 +210,51 @@ def test_vnni4_compiler_native_tile_invokes_of_a_layer(rt, vnni4, queue):
         rt.synchronize()
         rt.set_tile_queue(prev_q)
         rt.set_async(prev_async)
+
+
+@pytest.mark.parametrize("kind", ["vnni4", "flat"])
+@pytest.mark.parametrize("m,tile", [(512, 0), (1024, 1), (4096, 3)])
+def test_chain_launch_on_vnni4_and_flat_b_layers(rt, kind, m, tile):
+    """xsmm_hip_fused_brgemm_chain_invoke on layers whose B operands are VNNI-4 / flat (round 4: the B image is a template parameter
+    of the chain launch too): ONE launch, bit-identical to the same layers invoked one by one on the same tile, and equal to the
+    VNNI-2 chain on the same matrices (same tile, same MFMA k order)"""
+    import torch
+    N, L = 1024, 3
+    rng = np.random.default_rng(m + (7 if kind == "flat" else 0))
+    X = rand(rng, m * N, BF16)
+    Wf = [rand(rng, N * N, BF16, -0.06, 0.06) for _ in range(L)]
+    bs = [rand(rng, N, BF16, -0.5, 0.5) for _ in range(L)]
+    outs = {}
+    for k_ in (kind, "vnni2"):
+        v = {"vnni4": 4, "vnni2": 2, "flat": 0}[k_]
+        old = rt.set_vnni_factor(v if v else 2)
+        rt.force_variant({"vnni4": 28, "vnni2": 20, "flat": 24}[k_] + tile)
+        try:
+            h = rt.fused_brgemm_dispatch(BF16, m, N, 64, N, N, N, 64, 64 * N, 4 | (VB if v else 0), 0, 5, 4, 1)
+        finally:
+            rt.force_variant(-1)
+            rt.set_vnni_factor(old)
+        W = [dev(pack(w, N, N, N, v) if v else w) for w in Wf]
+        db = [dev(b) for b in bs]
+        dX = dev(X)
+        acts_f = [dev(np.full(m * N, 0x7fc0, np.uint16)) for _ in range(L)]
+        acts_s = [dev(np.full(m * N, 0x7fc0, np.uint16)) for _ in range(L)]
+        was = rt.set_async(True)
+        try:
+            calls = lambda acts: [(h, dX if l == 0 else acts[l - 1], 0, W[l], 0, acts[l], 0, db[l], 0, N // 64) for l in range(L)]  # noqa: E731
+            fused = rt.fused_brgemm_chain(BF16, calls(acts_f))
+            for c in calls(acts_s):
+                rt.fused_brgemm(BF16, *c)
+            rt.synchronize()
+        finally:
+            rt.set_async(was)
+        assert fused, "%s layers did not run as one chain launch (%s)" % (k_, rt.kernel_name(h))
+        for l in range(L):
+            assert torch.equal(acts_f[l], acts_s[l]), "%s chain layer %d differs from the separate launches" % (k_, l)
+        outs[k_] = host(acts_f[L - 1], X)
+        outs[k_ + "_layer0"] = host(acts_f[0], X)[:32 * N]
+    assert np.array_equal(outs[kind], outs["vnni2"]), "%s chain differs from the VNNI-2 chain on the same matrices" % kind
+    # layer 0 against the oracle on a row sample (flat operand)
+    ref = np.zeros(32 * N, np.uint16)
+    orc.fused_brgemm(BF16, 32, N, 64, N, N, N, 64, 64 * N, 4, 0, 5, 4, 1, X, 0, Wf[0], 0, ref, 0, bs[0], 0, N // 64)
+    check_close(outs[kind + "_layer0"], ref, BF16, "%s chain layer 0 (rows 0-31)" % kind)

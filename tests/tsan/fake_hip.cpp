@@ -126,8 +126,9 @@ hipError_t launch_gemm(const GemmDesc &d, const void *A_, const void *B_, void *
 }
 // the bf16 chain kernel has no host stand-in: plan_gemm above refuses bf16, so try_chain_launch never gets this far
 bool bf16_fast_eligible(const GemmDesc &) { return false; }
+int bf16_lw_b_kind(const GemmDesc &) { return -1; }
 void blw_tile_dims(int, int *bm, int *bn) { *bm = *bn = 128; }
-hipError_t launch_bf16_chain(int, const ChainArgs &, hipStream_t) { return hipErrorNotSupported; }
+hipError_t launch_bf16_chain(int, int, const ChainArgs &, hipStream_t) { return hipErrorNotSupported; }
 hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *it, int n, bool, bool, hipStream_t s) {
   for (int i = 0; i < n; ++i) (void)launch_gemm(d, it[i].A, it[i].B, it[i].C, it[i].D, it[i].br, s);
   return hipSuccess;

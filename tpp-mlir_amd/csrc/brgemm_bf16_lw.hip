@@ -749,16 +749,16 @@ void blw_tile_dims(int tile, int *bm, int *bn) {
 // (TPP_HIP_BLW_SUP=1 forces one chunk per barrier for A/B runs). Ring depths: 8 / 8 / 6 / 4 slots; a 5-slot ring with 2 + 2
 // loaders for the 128x128 tile and 4 against 6 slots for 64x128 measured the same (same box, +-0.5 %); FOUR chunks per barrier on
 // a 12-slot ring for the 32x64 tile measured 9 % slower than two on 8 slots (the prologue must request 8 chunks before the first barrier).
-#define BLW_DISPATCH(MULTI)                                                                  \
+#define BLW_DISPATCH(MULTI, FB)                                                              \
   switch (tile * 2 + (sup2 ? 1 : 0)) {                                                       \
-  case 0: return launch_blw_t<1, 2, 2, 1, 1, 8, 1, 2, 1, MULTI>(a, s);                       \
-  case 1: return launch_blw_t<1, 2, 2, 1, 1, 8, 1, 2, 2, MULTI>(a, s);                       \
-  case 2: return launch_blw_t<2, 2, 1, 1, 1, 8, 1, 1, 1, MULTI>(a, s);                       \
-  case 3: return launch_blw_t<2, 2, 1, 1, 1, 8, 1, 1, 2, MULTI>(a, s);                       \
+  case 0: return launch_blw_t<1, 2, 2, 1, 1, 8, 1, 2, 1, MULTI, FB>(a, s);                   \
+  case 1: return launch_blw_t<1, 2, 2, 1, 1, 8, 1, 2, 2, MULTI, FB>(a, s);                   \
+  case 2: return launch_blw_t<2, 2, 1, 1, 1, 8, 1, 1, 1, MULTI, FB>(a, s);                   \
+  case 3: return launch_blw_t<2, 2, 1, 1, 1, 8, 1, 1, 2, MULTI, FB>(a, s);                   \
   case 4:                                                                                    \
-  case 5: return launch_blw_t<2, 2, 1, 1, 2, 6, 1, 2, 1, MULTI>(a, s);                       \
+  case 5: return launch_blw_t<2, 2, 1, 1, 2, 6, 1, 2, 1, MULTI, FB>(a, s);                   \
   case 6:                                                                                    \
-  case 7: return launch_blw_t<2, 2, 1, 2, 2, 4, 1, 1, 1, MULTI>(a, s);                       \
+  case 7: return launch_blw_t<2, 2, 1, 2, 2, 4, 1, 1, 1, MULTI, FB>(a, s);                   \
   default: return hipErrorInvalidValue;                                                      \
   }
 static bool blw_sup2(const ChainArgs &a) {
@@ -776,7 +776,7 @@ static bool blw_sup2(const ChainArgs &a) {
 hipError_t launch_bf16_lw(int tile, const ChainArgs &a, hipStream_t s) {
   if (a.L[0].br < 1 || a.L[0].k < BLW_BK || tile < 0 || tile > 3) return hipErrorInvalidValue;
   const bool sup2 = blw_sup2(a);
-  BLW_DISPATCH(false)
+  BLW_DISPATCH(false, 0)
 }
 
 // One layer whose B operand is FLAT ([k][ldb] bf16, no VNNI flag on the dispatch - what xsmm.unary pack would have turned into
@@ -789,17 +789,8 @@ hipError_t launch_bf16_lw(int tile, const ChainArgs &a, hipStream_t s) {
 // 15-28 % slower (the ds_write path: ~79 B/clk and 2-way conflicts), removed.
 hipError_t launch_bf16_lw_flatb(int tile, const ChainArgs &a, hipStream_t s) {
   if (a.L[0].br < 1 || a.L[0].k < BLW_BK || tile < 0 || tile > 3) return hipErrorInvalidValue;
-  switch (tile * 2 + (blw_sup2(a) ? 1 : 0)) {
-  case 0: return launch_blw_t<1, 2, 2, 1, 1, 8, 1, 2, 1, false, 2>(a, s);
-  case 1: return launch_blw_t<1, 2, 2, 1, 1, 8, 1, 2, 2, false, 2>(a, s);
-  case 2: return launch_blw_t<2, 2, 1, 1, 1, 8, 1, 1, 1, false, 2>(a, s);
-  case 3: return launch_blw_t<2, 2, 1, 1, 1, 8, 1, 1, 2, false, 2>(a, s);
-  case 4:
-  case 5: return launch_blw_t<2, 2, 1, 1, 2, 6, 1, 2, 1, false, 2>(a, s);
-  case 6:
-  case 7: return launch_blw_t<2, 2, 1, 2, 2, 4, 1, 1, 1, false, 2>(a, s);
-  default: return hipErrorInvalidValue;
-  }
+  const bool sup2 = blw_sup2(a);
+  BLW_DISPATCH(false, 2)
 }
 
 // One layer whose B operand is VNNI-4 ([k/4][ldb][4] bf16: the dispatch carries the VNNI flag, the factor is the runtime's setting,
@@ -808,24 +799,21 @@ hipError_t launch_bf16_lw_flatb(int tile, const ChainArgs &a, hipStream_t s) {
 // fragment is two 8-byte reads (256 B/clk against the 128 B/clk of the VNNI-2 image's 4-byte reads).
 hipError_t launch_bf16_lw_vnni4(int tile, const ChainArgs &a, hipStream_t s) {
   if (a.L[0].br < 1 || a.L[0].k < BLW_BK || tile < 0 || tile > 3) return hipErrorInvalidValue;
-  switch (tile * 2 + (blw_sup2(a) ? 1 : 0)) {
-  case 0: return launch_blw_t<1, 2, 2, 1, 1, 8, 1, 2, 1, false, 4>(a, s);
-  case 1: return launch_blw_t<1, 2, 2, 1, 1, 8, 1, 2, 2, false, 4>(a, s);
-  case 2: return launch_blw_t<2, 2, 1, 1, 1, 8, 1, 1, 1, false, 4>(a, s);
-  case 3: return launch_blw_t<2, 2, 1, 1, 1, 8, 1, 1, 2, false, 4>(a, s);
-  case 4:
-  case 5: return launch_blw_t<2, 2, 1, 1, 2, 6, 1, 2, 1, false, 4>(a, s);
-  case 6:
-  case 7: return launch_blw_t<2, 2, 1, 2, 2, 4, 1, 1, 1, false, 4>(a, s);
-  default: return hipErrorInvalidValue;
-  }
+  const bool sup2 = blw_sup2(a);
+  BLW_DISPATCH(false, 4)
 }
 
-// a chain of layers in one launch; the caller guarantees co-residency (tiles <= CUs), beta = 0 and disjoint buffers
-hipError_t launch_bf16_chain(int tile, const ChainArgs &a, hipStream_t s) {
+// a chain of layers in one launch; the caller guarantees co-residency (tiles <= CUs), beta = 0, disjoint buffers and ONE kind of B
+// operand for every layer (b_kind 0: VNNI-2, 2: flat, 4: VNNI-4)
+hipError_t launch_bf16_chain(int tile, int b_kind, const ChainArgs &a, hipStream_t s) {
   if (tile < 0 || tile > 3) return hipErrorInvalidValue;
   const bool sup2 = blw_sup2(a);
-  BLW_DISPATCH(true)
+  if (b_kind == 2) {
+    BLW_DISPATCH(true, 2)
+  } else if (b_kind == 4) {
+    BLW_DISPATCH(true, 4)
+  }
+  BLW_DISPATCH(true, 0)
 }
 
 } // namespace tpp

@@ -755,6 +755,13 @@ static bool bf16_small_eligible(const GemmDesc &d) {
          !(d.stride_a & 7) && !(d.stride_b & 1) && !(d.ldc & 3);
 }
 
+int bf16_lw_b_kind(const GemmDesc &d) {
+  if (d.dtype != DT_BF16 || d.vnni_c) return -1;
+  if (d.vnni_b && d.vnni_factor == 4) return bf16_vnni4_eligible(d) ? 4 : -1;
+  if (d.vnni_b) return bf16_fast_eligible(d) ? 0 : -1;
+  return bf16_flat_eligible(d) ? 2 : -1;
+}
+
 hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_items, bool vec_ok, bool out_ok,
                                hipStream_t stream) {
   if (d.m <= 0 || d.n <= 0 || n_items <= 0) return hipSuccess;

@@ -1895,7 +1895,9 @@ bool try_chain_launch(int n, const GemmDesc *const *d, void *const *pa, void *co
   devmem.refresh();
   for (int i = 0; i < n; ++i) {
     const GemmDesc &g = *d[i];
-    if (g.dtype != DT_BF16 || !g.vnni_b || g.vnni_c || !g.beta0 || !bf16_fast_eligible(g)) NOCHAIN("a call is not bf16 / VNNI-2 B / beta 0 / aligned for the LDS-DMA tiles");
+    // every layer the same kind of B operand (VNNI-2, flat or VNNI-4: the B image is a template parameter of the launch)
+    if (g.dtype != DT_BF16 || g.vnni_c || !g.beta0 || bf16_lw_b_kind(g) < 0 || bf16_lw_b_kind(g) != bf16_lw_b_kind(*d[0]))
+      NOCHAIN("a call is not bf16 / beta 0 / aligned for the LDS-DMA tiles, or the calls' B operands differ in kind (VNNI-2 / flat / VNNI-4)");
     if (g.m != m || g.n != nn || br[i] < 1) NOCHAIN("the calls differ in m or n, or a batch is empty");
     if (g.variant == GEMM_VARIANT_GENERIC) NOCHAIN("a call was dispatched to the generic kernel"); // (a forced generic kernel stays generic)
     if (((uintptr_t)pa[i] | (uintptr_t)pb[i] | (uintptr_t)pc[i]) & 15) NOCHAIN("an operand is not 16-byte aligned");
@@ -1917,7 +1919,9 @@ bool try_chain_launch(int n, const GemmDesc *const *d, void *const *pa, void *co
     blw_tile_dims(t, &bm, &bn);
     return m % bm == 0 && nn % bn == 0 && (m / bm) * (nn / bn) <= cus;
   };
-  const int planned = d[0]->variant - GEMM_VARIANT_BF16_LW0;
+  const int b_kind = bf16_lw_b_kind(*d[0]);
+  // (variants 20 .. 23 VNNI-2, 24 .. 27 flat B, 28 .. 31 VNNI-4: the same four tiles)
+  const int planned = d[0]->variant - (b_kind == 2 ? GEMM_VARIANT_BF16_LW0 + 4 : b_kind == 4 ? GEMM_VARIANT_BF16_LW4_0 : GEMM_VARIANT_BF16_LW0);
   bool same = planned >= 0 && planned < 4;
   for (int i = 1; i < n && same; ++i) same = d[i]->variant == d[0]->variant;
   if (same && fits(planned)) tile = planned;
@@ -1966,7 +1970,7 @@ bool try_chain_launch(int n, const GemmDesc *const *d, void *const *pa, void *co
   c.err = blk.err;
   c.target = ++blk.epoch * (unsigned)blk.tiles_n;
   c.stamps = chain_stamps((size_t)blk.tiles_m * (size_t)blk.tiles_n);
-  HIP_OK(launch_bf16_chain(tile, c, s));
+  HIP_OK(launch_bf16_chain(tile, b_kind, c, s));
   g_chain_launched.store(1, std::memory_order_release);
   return true;
 }

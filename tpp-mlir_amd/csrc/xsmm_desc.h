@@ -72,6 +72,9 @@ constexpr int GEMM_VARIANT_GENERIC = 8; // = V_GENERIC of brgemm_f32.hip: the ge
 // bf16 + VNNI-2 B, k a multiple of 64, m and n of 64, 16-byte-aligned leading dimensions within the 32-bit lane offsets: what the
 // LDS-DMA bf16 tile families (brgemm_bf16.hip, brgemm_bf16_lw.hip) need
 bool bf16_fast_eligible(const GemmDesc &d);
+// which B image of the loader-wave bf16 tiles (brgemm_bf16_lw.hip) a descriptor's B operand needs - 0: VNNI-2, 2: flat [k][ldb],
+// 4: VNNI-4 - or -1 if the descriptor cannot run on those tiles (shape / alignment / lane-offset limits of the LDS-DMA panels)
+int bf16_lw_b_kind(const GemmDesc &d);
 hipError_t launch_unary(const UnaryDesc &d, const void *in, float scalar, bool use_scalar, void *out,
                         hipStream_t stream);
 hipError_t launch_binary(const BinaryDesc &d, const void *lhs, const void *rhs, void *out,
