@@ -783,6 +783,40 @@ def main():
                        "value": round(2.0 * M5 ** 3 * Ko / wf / 1e9, 1), "unit": "GFLOP/s", "us_per_step": round(wf / Ko * 1e6, 2),
                        "bit_identical_to_pack_plus_vnni": bool(torch.equal(C5f, C5))})
 
+        # the C4 layer on a VNNI-4 B operand (`--vnni=4` configs of the reference, benchmarks/config/omp/mlir-bf16.json:68-100):
+        # the same matrix packed [K/4][N][4], the runtime told the factor (xsmm_hip_set_vnni_factor), bit-compared with the VNNI-2 result
+        try:
+            M4, N4 = 4096, 1024
+            A4 = (torch.rand(M4, N4, device="cuda") - 0.5).to(torch.bfloat16)
+            Wf4 = (torch.rand(N4, N4, device="cuda") - 0.5).to(torch.bfloat16)
+            W2 = Wf4.view(N4 // 2, 2, N4).permute(0, 2, 1).contiguous()
+            W4 = Wf4.view(N4 // 4, 4, N4).permute(0, 2, 1).contiguous()
+            C42, C44 = torch.empty(M4, N4, device="cuda", dtype=torch.bfloat16), torch.empty(M4, N4, device="cuda", dtype=torch.bfloat16)
+            h42 = rt.brgemm_dispatch(BF16, M4, N4, 64, N4, N4, N4, 64, 64 * N4, 4 | 2048)
+            oldf = rt.set_vnni_factor(4)
+            h44 = rt.brgemm_dispatch(BF16, M4, N4, 64, N4, N4, N4, 64, 64 * N4, 4 | 2048)
+            rt.set_vnni_factor(oldf)
+
+            def l2_step():
+                rt.brgemm(BF16, h42, A4, 0, W2, 0, C42, 0, 16)
+
+            def l4_step():
+                rt.brgemm(BF16, h44, A4, 0, W4, 0, C44, 0, 16)
+            res4 = {}
+            for nm_, fn_ in (("vnni2", l2_step), ("vnni4", l4_step)):
+                spin_up(fn_, sync, 0.03)
+                warm(fn_, Wo, sync)
+                w4_, _ = timed(fn_, Ko, sync, barrier)
+                res4[nm_] = w4_ / Ko
+            f4 = 2.0 * M4 * N4 * N4
+            others.append({"workload": "C4 layer 4096x1024x1024 bf16 on a VNNI-4 B operand [K/4][N][4] (xsmm_hip_set_vnni_factor(4))", "kernel": rt.kernel_name(h44),
+                           "value": round(f4 / res4["vnni4"] / 1e9, 1), "unit": "GFLOP/s", "us_per_step": round(res4["vnni4"] * 1e6, 2),
+                           "frac_of_bf16_mfma_peak": round(f4 / res4["vnni4"] / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+                           "same_layer_vnni2_us": round(res4["vnni2"] * 1e6, 2), "bit_identical_to_vnni2": bool(torch.equal(C42, C44))})
+            del A4, Wf4, W2, W4, C42, C44
+        except Exception as ex:
+            others.append({"workload": "C4 layer on a VNNI-4 B operand", "error": str(ex)})
+
         # a large bf16 output (one 256x256 tile per CU): the shape class the 256-tile kernel exists for
         ML = 4096
         AL = (torch.rand(ML, ML, device="cuda") - 0.5).to(torch.bfloat16)
