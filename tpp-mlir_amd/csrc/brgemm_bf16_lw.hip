@@ -271,7 +271,8 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
   chain_kernarg_t &p = *pp;
   constexpr int NMW = WM * WN * WK, NOUT = WM * WN; // MFMA waves; waves that own output
   constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
-  constexpr int KS = 4 / WK, PD = KS / 2;            // k-steps of a chunk per wave; fragment prefetch distance
+  constexpr int KS = 4 / WK, PD = KS / 2;            // k-steps of a chunk per wave; fragment prefetch distance (three steps ahead
+                                                     // with the barrier one step earlier measured the same: profiles/r04_bf16_lw_read_interleave.txt)
   constexpr int A_SLOT = BM * 128, B_SLOT = BN * 128, SLOT = A_SLOT + B_SLOT;
   constexpr int ES = 64 * TN + 16;                   // bytes per staged output row (16 B pad: conflict-free 16-byte accesses)
   constexpr int STAGE_W = 32 * ES;                   // one 32-row block of a wave's tile
