@@ -258,6 +258,30 @@ __global__ __launch_bounds__(256) void vnni2_rows_kernel(int n8, int64_t ldi, in
   dst[1] = w1;
 }
 
+// The same with ONE 16-byte output piece per lane (4 columns x 2 rows): two 8-byte loads, one 16-byte store - a wave's store
+// instruction writes 1 KiB of whole lines (the 8-column variant's two stores per lane each write half of every line), and twice as
+// many lanes are in flight for the one round trip the kernel consists of. TPP_HIP_PACK_PIECE=8 selects the 8-column variant (A/B).
+typedef unsigned int u32x2_e __attribute__((ext_vector_type(2)));
+template <int POLICY> // 0 plain, 1 nontemporal loads + stores, 2 nontemporal loads + write-through (sc1) stores
+__global__ __launch_bounds__(256) void vnni2_rows4_kernel(int n4, int64_t ldi, int64_t ldo, const unsigned short *__restrict__ in,
+                                                          unsigned short *__restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x; // 4-column piece
+  if (c >= n4) return;
+  const int64_t r = blockIdx.y;
+  const u32x2_e *pe = (const u32x2_e *)(in + (2 * r) * ldi + 4 * (int64_t)c), *po = (const u32x2_e *)(in + (2 * r + 1) * ldi + 4 * (int64_t)c);
+  const u32x2_e e = POLICY ? __builtin_nontemporal_load(pe) : *pe;
+  const u32x2_e o = POLICY ? __builtin_nontemporal_load(po) : *po;
+  u32x4_e w;
+  w[0] = (e[0] & 0xffffu) | (o[0] << 16);
+  w[1] = (e[0] >> 16) | (o[0] & 0xffff0000u);
+  w[2] = (e[1] & 0xffffu) | (o[1] << 16);
+  w[3] = (e[1] >> 16) | (o[1] & 0xffff0000u);
+  u32x4_e *dst = (u32x4_e *)(out + r * (2 * ldo) + 8 * (int64_t)c);
+  if (POLICY == 1) __builtin_nontemporal_store(w, dst);
+  else if (POLICY == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(w) : "memory");
+  else *dst = w;
+}
+
 // ---- grouped variants (tile queue): ONE block per queued invoke of one small-tile descriptor ----
 // The compiler lowers tensor.pack / unpack and bias broadcasts to hundreds of unary / binary invokes
 // on <= 64x64 tiles (LowerPacksAndUnpacks.cpp:45-121); the queue runs them as one launch. Same
@@ -458,7 +482,26 @@ hipError_t launch_unary(const UnaryDesc &d, const void *in, float scalar, bool u
   if (d.m <= 0 || d.n <= 0) return hipSuccess;
   if (d.op == U_VNNI2) {
     const bool vec = d.n % 8 == 0 && d.ldi % 8 == 0 && (2 * d.ldo) % 8 == 0 && aligned(in, 16) && aligned(out, 16);
-    if (vec && d.m / 2 <= 65535 && d.n / 8 < (1 << 30))
+    static const int piece = [] {
+      const char *e = getenv("TPP_HIP_PACK_PIECE");
+      return e ? atoi(e) : 4;
+    }();
+    if (vec && piece == 4 && d.m / 2 <= 65535 && d.n / 4 < (1 << 30))
+    {
+      // store / load policy by size, measured (profiles/r04_vnni2_pack_ab.txt, same box): nontemporal loads + write-through (sc1)
+      // stores win up to 4096^2 (64 MiB moved: 10.5 -> 9.7 us) and lose beyond (8192^2: 37.4 -> 38.7 us); nontemporal STORES lose
+      // everywhere (-6 .. -11 %). TPP_HIP_PACK_POLICY=0|1|2 forces one (A/B runs).
+      static const int forced = [] {
+        const char *e = getenv("TPP_HIP_PACK_POLICY");
+        return e ? atoi(e) : -1;
+      }();
+      const int policy = forced >= 0 ? forced : ((double)d.m * (double)d.n * 4.0 <= 64.0 * 1024 * 1024 ? 2 : 0);
+      const dim3 g((unsigned)((d.n / 4 + 255) / 256), (unsigned)(d.m / 2));
+      if (policy == 1) hipLaunchKernelGGL(vnni2_rows4_kernel<1>, g, dim3(256), 0, s, (int)(d.n / 4), d.ldi, d.ldo, (const unsigned short *)in, (unsigned short *)out);
+      else if (policy == 2) hipLaunchKernelGGL(vnni2_rows4_kernel<2>, g, dim3(256), 0, s, (int)(d.n / 4), d.ldi, d.ldo, (const unsigned short *)in, (unsigned short *)out);
+      else hipLaunchKernelGGL(vnni2_rows4_kernel<0>, g, dim3(256), 0, s, (int)(d.n / 4), d.ldi, d.ldo, (const unsigned short *)in, (unsigned short *)out);
+    }
+    else if (vec && d.m / 2 <= 65535 && d.n / 8 < (1 << 30))
       hipLaunchKernelGGL(vnni2_rows_kernel, dim3((unsigned)((d.n / 8 + 255) / 256), (unsigned)(d.m / 2)), dim3(256), 0, s,
                          (int)(d.n / 8), d.ldi, d.ldo, (const unsigned short *)in, (unsigned short *)out);
     else if (vec)
