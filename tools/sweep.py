@@ -146,9 +146,9 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "vnni4":
     sys.exit(0)
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "lw128":
-    # the 128x128 loader-wave tile (forced 23 / flat B 27) under TPP_HIP_BLW_MODE: C4 layer, the same output at K = 8192 (time per
-    # chunk = the difference / 112), C5, two rounds of tiles, 4096^3
-    tag = "MODE=%s" % os.environ.get("TPP_HIP_BLW_MODE", "0")
+    # the 128x128 loader-wave tile (forced 23 / flat B 27): C4 layer, the same output at K = 8192 (time per chunk = the difference / 112),
+    # C5, two rounds of tiles, 4096^3. TPP_SWEEP_TAG labels the lines (A/B runs of side builds through TPP_XSMM_LIBRARY).
+    tag = os.environ.get("TPP_SWEEP_TAG", "")
     for (m, n, k, br, what) in ((4096, 1024, 64, 16, "C4 layer"), (4096, 1024, 64, 128, "C4 output, K=8192"), (2048, 2048, 128, 16, "C5"),
                                 (4096, 2048, 64, 32, "512 tiles"), (4096, 4096, 64, 64, "4096^3")):
         bf16_case(m, n, k, br, force=23, tag=what + " " + tag)
