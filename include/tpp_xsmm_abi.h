@@ -228,6 +228,10 @@ TPP_XSMM_EXPORT int xsmm_hip_host_release(const void *ptr);
 TPP_XSMM_EXPORT int xsmm_hip_device_count(void);
 /* Name of the HIP kernel variant a GEMM-like handle selected, for profiles. */
 TPP_XSMM_EXPORT const char *xsmm_hip_kernel_name(int64_t handle);
+/* Name of the kernel family the tile queue's most recent grouped GEMM launch ran on ("" before the first): a group of queued tile
+ * invokes may run on a faster family than a single invoke of its handle would (xsmm_hip_kernel_name), e.g. 32-k f32 tiles with even
+ * batch counts on the loader-wave kernels. A static string; diagnostics only. */
+TPP_XSMM_EXPORT const char *xsmm_hip_last_grouped_kernel(void);
 /* Force a GEMM tile variant for A/B benchmarking and tests (-1 = automatic): f32 0..4 (64x64,
  * 64x32+K2, 32x32+K4, 128x64, 64x64+K2), 5..7 the loader-wave kernels (64x64, 64x64+K2, 64x32+K4), 8 generic, 9 / 10 loader-wave 32x32+K4 / 128x64, bf16 16 / 17 / 18 / 19 (64x64, 128x128, 256x256, 32x32 + K split),
  * 20 .. 23 the bf16 loader-wave tiles for mid-size outputs (32x64 + K split, 64x64, 64x128, 128x128).

@@ -312,6 +312,81 @@ def test_packed_layers_k64_tiles_use_the_fast_families(rtq, tiles, nblk):
         close(host(dC, C0), ref, F32)
 
 
+@pytest.mark.parametrize("tiles", [(32, 32), (64, 32), (64, 64)], ids=lambda t: "x".join(map(str, t)))
+@pytest.mark.parametrize("layout", ["packed", "rowmajor"])
+@pytest.mark.parametrize("kb", [2, 6, 32, 5, 0], ids=lambda v: "kb%d" % v)
+def test_f32_tiles_of_32_k_pair_their_batch_elements(rtq, tiles, layout, kb):
+    """mlir-gen --tiles=32,32,32 (the reference's MLP benchmark, benchmarks/config/base/base.json:74-80): f32 tiles with k = 32 run on
+    the loader-wave families when every invoke of the group has an EVEN batch count - a 64-k chunk is the 32-k blocks of two batch
+    elements, wherever the stride puts them (packed blocks: stride = 1024; row-major panels: stride = 32 for A, 32 * ldb for B).
+    Odd counts (and groups that mix) stay on the generic grouped kernel; both against the oracle, beta = 1 and beta = 0 + bias + relu."""
+    rt = rtq
+    tm, tn = tiles
+    tk = 32
+    MB, NB = 3, 5
+    rng = np.random.default_rng(tm * 7 + tn + kb)
+    K = max(kb, 1) * tk
+    if layout == "packed":
+        lda, ldb, sa, sb = tk, tn, tm * tk, tk * tn
+        a_off = lambda i: i * max(kb, 1) * tm * tk
+        b_off = lambda j: j * max(kb, 1) * tk * tn
+        X = rng.uniform(-1, 1, MB * max(kb, 1) * tm * tk).astype(np.float32)
+        Wt = rng.uniform(-0.3, 0.3, NB * max(kb, 1) * tk * tn).astype(np.float32)
+    else:  # A [M][K] row-major, B [K][N] row-major: a batch element is the next 32 columns of A / the next 32 rows of B
+        N = NB * tn
+        lda, ldb, sa, sb = K, N, tk, tk * N
+        a_off = lambda i: i * tm * K
+        b_off = lambda j: j * tn
+        X = rng.uniform(-1, 1, MB * tm * K).astype(np.float32)
+        Wt = rng.uniform(-0.3, 0.3, K * N).astype(np.float32)
+    b = rng.uniform(-0.3, 0.3, NB * tn).astype(np.float32)
+    C0 = rng.uniform(-1, 1, MB * NB * tm * tn).astype(np.float32)
+    for (gflags, ukind, bflags, bkind) in ((4, 5, 4, 1), (0, 0, 0, 0)):
+        disp = (F32, tm, tn, tk, lda, ldb, tn, sa, sb, gflags, 0, ukind, bflags, bkind)
+        ref = C0.copy()
+        for i in range(MB):
+            for j in range(NB):
+                orc.fused_brgemm(*disp, X, a_off(i), Wt, b_off(j), ref, (i * NB + j) * tm * tn, b, j * tn, kb)
+        h = rt.fused_brgemm_dispatch(*disp)
+        dX, dW, db, dC = dev(X), dev(Wt), dev(b), dev(C0)
+        for rep in range(3):  # recorded, then replayed from the trace cache (the replay launches from the segment's device list)
+            dC.copy_(dev(C0))
+            rt.synchronize()
+            for i in range(MB):
+                for j in range(NB):
+                    rt.fused_brgemm(F32, h, dX, a_off(i), dW, b_off(j), dC, (i * NB + j) * tm * tn, db, j * tn, kb)
+            rt.synchronize()
+            close(host(dC, C0), ref, F32)
+            ran = rt.last_grouped_kernel()
+            assert ("32-k pairs" in ran) == (kb % 2 == 0), (ran, kb)
+
+
+def test_f32_tiles_of_32_k_mixed_batch_counts_in_one_group(rtq):
+    """one odd batch count in the group sends the whole group to the generic kernel (the pair flag is a property of the group)"""
+    rt = rtq
+    rng = np.random.default_rng(77)
+    KB = 8
+    X = rng.uniform(-1, 1, KB * 1024).astype(np.float32)
+    Wt = rng.uniform(-0.3, 0.3, 24 * KB * 1024).astype(np.float32)
+    C0 = rng.uniform(-1, 1, 24 * 1024).astype(np.float32)
+    b = np.zeros(32, dtype=np.float32)  # (unused: no bias in this dispatch)
+    disp = (F32, 32, 32, 32, 32, 32, 32, 1024, 1024, 0, 0, 0, 0, 0)
+    counts = [8, 6, 2, 7, 4, 8] * 4
+    ref = C0.copy()
+    for j, kb in enumerate(counts):
+        orc.fused_brgemm(*disp, X, 0, Wt, j * KB * 1024, ref, j * 1024, b, 0, kb)
+    h = rt.fused_brgemm_dispatch(*disp)
+    dX, dW, dC, db = dev(X), dev(Wt), dev(C0), dev(b)
+    for rep in range(2):
+        dC.copy_(dev(C0))
+        rt.synchronize()
+        for j, kb in enumerate(counts):
+            rt.fused_brgemm(F32, h, dX, 0, dW, j * KB * 1024, dC, j * 1024, db, 0, kb)
+        rt.synchronize()
+        close(host(dC, C0), ref, F32)
+        assert rt.last_grouped_kernel().startswith(("brgemm_grouped<f32>", "brgemm_f32_lw<32x32,k4> grouped")), rt.last_grouped_kernel()
+
+
 @pytest.mark.parametrize("nblk", [(2, 3), (4, 16)], ids=["few", "many"])
 def test_packed_layers_bf16_64_tiles(rtq, nblk):
     """bf16 + VNNI-2 W with --tiles=64,64,64: the 64x64 bf16 family in grouped mode"""

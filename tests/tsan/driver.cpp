@@ -169,6 +169,66 @@ static int run_fused(int reps, const char *what) {
   return bad;
 }
 
+// SOLO -> MULTI. The first thread to use the queue runs its replayed groups with plain stores (DirectWindow, SOLO: no locked
+// instruction on the caller's side); the first time another thread touches the queue state the process switches, once, to the
+// two-sided protocol (membarrier + wait for the solo section in flight). Here: the main thread replays the fused tiles alone, and
+// half way through a second thread starts flushing the queue and queueing its own tiles while the main thread keeps going.
+// Must be the FIRST use of the tile queue in the process (afterwards the process is multi for good).
+static int run_solo_handover(int reps, const char *what) {
+  std::vector<float *> act(LAYERS + 1), w(LAYERS), ref(LAYERS + 1);
+  for (int l = 0; l <= LAYERS; ++l) {
+    act[l] = dev_alloc((size_t)M * N);
+    ref[l] = (float *)malloc((size_t)M * N * sizeof(float));
+  }
+  float *scratch = dev_alloc((size_t)8 * TS * TS);
+  for (int l = 0; l < LAYERS; ++l) {
+    w[l] = dev_alloc((size_t)K * N);
+    fill(w[l], (size_t)K * N, 277u + l, 4);
+  }
+  fill(act[0], (size_t)M * K, 25u, 2);
+  memcpy(ref[0], act[0], (size_t)M * K * sizeof(float));
+  for (int l = 0; l < LAYERS; ++l) serial_layer(ref[l], w[l], ref[l + 1]);
+  const int64_t hf = xsmm_fused_brgemm_dispatch(XSMM_DTYPE_F32, TS, TS, KB, K, N, N, KB, (int64_t)KB * N, XSMM_GEMM_FLAG_BETA_0, 0,
+                                                XSMM_UNARY_RELU, 0, XSMM_BINARY_NONE);
+  const int64_t hz = xsmm_unary_dispatch(XSMM_UNARY_ZERO, XSMM_DTYPE_F32, TS, TS, TS, TS, 0);
+  int bad = 0;
+  std::atomic<int> stop{0};
+  std::thread other;
+  const int tiles_n = N / TS, tiles = (M / TS) * tiles_n;
+  for (int rep = 0; rep < reps; ++rep) {
+    if (rep == reps / 2)
+      other = std::thread([&] {
+        int k = 0; // (bounded: thousands of locked arrivals from two threads would hand the queue to the scheduler thread)
+        while (!stop.load(std::memory_order_acquire) && k < 600) {
+          xsmm_unary_invoke(XSMM_DTYPE_F32, hz, scratch, (int64_t)(k & 7) * TS * TS, scratch, (int64_t)(k & 7) * TS * TS);
+          if ((++k & 15) == 0) xsmm_hip_flush();
+          usleep(20);
+        }
+      });
+    for (int l = 1; l <= LAYERS; ++l) memset(act[l], 0xff, (size_t)M * N * sizeof(float));
+    for (int l = 0; l < LAYERS; ++l)
+      for (int t = 0; t < tiles; ++t) {
+        const int i = t / tiles_n, j = t % tiles_n;
+        xsmm_fused_brgemm_invoke(XSMM_DTYPE_F32, hf, act[l], (int64_t)i * TS * K, w[l], j * TS, act[l + 1], (int64_t)i * TS * N + j * TS,
+                                 nullptr, 0, K / KB);
+      }
+    xsmm_hip_synchronize();
+    for (int l = 1; l <= LAYERS; ++l)
+      if (memcmp(act[l], ref[l], (size_t)M * N * sizeof(float))) ++bad;
+  }
+  stop.store(1, std::memory_order_release);
+  other.join();
+  xsmm_hip_synchronize();
+  printf("%-46s reps %d: %s\n", what, reps, bad ? "MISMATCH" : "identical to the serial run");
+  for (int l = 0; l <= LAYERS; ++l) {
+    hipFree(act[l]);
+    free(ref[l]);
+  }
+  for (int l = 0; l < LAYERS; ++l) hipFree(w[l]);
+  hipFree(scratch);
+  return bad;
+}
+
 // A chain of dependent in-place ops on ONE tile, each step issued by a different thread, handed over through an atomic
 // (release / acquire) only: x = 0; then alternately x = 2 x and x = x + 1, i.e. after 2 n steps x = 2^n - 1 ... only if the
 // scheduler takes the steps in the order the hand-overs define (the ops do not commute).
@@ -228,6 +288,7 @@ int main(int argc, char **argv) {
   xsmm_hip_set_tile_queue(1);
   const int threads_before = thread_count();
   int64_t qs0[5], qs1[5];
+  bad += run_solo_handover(12, "tile queue, one caller, then a second thread");
   xsmm_hip_tile_queue_stats(qs0);
   bad += run_fused(12, "tile queue, fused tiles replayed, 8 callers");
   xsmm_hip_tile_queue_stats(qs1);

@@ -29,6 +29,9 @@ gemm = rt.brgemm_dispatch(F32, 32, 32, 32, 32, 32, 32, 1024, 1024, 0)
 gemm0 = rt.brgemm_dispatch(F32, 32, 32, 32, 32, 32, 32, 1024, 1024, 4)
 
 
+BR = [1]
+
+
 def issue(op, bufs):
     kind, s, st, s2, s2t, d, dt = op
     S, S2, D = bufs[s], bufs[s2], bufs[d]
@@ -45,7 +48,8 @@ def issue(op, bufs):
     elif d in (s, s2):  # a gemm must not write a buffer it reads
         rt.binary(F32, add, S, st * 1024, S2, s2t * 1024, D, dt * 1024)
     else:
-        rt.brgemm(F32, gemm if kind == 5 else gemm0, S, st * 1024, S2, s2t * 1024, D, dt * 1024, 1)
+        # batch count of the program (1, 2 or 4; even counts run on the loader-wave pair kernel, queued or not)
+        rt.brgemm(F32, gemm if kind == 5 else gemm0, S, min(st, NTILE - BR[0]) * 1024, S2, min(s2t, NTILE - BR[0]) * 1024, D, dt * 1024, BR[0])
 
 
 def make_program(rng):
@@ -96,6 +100,7 @@ while time.time() < t_end:
     rng = np.random.default_rng(seed)
     init = [(rng.uniform(-1, 1, NTILE * 1024) * 0.2).astype(np.float32) for _ in range(NBUF)]
     phases = make_program(rng)
+    BR[0] = int(rng.choice([1, 2, 4]))
     q_bufs = [torch.from_numpy(b.copy()).cuda() for b in init]
     r_bufs = [torch.from_numpy(b.copy()).cuda() for b in init]
     for rep in range(int(rng.integers(2, 6))):

@@ -164,7 +164,12 @@ int main(int argc, char **argv) {
                                      (i * NB + j) * tile * tn, B[l], j * tn, KB);
           }
         };
-        if (threads <= 1) run(0, MB * NB);
+        if (threads <= 1) { // the lowered scf.forall: two nested loops (no index arithmetic per tile)
+          for (int64_t i = 0; i < MB; ++i)
+            for (int64_t j = 0; j < NB; ++j)
+              xsmm_fused_brgemm_invoke(dt, handle[l], act[l], i * KB * tile * tk, W[l], j * KB * tk * tn, act[l + 1],
+                                       (i * NB + j) * tile * tn, B[l], j * tn, KB);
+        }
         else { // the reference's scf.parallel -> OpenMP parallel-for over the tile grid (static schedule, barrier at the end)
           const int64_t total = MB * NB;
 #pragma omp parallel for schedule(static) num_threads(threads)
@@ -185,7 +190,7 @@ int main(int argc, char **argv) {
   fprintf(stderr, "tpp_replay: %s, batch %ld, %d layer(s), queue %d: mean %.3f us (host side of the invokes %.3f us), %.1f GFLOP/s (BENCH_TOTAL_FLOPS %.0f), kernel %s\n",
           whole ? "whole-layer dispatch" : "packed tile invokes", (long)batch, L, queue, mean * 1e6,
           host_dt / (double)n_iter * 1e6, flops / mean / 1e9, flops,
-          xsmm_hip_kernel_name(handle[0]));
+          (queue && !whole && xsmm_hip_last_grouped_kernel()[0]) ? xsmm_hip_last_grouped_kernel() : xsmm_hip_kernel_name(handle[0]));
   if (queue) {
     int64_t qs[5];
     xsmm_hip_tile_queue_stats(qs);

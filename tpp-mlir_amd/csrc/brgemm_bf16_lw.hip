@@ -63,6 +63,40 @@ __device__ __forceinline__ void blw_stamp(chain_kernarg_t &p, int layer, int slo
 #endif
 }
 
+// Per-chunk stamps of the LOADER waves (ablation builds, TPP_HIP_CHAIN_DBG & 1024, chain launches; the first 16 workgroups): shader-clock
+// stamps (s_memtime) at three points of every steady-state iteration - the chunk awaited has landed / the barrier has released /
+// the next chunk's DMA instructions are issued - buffered in LDS behind the ring (a VMEM store would count in the loaders' vmcnt
+// bookkeeping) and copied to p.stamps behind the per-layer stamps when the wave ends. A stamp is REQUESTED at its point and
+// collected at the next one (s_memtime returns through lgkmcnt, ~70 cycles: waiting for it on the spot stretched the
+// 4096-row chain from 28.9 to 38.3 us; collected late the three stamps cost a few issue slots). The MFMA waves are not
+// stamped: s_memtime shares lgkmcnt with their fragment reads. landed -> released = how long the loader waited for the
+// slowest wave at the barrier; issued(t-1) -> landed(t) = how long it waited for its own DMA. tools/stamps_report.py --chunks.
+constexpr int BLW_CS_ENTRIES = 64; // (layer, chunk) records per loader wave
+struct BlwChunkStamps {
+  unsigned long long pend = 0; // (an SGPR pair: the s_memtime in flight)
+  int pend_off = -1;           // LDS byte offset it belongs to
+  __device__ __forceinline__ void collect(unsigned char *smem, int lane) {
+#ifdef TPP_HIP_ABLATION
+    if (pend_off >= 0) {
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(pend)::"memory");
+      if (lane == 0) *(unsigned long long *)(smem + pend_off) = pend;
+      pend_off = -1;
+    }
+#endif
+  }
+  __device__ __forceinline__ void stamp(unsigned char *smem, int area, int which, int idx, int k, int lane) {
+#ifdef TPP_HIP_ABLATION
+    if (area >= 0) {
+      collect(smem, lane);
+      if (idx < BLW_CS_ENTRIES) {
+        pend_off = area + ((which * BLW_CS_ENTRIES + idx) * 3 + k) * 8;
+        asm volatile("s_memtime %0" : "=s"(pend)::"memory");
+      }
+    }
+#endif
+  }
+};
+
 // s_waitcnt vmcnt(younger * PPL): this wave's DMA of all but the `younger` most recent chunks has landed
 template <int PPL> __device__ __forceinline__ void blw_wait_younger(int younger) {
 #define BLW_CASE(K)                                                                   \
@@ -104,6 +138,11 @@ __device__ __forceinline__ void blw_loader(chain_kernarg_t *pp, unsigned char *s
   constexpr int dbg = 0; // the timing switches exist in ablation builds only (chain_args.h)
 #endif
   const bool no_dma = (dbg & (16 | (IS_A ? 128 : 64))) != 0; // timing experiments: this panel is not fetched
+  // per-chunk stamps (see BlwChunkStamps): LDS area behind the ring, this wave's row = 0 (A loader 0) / 1 (B loader 0)
+  const int cs_area = ((dbg & 1024) && MULTI && part == 0 && blockIdx.x < 16 && p.stamps) ? NSLOT_C * SLOT + (WK > 1 ? (BM / 32) * (BN / 32) * 4096 : 0) : -1;
+  constexpr int cs_which = IS_A ? 0 : 1;
+  int cs_idx = 0;
+  BlwChunkStamps cs;
   bool ahead = false;
   if (MULTI && !IS_A) {
     ahead = true;
@@ -239,8 +278,12 @@ __device__ __forceinline__ void blw_loader(chain_kernarg_t *pp, unsigned char *s
     // mid-chunk barrier of chunk t) publishes it and retires the slot of chunk t-1, which takes chunk t + NSLOT - 1
     for (; t + NSLOT - 1 < T; ++t) {
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSLOT - 3) * PPL) : "memory");
+      cs.stamp(smem, cs_area, cs_which, cs_idx, 0, lane);
       __builtin_amdgcn_s_barrier();
+      cs.stamp(smem, cs_area, cs_which, cs_idx, 1, lane);
       BLW_ISSUE(slot);
+      cs.stamp(smem, cs_area, cs_which, cs_idx, 2, lane);
+      ++cs_idx;
     }
     // the last NSLOT - 2 barriers of the layer: nothing of THIS layer is left to request
     if (MULTI && ahead && lc + 1 < L) {
@@ -256,7 +299,19 @@ __device__ __forceinline__ void blw_loader(chain_kernarg_t *pp, unsigned char *s
         __builtin_amdgcn_s_barrier();
       }
     }
-    if (lc + 1 == L) return;
+    if (lc + 1 == L) {
+#ifdef TPP_HIP_ABLATION
+      cs.collect(smem, lane);
+      if (cs_area >= 0 && lane == 0) { // copy this wave's records out: [workgroup < 16][A, B][entry][3] behind the per-layer stamps
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        unsigned long long *dst = p.stamps + (size_t)p.tiles_m * p.tiles_n * CH_MAXL * 8 + ((size_t)blockIdx.x * 2 + cs_which) * (BLW_CS_ENTRIES * 3 + 1);
+        dst[0] = (unsigned long long)cs_idx;
+        const unsigned long long *src = (const unsigned long long *)(smem + cs_area) + cs_which * BLW_CS_ENTRIES * 3;
+        for (int i = 0; i < BLW_CS_ENTRIES * 3; ++i) dst[1 + i] = i < cs_idx * 3 ? src[i] : 0ull;
+      }
+#endif
+      return;
+    }
     if constexpr (WK > 1) __builtin_amdgcn_s_barrier(); // R1 (K groups combine)
     __builtin_amdgcn_s_barrier();                        // S1 (tile stored and drained)
     s0 = (s0 + T) % NSLOT;
@@ -338,7 +393,7 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
   // 1-2 MFMAs (32-64 cycles), less than an LDS read takes to come back, so the fragments of chunk t+1 are all read during the
   // second half of chunk t (measured on the 64x64 tile with a two-step lookahead: 420 cycles per chunk for 128 cycles of MFMA).
   // The 128x128 tile (four accumulators, 128 cycles per k-step) reads two k-steps ahead out of one set.
-  constexpr bool FULLPF = TM * TN <= 2;
+  constexpr bool FULLPF = TM * TN <= 2 && WM * WN * WK <= 4; // (eight MFMA waves: two per SIMD cover each other, step-wise prefetch)
   constexpr int BLW_RD = 3; // SUP = 2: k-steps the fragment reads run ahead of their MFMA
   constexpr int NFB = FULLPF ? 2 * KS : KS;
   static_assert(!FULLPF || NSLOT % 2 == 0, "chunk parity from the ring slot");
@@ -708,10 +763,15 @@ template <int WM, int WN, int WK, int TM, int TN, int NSLOT, int NLA, int NLB, i
 static hipError_t launch_blw_t(const ChainArgs &a, hipStream_t s) {
   constexpr int NOUT = WM * WN, BM = 32 * WM * TM, BN = 32 * WN * TN, NT = 64 * (WM * WN * WK + NLA + NLB);
   constexpr size_t lds = (size_t)NSLOT * (BM + BN) * 128 + (WK > 1 ? (size_t)NOUT * 4096 : 0);
+#ifdef TPP_HIP_ABLATION
+  constexpr size_t lds_alloc = lds + (lds + 4096 <= 160 * 1024 ? 4096 : 0); // room for the loaders' per-chunk stamps (BlwChunkStamps)
+#else
+  constexpr size_t lds_alloc = lds;
+#endif
   static_assert(lds <= 160 * 1024, "LDS budget");
   auto kern = brgemm_bf16_lw<WM, WN, WK, TM, TN, NSLOT, NLA, NLB, SUP, MULTI, FLATB>;
   static std::atomic<unsigned long long> lds_set{0};
-  if (hipError_t e = ensure_dynamic_lds((const void *)kern, (int)lds, lds_set); e != hipSuccess) return e;
+  if (hipError_t e = ensure_dynamic_lds((const void *)kern, (int)lds_alloc, lds_set); e != hipSuccess) return e;
   ChainArgs args = a;
   args.tiles_m = a.m / BM;
   args.tiles_n = a.n / BN;
@@ -733,7 +793,7 @@ static hipError_t launch_blw_t(const ChainArgs &a, hipStream_t s) {
       args.xm = xm;
     }
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(NT), lds, s, args);
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(NT), lds_alloc, s, args);
   return hipGetLastError();
 }
 
@@ -759,9 +819,18 @@ void blw_tile_dims(int tile, int *bm, int *bn) {
   case 4:                                                                                    \
   case 5: return launch_blw_t<2, 2, 1, 1, 2, 6, 1, 2, 1, MULTI, FB>(a, s);                   \
   case 6:                                                                                    \
-  case 7: return launch_blw_t<2, 2, 1, 2, 2, 4, 1, 1, 1, MULTI, FB>(a, s);                   \
+  case 7: return blw_t3_alt() ? launch_blw_t<2, 4, 1, 2, 1, 4, 1, 1, 1, MULTI, FB>(a, s)     \
+                              : launch_blw_t<2, 2, 1, 2, 2, 4, 1, 1, 1, MULTI, FB>(a, s);    \
   default: return hipErrorInvalidValue;                                                      \
   }
+// TPP_HIP_BLW_T3=1 (A/B runs): the 128x128 tile on EIGHT MFMA waves as 2 x 4 waves of 64x32 (two per SIMD, no K split, no exchange)
+static bool blw_t3_alt() {
+  static const int v = [] {
+    const char *e = getenv("TPP_HIP_BLW_T3");
+    return e ? atoi(e) : 0;
+  }();
+  return v != 0;
+}
 static bool blw_sup2(const ChainArgs &a) {
   static const int forced = [] {
     const char *e = getenv("TPP_HIP_BLW_SUP");

@@ -762,7 +762,24 @@ int bf16_lw_b_kind(const GemmDesc &d) {
   return bf16_flat_eligible(d) ? 2 : -1;
 }
 
-hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_items, bool vec_ok, bool out_ok,
+static bool k32_pairs_on() {
+  static const bool on = [] {
+    const char *e = getenv("TPP_HIP_GROUPED_K32_PAIRS"); // A/B runs: 0 = 32-k tiles on the generic grouped kernel, as before round 4
+#ifdef TPP_GROUPED_FAST
+    (void)e;
+    return false;
+#else
+    return !e || atoi(e) != 0;
+#endif
+  }();
+  return on;
+}
+// name of the kernel family of the most recent grouped GEMM launch (xsmm_hip_last_grouped_kernel: tests and tools/tpp_replay
+// report which kernel a tile-queue group ran on - the descriptor's own name is what a SINGLE invoke would run on)
+static std::atomic<const char *> g_last_grouped{""};
+const char *last_grouped_kernel() { return g_last_grouped.load(std::memory_order_relaxed); }
+#define note_grouped(name, ...) (g_last_grouped.store(name, std::memory_order_relaxed), (__VA_ARGS__))
+hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_items, bool vec_ok, bool out_ok, bool pair_ok,
                                hipStream_t stream) {
   if (d.m <= 0 || d.n <= 0 || n_items <= 0) return hipSuccess;
   GemmArgs a;
@@ -778,19 +795,24 @@ hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_i
   // f32 tiles with k a multiple of 64 (mlir-gen --tiles=64,64,64, the most common setting of the reference's
   // benchmark configs): the fast tile families in grouped mode, the largest tile that still yields about one
   // workgroup per CU over the whole work list (the same rule as pick_f32_variant)
-  if (vec && d.m % 32 == 0 && d.n % 32 == 0 && d.k % BK == 0 && d.variant != V_GENERIC && d.lda < (1 << 22) && d.ldb < (1 << 22) && d.ldc < (1 << 22)) {
+  // ... and 32-k tiles (--tiles=32,32,32, the reference's MLP benchmark) when every batch count is even: the loader waves build a
+  // 64-k chunk from the blocks of two batch elements (brgemm_f32_lw.hip, pair mode)
+  const bool k_pairs = k32_pairs_on() && d.k == 32 && pair_ok && d.stride_a >= 0 && d.stride_b >= 0 && d.stride_a < (1 << 26) && d.stride_b < (1 << 26);
+  if (vec && d.m % 32 == 0 && d.n % 32 == 0 && ((d.k % BK == 0 && d.variant != V_GENERIC) || (k_pairs && !d.generic_forced)) && d.lda < (1 << 22) && d.ldb < (1 << 22) && d.ldc < (1 << 22)) {
     const int64_t t64 = (d.m % 64 == 0 && d.n % 64 == 0) ? (int64_t)n_items * (d.m / 64) * (d.n / 64) : 0;
     const int64_t t6432 = (d.m % 64 == 0) ? (int64_t)n_items * (d.m / 64) * (d.n / 32) : 0;
     if (n_items <= 65535 * 32) { // grid.x carries the item index
+      auto nm = [&](const char *plain, const char *pairs) { return d.k == 32 ? pairs : plain; };
+      (void)nm;
       // the loader-wave kernels (brgemm_f32_lw.hip) in grouped mode; TPP_GROUPED_FAST builds the round-1 register-staged family for A/B runs
 #ifdef TPP_GROUPED_FAST
-      if (t64 >= g_num_cus) return launch_fast_grouped_t<2, 2, 1, TPP_NACC, true>(a, items, n_items, stream);
-      if (t6432 >= g_num_cus) return launch_fast_grouped_t<2, 1, 2, TPP_NACC, true>(a, items, n_items, stream);
-      return launch_fast_grouped_t<1, 1, 4, TPP_NACC, false>(a, items, n_items, stream);
+      if (t64 >= g_num_cus) return note_grouped("brgemm_f32_fast<64x64> grouped", launch_fast_grouped_t<2, 2, 1, TPP_NACC, true>(a, items, n_items, stream));
+      if (t6432 >= g_num_cus) return note_grouped("brgemm_f32_fast<64x32,k2> grouped", launch_fast_grouped_t<2, 1, 2, TPP_NACC, true>(a, items, n_items, stream));
+      return note_grouped("brgemm_f32_fast<32x32,k4> grouped", launch_fast_grouped_t<1, 1, 4, TPP_NACC, false>(a, items, n_items, stream));
 #else
-      if (t64 >= g_num_cus) return launch_f32_lw_grouped(t64 >= 2 * g_num_cus ? 0 : 1, a, items, n_items, stream);
-      if (t6432 >= g_num_cus) return launch_f32_lw_grouped(2, a, items, n_items, stream);
-      return launch_f32_lw_grouped(3, a, items, n_items, stream);
+      if (t64 >= g_num_cus) return note_grouped(t64 >= 2 * g_num_cus ? nm("brgemm_f32_lw<64x64> grouped", "brgemm_f32_lw<64x64> grouped, 32-k pairs") : nm("brgemm_f32_lw<64x64,k2> grouped", "brgemm_f32_lw<64x64,k2> grouped, 32-k pairs"), launch_f32_lw_grouped(t64 >= 2 * g_num_cus ? 0 : 1, a, items, n_items, stream));
+      if (t6432 >= g_num_cus) return note_grouped(nm("brgemm_f32_lw<64x32,k4> grouped", "brgemm_f32_lw<64x32,k4> grouped, 32-k pairs"), launch_f32_lw_grouped(2, a, items, n_items, stream));
+      return note_grouped(nm("brgemm_f32_lw<32x32,k4> grouped", "brgemm_f32_lw<32x32,k4> grouped, 32-k pairs"), launch_f32_lw_grouped(3, a, items, n_items, stream));
 #endif
     }
   }
@@ -803,14 +825,14 @@ hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_i
   // row pieces and reads the bias 8 bytes at a time: checked per item by the queue through out_ok)
   if (vec16 && out_ok && d.variant >= V_BF16_FAST && d.variant != V_BF16_SMALL32 && bf16_fast_eligible(d) &&
       (int64_t)n_items * (d.m / 64) * (d.n / 64) >= (3 * g_num_cus) / 4)
-    return launch_bf16_grouped64(a, items, n_items, stream);
-  if (vec_ok && out_ok && d.variant != V_GENERIC && bf16_small_eligible(d)) return launch_bf16_small32(a, items, n_items, stream);
-  if (d.dtype == DT_F32) return vec ? launch_grouped_t<float, false, true>(a, items, n_items, stream)
-                                    : launch_grouped_t<float, false, false>(a, items, n_items, stream);
-  if (d.vnni_b && vec16_4) return launch_grouped_t<unsigned short, true, true, 4>(a, items, n_items, stream); // VNNI-4 on the bf16 MFMA path
-  if (d.vnni_b) return vec16 ? launch_grouped_t<unsigned short, true, true>(a, items, n_items, stream)
-                             : launch_grouped_t<unsigned short, true, false>(a, items, n_items, stream);
-  return launch_grouped_t<unsigned short, false, false>(a, items, n_items, stream);
+    return note_grouped("brgemm_bf16_fast<64x64> grouped", launch_bf16_grouped64(a, items, n_items, stream));
+  if (vec_ok && out_ok && d.variant != V_GENERIC && bf16_small_eligible(d)) return note_grouped("brgemm_bf16_small32 grouped", launch_bf16_small32(a, items, n_items, stream));
+  if (d.dtype == DT_F32) return note_grouped("brgemm_grouped<f32>", vec ? launch_grouped_t<float, false, true>(a, items, n_items, stream)
+                                                                        : launch_grouped_t<float, false, false>(a, items, n_items, stream));
+  if (d.vnni_b && vec16_4) return note_grouped("brgemm_grouped<bf16,vnni4>", launch_grouped_t<unsigned short, true, true, 4>(a, items, n_items, stream)); // VNNI-4 on the bf16 MFMA path
+  if (d.vnni_b) return note_grouped("brgemm_grouped<bf16,vnni2>", vec16 ? launch_grouped_t<unsigned short, true, true>(a, items, n_items, stream)
+                                                                        : launch_grouped_t<unsigned short, true, false>(a, items, n_items, stream));
+  return note_grouped("brgemm_grouped<bf16,flat>", launch_grouped_t<unsigned short, false, false>(a, items, n_items, stream));
 }
 
 
@@ -974,6 +996,7 @@ bool plan_gemm(GemmDesc &d, int forced_variant) {
     v = V_GENERIC;
   }
   d.variant = v;
+  d.generic_forced = forced_variant == V_GENERIC;
   strncpy(d.name, variant_name(v), sizeof(d.name) - 1);
   d.name[sizeof(d.name) - 1] = 0;
   return true;
@@ -1059,6 +1082,16 @@ hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C,
   const bool vec16_4 = vec16x && d.vnni_factor == 4 && aligned16 && d.n % 2 == 0 && d.k % GK == 0 && !(d.ldb & 1); // VNNI-4: 16-byte pieces of 2 columns
   const bool vec16 = tiles_ok && d.dtype == DT_BF16 && d.vnni_b && d.vnni_factor == 2 && !((d.lda | d.stride_a | d.stride_b) & 7) && !(d.ldb & 3) &&
                      d.lda < (1 << 21) && d.ldb < (1 << 21); // (32-bit lane offsets)
+  // a SINGLE invoke of a 32-k f32 tile with an even batch count: the kernel its group would run on in the tile queue (the
+  // loader-wave pair mode, tile chosen as launch_gemm_grouped does for one item) - queue on and queue off then add in the same order
+  if (vec && k32_pairs_on() && !d.generic_forced && d.k == 32 && a.br >= 2 && !(a.br & 1) && d.m % 32 == 0 && d.n % 32 == 0 && d.stride_a >= 0 &&
+      d.stride_b >= 0 && d.stride_a < (1 << 26) && d.stride_b < (1 << 26) && d.lda < (1 << 22) && d.ldb < (1 << 22) && d.ldc < (1 << 22)) {
+    const int64_t t64 = (d.m % 64 == 0 && d.n % 64 == 0) ? (d.m / 64) * (d.n / 64) : 0;
+    const int64_t t6432 = (d.m % 64 == 0) ? (d.m / 64) * (d.n / 32) : 0;
+    if (t64 >= g_num_cus) return launch_f32_lw_grouped(t64 >= 2 * g_num_cus ? 0 : 1, a, nullptr, 1, stream);
+    if (t6432 >= g_num_cus) return launch_f32_lw_grouped(2, a, nullptr, 1, stream);
+    return launch_f32_lw_grouped(3, a, nullptr, 1, stream);
+  }
   if (d.dtype == DT_F32) return vec ? launch_grouped_t<float, false, true>(a, nullptr, 1, stream)
                                     : launch_grouped_t<float, false, false>(a, nullptr, 1, stream);
   if (d.vnni_b && vec16_4) return launch_grouped_t<unsigned short, true, true, 4>(a, nullptr, 1, stream);

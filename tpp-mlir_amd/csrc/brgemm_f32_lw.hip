@@ -54,15 +54,21 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + 2 * NL)) void brgemm_f32_lw(Ge
   // tiles_n, tiles_m), workgroup = one tile of one queued invoke, operands and batch count from its item. A template
   // parameter, not a run-time test: the plain kernel is the headline kernel and must not carry a second mode (measured: 0.6 %).
   WorkItem it{p.A, p.B, p.C, p.D, (int64_t)p.br};
-  if constexpr (GROUPED) it = items[blockIdx.x];
+  if constexpr (GROUPED) {
+    if (items) it = items[blockIdx.x]; // (no list: a single invoke of the grouped kernel, operands in the arguments)
+  }
   const int tm = GROUPED ? (int)blockIdx.z : (int)(blockIdx.x >> 1) * p.tiles_m + (int)blockIdx.z;
   const int tn = GROUPED ? (int)blockIdx.y : (int)(blockIdx.x & 1) * p.tiles_n + (int)blockIdx.y;
   const int m0 = tm * BM, n0 = tn * BN;
   const float *__restrict__ A = (const float *)it.A;
   const float *__restrict__ B = (const float *)it.B;
   float *__restrict__ C = (float *)it.C;
-  const int kchunks = p.k / LW_BK;
-  const int T = (int)it.br * kchunks;
+  // GROUPED, k = 32 (the compiler's 32^3 tiles, mlir-gen --tiles=32,32,32): a 64-k chunk is the 32-k blocks of TWO consecutive
+  // batch elements (even batch counts only: launch_gemm_grouped checks) - k 0..31 of the chunk image from element 2t, k 32..63
+  // from element 2t+1. Only the loaders' source offsets know; the LDS images and the MFMA waves are the same.
+  const bool pair = GROUPED && p.k == 32;
+  const int kchunks = pair ? 1 : p.k / LW_BK;
+  const int T = pair ? (int)it.br / 2 : (int)it.br * kchunks;
 
   if (wave >= NMW) {
     // ---- loader waves --------------------------------------------------------------------
@@ -75,21 +81,22 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + 2 * NL)) void brgemm_f32_lw(Ge
     unsigned voA[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int r = 4 * j + (lane >> 4);
-      voA[j] = (unsigned)((r * (int)p.lda + 4 * ((lane & 15) ^ r)) * 4);
+      const int r = 4 * j + (lane >> 4), pc = (lane & 15) ^ r; // 16-byte piece of the chunk's row: k 4 pc .. 4 pc + 3
+      voA[j] = (unsigned)((r * (int)p.lda + (pair ? (pc >> 3) * (int)p.stride_a + 4 * (pc & 7) : 4 * pc)) * 4);
     }
     unsigned voA2[2]; // NL = 2: this wave's instructions have v & 3 = part and part + 2 (NL = 4: always part)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int r = 4 * (part + 2 * j) + (lane >> 4);
-      voA2[j] = (unsigned)((r * (int)p.lda + 4 * ((lane & 15) ^ r)) * 4);
+      const int r = 4 * (part + 2 * j) + (lane >> 4), pc = (lane & 15) ^ r;
+      voA2[j] = (unsigned)((r * (int)p.lda + (pair ? (pc >> 3) * (int)p.stride_a + 4 * (pc & 7) : 4 * pc)) * 4);
     }
     const unsigned voB = (unsigned)(((lane / (BN / 4)) * (int)p.ldb + 4 * (lane % (BN / 4))) * 4);
     const unsigned stepA = (unsigned)(16 * (int)p.lda * 4), stepB = (unsigned)(RPI * (int)p.ldb * 4);
     const float *g = isA ? A + (int64_t)m0 * p.lda : B + n0; // panel base of the chunk being fetched
     int kc = 0;
     const int64_t d_in = isA ? (int64_t)LW_BK : (int64_t)LW_BK * p.ldb;
-    const int64_t d_wrap = (isA ? p.stride_a : p.stride_b) - (int64_t)(kchunks - 1) * d_in;
+    const int64_t d_wrap = (isA ? p.stride_a : p.stride_b) * (pair ? 2 : 1) - (int64_t)(kchunks - 1) * d_in;
+    const unsigned pairB = pair ? (unsigned)(((int)p.stride_b - 32 * (int)p.ldb) * 4) : 0u; // rows 32.. of a pair chunk: the second element
     auto issue = [&](int slot) __attribute__((always_inline)) {
       float *base = smem_lw + slot * SLOT + (isA ? 0 : A_STAGE);
       const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)g, 0, 0x7fffffff, 0x00020000);
@@ -104,7 +111,8 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + 2 * NL)) void brgemm_f32_lw(Ge
 #pragma unroll
         for (int i = 0; i < NB / NL; ++i) {
           const int v = part + NL * i;
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_lw *)(base + v * 256), 16, voB, (unsigned)v * stepB, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_lw *)(base + v * 256), 16, voB,
+                                                   (unsigned)v * stepB + (GROUPED && v * RPI >= 32 ? pairB : 0u), 0, 0);
         }
       }
       if (++kc == kchunks) {
@@ -308,7 +316,8 @@ template <int WM, int WN, int WK, int NL = 1, int NSLOT = LW_NSLOT> static hipEr
   return hipGetLastError();
 }
 
-// grouped launch (tile queue): one workgroup per (item, tile of the item); m, n multiples of the tile, k of 64
+// grouped launch (tile queue): one workgroup per (item, tile of the item); m, n multiples of the tile, k of 64 - or k = 32 with
+// even batch counts and 0 <= stride < 2^26 elements (the kernel's pair mode)
 template <int WM, int WN, int WK>
 static hipError_t launch_lw_grouped_t(const GemmArgs &a, const WorkItem *items, int n_items, hipStream_t s) {
   constexpr int BM = 32 * WM, BN = 32 * WN, NT = 64 * (WM * WN * WK + 2);

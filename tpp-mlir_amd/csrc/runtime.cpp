@@ -28,6 +28,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <time.h>
 #include <unordered_map>
@@ -207,6 +208,12 @@ struct DeviceRanges {
         return true;
       }
     return false;
+  }
+  Range range_of(const void *p) const { // the allocation that holds p, {0, 0} if unknown
+    const uintptr_t a = (uintptr_t)p;
+    for (const Range &r : known)
+      if (a >= r.b && a < r.e) return r;
+    return Range{0, 0};
   }
   uintptr_t base_of(const void *p) const { // allocation base, 0 if unknown
     const uintptr_t a = (uintptr_t)p;
@@ -469,7 +476,7 @@ struct QueuedOps {
   Operand op[4];
   int n_in;      // op[0 .. n_in) are read
   int out;       // index of the written operand
-  bool vec_ok, out_ok;
+  bool vec_ok, out_ok, pair_ok; // 16-byte input pieces / 16-byte output pieces + 8-byte bias / even batch count (launch_gemm_grouped)
   QueuedOps() {} // members are filled by queued_operands (no zero-fill on the enqueue path)
 };
 __attribute__((always_inline)) inline void set_operand(Operand &o, void *ptr, size_t bytes, bool written) {
@@ -547,16 +554,17 @@ __attribute__((always_inline)) inline void queued_operands(const void *desc, con
     q.out = 3;
     q.vec_ok = (((uintptr_t)w.A | (uintptr_t)w.B) & 15) == 0;
     q.out_ok = (((uintptr_t)w.C) & 15) == 0 && (((uintptr_t)w.D) & 7) == 0;
+    q.pair_ok = !(w.br & 1);
   } else if (kind == KIND_UNARY) {
     unary_operands((const UnaryDesc *)desc, (void *)w.A, w.C, q.op[0], q.op[1]);
     q.n_in = 1;
     q.out = 1;
-    q.vec_ok = q.out_ok = true;
+    q.vec_ok = q.out_ok = q.pair_ok = true;
   } else {
     binary_operands((const BinaryDesc *)desc, (void *)w.A, (void *)w.B, w.C, q.op[0], q.op[1], q.op[2]);
     q.n_in = 2;
     q.out = 2;
-    q.vec_ok = q.out_ok = true;
+    q.vec_ok = q.out_ok = q.pair_ok = true;
   }
 }
 
@@ -711,7 +719,7 @@ struct Segment {
                               // exchanges: callers mark their own arrivals while a direct window is open (DirectWindow)
   std::vector<int32_t> table; // open addressing over items, -1 = empty
   uint32_t round = 0;
-  bool vec_ok = true, out_ok = true;
+  bool vec_ok = true, out_ok = true, pair_ok = true;
   uint64_t last_use = 0;
   // The group's work list as the grouped kernels read it: items[i].w in recorded order, in pinned host memory, written once when
   // the group is first replayed. A replay in which EVERY member arrives launches straight from it - nobody copies a work item.
@@ -746,7 +754,57 @@ struct Segment {
     list_valid = true;
     return true;
   }
+  // Proof that every recorded pointer is device memory, per synchronisation epoch (DeviceRanges): the (few) allocations that hold
+  // them, collected the first time the group is replayed and re-verified - same base, same extent - once per epoch by whoever
+  // opens the group's window, under the queue's lock. A caller whose invoke matches a recorded member while dev_epoch is the
+  // current epoch skips its own four range checks (a quarter of the lock-free path); without a proof it checks as before.
+  static constexpr int MAX_ALLOC = 12;
+  Range alloc[MAX_ALLOC];
+  int n_alloc = -1;       // -1: not collected
+  uint64_t dev_epoch = 0; // written under the lock before the window opens, read inside the window
+  bool prove(DeviceRanges &dm, uint64_t epoch) {
+    if (dev_epoch == epoch) return true;
+    dev_epoch = 0;
+    if (n_alloc >= 0) {
+      bool same = true;
+      for (int i = 0; i < n_alloc && same; ++i) {
+        const Range r = dm.is_device((const void *)alloc[i].b) ? dm.range_of((const void *)alloc[i].b) : Range{0, 0};
+        same = r.b == alloc[i].b && r.e == alloc[i].e;
+      }
+      if (same) {
+        dev_epoch = epoch;
+        return true;
+      }
+      n_alloc = -1; // an allocation went away or changed: collect again
+    }
+    int n = 0, last = 0;
+    for (const TraceItem &t : items) {
+      const void *ptrs[4] = {t.w.A, t.w.B, t.w.C, t.w.D};
+      for (const void *q : ptrs) {
+        if (!q) continue;
+        const uintptr_t a = (uintptr_t)q;
+        if (n && a >= alloc[last].b && a < alloc[last].e) continue;
+        int j = 0;
+        while (j < n && !(a >= alloc[j].b && a < alloc[j].e)) ++j;
+        if (j == n) {
+          if (n == MAX_ALLOC || !dm.is_device(q)) return false;
+          const Range r = dm.range_of(q);
+          if (!r.e) return false; // (device memory without an address range: not provable, the callers keep checking)
+          alloc[n++] = r;
+        }
+        last = j;
+      }
+    }
+    n_alloc = n;
+    dev_epoch = epoch;
+    return true;
+  }
   bool mark(int idx) { return __atomic_exchange_n(&seen[idx], round, __ATOMIC_RELAXED) != round; } // false: joined this round already
+  bool mark_solo(int idx) { // one caller in the whole process (DirectWindow, SOLO): nobody else marks
+    if (__atomic_load_n(&seen[idx], __ATOMIC_RELAXED) == round) return false;
+    __atomic_store_n(&seen[idx], round, __ATOMIC_RELAXED);
+    return true;
+  }
   static size_t hash(const WorkItem &w) {
     uint64_t h = (uint64_t)(uintptr_t)w.C * 0x9E3779B97F4A7C15ull;
     h ^= ((uint64_t)(uintptr_t)w.A >> 4) * 0xC2B2AE3D27D4EB4Full;
@@ -769,6 +827,8 @@ struct Segment {
     seen.assign(items.size(), 0);
     round = 0;
     list_valid = false;
+    n_alloc = -1;
+    dev_epoch = 0;
   }
   int index_of(const void *d, const WorkItem &w, hipStream_t st) const {
     if (table.empty()) return -1;
@@ -795,6 +855,19 @@ struct Segment {
 // for its arrival to be complete. Invokes are processed synchronously on this path (when xsmm_*_invoke returns, the invoke is in the
 // group or launched), so everything that happened before an invoke is in the queue state when it arrives: program order and every
 // happens-before between callers hold without time stamps. Membership was proven conflict-free when the group was recorded.
+//
+// SOLO: as long as ONE thread is all the queue has ever seen (tpp-run without OpenMP, the reference's default), the caller's half of
+// the Dekker pair is plain stores and loads and the arrival mark a load + store: the two locked instructions (xchg for the seq_cst
+// store of `busy`, xchg for the mark) are 35-40 cycles of an invoke that costs ~100. The fence moves to the side that runs ONCE: the
+// first time a second thread touches the queue state (claims a caller slot, or takes the queue's lock) it sets `multi`, issues
+// membarrier(PRIVATE_EXPEDITED) - a full barrier on every CPU running a thread of this process - and waits until no solo section
+// is in flight (`seq` of every caller even; a section brackets itself with seq++ ... seq++, and a section that read multi = false
+// before the barrier had made its seq store by then: stores are not reordered with OLDER loads' retirement, an interrupt discards
+// a load that ran ahead of an unretired store). From then on, for good, the protocol above. No membarrier (seccomp): never solo.
+static uintptr_t thread_token() {
+  static thread_local char t;
+  return (uintptr_t)&t;
+}
 struct DirectWindow {
   static constexpr int MAXC = 256;
   struct alignas(64) Caller {
@@ -803,11 +876,42 @@ struct DirectWindow {
     uint32_t count = 0; // arrivals in that window
     uint32_t hint = 0;  // index after this caller's last arrival
     std::atomic<int> owned{0};
+    std::atomic<uint64_t> seq{0}; // odd while the owner is inside a SOLO section (written by the owner only, relaxed)
   };
   alignas(64) std::atomic<uint64_t> cur{0};
   alignas(64) std::atomic<int> ncallers{0}; // high-water mark of claimed caller slots
+  std::atomic<bool> multi{true};             // false: SOLO
+  std::atomic<bool> multi_ready{true};       // the switch to multi has completed (nobody is inside a solo section any more)
+  std::atomic<uintptr_t> solo_owner{0};      // thread_token() of the one thread
   Caller callers[MAXC];
+  DirectWindow() {
+    const char *e = getenv("TPP_HIP_QUEUE_SOLO"); // 0: the two-sided protocol from the start (A/B runs)
+    if ((!e || atoi(e) != 0) && syscall(__NR_membarrier, MEMBARRIER_CMD_REGISTER_PRIVATE_EXPEDITED, 0) == 0) {
+      multi.store(false, std::memory_order_relaxed);
+      multi_ready.store(false, std::memory_order_relaxed);
+    }
+  }
+  // every entry to the queue state that is not a solo section (claiming a slot, taking the queue's lock) says who it is
+  void touch(uintptr_t me) {
+    if (multi.load(std::memory_order_acquire)) {
+      while (!multi_ready.load(std::memory_order_acquire)) cpu_relax(); // (another thread is switching right now)
+      return;
+    }
+    uintptr_t o = solo_owner.load(std::memory_order_acquire);
+    if (o == me) return;
+    if (o == 0 && solo_owner.compare_exchange_strong(o, me, std::memory_order_seq_cst)) return;
+    bool expect = false;
+    if (multi.compare_exchange_strong(expect, true, std::memory_order_seq_cst)) {
+      if (syscall(__NR_membarrier, MEMBARRIER_CMD_PRIVATE_EXPEDITED, 0) != 0) die("tpp-xsmm-hip: membarrier failed");
+      for (int i = 0; i < MAXC; ++i)
+        while (callers[i].seq.load(std::memory_order_acquire) & 1) cpu_relax();
+      multi_ready.store(true, std::memory_order_release);
+    } else {
+      while (!multi_ready.load(std::memory_order_acquire)) cpu_relax();
+    }
+  }
   Caller *claim() {
+    touch(thread_token());
     const int n = ncallers.load(std::memory_order_acquire);
     for (int i = 0; i < MAXC; ++i) {
       int expect = 0;
@@ -849,7 +953,7 @@ struct TileQueue {
   unsigned backoff = 0, backoff_next = 2; // groups to collect without consulting the cache / after the next mismatch
   int kind = 0;               // KIND_GEMM / KIND_UNARY / KIND_BINARY of the queued invokes
   const void *desc = nullptr; // their (single) descriptor
-  bool vec_ok = true, out_ok = true;
+  bool vec_ok = true, out_ok = true, pair_ok = true;
   int n = 0;
   Footprint reads, writes;
   // Work lists live in host-pinned (device-mapped) memory and every workgroup reads its 40-byte item over PCIe, once,
@@ -877,7 +981,7 @@ struct TileQueue {
     int kind = 0;
     const void *desc = nullptr;
     int seg = -1, n = 0;
-    bool vec_ok = true, out_ok = true;
+    bool vec_ok = true, out_ok = true, pair_ok = true;
     hipStream_t stream = nullptr;
   } pending;
   TileQueue() { segs.reserve(NSEG); } // callers inside a direct window hold pointers into segs: it never reallocates
@@ -920,7 +1024,7 @@ struct TileQueue {
     if (!pending.armed) return;
     pending.armed = false;
     Segment &S = segs[pending.seg];
-    if (pending.kind == KIND_GEMM) HIP_OK(launch_gemm_grouped(*(const GemmDesc *)pending.desc, S.list_dev, pending.n, pending.vec_ok, pending.out_ok, pending.stream));
+    if (pending.kind == KIND_GEMM) HIP_OK(launch_gemm_grouped(*(const GemmDesc *)pending.desc, S.list_dev, pending.n, pending.vec_ok, pending.out_ok, pending.pair_ok, pending.stream));
     else if (pending.kind == KIND_UNARY) HIP_OK(launch_unary_grouped(*(const UnaryDesc *)pending.desc, S.list_dev, pending.n, pending.stream));
     else HIP_OK(launch_binary_grouped(*(const BinaryDesc *)pending.desc, S.list_dev, pending.n, pending.stream));
     S.list_used = true;
@@ -957,6 +1061,7 @@ struct TileQueue {
       if (next) rec.terminators.push_back(*next);
       rec.vec_ok = vec_ok;
       rec.out_ok = out_ok;
+      rec.pair_ok = pair_ok;
       rec.last_use = ++use_clock;
       rec.build();
       size_t at = segs.size();
@@ -1001,17 +1106,17 @@ struct TileQueue {
     if (n == 0) return;
     bump(g_q_launches);
     if (whole) {
-      pending = Pending{true, kind, desc, rp, n, vec_ok, out_ok, stream};
+      pending = Pending{true, kind, desc, rp, n, vec_ok, out_ok, pair_ok, stream};
       if (!defer) issue_pending();
     } else {
-      if (kind == KIND_GEMM) HIP_OK(launch_gemm_grouped(*(const GemmDesc *)desc, pinned[slot], n, vec_ok, out_ok, stream));
+      if (kind == KIND_GEMM) HIP_OK(launch_gemm_grouped(*(const GemmDesc *)desc, pinned[slot], n, vec_ok, out_ok, pair_ok, stream));
       else if (kind == KIND_UNARY) HIP_OK(launch_unary_grouped(*(const UnaryDesc *)desc, pinned[slot], n, stream));
       else HIP_OK(launch_binary_grouped(*(const BinaryDesc *)desc, pinned[slot], n, stream));
       launched();
     }
     n = 0;
     desc = nullptr;
-    vec_ok = out_ok = true;
+    vec_ok = out_ok = pair_ok = true;
     reads.clear();
     writes.clear();
   }
@@ -1040,13 +1145,14 @@ inline bool conflicts_with_group(const TileQueue &q, int kind, const void *desc,
 // appends one invoke to the group being collected (full bookkeeping; the group is recorded for the trace cache)
 inline void append_to_group(TileQueue &q, int kind, const void *desc, const WorkItem &w, const Operand &out, uintptr_t anchor_out,
                             const Operand *const *in, const uintptr_t *anchor_in, int n_in, bool vec_ok, bool out_ok,
-                            hipStream_t stream) {
+                            bool pair_ok, hipStream_t stream) {
   q.ensure_slot();
   q.kind = kind;
   q.desc = desc;
   q.stream = stream;
   q.vec_ok = q.vec_ok && vec_ok;
   q.out_ok = q.out_ok && out_ok;
+  q.pair_ok = q.pair_ok && pair_ok;
   if (q.n == 0) { // a new group: record it
     q.rec.items.clear();
     q.rec_open = true;
@@ -1063,7 +1169,7 @@ inline void append_to_group(TileQueue &q, int kind, const void *desc, const Work
   q.writes.insert(out, anchor_out);
 }
 // the first invoke of a group on an empty queue: replay the recorded group it belongs to, if there is one
-inline bool try_start_replay(TileQueue &q, const void *desc, const WorkItem &w, hipStream_t stream) {
+inline bool try_start_replay(TileQueue &q, DeviceRanges &devmem, const void *desc, const WorkItem &w, hipStream_t stream) {
   if (q.backoff > 0) {
     --q.backoff;
     return false;
@@ -1084,11 +1190,13 @@ inline bool try_start_replay(TileQueue &q, const void *desc, const WorkItem &w, 
   q.stream = stream;
   q.vec_ok = S.vec_ok;
   q.out_ok = S.out_ok;
+  q.pair_ok = S.pair_ok;
   q.n = 1; // members are marked and counted, not copied: the work list is S.list (all of them) or is gathered at the flush
   q.replay = idx;
   q.rpos = (size_t)item + 1;
   S.last_use = ++q.use_clock;
   bump(g_q_replayed);
+  if (q.dw) (void)S.prove(devmem, devmem.epoch); // (devmem belongs to the thread that runs this and is of the current epoch)
   q.open_window(idx); // from here on the other members may arrive without the lock
   return true;
 }
@@ -1112,9 +1220,9 @@ __attribute__((always_inline)) inline void process_item(TileQueue &q, DeviceRang
   if (conflicts_with_group(q, kind, desc, out, anchor_out, in, anchor_in, o.n_in, stream)) {
     const TraceItem term{desc, w, stream};
     q.flush(&term);
-    if (try_start_replay(q, desc, w, stream)) return; // the group this invoke starts has been collected before
+    if (try_start_replay(q, devmem, desc, w, stream)) return; // the group this invoke starts has been collected before
   }
-  append_to_group(q, kind, desc, w, out, anchor_out, in, anchor_in, o.n_in, o.vec_ok, o.out_ok, stream);
+  append_to_group(q, kind, desc, w, out, anchor_out, in, anchor_in, o.n_in, o.vec_ok, o.out_ok, o.pair_ok, stream);
 }
 
 // footprints of the queued invokes into the (empty) read / write sets: a replay is being abandoned
@@ -1173,7 +1281,7 @@ inline void submit_item(TileQueue &q, DeviceRanges &devmem, const void *desc, co
       q.rec_open = true;
     }
   }
-  if (q.n == 0 && try_start_replay(q, desc, w, stream)) {
+  if (q.n == 0 && try_start_replay(q, devmem, desc, w, stream)) {
     q.issue_pending();
     return;
   }
@@ -1618,6 +1726,7 @@ void flush_tile_queue() {
   if (!cfg().tile_queue.load(std::memory_order_relaxed)) return;
   InlineQueue &iq = inl();
   if (!iq.scheduled.load(std::memory_order_acquire)) {
+    iq.dw.touch(thread_token());
     std::lock_guard<SpinLock> lk(iq.mu);
     if (!iq.scheduled.load(std::memory_order_relaxed)) {
       iq.q.flush();
@@ -1649,33 +1758,57 @@ void check_queue_device() {
 
 // everything a calling thread keeps for the enqueue path, behind ONE thread-local lookup per invoke (in a shared library every
 // thread_local access is a call into the dynamic TLS resolver)
+struct CallerState;
+// One pointer in the static TLS block (initial-exec: a %fs-relative load; the general-dynamic model of a shared library calls
+// __tls_get_addr on every access - 10-15 cycles of an invoke), the state itself behind the usual thread_local so that it is
+// destroyed with its thread. 8 bytes of the loader's static-TLS reserve: dlopen-safe.
+static __thread CallerState *tl_fast __attribute__((tls_model("initial-exec"))) = nullptr;
 struct CallerState {
   DeviceRanges devmem; // per caller: no sharing, no lock
   DirectWindow::Caller *me = nullptr;
   bool claimed = false;
   ~CallerState() {
+    tl_fast = nullptr;
     if (me) me->owned.store(0, std::memory_order_release);
   }
 };
 
-bool enqueue_item(const void *desc, const WorkItem &item, const void *const *ptrs, int n_ptrs, hipStream_t s) {
+static __attribute__((noinline)) CallerState &caller_state_slow() {
   thread_local CallerState tl;
+  tl_fast = &tl;
+  return tl;
+}
+static inline CallerState &caller_state() {
+  CallerState *p = tl_fast;
+  return p ? *p : caller_state_slow();
+}
+
+bool enqueue_item(const void *desc, const WorkItem &item, const void *const *ptrs, int n_ptrs, hipStream_t s) {
+  CallerState &tl = caller_state();
   DeviceRanges &devmem = tl.devmem;
-  if (devmem.refresh()) check_queue_device();
-  for (int i = 0; i < n_ptrs; ++i)
-    if (!devmem.is_device(ptrs[i], i)) return false;
   static InlineQueue &iq = inl();
-  // DIRECT: the invoke is a member of the recorded group being replayed
-  if (const uint64_t c = iq.dw.cur.load(std::memory_order_acquire)) {
+  // DIRECT: the invoke is a member of the recorded group being replayed. proven: only if the group's pointers have been proven
+  // device memory in this epoch (Segment::prove) - the caller has not looked at its operands yet
+  auto join_window = [&](bool proven, uint64_t epoch) __attribute__((always_inline)) -> bool {
+    const uint64_t c = iq.dw.cur.load(std::memory_order_acquire);
+    if (!c) return false;
     if (!tl.claimed) {
       tl.claimed = true;
       tl.me = iq.dw.claim();
     }
-    if (DirectWindow::Caller *me = tl.me) {
+    DirectWindow::Caller *me = tl.me;
+    if (!me) return false;
+    const bool solo = !iq.dw.multi.load(std::memory_order_relaxed); // (a thread that holds a slot and sees solo IS the one thread)
+    if (solo) {
+      me->seq.store(me->seq.load(std::memory_order_relaxed) + 1, std::memory_order_relaxed);
+      me->busy.store(c, std::memory_order_relaxed);
+    } else {
       me->busy.store(c, std::memory_order_seq_cst);
-      bool joined = false;
-      if (iq.dw.cur.load(std::memory_order_seq_cst) == c) {
-        Segment &S = iq.q.segs[(c & 127) - 1];
+    }
+    bool joined = false;
+    if (iq.dw.cur.load(solo ? std::memory_order_relaxed : std::memory_order_seq_cst) == c) {
+      Segment &S = iq.q.segs[(c & 127) - 1];
+      if (!proven || S.dev_epoch == epoch) {
         if (me->tag != c) {
           me->tag = c;
           me->count = 0;
@@ -1683,17 +1816,25 @@ bool enqueue_item(const void *desc, const WorkItem &item, const void *const *ptr
         int idx = -1;
         if (me->hint < S.items.size() && S.items[me->hint].same(desc, item, s)) idx = (int)me->hint;
         else idx = S.index_of(desc, item, s);
-        if (idx >= 0 && S.mark(idx)) {
+        if (idx >= 0 && (solo ? S.mark_solo(idx) : S.mark(idx))) {
           ++me->count;
           me->hint = (uint32_t)idx + 1;
           joined = true;
         }
       }
-      me->busy.store(0, std::memory_order_release);
-      if (joined) return true;
     }
-  }
+    me->busy.store(0, std::memory_order_release);
+    if (solo) me->seq.store(me->seq.load(std::memory_order_relaxed) + 1, std::memory_order_release);
+    return joined;
+  };
+  const uint64_t epoch = g_devmem_epoch.load(std::memory_order_relaxed);
+  if (devmem.epoch == epoch && join_window(true, epoch)) return true; // (this thread has been through the checks below in this epoch)
+  if (devmem.refresh()) check_queue_device();
+  for (int i = 0; i < n_ptrs; ++i)
+    if (!devmem.is_device(ptrs[i], i)) return false;
+  if (join_window(false, 0)) return true;
   if (!iq.scheduled.load(std::memory_order_acquire)) {
+    iq.dw.touch(thread_token());
     std::lock_guard<SpinLock> lk(iq.mu);
     if (!iq.scheduled.load(std::memory_order_relaxed)) {
       const uint64_t me = (uint64_t)(uintptr_t)&devmem; // the address of this thread's cache identifies the thread (one TLS lookup per invoke, not two)
@@ -1860,6 +2001,20 @@ void dump_chain_stamps() {
         fputc('\n', f);
       }
     fclose(f);
+  }
+  // the loaders' per-chunk records of the first 16 workgroups (TPP_HIP_CHAIN_DBG & 1024; brgemm_bf16_lw.hip BlwChunkStamps)
+  if (chain_ablation_bits() & 1024) {
+    const std::string p2 = std::string(path) + ".chunks";
+    if (FILE *f = fopen(p2.c_str(), "w")) {
+      const unsigned long long *base = g_stamps + g_stamps_wgs * CH_MAXL * 8;
+      for (int w = 0; w < 16 && (size_t)w < g_stamps_wgs; ++w)
+        for (int which = 0; which < 2; ++which) {
+          const unsigned long long *r = base + ((size_t)w * 2 + which) * (64 * 3 + 1);
+          const int n = (int)(r[0] > 64 ? 64 : r[0]);
+          for (int i = 0; i < n; ++i) fprintf(f, "%d %d %d %llu %llu %llu\n", w, which, i, r[1 + 3 * i], r[2 + 3 * i], r[3 + 3 * i]);
+        }
+      fclose(f);
+    }
   }
 }
 
@@ -2200,6 +2355,7 @@ extern "C" int xsmm_hip_set_tile_queue(int enable) {
     // leaving mode 2: back to the inline / direct path (a mode switch happens between bursts - no invoke is in flight - and the
     // flush above has drained the scheduler's rings)
     InlineQueue &iq = inl();
+    iq.dw.touch(thread_token());
     std::lock_guard<SpinLock> lk(iq.mu);
     iq.scheduled.store(false, std::memory_order_release);
     iq.owner = 0;
@@ -2310,6 +2466,7 @@ extern "C" const char *xsmm_hip_kernel_name(int64_t handle) {
   const GemmDesc *d = reinterpret_cast<const GemmDesc *>(handle);
   return (d && d->kind == KIND_GEMM) ? d->name : "";
 }
+extern "C" const char *xsmm_hip_last_grouped_kernel(void) { return last_grouped_kernel(); }
 extern "C" void xsmm_hip_force_variant(int v) { cfg().forced_variant.store(v); }
 // the VNNI blocking factor of bf16 B operands dispatched from now on (2 or 4); returns the previous one, -1 for an invalid factor
 extern "C" int xsmm_hip_set_vnni_factor(int v) {

@@ -25,6 +25,7 @@ struct GemmDesc {
   int vnni_factor;      // blocking factor v of a VNNI B operand [k/v][n][v]: 2, or 4 (xsmm_hip_set_vnni_factor at dispatch time; the
                         // factor is not on the wire - the reference asks libxsmm_cpuid_dot_pack_factor, VNNIUtils.cpp:25-45)
   int variant;          // kernel variant chosen at dispatch (see gemm_variants.h), -1 = by invoke
+  int generic_forced;   // variant = generic because it was asked for (xsmm_hip_force_variant / a VNNI C store), not because no fast tile fits
   char name[64];        // kernel name for profiles
   char trace[160];      // dispatch tuple + kernel name as text (trace ranges)
 };
@@ -61,9 +62,11 @@ struct WorkItem {
 hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C, const void *D,
                        int64_t br, hipStream_t stream);
 // n_items invokes of ONE descriptor in one launch (items: device array of WorkItem)
-// vec_ok: every item's A and B are 16-byte aligned; out_ok: every item's C is 16-byte and D 8-byte aligned
-hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_items, bool vec_ok, bool out_ok,
+// vec_ok: every item's A and B are 16-byte aligned; out_ok: every item's C is 16-byte and D 8-byte aligned;
+// pair_ok: every item's batch count is even (32-k tiles on the loader-wave kernels)
+hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_items, bool vec_ok, bool out_ok, bool pair_ok,
                                hipStream_t stream);
+const char *last_grouped_kernel(); // kernel family of the most recent launch_gemm_grouped ("" before the first)
 // fills d.variant / d.name; returns false if no kernel can run the descriptor
 bool plan_gemm(GemmDesc &d, int forced_variant);
 constexpr int GEMM_VARIANT_BF16_LW0 = 20; // = V_BF16_LW_32x64: first of the four loader-wave bf16 tiles (brgemm_bf16_lw.hip)

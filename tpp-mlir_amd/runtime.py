@@ -98,6 +98,7 @@ _SIGNATURES = {
     "xsmm_hip_host_release": (ctypes.c_int, [VP]),
     "xsmm_hip_device_count": (ctypes.c_int, []),
     "xsmm_hip_kernel_name": (ctypes.c_char_p, [I64]),
+    "xsmm_hip_last_grouped_kernel": (ctypes.c_char_p, []),
     "xsmm_hip_force_variant": (None, [ctypes.c_int]),
     "xsmm_hip_set_vnni_factor": (ctypes.c_int, [ctypes.c_int]),
     "xsmm_hip_get_vnni_factor": (ctypes.c_int, []),
@@ -256,6 +257,9 @@ class XsmmRuntime:
 
     def kernel_name(self, handle):
         return self.lib.xsmm_hip_kernel_name(handle).decode()
+
+    def last_grouped_kernel(self):
+        return self.lib.xsmm_hip_last_grouped_kernel().decode()
 
     def force_variant(self, v):
         self.lib.xsmm_hip_force_variant(v)
