@@ -393,7 +393,7 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
   // 1-2 MFMAs (32-64 cycles), less than an LDS read takes to come back, so the fragments of chunk t+1 are all read during the
   // second half of chunk t (measured on the 64x64 tile with a two-step lookahead: 420 cycles per chunk for 128 cycles of MFMA).
   // The 128x128 tile (four accumulators, 128 cycles per k-step) reads two k-steps ahead out of one set.
-  constexpr bool FULLPF = TM * TN <= 2 && WM * WN * WK <= 4; // (eight MFMA waves: two per SIMD cover each other, step-wise prefetch)
+  constexpr bool FULLPF = TM * TN <= 2;
   constexpr int BLW_RD = 3; // SUP = 2: k-steps the fragment reads run ahead of their MFMA
   constexpr int NFB = FULLPF ? 2 * KS : KS;
   static_assert(!FULLPF || NSLOT % 2 == 0, "chunk parity from the ring slot");
@@ -819,18 +819,9 @@ void blw_tile_dims(int tile, int *bm, int *bn) {
   case 4:                                                                                    \
   case 5: return launch_blw_t<2, 2, 1, 1, 2, 6, 1, 2, 1, MULTI, FB>(a, s);                   \
   case 6:                                                                                    \
-  case 7: return blw_t3_alt() ? launch_blw_t<2, 4, 1, 2, 1, 4, 1, 1, 1, MULTI, FB>(a, s)     \
-                              : launch_blw_t<2, 2, 1, 2, 2, 4, 1, 1, 1, MULTI, FB>(a, s);    \
+  case 7: return launch_blw_t<2, 2, 1, 2, 2, 4, 1, 1, 1, MULTI, FB>(a, s);                   \
   default: return hipErrorInvalidValue;                                                      \
   }
-// TPP_HIP_BLW_T3=1 (A/B runs): the 128x128 tile on EIGHT MFMA waves as 2 x 4 waves of 64x32 (two per SIMD, no K split, no exchange)
-static bool blw_t3_alt() {
-  static const int v = [] {
-    const char *e = getenv("TPP_HIP_BLW_T3");
-    return e ? atoi(e) : 0;
-  }();
-  return v != 0;
-}
 static bool blw_sup2(const ChainArgs &a) {
   static const int forced = [] {
     const char *e = getenv("TPP_HIP_BLW_SUP");
