@@ -172,6 +172,10 @@ TPP_XSMM_EXPORT void xsmm_hip_flush(void);
  * Same arithmetic as the separate launches (f32 accumulation in k order, one rounding per layer); bit-identical to them when
  * they run on the same tile, which is the case whenever dispatch planned the layers with a loader-wave tile (variants 20 .. 23)
  * that fits the chip. Returns 1 if the chain ran as one launch, 0 if it ran call by call.
+ * f32 (round 4): chains of whole-layer f32 calls (no VNNI operand, beta 0, 16-byte aligned operands and bias) run as one launch when
+ * EVERY call was planned on the same 64-row K-split loader-wave tile (64x64 + K2 or 64x32 + K4: 512 .. 1024 rows of a 1024-wide
+ * layer) and that tile fits the chip - bit-identical to the calls, 1-2.5 % faster; 32-row tiles (256 rows) stay call by call, which
+ * measured faster there (profiles/r04_f32_chain.txt).
  * Call i > 0 must keep every batch element inside its predecessor's rows ((br - 1) * stride_a + k <= lda): the hand-off is per row
  * block; a row-striding later call runs call by call.
  * RESIDENCY: the single launch needs every workgroup of its grid on a compute unit at the same time (one per CU). The grid is

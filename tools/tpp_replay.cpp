@@ -39,7 +39,7 @@ static std::vector<int64_t> parse_list(const char *s) {
 int main(int argc, char **argv) {
   int64_t batch = 256, tile = 32, tile_n = 0, tile_k = 0, n_iter = 100;
   std::vector<int64_t> layers = {1024, 1024, 1024, 1024};
-  bool bias = false, relu = false, whole = false, print = false, c1 = false, rnd = false, bf16 = false;
+  bool bias = false, relu = false, whole = false, chain = false, print = false, c1 = false, rnd = false, bf16 = false;
   int queue = 1, threads = 1;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
@@ -57,6 +57,7 @@ int main(int argc, char **argv) {
     else if (a == "--bias") bias = true;
     else if (a == "--relu") relu = true;
     else if (a == "--whole-layer") whole = true;
+    else if (a == "--chain") whole = chain = true; // the whole-layer calls of an iteration handed over together (xsmm_hip_fused_brgemm_chain_invoke)
     else if (a == "--print") print = true;
     else if (a == "--c1") c1 = true;
     else if (a == "--bf16") bf16 = true; // mlir-gen --float-type=bf16 --vnni=2: bf16 storage, W in VNNI-2 blocks
@@ -150,7 +151,16 @@ int main(int argc, char **argv) {
     else       // packed tiles: [MB][KB][t][t] x [NB][KB][t][t] -> [MB][NB][t][t]
       handle[l] = xsmm_fused_brgemm_dispatch(dt, tile, tn, tk, tk, tn, tn, tile * tk, tk * tn, gflags, 0, ukind, bflags, bkind);
   }
+  int chained = -1;
+  std::vector<void *> pa(L), pb(L), pc(L), pd(L);
+  std::vector<int64_t> z(L, 0), br(L);
+  for (int l = 0; l < L; ++l) pa[l] = act[l], pb[l] = W[l], pc[l] = act[l + 1], pd[l] = B[l], br[l] = layers[l] / 64;
   auto kernel = [&]() {
+    if (chain) {
+      chained = xsmm_hip_fused_brgemm_chain_invoke(dt, L, handle.data(), pa.data(), z.data(), pb.data(), z.data(), pc.data(), z.data(), pd.data(),
+                                                   z.data(), br.data());
+      return;
+    }
     for (int l = 0; l < L; ++l) {
       const int64_t K = layers[l], N = layers[l + 1];
       if (whole) {
@@ -188,7 +198,7 @@ int main(int argc, char **argv) {
   const double mean = elapsed / (double)n_iter;
   printf("%g\n", mean); // tpp-run prints the mean seconds (MLIRBench.cpp:297-300)
   fprintf(stderr, "tpp_replay: %s, batch %ld, %d layer(s), queue %d: mean %.3f us (host side of the invokes %.3f us), %.1f GFLOP/s (BENCH_TOTAL_FLOPS %.0f), kernel %s\n",
-          whole ? "whole-layer dispatch" : "packed tile invokes", (long)batch, L, queue, mean * 1e6,
+          chain ? (chained == 1 ? "whole-layer calls as ONE chain launch" : "whole-layer calls handed over together, run call by call") : whole ? "whole-layer dispatch" : "packed tile invokes", (long)batch, L, queue, mean * 1e6,
           host_dt / (double)n_iter * 1e6, flops / mean / 1e9, flops,
           (queue && !whole && xsmm_hip_last_grouped_kernel()[0]) ? xsmm_hip_last_grouped_kernel() : xsmm_hip_kernel_name(handle[0]));
   if (queue) {

@@ -755,6 +755,20 @@ static bool bf16_small_eligible(const GemmDesc &d) {
          !(d.stride_a & 7) && !(d.stride_b & 1) && !(d.ldc & 3);
 }
 
+// the f32 chain tile (brgemm_f32_lw.hip, launch_f32_chain) a whole-layer f32 descriptor was planned on: 1 / 2 / 3, or -1 (another
+// kernel family, a VNNI operand, k not in 64-k chunks ... - whatever pick_f32_variant sent elsewhere)
+int f32_chain_tile(const GemmDesc &d) {
+  if (d.dtype != DT_F32 || d.vnni_b || d.vnni_c || d.k <= 0 || d.k % BK) return -1;
+  // (the 32x32 + K4 tile - the reference's batch-256 layers, 3.4 us of MFMA work per tile - is NOT chained: measured 21.9 us per
+  // three-layer step as one launch against 20.6 as three, profiles/r04_f32_chain.txt: a seam is four dependent memory round trips
+  // - store drain, counter add, poll, A fetch - and 32 producers + 32 pollers share one counter line; the 64-row tiles gain 1-2.5 %)
+  switch (d.variant) {
+  case V_F32_LW_64x64K2: return 1;
+  case V_F32_LW_64x32K2: return 2;
+  default: return -1;
+  }
+}
+
 int bf16_lw_b_kind(const GemmDesc &d) {
   if (d.dtype != DT_BF16 || d.vnni_c) return -1;
   if (d.vnni_b && d.vnni_factor == 4) return bf16_vnni4_eligible(d) ? 4 : -1;

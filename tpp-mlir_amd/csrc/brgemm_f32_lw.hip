@@ -18,6 +18,7 @@
 //     variants each ran once per launch: instruction-cache cold misses in a 16-chunk kernel).
 #include "gemm_common.h"
 #include "xsmm_desc.h"
+#include "chain_args.h"
 #include <type_traits>
 
 namespace tpp {
@@ -337,6 +338,278 @@ hipError_t launch_f32_lw_grouped(int tile, const GemmArgs &a, const WorkItem *it
   case 1: return launch_lw_grouped_t<2, 2, 2>(a, items, n_items, s);
   case 2: return launch_lw_grouped_t<2, 1, 4>(a, items, n_items, s);
   case 3: return launch_lw_grouped_t<1, 1, 4>(a, items, n_items, s);
+  default: return hipErrorInvalidValue;
+  }
+}
+
+// ---- a CHAIN of whole-layer f32 BRGEMMs in one launch ------------------------------------------------------------------------
+// The reference's MLP benchmark (mlir-gen --batch=256 --layers=1024,1024,1024,1024, fp32, benchmarks/config/base/base.json:74-80)
+// lowers to one whole-layer xsmm_fused_brgemm_invoke per layer; a layer of 256 x 1024 x 1024 is 3.4 us of MFMA work behind a
+// 2.5 us launch. xsmm_hip_fused_brgemm_chain_invoke (runtime.cpp) runs the layers of such a step as ONE launch of this kernel: the
+// same tile, the same loader-wave structure, the same order of additions as brgemm_f32_lw<WM, WN, WK> (results bit-identical to
+// the separate launches), one workgroup per output tile, all co-resident (tiles <= CUs), and between two layers the hand-off of
+// the bf16 chain (brgemm_bf16_lw.hip): a tile is stored with 16-byte write-through stores, every storing wave drains them, the
+// workgroup adds 1 to the arrival counter of its ROW BLOCK; the A loaders of the next layer wait until all tiles_n tiles of their
+// row block have arrived and fetch the rows with sc1 loads (another XCD's L2 may hold them). Counters only grow (target = epoch x
+// tiles_n, runtime.cpp); every spin is bounded (CHAIN_TIMEOUT_TICKS) and reports through p.err instead of hanging the GPU.
+// The ring restarts at slot 0 with every layer (the K-group combine parks its partials in slot 0): the B loader of layer l+1
+// requests its first chunks right behind the seam barrier, while the A loaders still poll.
+//   barriers per layer, every wave: P (chunk 0 published), T - 1 mid-chunk barriers, R1 + R2 (combine), S1 (tile stored and
+//   drained; not after the last layer)
+typedef __attribute__((address_space(1))) unsigned int g_u32_f32c;
+
+template <int WM, int WN, int WK, int NL>
+__global__ __launch_bounds__(64 * (WM * WN * WK + 2 * NL)) void brgemm_f32_lw_chain(ChainArgs p) {
+  static_assert(WK > 1, "the hand-off needs the 16-byte stores of the K-split tiles' epilogue");
+  constexpr int NSLOT = LW_NSLOT;
+  constexpr int NMW = WM * WN * WK;
+  constexpr int BM = 32 * WM, BN = 32 * WN;
+  constexpr int A_STAGE = BM * LW_BK, B_STAGE = LW_BK * BN, SLOT = A_STAGE + B_STAGE; // floats
+  constexpr int NA = BM / 4, RPI = 256 / BN, NB = LW_BK / RPI;
+  constexpr int KB_PER_WAVE = 8 / WK, KB_HALF = KB_PER_WAVE / 2;
+  static_assert(KB_HALF >= 1 && NA / NL <= 31 && NB / NL <= 31 && NA % NL == 0 && NB % NL == 0, "tile outside the schedule's limits");
+  extern __shared__ __attribute__((aligned(16))) float smem_lw[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int hw_wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = hw_wave < 2 * NL ? NMW + hw_wave : hw_wave - 2 * NL; // loaders first, as in brgemm_f32_lw
+  const int tm = (int)blockIdx.x / p.tiles_n, tn = (int)blockIdx.x % p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int L = p.nlayers;
+
+  if (wave >= NMW) {
+    // ---- loader waves ------------------------------------------------------------------------------------------
+    const bool isA = (wave - NMW) < NL;
+    const int part = (wave - NMW) % NL;
+    for (int l = 0; l < L; ++l) {
+      const ChainLayer &Y = p.L[l];
+      const int lda = (int)(l == 0 ? p.lda : p.L[l > 0 ? l - 1 : 0].ldc), ldb = (int)Y.ldb;
+      const float *Asrc = (const float *)(l == 0 ? p.A : p.L[l > 0 ? l - 1 : 0].C);
+      const int kchunks = Y.k / LW_BK;
+      const int T = Y.br * kchunks;
+      unsigned voA[4], voA2[2];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = 4 * j + (lane >> 4);
+        voA[j] = (unsigned)((r * lda + 4 * ((lane & 15) ^ r)) * 4);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int r = 4 * (part + 2 * j) + (lane >> 4);
+        voA2[j] = (unsigned)((r * lda + 4 * ((lane & 15) ^ r)) * 4);
+      }
+      const unsigned voB = (unsigned)(((lane / (BN / 4)) * ldb + 4 * (lane % (BN / 4))) * 4);
+      const unsigned stepA = (unsigned)(16 * lda * 4), stepB = (unsigned)(RPI * ldb * 4);
+      const float *g = isA ? Asrc + (int64_t)m0 * lda : (const float *)Y.B + n0;
+      int kc = 0;
+      const int64_t d_in = isA ? (int64_t)LW_BK : (int64_t)LW_BK * ldb;
+      const int64_t d_wrap = (isA ? Y.stride_a : Y.stride_b) - (int64_t)(kchunks - 1) * d_in;
+      const bool sc1 = isA && l > 0; // rows written by other workgroups of THIS launch
+      auto issue = [&](int slot) __attribute__((always_inline)) {
+        float *base = smem_lw + slot * SLOT + (isA ? 0 : A_STAGE);
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)g, 0, 0x7fffffff, 0x00020000);
+        if (isA && sc1) {
+#pragma unroll
+          for (int i = 0; i < NA / NL; ++i) {
+            const int v = part + NL * i;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_lw *)(base + v * 256), 16, NL == 1 ? voA[i & 3] : NL == 2 ? voA2[i & 1] : voA2[0],
+                                                     (unsigned)(v >> 2) * stepA, 0, 16);
+          }
+        } else if (isA) {
+#pragma unroll
+          for (int i = 0; i < NA / NL; ++i) {
+            const int v = part + NL * i;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_lw *)(base + v * 256), 16, NL == 1 ? voA[i & 3] : NL == 2 ? voA2[i & 1] : voA2[0],
+                                                     (unsigned)(v >> 2) * stepA, 0, 0);
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < NB / NL; ++i) {
+            const int v = part + NL * i;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_lw *)(base + v * 256), 16, voB, (unsigned)v * stepB, 0, 0);
+          }
+        }
+        if (++kc == kchunks) {
+          kc = 0;
+          g += d_wrap;
+        } else {
+          g += d_in;
+        }
+      };
+      auto wait_left = [&](int chunks) __attribute__((always_inline)) {
+        if (chunks == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (isA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA / NL) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB / NL) : "memory");
+      };
+      if (isA && l > 0) {
+        // every producer tile of row block tm of layer l-1 has been stored (write-through) and drained
+        g_u32_f32c *c = (g_u32_f32c *)(p.cnt + ((size_t)(l - 1) * p.tiles_m + tm) * CHAIN_CNT_STRIDE);
+        const unsigned target = p.target;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        for (;;) {
+          const unsigned v = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((int)(v - target) >= 0) break;
+          if (__builtin_amdgcn_s_memrealtime() - t0 > CHAIN_TIMEOUT_TICKS) { // never hang the GPU: flag it and go on
+            if (lane == 0) __hip_atomic_store((g_u32_f32c *)p.err, 1u + (unsigned)l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        asm volatile("" ::: "memory");
+      }
+      issue(0);
+      if (T > 1) issue(1);
+      wait_left(T > 1 ? 1 : 0);
+      __builtin_amdgcn_s_barrier(); // P: chunk 0 published
+      if (T > 2) issue(2);
+      for (int t = 0; t + 1 < T; ++t) {
+        wait_left(t + 2 < T ? 1 : 0);
+        __builtin_amdgcn_s_barrier();
+        if (t + NSLOT - 1 < T) issue((t + NSLOT - 1) % NSLOT);
+      }
+      __builtin_amdgcn_s_barrier(); // R1
+      __builtin_amdgcn_s_barrier(); // R2
+      if (l + 1 < L) __builtin_amdgcn_s_barrier(); // S1
+    }
+    return;
+  }
+
+  // ---- MFMA waves ------------------------------------------------------------------------------------------------
+  const int wk = wave / (WM * WN), wmn = wave % (WM * WN), wm = wmn / WN, wn = wmn % WN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int a_off = (wm * 32 + li) * LW_BK, b_off = wn * 32 + li;
+  const int kbw = wk * KB_PER_WAVE;
+  for (int l = 0; l < L; ++l) {
+    const ChainLayer &Y = p.L[l];
+    const int T = Y.br * (Y.k / LW_BK);
+    float *__restrict__ C = (float *)Y.C;
+    const int ldc = (int)Y.ldc;
+    const __amdgpu_buffer_rsrc_t rsrcC = __builtin_amdgcn_make_buffer_rsrc((void *)(C + (int64_t)m0 * ldc + n0), 0, 0x7fffffff, 0x00020000);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    f32x4 fa[2];
+    float fb[2][4];
+    auto frag_load = [&](int buf, int slot, int kb) __attribute__((always_inline)) {
+      const float *as = smem_lw + slot * SLOT + a_off;
+      const float *bs = smem_lw + slot * SLOT + A_STAGE + b_off;
+      fa[buf] = *(const f32x4 *)(as + (((2 * kb + lh) ^ (li & 15)) << 2));
+#pragma unroll
+      for (int s = 0; s < 4; ++s) fb[buf][s] = bs[(8 * kb + 4 * lh + s) * BN];
+    };
+    auto chunk = [&](auto slot_c, auto hn_c, bool has_next_rt) __attribute__((always_inline)) {
+      constexpr int S = decltype(slot_c)::value, NS = (S + 1) % NSLOT;
+      const bool has_next = decltype(hn_c)::value == 1 ? true : has_next_rt;
+#pragma unroll
+      for (int q = 0; q < KB_PER_WAVE; ++q) {
+        const int cur = q & 1, nxt = cur ^ 1;
+        if (q + 1 < KB_PER_WAVE) frag_load(nxt, S, kbw + q + 1);
+        else frag_load(nxt, NS, kbw);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][s], fb[cur][s], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (q == KB_HALF - 1 && has_next) {
+          __builtin_amdgcn_s_barrier();
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      constexpr int PF = KB_PER_WAVE & 1;
+      if constexpr (decltype(hn_c)::value != 1)
+        asm volatile("" : "+v"(fa[PF]), "+v"(fb[PF][0]), "+v"(fb[PF][1]), "+v"(fb[PF][2]), "+v"(fb[PF][3]));
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using S2 = std::integral_constant<int, 2>;
+    using S3 = std::integral_constant<int, 3>;
+    using HY = std::integral_constant<int, 1>;
+    using HR = std::integral_constant<int, 2>;
+
+    __builtin_amdgcn_s_barrier(); // P
+    __builtin_amdgcn_sched_barrier(0);
+    frag_load(0, 0, kbw);
+    {
+      int t = 0;
+      for (; t + NSLOT < T; t += NSLOT) {
+        chunk(S0{}, HY{}, true);
+        chunk(S1{}, HY{}, true);
+        chunk(S2{}, HY{}, true);
+        chunk(S3{}, HY{}, true);
+      }
+      for (;;) {
+        chunk(S0{}, HR{}, t + 1 < T);
+        if (++t == T) break;
+        chunk(S1{}, HR{}, t + 1 < T);
+        if (++t == T) break;
+        chunk(S2{}, HR{}, t + 1 < T);
+        if (++t == T) break;
+        chunk(S3{}, HR{}, t + 1 < T);
+        if (++t == T) break;
+      }
+    }
+    // combine the K groups and store, exactly as brgemm_f32_lw does (group order; bias; relu; 16-byte write-through stores)
+    __syncthreads(); // R1
+    float *red = smem_lw;
+    {
+      float *dst = red + (wk * (WM * WN) + wmn) * 1024 + lane;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[r * 64] = acc[r];
+    }
+    __syncthreads(); // R2
+    constexpr int IPG = 4 / WK;
+    const int c4 = lane & 7, rsel = lane >> 3;
+    f32x4 bias4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (Y.ep & EP_BIAS) bias4 = *(const f32x4 *)((const float *)Y.D + n0 + wn * 32 + 4 * c4);
+#pragma unroll
+    for (int j = 0; j < IPG; ++j) {
+      const int q = 8 * (wk * IPG + j) + rsel;
+      const int r = (q & 3) + 4 * (q >> 3), lh2 = (q >> 2) & 1;
+      const float *src = red + wmn * 1024 + r * 64 + lh2 * 32 + 4 * c4;
+      f32x4 v = *(const f32x4 *)src;
+#pragma unroll
+      for (int g = 1; g < WK; ++g) v += *(const f32x4 *)(src + g * (WM * WN) * 1024);
+      v += bias4;
+      if (Y.ep & EP_RELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrcC, (unsigned)(((wm * 32 + q) * ldc + wn * 32 + 4 * c4) * 4), 0, 16);
+    }
+    if (l + 1 == L) break;
+    // ---- seam: publish this tile to the row block's consumers ---------------------------------------------------
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // every storing wave drains its write-through stores (and is done with `red`)
+    __builtin_amdgcn_s_barrier();                                // S1
+    if (wave == 0 && lane == 0)
+      __hip_atomic_fetch_add((g_u32_f32c *)(p.cnt + ((size_t)l * p.tiles_m + tm) * CHAIN_CNT_STRIDE), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+template <int WM, int WN, int WK, int NL> static hipError_t launch_f32_chain_t(const ChainArgs &a, hipStream_t s) {
+  constexpr int BM = 32 * WM, BN = 32 * WN, NT = 64 * (WM * WN * WK + 2 * NL);
+  constexpr size_t lds = (size_t)LW_NSLOT * (BM * LW_BK + LW_BK * BN) * sizeof(float);
+  static std::atomic<unsigned long long> lds_set{0};
+  if (hipError_t e = ensure_dynamic_lds((const void *)brgemm_f32_lw_chain<WM, WN, WK, NL>, (int)lds, lds_set); e != hipSuccess) return e;
+  ChainArgs args = a;
+  args.tiles_m = a.m / BM;
+  args.tiles_n = a.n / BN;
+  const long long tiles = (long long)args.tiles_m * args.tiles_n;
+  if (tiles <= 0 || tiles > 0x7fffffffLL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL((brgemm_f32_lw_chain<WM, WN, WK, NL>), dim3((unsigned)tiles), dim3(NT), lds, s, args);
+  return hipGetLastError();
+}
+
+// tile as in launch_f32_lw: 1 = 64x64 + K2, 2 = 64x32 + K4 (K-split tiles: 16-byte stores; 32x32 + K4 measured slower than three launches)
+bool f32_chain_tile_dims(int tile, int *bm, int *bn) {
+  switch (tile) {
+  case 1: *bm = 64, *bn = 64; return true;
+  case 2: *bm = 64, *bn = 32; return true;
+  default: return false;
+  }
+}
+hipError_t launch_f32_chain(int tile, const ChainArgs &a, hipStream_t s) {
+  switch (tile) {
+  case 1: return launch_f32_chain_t<2, 2, 2, 2>(a, s);
+  case 2: return launch_f32_chain_t<2, 1, 4, 1>(a, s);
   default: return hipErrorInvalidValue;
   }
 }

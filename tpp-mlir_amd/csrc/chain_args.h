@@ -59,4 +59,8 @@ hipError_t launch_bf16_lw_flatb(int tile, const ChainArgs &a, hipStream_t s); //
 hipError_t launch_bf16_lw_vnni4(int tile, const ChainArgs &a, hipStream_t s); // the same tiles, B operand VNNI-4 [k/4][ldb][4]
 hipError_t launch_bf16_chain(int tile, int b_kind, const ChainArgs &a, hipStream_t s); // b_kind: 0 VNNI-2, 2 flat, 4 VNNI-4 (every layer the same)
 
+// f32 chains (brgemm_f32_lw.hip): tile 1 = 64x64 + K2, 2 = 64x32 + K4 - the 64-row K-split loader-wave tiles
+bool f32_chain_tile_dims(int tile, int *bm, int *bn);
+hipError_t launch_f32_chain(int tile, const ChainArgs &a, hipStream_t s);
+
 } // namespace tpp

@@ -2048,8 +2048,17 @@ bool try_chain_launch(int n, const GemmDesc *const *d, void *const *pa, void *co
   const int64_t m = d[0]->m, nn = d[0]->n;
   thread_local DeviceRanges devmem;
   devmem.refresh();
+  // f32 chains (round 4): every call planned on the SAME K-split loader-wave tile (the launch is then bit-identical to the calls)
+  const bool f32 = d[0]->dtype == DT_F32;
+  const int f32_tile = f32 ? f32_chain_tile(*d[0]) : -1;
   for (int i = 0; i < n; ++i) {
     const GemmDesc &g = *d[i];
+    if (f32) {
+      if (g.dtype != DT_F32 || !g.beta0 || f32_chain_tile(g) < 0 || f32_chain_tile(g) != f32_tile)
+        NOCHAIN("an f32 call is not beta 0 / not planned on the K-split loader-wave tile of the first call");
+      if (g.bias && ((uintptr_t)pd[i] & 15)) NOCHAIN("an f32 bias operand is not 16-byte aligned");
+      if (g.ldc & 3) NOCHAIN("an f32 output's leading dimension is not a multiple of 4");
+    } else
     // every layer the same kind of B operand (VNNI-2, flat or VNNI-4: the B image is a template parameter of the launch)
     if (g.dtype != DT_BF16 || g.vnni_c || !g.beta0 || bf16_lw_b_kind(g) < 0 || bf16_lw_b_kind(g) != bf16_lw_b_kind(*d[0]))
       NOCHAIN("a call is not bf16 / beta 0 / aligned for the LDS-DMA tiles, or the calls' B operands differ in kind (VNNI-2 / flat / VNNI-4)");
@@ -2071,14 +2080,17 @@ bool try_chain_launch(int n, const GemmDesc *const *d, void *const *pa, void *co
   int tile = -1, bm = 0, bn = 0;
   const int64_t cus = stream_cus(cfg().stream.load(std::memory_order_relaxed));
   auto fits = [&](int t) {
-    blw_tile_dims(t, &bm, &bn);
+    if (f32) (void)f32_chain_tile_dims(t, &bm, &bn);
+    else blw_tile_dims(t, &bm, &bn);
     return m % bm == 0 && nn % bn == 0 && (m / bm) * (nn / bn) <= cus;
   };
-  const int b_kind = bf16_lw_b_kind(*d[0]);
+  if (f32 && !fits(f32_tile)) NOCHAIN("more tiles than compute units");
+  const int b_kind = f32 ? 0 : bf16_lw_b_kind(*d[0]);
   // (variants 20 .. 23 VNNI-2, 24 .. 27 flat B, 28 .. 31 VNNI-4: the same four tiles)
   const int planned = d[0]->variant - (b_kind == 2 ? GEMM_VARIANT_BF16_LW0 + 4 : b_kind == 4 ? GEMM_VARIANT_BF16_LW4_0 : GEMM_VARIANT_BF16_LW0);
-  bool same = planned >= 0 && planned < 4;
+  bool same = !f32 && planned >= 0 && planned < 4;
   for (int i = 1; i < n && same; ++i) same = d[i]->variant == d[0]->variant;
+  if (f32) tile = f32_tile;
   if (same && fits(planned)) tile = planned;
   for (int t = 0; t < 4 && tile < 0; ++t)
     if (fits(t)) tile = t;
@@ -2125,7 +2137,8 @@ bool try_chain_launch(int n, const GemmDesc *const *d, void *const *pa, void *co
   c.err = blk.err;
   c.target = ++blk.epoch * (unsigned)blk.tiles_n;
   c.stamps = chain_stamps((size_t)blk.tiles_m * (size_t)blk.tiles_n);
-  HIP_OK(launch_bf16_chain(tile, b_kind, c, s));
+  if (f32) HIP_OK(launch_f32_chain(tile, c, s));
+  else HIP_OK(launch_bf16_chain(tile, b_kind, c, s));
   g_chain_launched.store(1, std::memory_order_release);
   return true;
 }

@@ -66,6 +66,7 @@ hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C,
 // pair_ok: every item's batch count is even (32-k tiles on the loader-wave kernels)
 hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_items, bool vec_ok, bool out_ok, bool pair_ok,
                                hipStream_t stream);
+int f32_chain_tile(const GemmDesc &d); // 1 / 2 / 3 = the f32 chain tile the descriptor was planned on, -1 = none (brgemm_f32.hip)
 const char *last_grouped_kernel(); // kernel family of the most recent launch_gemm_grouped ("" before the first)
 // fills d.variant / d.name; returns false if no kernel can run the descriptor
 bool plan_gemm(GemmDesc &d, int forced_variant);
