@@ -30,8 +30,9 @@ constexpr int LW_C_AUX = C_STORE_AUX; // write-through C stores (gemm_common.h)
 typedef __attribute__((address_space(3))) void lds_void_lw;
 
 // NSLOT: ring depth (4; 3 for the 128x64 tile, whose 48 KiB slots would not fit four times)
-template <int WM, int WN, int WK, bool GROUPED, int NL = 1, int NSLOT = LW_NSLOT>
-__global__ __launch_bounds__(64 * (WM * WN * WK + 2 * NL)) void brgemm_f32_lw(GemmArgs p, const WorkItem *__restrict__ items) {
+// NL loader waves for the A panel, NLB (default NL) for the B panel
+template <int WM, int WN, int WK, bool GROUPED, int NL = 1, int NSLOT = LW_NSLOT, int NLB = NL>
+__global__ __launch_bounds__(64 * (WM * WN * WK + NL + NLB)) void brgemm_f32_lw(GemmArgs p, const WorkItem *__restrict__ items) {
   constexpr int NMW = WM * WN * WK; // MFMA waves
   constexpr int BM = 32 * WM, BN = 32 * WN;
   constexpr int A_STAGE = BM * LW_BK, B_STAGE = LW_BK * BN, SLOT = A_STAGE + B_STAGE; // floats
@@ -39,7 +40,7 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + 2 * NL)) void brgemm_f32_lw(Ge
   constexpr int RPI = 256 / BN;    // B rows per DMA instruction
   constexpr int NB = LW_BK / RPI;  // DMA instructions per chunk of B
   constexpr int KB_PER_WAVE = 8 / WK, KB_HALF = KB_PER_WAVE / 2;
-  static_assert(KB_HALF >= 1 && NA / NL <= 31 && NB / NL <= 31, "tile outside the schedule's limits (vmcnt is 6 bits)");
+  static_assert(KB_HALF >= 1 && NA / NL <= 31 && NB / NLB <= 31, "tile outside the schedule's limits (vmcnt is 6 bits)");
   static_assert(NSLOT == 3 || NSLOT == 4, "ring depth");
   extern __shared__ __attribute__((aligned(16))) float smem_lw[];
 
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + 2 * NL)) void brgemm_f32_lw(Ge
   // the two loader waves are the FIRST two hardware waves of the workgroup (waves start in order: the panels' first
   // chunks are requested before the MFMA waves have been launched); `wave` is the role index: MFMA waves 0 .. NMW-1, loaders NMW, NMW+1
   const int hw_wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wave = TPP_LW_LOADERS_FIRST ? (hw_wave < 2 * NL ? NMW + hw_wave : hw_wave - 2 * NL) : hw_wave;
+  const int wave = TPP_LW_LOADERS_FIRST ? (hw_wave < NL + NLB ? NMW + hw_wave : hw_wave - (NL + NLB)) : hw_wave;
   // XCD-blocked (8, bn, bm) or plain (1, tiles_n, tiles_m) grid: see brgemm_f32.hip. GROUPED (tile queue): grid (items,
   // tiles_n, tiles_m), workgroup = one tile of one queued invoke, operands and batch count from its item. A template
   // parameter, not a run-time test: the plain kernel is the headline kernel and must not carry a second mode (measured: 0.6 %).
@@ -74,8 +75,8 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + 2 * NL)) void brgemm_f32_lw(Ge
   if (wave >= NMW) {
     // ---- loader waves --------------------------------------------------------------------
     const bool isA = (wave - NMW) < NL; // NL loader waves per panel: wave `part` issues the instructions part, part + NL, ...
-    const int part = (wave - NMW) % NL;
-    static_assert(NA % NL == 0 && NB % NL == 0, "panel instructions divide over the loader waves");
+    const int part = isA ? wave - NMW : wave - NMW - NL;
+    static_assert(NA % NL == 0 && NB % NLB == 0, "panel instructions divide over the loader waves");
     // per-lane source offsets, constant for the whole kernel. A instruction v covers rows 4v .. 4v+3
     // (lane -> row 4v + lane/16, 16-byte piece lane%16, XOR-ed with row&15 = 4(v&3) + lane/16: the
     // fragment read applies the same XOR); the 16-row group v>>2 goes into the scalar offset.
@@ -110,8 +111,8 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + 2 * NL)) void brgemm_f32_lw(Ge
         }
       } else {
 #pragma unroll
-        for (int i = 0; i < NB / NL; ++i) {
-          const int v = part + NL * i;
+        for (int i = 0; i < NB / NLB; ++i) {
+          const int v = part + NLB * i;
           __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_lw *)(base + v * 256), 16, voB,
                                                    (unsigned)v * stepB + (GROUPED && v * RPI >= 32 ? pairB : 0u), 0, 0);
         }
@@ -130,8 +131,8 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + 2 * NL)) void brgemm_f32_lw(Ge
         if (chunks == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA / NL) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NA / NL) : "memory");
       } else {
-        if (chunks == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB / NL) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NB / NL) : "memory");
+        if (chunks == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB / NLB) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NB / NLB) : "memory");
       }
     };
     // Prologue: chunks 0 and 1 are requested, chunk 0 is PUBLISHED as soon as it has landed, chunk 2 follows behind the barrier.
@@ -295,12 +296,12 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + 2 * NL)) void brgemm_f32_lw(Ge
   }
 }
 
-template <int WM, int WN, int WK, int NL = 1, int NSLOT = LW_NSLOT> static hipError_t launch_lw_t(const GemmArgs &a, hipStream_t s) {
-  constexpr int BM = 32 * WM, BN = 32 * WN, NT = 64 * (WM * WN * WK + 2 * NL);
+template <int WM, int WN, int WK, int NL = 1, int NSLOT = LW_NSLOT, int NLB = NL> static hipError_t launch_lw_t(const GemmArgs &a, hipStream_t s) {
+  constexpr int BM = 32 * WM, BN = 32 * WN, NT = 64 * (WM * WN * WK + NL + NLB);
   constexpr size_t lds = (size_t)NSLOT * (BM * LW_BK + LW_BK * BN) * sizeof(float);
   static_assert(lds <= 160 * 1024, "LDS budget");
   static std::atomic<unsigned long long> lds_set{0};
-  if (hipError_t e = ensure_dynamic_lds((const void *)brgemm_f32_lw<WM, WN, WK, false, NL, NSLOT>, (int)lds, lds_set); e != hipSuccess) return e;
+  if (hipError_t e = ensure_dynamic_lds((const void *)brgemm_f32_lw<WM, WN, WK, false, NL, NSLOT, NLB>, (int)lds, lds_set); e != hipSuccess) return e;
   GemmArgs args = a;
   const int tiles_m = a.m / BM, tiles_n = a.n / BN;
   dim3 grid;
@@ -313,7 +314,7 @@ template <int WM, int WN, int WK, int NL = 1, int NSLOT = LW_NSLOT> static hipEr
     if (tiles_m > 65535 || tiles_n > 65535) return hipErrorInvalidValue;
     grid = dim3(1, tiles_n, tiles_m);
   }
-  hipLaunchKernelGGL((brgemm_f32_lw<WM, WN, WK, false, NL, NSLOT>), grid, dim3(NT), lds, s, args, (const WorkItem *)nullptr);
+  hipLaunchKernelGGL((brgemm_f32_lw<WM, WN, WK, false, NL, NSLOT, NLB>), grid, dim3(NT), lds, s, args, (const WorkItem *)nullptr);
   return hipGetLastError();
 }
 
@@ -614,6 +615,16 @@ hipError_t launch_f32_chain(int tile, const ChainArgs &a, hipStream_t s) {
   }
 }
 
+// The 64x32 tile's loader waves: 21 (default) = two for the A panel (16 requests per chunk) and one for B (8) - every loader issues 8;
+// C3 9.912 -> 9.881 us, four alternating pairs on one box (profiles/r04_c3_loaders_and_launch_knobs.txt); 11 = one per panel
+// (rounds 2-3), 22 = two each (9.888). TPP_HIP_F32_LW_C3_LOADERS for A/B runs.
+static int f32_lw_c3_loaders() {
+  static const int v = [] {
+    const char *e = getenv("TPP_HIP_F32_LW_C3_LOADERS");
+    return e ? atoi(e) : 21;
+  }();
+  return v;
+}
 // tile: 0 = 64x64 (4 MFMA waves), 1 = 64x64 with K split over 2 wave groups (8 MFMA waves, two per
 // SIMD), 2 = 64x32 with K split over 4 (8 MFMA waves), 3 = 32x32 with K split over 4 (4 MFMA waves)
 hipError_t launch_f32_lw(int tile, const GemmArgs &a, hipStream_t s) {
@@ -624,7 +635,7 @@ hipError_t launch_f32_lw(int tile, const GemmArgs &a, hipStream_t s) {
   case 1: return launch_lw_t<2, 2, 2, 2>(a, s); // (four per panel: 18.25 us)
   // 64x32 with K split over FOUR wave groups: 8 MFMA waves = two per SIMD, like the 64x64 k2 tile - one wave's fragment reads and
   // barrier waits hide behind the other's MFMAs. C3 (512 x 1024 x 1024): 10.52 -> 10.21 us same-box against the K2 split (4 waves).
-  case 2: return launch_lw_t<2, 1, 4>(a, s);
+  case 2: return f32_lw_c3_loaders() == 11 ? launch_lw_t<2, 1, 4>(a, s) : f32_lw_c3_loaders() == 22 ? launch_lw_t<2, 1, 4, 2>(a, s) : launch_lw_t<2, 1, 4, 2, LW_NSLOT, 1>(a, s);
   case 3: return launch_lw_t<1, 1, 4>(a, s);
   // 128x64 for large outputs: 8 MFMA waves (4 x 2 tiles of 32x32), two loader waves per panel, a 3-slot ring (48 KiB per slot)
   case 4: return launch_lw_t<4, 2, 1, 2, 3>(a, s);
