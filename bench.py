@@ -679,7 +679,9 @@ def main():
             mlp["per_rank_step_note"] = ("per-rank share of the bs=4096 step for a world of N GPUs, run on one GPU: the scaling model of the "
                                          "row sharding WITHOUT the all-gather (strong-scaling speed-up of the compute part = "
                                          "chain_us[1] / chain_us[N])")
-        if use_dist:
+        if use_dist and not one_device:
+            # (not on the one-device test rig: two processes' chip-filling kernels time-slice ONE GPU there, and a gather kernel that
+            # spins for a peer whose GEMM cannot get a compute unit meanwhile runs into its - bounded - wait: 2 of 9 runs)
             # the same MLP at a batch where compute dominates (8 x 4096 rows): what the sharding itself scales like
             Kl, Wl = max(20, K // 10), max(5, W // 10)
             spec_l, sh_l, lcompute, _ = run_mlp(32768, Kl, Wl)
