@@ -886,7 +886,7 @@ struct DirectWindow {
   Caller callers[MAXC];
   DirectWindow() {
     const char *e = getenv("TPP_HIP_QUEUE_SOLO"); // 0: the two-sided protocol from the start (A/B runs)
-    if ((!e || atoi(e) != 0) && syscall(__NR_membarrier, MEMBARRIER_CMD_REGISTER_PRIVATE_EXPEDITED, 0) == 0) {
+    if ((!e || atoi(e) != 0) && !getenv("TPP_HIP_NO_MEMBARRIER") && syscall(__NR_membarrier, MEMBARRIER_CMD_REGISTER_PRIVATE_EXPEDITED, 0) == 0) {
       multi.store(false, std::memory_order_relaxed);
       multi_ready.store(false, std::memory_order_relaxed);
     }
