@@ -71,6 +71,20 @@ __device__ __forceinline__ void blw_stamp(chain_kernarg_t &p, int layer, int slo
 // 4096-row chain from 28.9 to 38.3 us; collected late the three stamps cost a few issue slots). The MFMA waves are not
 // stamped: s_memtime shares lgkmcnt with their fragment reads. landed -> released = how long the loader waited for the
 // slowest wave at the barrier; issued(t-1) -> landed(t) = how long it waited for its own DMA. tools/stamps_report.py --chunks.
+// dbg & 2048 (ablation builds): the loaders' DMA instructions are ISSUED with every lane switched off - no memory traffic, no LDS
+// write, but the same instruction stream on the SIMD: what of the DMA's cost to the MFMA waves is issue-side
+#ifdef TPP_HIP_ABLATION
+#define BLW_DBG_EXEC_OFF() do { if (dbg & 2048) asm volatile("s_mov_b64 exec, 0" ::: "memory"); } while (0)
+#define BLW_DBG_EXEC_ON() do { if (dbg & 2048) asm volatile("s_mov_b64 exec, -1" ::: "memory"); } while (0)
+#else
+#define BLW_DBG_EXEC_OFF() ((void)0)
+#define BLW_DBG_EXEC_ON() ((void)0)
+#endif
+#ifdef TPP_BLW_SKIP_BARRIER
+#define BLW_MID_BARRIER() ((void)0) // (timing side build: see brgemm_bf16_lw's skip switches)
+#else
+#define BLW_MID_BARRIER() __builtin_amdgcn_s_barrier()
+#endif
 constexpr int BLW_CS_ENTRIES = 64; // (layer, chunk) records per loader wave
 struct BlwChunkStamps {
   unsigned long long pend = 0; // (an SGPR pair: the s_memtime in flight)
@@ -212,6 +226,7 @@ __device__ __forceinline__ void blw_loader(chain_kernarg_t *pp, unsigned char *s
     _Pragma("unroll") for (int sub_ = 0; sub_ < SUP; ++sub_) {                                                         \
       unsigned char *base_ = smem + ((slot) * SUP + sub_) * SLOT + (IS_A ? 0 : A_SLOT) + part * 1024;                  \
       const __amdgpu_buffer_rsrc_t r_ = __builtin_amdgcn_make_buffer_rsrc((void *)g, 0, 0x7fffffff, 0x00020000);       \
+      BLW_DBG_EXEC_OFF();                                                                                              \
       if (no_dma) {                                                                                                    \
       } else if (IS_A && sc1) {                                                                                        \
         _Pragma("unroll") for (int v = 0; v < PPC; ++v)                                                                \
@@ -220,6 +235,7 @@ __device__ __forceinline__ void blw_loader(chain_kernarg_t *pp, unsigned char *s
         _Pragma("unroll") for (int v = 0; v < PPC; ++v)                                                                \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(r_, (lds_void_b *)(base_ + v * NL * 1024), 16, (v & 1) ? vo1 : vo0, v * step, 0, 0); \
       }                                                                                                                \
+      BLW_DBG_EXEC_ON();                                                                                               \
       if (flat) { /* the batch elements continue each other (whole-layer dispatches): one 64-bit add */               \
         g += d_in;                                                                                                     \
       } else if (++kc == kchunks) {                                                                                    \
@@ -279,7 +295,7 @@ __device__ __forceinline__ void blw_loader(chain_kernarg_t *pp, unsigned char *s
     for (; t + NSLOT - 1 < T; ++t) {
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSLOT - 3) * PPL) : "memory");
       cs.stamp(smem, cs_area, cs_which, cs_idx, 0, lane);
-      __builtin_amdgcn_s_barrier();
+      BLW_MID_BARRIER();
       cs.stamp(smem, cs_area, cs_which, cs_idx, 1, lane);
       BLW_ISSUE(slot);
       cs.stamp(smem, cs_area, cs_which, cs_idx, 2, lane);
@@ -290,13 +306,13 @@ __device__ __forceinline__ void blw_loader(chain_kernarg_t *pp, unsigned char *s
       BLW_LOAD_STATE(lc + 1); // (the slot rotation carries over into the next layer)
       for (; t + 1 < T; ++t) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSLOT - 3) * PPL) : "memory");
-        __builtin_amdgcn_s_barrier();
+        BLW_MID_BARRIER();
         BLW_ISSUE(slot);
       }
     } else {
       for (; t + 1 < T; ++t) {
         blw_wait_younger<PPL>(T - 2 - t);
-        __builtin_amdgcn_s_barrier();
+        BLW_MID_BARRIER();
       }
     }
     if (lc + 1 == L) {
@@ -463,6 +479,14 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
   constexpr bool skip_math = false;
   (void)dbg;
 #endif
+  // two more compile-time timing switches (side builds only, results WRONG by design): -DTPP_BLW_SKIP_READS = the MFMAs run on
+  // whatever the fragment registers hold (no LDS reads in the K loop), -DTPP_BLW_SKIP_BARRIER = no mid-chunk barrier in any wave
+  // (with TPP_HIP_CHAIN_DBG=16, no DMA: what the MFMA side alone costs per chunk, and what of it is the barrier / the reads)
+#ifdef TPP_BLW_SKIP_READS
+  constexpr bool skip_reads = true;
+#else
+  constexpr bool skip_reads = false;
+#endif
   // One chunk in ring slot `slot` (a run-time value: ONE body - two for the tiles that alternate fragment sets - instead of one per
   // ring slot entered through a switch; the slot's LDS offset costs TM + TN vector adds per k-step. The per-slot bodies with their
   // exit after every chunk made hipcc rename the accumulators from body to body - v_mfma D != C - in the chain and flat-B
@@ -484,7 +508,7 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
     constexpr int CUR = FULLPF ? PAR * KS : 0, NXT = FULLPF ? (PAR ^ 1) * KS : 0; // fragment sets of chunk t / t+1
 #pragma unroll
     for (int q = 0; q < KS; ++q) {
-      if (!skip_math) {
+      if (!skip_math && !skip_reads) {
         if constexpr (FULLPF && SUP == 2) {
           // two chunks per barrier: everything up to the end of chunk t+1 was published before chunk t began (the odd chunk with
           // its pair, the next even one by the barrier in the middle of the even chunk before it) and the step after the barrier
@@ -538,10 +562,12 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
         }
       }
       __builtin_amdgcn_sched_barrier(0);
+#ifndef TPP_BLW_SKIP_BARRIER
       if (q == KS / 2 - 1 && has_next) {
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
       }
+#endif
     }
   };
   using P0 = std::integral_constant<int, 0>;
@@ -810,6 +836,22 @@ void blw_tile_dims(int tile, int *bm, int *bn) {
 // (TPP_HIP_BLW_SUP=1 forces one chunk per barrier for A/B runs). Ring depths: 8 / 8 / 6 / 4 slots; a 5-slot ring with 2 + 2
 // loaders for the 128x128 tile and 4 against 6 slots for 64x128 measured the same (same box, +-0.5 %); FOUR chunks per barrier on
 // a 12-slot ring for the 32x64 tile measured 9 % slower than two on 8 slots (the prologue must request 8 chunks before the first barrier).
+// side builds only (-DTPP_HIP_ABLATION): TPP_HIP_BLW_T3 = 1: the 128x128 tile with a 5-slot ring and two loader waves per panel,
+// 2: 4 slots, two loader waves per panel (timing experiments on the fill loop; the product has ONE instance of the tile)
+#ifdef TPP_HIP_ABLATION
+static int blw_t3_alt() {
+  static const int v = [] {
+    const char *e = getenv("TPP_HIP_BLW_T3");
+    return e ? atoi(e) : 0;
+  }();
+  return v;
+}
+#define BLW_T3_ALTS(MULTI, FB)                                                                 \
+  if (blw_t3_alt() == 1) return launch_blw_t<2, 2, 1, 2, 2, 5, 2, 2, 1, MULTI, FB>(a, s);      \
+  if (blw_t3_alt() == 2) return launch_blw_t<2, 2, 1, 2, 2, 4, 2, 2, 1, MULTI, FB>(a, s);
+#else
+#define BLW_T3_ALTS(MULTI, FB)
+#endif
 #define BLW_DISPATCH(MULTI, FB)                                                              \
   switch (tile * 2 + (sup2 ? 1 : 0)) {                                                       \
   case 0: return launch_blw_t<1, 2, 2, 1, 1, 8, 1, 2, 1, MULTI, FB>(a, s);                   \
@@ -819,7 +861,7 @@ void blw_tile_dims(int tile, int *bm, int *bn) {
   case 4:                                                                                    \
   case 5: return launch_blw_t<2, 2, 1, 1, 2, 6, 1, 2, 1, MULTI, FB>(a, s);                   \
   case 6:                                                                                    \
-  case 7: return launch_blw_t<2, 2, 1, 2, 2, 4, 1, 1, 1, MULTI, FB>(a, s);                   \
+  case 7: BLW_T3_ALTS(MULTI, FB) return launch_blw_t<2, 2, 1, 2, 2, 4, 1, 1, 1, MULTI, FB>(a, s); \
   default: return hipErrorInvalidValue;                                                      \
   }
 static bool blw_sup2(const ChainArgs &a) {

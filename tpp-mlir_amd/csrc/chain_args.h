@@ -33,7 +33,8 @@ struct ChainArgs {
                         // 2 no wait at the seams, 4 plain stores, 16 no DMA, 32 no fragment reads / MFMAs, 64 no B DMA, 128 no A DMA,
                         // 256 whole prologue before the first barrier, 512 every workgroup loads the panels of tile (0, 0) (no fabric
                         // traffic: the K loop on L2 hits only), 1024 per-chunk s_memtime stamps of the loader waves of the first 16
-                        // workgroups (needs stamps; written to <TPP_HIP_CHAIN_STAMPS>.chunks, tools/stamps_report.py --chunks). The shipped library compiles the kernels with dbg == 0 and
+                        // workgroups (needs stamps; written to <TPP_HIP_CHAIN_STAMPS>.chunks, tools/stamps_report.py --chunks), 2048 the loaders issue
+                        // their DMA instructions with every lane switched off (no traffic, no LDS write: the issue-side cost alone). The shipped library compiles the kernels with dbg == 0 and
                         // never reads the variable: several of these switches give wrong results by design.
   unsigned long long *stamps; // profiling (ablation builds, TPP_HIP_CHAIN_STAMPS=file): [workgroup][layer][8] s_memrealtime stamps, else nullptr
   ChainLayer L[CH_MAXL];
