@@ -586,6 +586,30 @@ def main():
                 pg_.check()
             return spec_, sh_, float(tw[0]) / steps, last[0]
 
+        def run_gathered(batch, steps, warmup, path):
+            """run_mlp with a gather path, failure-safe ACROSS the ranks: a rank whose peer-store gather ran into its bounded wait
+            raises at the very end of run_mlp (behind its last collective); here every rank then votes, so either all ranks use
+            the result or all of them drop the path (and the peer buffers of that batch size). Returns (seconds per step, gathered
+            output, None) or (None, None, reason)."""
+            err = None
+            t_ = full_ = None
+            try:
+                _, _, t_, full_ = run_mlp(batch, steps, warmup, gather=path)
+                sync()
+                if path == "peer":
+                    peer_for(batch).drain()
+                    if os.environ.get("TPP_BENCH_TEST_FAIL_PEER") == str(rank):  # TEST SWITCH (tests/test_bench_multi_gpu.py)
+                        raise RuntimeError("injected failure of the peer path on rank %d" % rank)
+            except RuntimeError as ex:
+                err = str(ex)
+            ok = torch.tensor([0 if err else 1], device="cuda")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok[0]):
+                return t_, full_, None
+            if path == "peer":
+                peer_objs[batch] = None
+            return None, None, err or "failed on another rank"
+
         def unsharded_on_the_shards_tile(batch, sh_):
             """the full batch on THIS GPU with the tile the rank shares ran on (three launches: more tiles than CUs is fine there) -
             the same arithmetic per element as the sharded run, so the gathered output must equal it bit for bit"""
@@ -614,18 +638,18 @@ def main():
             gathers = {}
             ref, ref_kernel, shard_kernel = unsharded_on_the_shards_tile(4096, sh)
             for path in (["peer"] if peer_for(4096) is not None else []) + ["rccl"]:
-                _, _, t_, full_ = run_mlp(4096, K, W, gather=path)
-                sync()
-                if path == "peer":
-                    peer_for(4096).drain()
+                t_, full_, err_ = run_gathered(4096, K, W, path)
+                if err_ is not None:  # (every rank agrees: run_gathered votes) the other path still produces the line
+                    gathers[path] = {"failed": err_}
+                    continue
                 same = torch.equal(full_.view(torch.int16).reshape(-1), ref.view(torch.int16).reshape(-1))
                 ok_ = torch.tensor([1 if same else 0], device="cuda")
                 dist.all_reduce(ok_, op=dist.ReduceOp.MIN)
                 gathers[path] = {"ms_per_step": round(t_ * 1e3, 5), "value": round(spec.flops() / t_ / 1e9, 1), "unit": "GFLOP/s",
                                  "gathered_bit_identical": bool(int(ok_[0]))}
-            best = min(gathers, key=lambda p_: gathers[p_]["ms_per_step"])
+            best = min((p_ for p_ in gathers if "ms_per_step" in gathers[p_]), key=lambda p_: gathers[p_]["ms_per_step"])
             mstep = gathers[best]["ms_per_step"] * 1e-3
-            if peer_for(4096) is None:
+            if peer_for(4096) is None and "peer" not in gathers:
                 gathers["peer"] = {"unavailable": "the peer buffers could not be mapped or the self-test failed on a rank: RCCL only"}
             # the same step on ONE GPU in the same run (rank 0's device, the others wait): the denominator of the speed-up
             _, sh1, t1_, _ = run_mlp(4096, K, W, as_world=1, as_rank=0)
@@ -686,8 +710,11 @@ def main():
             Kl, Wl = max(20, K // 10), max(5, W // 10)
             spec_l, sh_l, lcompute, _ = run_mlp(32768, Kl, Wl)
             lpath = "peer" if peer_for(32768) is not None else "rccl"
-            _, _, lstep, _ = run_mlp(32768, Kl, Wl, gather=lpath)
-            mlp["large_batch_variant"] = {
+            lstep, _, lerr = run_gathered(32768, Kl, Wl, lpath)
+            if lerr is not None and lpath == "peer":
+                lpath = "rccl"
+                lstep, _, lerr = run_gathered(32768, Kl, Wl, lpath)
+            mlp["large_batch_variant"] = {"failed": lerr} if lerr is not None else {
                 "workload": "same MLP, bs=32768, rows sharded over %d GPU(s) + all-gather of the output (64 MiB, %s)" % (world, lpath),
                 "value": round(spec_l.flops() / lstep / 1e9, 1), "unit": "GFLOP/s", "scaling": "strong",
                 "ms_per_step": round(lstep * 1e3, 5), "ms_per_step_compute_only": round(lcompute * 1e3, 5),

@@ -51,3 +51,20 @@ def test_bench_two_ranks_on_one_device_reports_verified_strong_scaling():
     assert mlp["gather"] in ("peer", "rccl") and mlp["one_gpu_same_run"]["ms_per_step"] > 0
     assert mlp["speedup_vs_one_gpu_same_run"] > 0
     assert "TEST RIG" in d["data"]
+
+
+def test_bench_survives_a_peer_path_that_fails_on_one_rank():
+    """a rank whose peer-store gather fails (here: injected on rank 1 behind its timed region) must not cost the line or hang the
+    job: every rank votes, all of them drop the path, the RCCL path is the headline and the failure is in the line"""
+    env = dict(os.environ, TPP_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", TPP_BENCH_TEST_FAIL_PEER="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "3",
+           "--no-cpu-baseline", "--no-pmc"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    if r.returncode != 0:
+        pytest.fail("bench.py --gpus 2 exited %d\n--- stdout (tail)\n%s\n--- stderr (tail)\n%s" % (r.returncode, r.stdout[-1500:], r.stderr[-6000:]), pytrace=False)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    mlp = json.loads(lines[0])["mlp"]
+    assert "failed" in mlp["gathers"]["peer"] and "injected" in mlp["gathers"]["peer"]["failed"] or "another rank" in mlp["gathers"]["peer"]["failed"]
+    assert mlp["gather"] == "rccl" and mlp["gathers"]["rccl"]["gathered_bit_identical"] is True and mlp["gathered_bit_identical"] is True
