@@ -361,6 +361,35 @@ def test_f32_tiles_of_32_k_pair_their_batch_elements(rtq, tiles, layout, kb):
             assert ("32-k pairs" in ran) == (kb % 2 == 0), (ran, kb)
 
 
+@pytest.mark.parametrize("tm,tn,items,family", [(64, 64, 272, "64x64,k2"), (64, 64, 544, "64x64>"), (64, 32, 288, "64x32,k4"), (32, 32, 300, "32x32,k4")],
+                         ids=["64x64k2", "64x64", "64x32k4", "32x32k4"])
+def test_f32_tiles_of_32_k_pairs_on_every_grouped_family(rtq, tm, tn, items, family):
+    """many 32-k tile invokes in one group: the pair mode on each of the four loader-wave families the group size selects
+    (launch_gemm_grouped: the largest tile that still gives every CU a workgroup)"""
+    rt = rtq
+    kb = 4
+    rng = np.random.default_rng(tm + tn + items)
+    A = rng.uniform(-1, 1, 4 * kb * tm * 32).astype(np.float32)        # four A tiles, reused
+    Bm = rng.uniform(-0.3, 0.3, 8 * kb * 32 * tn).astype(np.float32)   # eight B tiles, reused
+    bias = rng.uniform(-0.3, 0.3, 8 * tn).astype(np.float32)
+    C0 = np.zeros(items * tm * tn, dtype=np.float32)
+    disp = (F32, tm, tn, 32, 32, tn, tn, tm * 32, 32 * tn, 4, 0, 5, 4, 1)
+    ref = C0.copy()
+    for t in range(items):
+        orc.fused_brgemm(*disp, A, (t % 4) * kb * tm * 32, Bm, (t % 8) * kb * 32 * tn, ref, t * tm * tn, bias, (t % 8) * tn, kb)
+    h = rt.fused_brgemm_dispatch(*disp)
+    dA, dB, db, dC = dev(A), dev(Bm), dev(bias), dev(C0)
+    for rep in range(2):
+        dC.zero_()
+        rt.synchronize()
+        for t in range(items):
+            rt.fused_brgemm(F32, h, dA, (t % 4) * kb * tm * 32, dB, (t % 8) * kb * 32 * tn, dC, t * tm * tn, db, (t % 8) * tn, kb)
+        rt.synchronize()
+        close(host(dC, C0), ref, F32)
+        ran = rt.last_grouped_kernel()
+        assert "32-k pairs" in ran and family in ran, ran
+
+
 def test_f32_tiles_of_32_k_mixed_batch_counts_in_one_group(rtq):
     """one odd batch count in the group sends the whole group to the generic kernel (the pair flag is a property of the group)"""
     rt = rtq
