@@ -895,6 +895,15 @@ def main():
                 if mm:
                     others.append({"workload": "mlir-gen mlp 3x1024 bs=256 bias+relu (fp32 unless noted), " + label + " (tools/tpp_replay)",
                                    "value": float(mm.group(2)), "unit": "GFLOP/s", "us_per_step": float(mm.group(1))})
+            # the same fp32 MLP at batch 512 as whole-layer calls: three launches, and handed over together (ONE launch of the f32
+            # layer chain, bit-identical to the three: tests/test_chain_f32_gpu.py)
+            for label, extra in (("three whole-layer launches", ["--whole-layer"]), ("ONE chain launch (xsmm_hip_fused_brgemm_chain_invoke)", ["--chain"])):
+                r = subprocess.run([replay, "--batch", "512", "--layers", "1024,1024,1024,1024", "--bias", "--relu", "-n", "1000"] + extra,
+                                   capture_output=True, text=True, timeout=300)
+                mm = re.search(r"mean ([0-9.]+) us[^,]*, ([0-9.]+) GFLOP/s", r.stderr)
+                if mm:
+                    others.append({"workload": "mlir-gen mlp 3x1024 bs=512 bias+relu fp32, " + label + " (tools/tpp_replay)",
+                                   "value": float(mm.group(2)), "unit": "GFLOP/s", "us_per_step": float(mm.group(1))})
 
     cpu = per_launch = mfma_busy = None
     traffic, traffic_source, traffic_detail = None, None, None
