@@ -167,6 +167,16 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NL + NLB)) void brgemm_f32_lw(
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
   float bias = 0.0f;
   if (p.ep & EP_BIAS) bias = ((const float *)it.D)[ccol]; // (every K group: the groups share the epilogue)
+  // ... and the K-split tiles' float4 epilogue: its four bias values per lane (16-byte column piece lane & 7). With ONE MFMA wave
+  // per SIMD (32x32 + K4) they come in here as well - behind the combine's second barrier the load was an exposed round trip:
+  // the batch-256 layer of the reference's MLP 7.05 -> 6.82 us per launch, its tile-queue iteration 19.47 -> 19.25 us (same box,
+  // profiles/r04_c3_loaders_and_launch_knobs.txt (4)); with two MFMA waves per SIMD the other wave hides it and the early fetch
+  // measured 0.02 us SLOWER on C3, so those tiles keep the load in the epilogue
+  constexpr bool BIAS_EARLY = WK > 1 && WM * WN * WK <= 4;
+  f32x4 bias4 = {0.0f, 0.0f, 0.0f, 0.0f};
+  if constexpr (BIAS_EARLY) {
+    if (p.ep & EP_BIAS) bias4 = *(const f32x4 *)((const float *)it.D + n0 + wn * 32 + 4 * (lane & 7));
+  }
   if (wk == 0) {
     if (!(p.ep & EP_BETA0)) {
 #pragma unroll
@@ -267,8 +277,9 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NL + NLB)) void brgemm_f32_lw(
     // rows - so a tile is 4 x 16-byte stores per lane split over the K groups, instead of 16 dword stores (round 2).
     constexpr int IPG = 4 / WK; // store instructions per lane per group
     const int c4 = lane & 7, rsel = lane >> 3; // 16-byte column piece, row within the instruction's 8 rows
-    f32x4 bias4 = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (p.ep & EP_BIAS) bias4 = *(const f32x4 *)((const float *)it.D + n0 + wn * 32 + 4 * c4);
+    if constexpr (!BIAS_EARLY) {
+      if (p.ep & EP_BIAS) bias4 = *(const f32x4 *)((const float *)it.D + n0 + wn * 32 + 4 * c4);
+    }
 #pragma unroll
     for (int j = 0; j < IPG; ++j) {
       const int q = 8 * (wk * IPG + j) + rsel;  // row of the 32x32 tile: q = (r & 3) + 4 * lh + 8 * (r >> 2)
@@ -636,6 +647,8 @@ hipError_t launch_f32_lw(int tile, const GemmArgs &a, hipStream_t s) {
   // 64x32 with K split over FOUR wave groups: 8 MFMA waves = two per SIMD, like the 64x64 k2 tile - one wave's fragment reads and
   // barrier waits hide behind the other's MFMAs. C3 (512 x 1024 x 1024): 10.52 -> 10.21 us same-box against the K2 split (4 waves).
   case 2: return f32_lw_c3_loaders() == 11 ? launch_lw_t<2, 1, 4>(a, s) : f32_lw_c3_loaders() == 22 ? launch_lw_t<2, 1, 4, 2>(a, s) : launch_lw_t<2, 1, 4, 2, LW_NSLOT, 1>(a, s);
+  // (the same tile with its K split over EIGHT wave groups - two MFMA waves per SIMD, one k-block per wave and chunk, the barrier behind
+  // the block - measured 3-4.5 % slower on the reference's batch-256 layers: profiles/r04_c3_loaders_and_launch_knobs.txt (5))
   case 3: return launch_lw_t<1, 1, 4>(a, s);
   // 128x64 for large outputs: 8 MFMA waves (4 x 2 tiles of 32x32), two loader waves per panel, a 3-slot ring (48 KiB per slot)
   case 4: return launch_lw_t<4, 2, 1, 2, 3>(a, s);
