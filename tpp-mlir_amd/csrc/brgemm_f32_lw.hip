@@ -59,8 +59,8 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NL + NLB)) void brgemm_f32_lw(
   if constexpr (GROUPED) {
     if (items) it = items[blockIdx.x]; // (no list: a single invoke of the grouped kernel, operands in the arguments)
   }
-  const int tm = GROUPED ? (int)blockIdx.z : (int)(blockIdx.x >> 1) * p.tiles_m + (int)blockIdx.z;
-  const int tn = GROUPED ? (int)blockIdx.y : (int)(blockIdx.x & 1) * p.tiles_n + (int)blockIdx.y;
+  const int tm = GROUPED ? (int)blockIdx.z : (int)(blockIdx.x >> p.xn_shift) * p.tiles_m + (int)blockIdx.z;
+  const int tn = GROUPED ? (int)blockIdx.y : (int)(blockIdx.x & ((1u << p.xn_shift) - 1)) * p.tiles_n + (int)blockIdx.y;
   const int m0 = tm * BM, n0 = tn * BN;
   const float *__restrict__ A = (const float *)it.A;
   const float *__restrict__ B = (const float *)it.B;
@@ -316,9 +316,31 @@ template <int WM, int WN, int WK, int NL = 1, int NSLOT = LW_NSLOT, int NLB = NL
   GemmArgs args = a;
   const int tiles_m = a.m / BM, tiles_n = a.n / BN;
   dim3 grid;
-  if ((tiles_m & 3) == 0 && (tiles_n & 1) == 0 && tiles_m / 4 <= 65535 && tiles_n / 2 <= 65535) {
-    args.tiles_m = tiles_m / 4; // XCD-blocked: 4 (M) x 2 (N) XCD blocks of tiles_m/4 x tiles_n/2 tiles
-    args.tiles_n = tiles_n / 2;
+  // XCD-blocked grid: xm x xn = 8 XCD blocks of tiles_m/xm x tiles_n/xn tiles (blockIdx.x = the XCD: workgroups go to XCDs round
+  // robin). Each XCD's L2 then fetches m/xm rows of A and n/xn columns of B: the split that minimises m/xm + n/xn - 4 x 2 for
+  // square outputs (C2; ties keep it: rounds 1-3 had only this one), 2 x 4 for C3's 512 x 1024 and the batch-256 layers (-20 / -33 % of
+  // the L2 fill). TPP_HIP_F32_LW_XM forces xm (A/B runs).
+  static const int forced_xm = [] {
+    const char *e = getenv("TPP_HIP_F32_LW_XM");
+    return e ? atoi(e) : 0;
+  }();
+  int xm = 0;
+  long long best = -1;
+  for (int c : {4, 2, 8, 1}) {
+    const int xn = 8 / c;
+    if (tiles_m % c || tiles_n % xn || tiles_m / c > 65535 || tiles_n / xn > 65535) continue;
+    const long long cost = (long long)a.m / c + (long long)a.n / xn;
+    if (forced_xm ? c == forced_xm : (best < 0 || cost < best)) {
+      best = cost;
+      xm = c;
+    }
+  }
+  args.xn_shift = 0;
+  if (xm) {
+    const int xn = 8 / xm;
+    args.tiles_m = tiles_m / xm;
+    args.tiles_n = tiles_n / xn;
+    args.xn_shift = xn == 8 ? 3 : xn == 4 ? 2 : xn == 2 ? 1 : 0;
     grid = dim3(8, args.tiles_n, args.tiles_m);
   } else {
     args.tiles_m = args.tiles_n = 0;
@@ -339,6 +361,7 @@ static hipError_t launch_lw_grouped_t(const GemmArgs &a, const WorkItem *items, 
   if (hipError_t e = ensure_dynamic_lds((const void *)brgemm_f32_lw<WM, WN, WK, true>, (int)lds, lds_set); e != hipSuccess) return e;
   GemmArgs args = a;
   args.tiles_m = args.tiles_n = 0;
+  args.xn_shift = 0;
   hipLaunchKernelGGL((brgemm_f32_lw<WM, WN, WK, true>), dim3((unsigned)n_items, a.n / BN, a.m / BM), dim3(NT), lds, s, args, items);
   return hipGetLastError();
 }

@@ -23,6 +23,7 @@ struct GemmArgs {
   int ep;              // EP_* bits
   int tiles_m, tiles_n;
   int vf;              // VNNI blocking factor of B (2 or 4) when the operand is VNNI-packed
+  int xn_shift;        // brgemm_f32_lw, XCD-blocked grid: log2 of the XCD blocks along N (set by its launcher; blockIdx.x = M block << xn_shift | N block)
 };
 
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short h) {
