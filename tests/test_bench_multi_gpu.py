@@ -53,6 +53,25 @@ def test_bench_two_ranks_on_one_device_reports_verified_strong_scaling():
     assert "TEST RIG" in d["data"]
 
 
+def test_bench_gpus_2_without_a_launcher_starts_its_own_ranks():
+    """`python3 bench.py --gpus 2 --steps 6 --warmup 3` - NO torchrun, no WORLD_SIZE - must start its own two ranks
+    and print ONE line with n_gpus 2 (never an N = 1 line under an N > 1 command)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(TPP_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "3"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    if r.returncode != 0:
+        pytest.fail("bench.py --gpus 2 exited %d\n--- stdout (tail)\n%s\n--- stderr (tail)\n%s" % (r.returncode, r.stdout[-1500:], r.stderr[-6000:]), pytrace=False)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 3
+    assert d["process_group"]["world_size"] == 2 and len(d["process_group"]["ranks"]) == 2
+    g = d["mlp"]["gathers"]
+    assert set(g) == {"peer", "rccl"} and all(g[p]["gathered_bit_identical"] is True for p in g), g
+    assert d["mlp"]["gathered_bit_identical"] is True
+
+
 def test_bench_survives_a_peer_path_that_fails_on_one_rank():
     """a rank whose peer-store gather fails (here: injected on rank 1 behind its timed region) must not cost the line or hang the
     job: every rank votes, all of them drop the path, the RCCL path is the headline and the failure is in the line"""

@@ -93,3 +93,31 @@ def test_shipped_library_has_no_measurement_switches():
     blob = open(build.build(), "rb").read()
     for name in (b"TPP_HIP_CHAIN_DBG", b"TPP_HIP_CHAIN_STAMPS"):
         assert name not in blob, name
+
+
+def _run_bench(argv, env_extra, drop=("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")):
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+
+
+def test_bench_refuses_a_world_size_that_differs_from_gpus():
+    """never an N = 1 line under an N > 1 command - a launcher-set WORLD_SIZE that differs from --gpus is an
+    error for world == 1 too (checked before anything touches a GPU)"""
+    r = _run_bench(["--gpus", "8", "--steps", "2", "--warmup", "1"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "--gpus 8 but WORLD_SIZE=1" in r.stderr and "{" not in r.stdout
+    r = _run_bench(["--gpus", "1", "--steps", "2", "--warmup", "1"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "--gpus 1 but WORLD_SIZE=2" in r.stderr and "{" not in r.stdout
+
+
+def test_bench_gpus_n_without_world_size_launches_n_ranks():
+    """`python bench.py --gpus 2` with no launcher starts two ranks itself (here, without a GPU, each rank stops at 'needs an
+    MI355X' - what matters is that TWO ranks with WORLD_SIZE=2 were started, no JSON line was printed and the exit code is not 0)"""
+    r = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1"], {})
+    assert "launching 2 ranks" in r.stderr and "torch.distributed.run" in r.stderr
+    import torch
+    if not torch.cuda.is_available():
+        assert r.returncode != 0 and r.stderr.count("needs an MI355X") >= 2, r.stderr[-3000:]
+        assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
