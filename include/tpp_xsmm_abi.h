@@ -242,6 +242,14 @@ TPP_XSMM_EXPORT const char *xsmm_hip_last_grouped_kernel(void);
  * Honoured at dispatch when the shape divides the tile;
  * 24 .. 27 the same tiles for a flat bf16 B operand, 28 .. 31 for a VNNI-4 B operand. */
 TPP_XSMM_EXPORT void xsmm_hip_force_variant(int variant);
+/* Skinny f32 outputs (fewer output tiles than compute units, a long batch-reduce: the reference's M = 128 / 256 benchmark shapes,
+ * benchmarks/config/matmul/128x1024x4096.json ...) run with the batch-reduce range of ONE output tile split over several workgroups:
+ * each adds its chunks, the workgroup that finishes last sums the partial tiles in split order (a fixed order of additions: the same
+ * call pattern gives the same bits every run; no float atomics). How many workgroups share a tile is chosen per launch from the
+ * descriptor, the batch count and the number of tiles in the launch; this call overrides it for the launches that FOLLOW (a test /
+ * measurement switch): -1 = the model (default), 0 or 1 = never split, n > 1 = n workgroups per tile (at most 16 and at most the
+ * number of 64-k chunks). Also TPP_HIP_SPLIT. Returns the previous setting. */
+TPP_XSMM_EXPORT int xsmm_hip_force_split(int workgroups_per_tile);
 /* The VNNI blocking factor v of bf16 B operands ([k/v][ldb][v]) of gemm / brgemm / fused_brgemm handles dispatched FROM NOW ON with
  * the VNNI_B wire flag: 2 (default) or 4; also TPP_HIP_VNNI_FACTOR. The factor is not on the wire - the reference's compiler and its
  * runtime library both ask libxsmm_cpuid_dot_pack_factor(LIBXSMM_DATATYPE_BF16) (lib/TPP/Transforms/Utils/VNNIUtils.cpp:25-45; the

@@ -798,7 +798,9 @@ def test_c2_full_size_and_properties(rt):
         rt.brgemm(F32, h, dA, 0, dB, 0, dC, 0, br)
         got = host(dC, C)
         truth = C.astype(np.float64).reshape(m, n) + A.astype(np.float64).reshape(m, 1024) @ B.astype(np.float64).reshape(1024, n)
-        check_close(got, ref, F32, "C2 trial %d" % trial, truth=truth.reshape(-1))
+        # the element-wise bar of SURVEY 8(d) at BASELINE size: |C| + sum_k |a||b| per element, in fp64 by numpy
+        mag = np.abs(C).astype(np.float64).reshape(m, n) + np.abs(A).astype(np.float64).reshape(m, 1024) @ np.abs(B).astype(np.float64).reshape(1024, n)
+        check_close(got, ref, F32, "C2 trial %d" % trial, mag=mag.reshape(-1), K=1024, truth=truth.reshape(-1))
         # determinism: same inputs -> bit-identical output (no atomics, fixed summation order)
         dC2 = dev(C)
         rt.brgemm(F32, h, dA, 0, dB, 0, dC2, 0, br)
@@ -833,7 +835,9 @@ def test_c3_fused_layer_full_size(rt):
     rt.fused_brgemm(F32, h, dev(A), 0, dev(W), 0, dC, 0, dev(bias), 0, br)
     got = host(dC, C)
     truth = np.maximum(A.astype(np.float64).reshape(m, 1024) @ W.astype(np.float64).reshape(1024, n) + bias.astype(np.float64), 0.0)
-    check_close(got, ref, F32, "C3 fused layer", truth=truth.reshape(-1))
+    # the element-wise bar at BASELINE size: sum_k |a||w| + |bias| per element (beta = 0: C does not enter), in fp64 by numpy
+    mag = np.abs(A).astype(np.float64).reshape(m, 1024) @ np.abs(W).astype(np.float64).reshape(1024, n) + np.abs(bias).astype(np.float64)
+    check_close(got, ref, F32, "C3 fused layer", mag=mag.reshape(-1), K=1024, truth=truth.reshape(-1))
     assert (got >= 0).all() and (got == 0).any()
     # relu idempotence: applying xsmm.unary relu to the output changes nothing
     hr = rt.unary_dispatch(5, F32, m, n, n, n, 0)

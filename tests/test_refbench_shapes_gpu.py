@@ -1,0 +1,201 @@
+"""The reference's benchmark shape set on the HIP path (VERDICT r4 row g): one layer of every distinct --tiles setting of
+benchmarks/config/matmul/*.json and fc/*.json (64,64,64 / 64,48,64 / 32,48,32 / 32,64,64 / 32,32,32; mlir-gen's tiles are
+(batch tile, out-feature tile, in-feature tile) = the tile BRGEMM's (m, n, k), MLIRGen.cpp:641-676), replayed as the compiler emits
+it - packed block layouts, one fused_brgemm dispatch [m,n,k,k,n,n,m*k,k*n], (M/m)*(N/n) invokes with br = K/k through the tile queue -
+and as ONE whole-layer dispatch, f32 and bf16 + VNNI-2, against the oracle. And the SPLIT kernels behind the skinny shapes (the
+batch-reduce range of an output tile over several workgroups): every forced split count against the oracle, bit-reproducible from
+run to run, with beta = 1, bias + relu, ragged chunk counts and empty ranges."""
+import importlib
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as orc
+from test_parity_gpu import BF16, F32, VB, check_close, dev, host, rand
+
+pytestmark = pytest.mark.gpu
+pkg = importlib.import_module("tpp-mlir_amd")
+
+
+@pytest.fixture(scope="module")
+def rt():
+    r = pkg.get_runtime()
+    assert r.device_count() >= 1, "no HIP device visible: the gpu tests need an MI355X"
+    yield r
+    r.force_split(-1)
+
+
+def pack_a(X, M, K, tm, tk):  # [M][K] -> [M/tm][K/tk][tm][tk]
+    return np.ascontiguousarray(X.reshape(M // tm, tm, K // tk, tk).transpose(0, 2, 1, 3)).reshape(-1)
+
+
+def pack_w(W, K, N, tk, tn, vnni):  # [K][N] -> [N/tn][K/tk][tk][tn] (VNNI-v: [N/tn][K/tk][tk/v][tn][v])
+    blk = W.reshape(K // tk, tk, N // tn, tn).transpose(2, 0, 1, 3)  # [NB][KB][tk][tn]
+    if vnni:
+        blk = blk.reshape(N // tn, K // tk, tk // vnni, vnni, tn).transpose(0, 1, 2, 4, 3)
+    return np.ascontiguousarray(blk).reshape(-1)
+
+
+def pack_c(C, M, N, tm, tn):
+    return np.ascontiguousarray(C.reshape(M // tm, tm, N // tn, tn).transpose(0, 2, 1, 3)).reshape(-1)
+
+
+def unpack_c(Cp, M, N, tm, tn):
+    return np.ascontiguousarray(Cp.reshape(M // tm, N // tn, tm, tn).transpose(0, 2, 1, 3)).reshape(M, N)
+
+
+# (M, N, K, tiles) - one benchmark per distinct tile shape, the skinniest of its kind
+LAYERS = [
+    (128, 1024, 1024, (64, 64, 64)),   # benchmarks/config/fc/128x1024x1024.json
+    (128, 768, 2304, (64, 48, 64)),    # fc/128x768x2304.json:40-64
+    (128, 768, 3072, (32, 48, 32)),    # matmul/128x768x3072.json:37-51
+    (128, 768, 768, (32, 64, 64)),     # fc/128x768x768.json
+    (1024, 352, 512, (32, 32, 32)),    # fc/1024x352x512.json
+]
+
+
+@pytest.mark.parametrize("fc", [False, True], ids=["matmul", "fc"])
+@pytest.mark.parametrize("dt", [F32, BF16], ids=["f32", "bf16vnni2"])
+@pytest.mark.parametrize("M,N,K,tiles", LAYERS, ids=lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else str(v))
+def test_one_layer_of_every_tile_shape_as_the_compiler_emits_it(rt, M, N, K, tiles, dt, fc):
+    tm, tn, tk = tiles
+    rng = np.random.default_rng(M + N + K + tm)
+    X = rng.uniform(-1, 1, (M, K)).astype(np.float32)
+    W = (rng.uniform(-1, 1, (K, N)) / np.sqrt(K)).astype(np.float32)
+    C0 = rng.uniform(-1, 1, (M, N)).astype(np.float32)  # --kernel=args: the output is an argument, the layer accumulates into it
+    bias = rng.uniform(-1, 1, N).astype(np.float32)
+    if dt == BF16:
+        X, W, C0, bias = (orc.bf16_to_f32(orc.f32_to_bf16(v.reshape(-1))).reshape(v.shape) for v in (X, W, C0, bias))
+    conv = (lambda v: v) if dt == F32 else orc.f32_to_bf16
+    vn = 2 if dt == BF16 else 0
+    flags = VB if dt == BF16 else 0  # beta = 1
+    # the oracle on the flat tensors (one whole-layer call; the packed replay computes the same sums per element)
+    ref = conv(C0.reshape(-1).copy())
+    Wflat = W if not vn else W.reshape(K // 2, 2, N).transpose(0, 2, 1)
+    a_o, w_o, b_o = conv(X.reshape(-1)), conv(np.ascontiguousarray(Wflat).reshape(-1)), conv(bias)
+    if fc:
+        orc.fused_brgemm(dt, M, N, K, K, N, N, 0, 0, flags, 0, 5, 4, 1, a_o, 0, w_o, 0, ref, 0, b_o, 0, 1)
+    else:
+        orc.brgemm(dt, M, N, K, K, N, N, 0, 0, flags, a_o, 0, w_o, 0, ref, 0, 1)
+    mag = None
+    if dt == F32:
+        mag = (np.abs(X).astype(np.float64) @ np.abs(W).astype(np.float64) + np.abs(C0) + (np.abs(bias)[None, :] if fc else 0)).reshape(-1)
+    # (1) as the compiler emits it: packed blocks, tile invokes through the tile queue
+    dA, dW, dC, dB = dev(conv(pack_a(X, M, K, tm, tk))), dev(conv(pack_w(W, K, N, tk, tn, vn))), dev(conv(pack_c(C0, M, N, tm, tn))), dev(conv(bias))
+    disp = (dt, tm, tn, tk, tk, tn, tn, tm * tk, tk * tn, flags)
+    h = rt.fused_brgemm_dispatch(*disp, 0, 5, 4, 1) if fc else rt.brgemm_dispatch(*disp)
+    MB, NB, KB = M // tm, N // tn, K // tk
+    old_async, old_q = rt.set_async(True), rt.set_tile_queue(1)
+    try:
+        for i in range(MB):
+            for j in range(NB):
+                if fc:
+                    rt.fused_brgemm(dt, h, dA, i * KB * tm * tk, dW, j * KB * tk * tn, dC, (i * NB + j) * tm * tn, dB, j * tn, KB)
+                else:
+                    rt.brgemm(dt, h, dA, i * KB * tm * tk, dW, j * KB * tk * tn, dC, (i * NB + j) * tm * tn, KB)
+        rt.synchronize()
+        grouped = rt.last_grouped_kernel()
+    finally:
+        rt.set_tile_queue(old_q)
+        rt.set_async(old_async)
+    got = host(dC, conv(C0.reshape(-1)))
+    got = unpack_c(orc.bf16_to_f32(got) if dt == BF16 else got, M, N, tm, tn).reshape(-1)
+    check_close(got if dt == F32 else orc.f32_to_bf16(got), ref, dt, "tile invokes %s tiles %s [%s]" % ((M, N, K), tiles, grouped), mag=mag, K=K)
+    # (2) ONE whole-layer dispatch on the flat tensors (k = 64 chunks)
+    dA2, dW2, dC2 = dev(a_o), dev(w_o), dev(conv(C0.reshape(-1)))
+    disp = (dt, M, N, 64, K, N, N, 64, 64 * N, flags)
+    h2 = rt.fused_brgemm_dispatch(*disp, 0, 5, 4, 1) if fc else rt.brgemm_dispatch(*disp)
+    if fc:
+        rt.fused_brgemm(dt, h2, dA2, 0, dW2, 0, dC2, 0, dB, 0, K // 64)
+    else:
+        rt.brgemm(dt, h2, dA2, 0, dW2, 0, dC2, 0, K // 64)
+    check_close(host(dC2, ref), ref, dt, "whole layer %s [%s]" % ((M, N, K), rt.kernel_name(h2)), mag=mag, K=K)
+
+
+SPLIT_CASES = [
+    # m, n, k, br, forced variant, beta0, bias, relu
+    (128, 1024, 64, 64, None, True, False, False),   # matmul 128x1024x4096 as one dispatch
+    (128, 768, 64, 36, None, False, True, True),     # fc 128x768x2304: 36 chunks (uneven ranges for most split counts)
+    (128, 256, 64, 7, 6, False, True, False),        # 64x64 + K2 tile, fewer chunks than the largest split counts (empty ranges)
+    (64, 96, 64, 5, 7, True, False, True),           # 64x32 + K4 tile
+    (96, 160, 128, 3, 9, False, False, False),       # 32x32 + K4 tile, k = 2 chunks per batch element: a range may start inside an element
+]
+
+
+@pytest.mark.parametrize("m,n,k,br,force,beta0,bias,relu", SPLIT_CASES)
+def test_split_batch_reduce_every_count_against_the_oracle_and_reproducible(rt, m, n, k, br, force, beta0, bias, relu):
+    rng = np.random.default_rng(m * 7 + n + br)
+    K = k * br
+    A, B = rand(rng, m * K + 8, F32), rand(rng, K * n + 8, F32)
+    C, D = rand(rng, m * n + 8, F32), rand(rng, n + 8, F32)
+    flags = 4 if beta0 else 0
+    fused = bias or relu
+    ref = C.copy()
+    args = (F32, m, n, k, K, n, n, k, k * n, flags)
+    if fused:
+        orc.fused_brgemm(*args, 0, 5 if relu else 0, 4 if bias else 0, 1 if bias else 0, A, 4, B, 8, ref, 4, D, 4, br)
+    else:
+        orc.brgemm(*args, A, 4, B, 8, ref, 4, br)
+    a2 = np.abs(A[4:4 + m * K]).reshape(m, K).astype(np.float64)
+    b2 = np.abs(B[8:8 + K * n]).reshape(K, n).astype(np.float64)
+    mag = np.zeros(m * n + 8)
+    mag[4:4 + m * n] = (a2 @ b2 + (0 if beta0 else np.abs(C[4:4 + m * n]).reshape(m, n)) + (np.abs(D[4:4 + n])[None, :] if bias else 0)).reshape(-1)
+    if force is not None:
+        rt.force_variant(force)
+    try:
+        h = rt.fused_brgemm_dispatch(*args, 0, 5 if relu else 0, 4 if bias else 0, 1 if bias else 0) if fused else rt.brgemm_dispatch(*args)
+    finally:
+        rt.force_variant(-1)
+    dA, dB, dD = dev(A), dev(B), dev(D)
+    seen = {}
+    try:
+        for S in (1, 2, 3, 4, 5, 8, 16, -1):
+            rt.force_split(S)
+            outs = []
+            for rep in range(3):
+                dC = dev(C)
+                if fused:
+                    rt.fused_brgemm(F32, h, dA, 4, dB, 8, dC, 4, dD, 4, br)
+                else:
+                    rt.brgemm(F32, h, dA, 4, dB, 8, dC, 4, br)
+                outs.append(host(dC, C))
+            assert all(np.array_equal(outs[0], o) for o in outs[1:]), "split %d: results differ from run to run" % S
+            check_close(outs[0], ref, F32, "split %d m%d n%d k%d br%d [%s]" % (S, m, n, k, br, rt.kernel_name(h)), mag=mag, K=K)
+            seen[S] = outs[0]
+    finally:
+        rt.force_split(-1)
+    # the guard bytes around C stay untouched, and a forced count really changes the order of additions somewhere (i.e. the split ran)
+    assert np.array_equal(seen[4][:4], C[:4]) and np.array_equal(seen[4][4 + m * n:], C[4 + m * n:])
+    assert any(not np.array_equal(seen[1], seen[S]) for S in (2, 3, 4))
+
+
+def test_split_groups_through_the_tile_queue(rt):
+    """a skinny layer as tile invokes (32 invokes of 64x64x64, br = 64: matmul 128x1024x4096): the group runs split; the result is
+    the oracle's within the bar and the same bits as the same group run again"""
+    M, N, K, t = 128, 1024, 4096, 64
+    rng = np.random.default_rng(11)
+    X = rng.uniform(-1, 1, (M, K)).astype(np.float32)
+    W = (rng.uniform(-1, 1, (K, N)) / 64).astype(np.float32)
+    C0 = rng.uniform(-1, 1, (M, N)).astype(np.float32)
+    ref = C0.reshape(-1).copy()
+    orc.brgemm(F32, M, N, K, K, N, N, 0, 0, 0, X.reshape(-1), 0, W.reshape(-1), 0, ref, 0, 1)
+    mag = (np.abs(X).astype(np.float64) @ np.abs(W).astype(np.float64) + np.abs(C0)).reshape(-1)
+    dA, dW = dev(pack_a(X, M, K, t, t)), dev(pack_w(W, K, N, t, t, 0))
+    h = rt.brgemm_dispatch(F32, t, t, t, t, t, t, t * t, t * t, 0)
+    MB, NB, KB = M // t, N // t, K // t
+    old_async, old_q = rt.set_async(True), rt.set_tile_queue(1)
+    outs = []
+    try:
+        for rep in range(3):
+            dC = dev(pack_c(C0, M, N, t, t))
+            for i in range(MB):
+                for j in range(NB):
+                    rt.brgemm(F32, h, dA, i * KB * t * t, dW, j * KB * t * t, dC, (i * NB + j) * t * t, KB)
+            rt.synchronize()
+            outs.append(host(dC, ref))
+            assert "split" in rt.last_grouped_kernel(), rt.last_grouped_kernel()
+    finally:
+        rt.set_tile_queue(old_q)
+        rt.set_async(old_async)
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    check_close(unpack_c(outs[0], M, N, t, t).reshape(-1), ref, F32, "split group", mag=mag, K=K)

@@ -130,10 +130,11 @@ int bf16_lw_b_kind(const GemmDesc &) { return -1; }
 void blw_tile_dims(int, int *bm, int *bn) { *bm = *bn = 128; }
 hipError_t launch_bf16_chain(int, int, const ChainArgs &, hipStream_t) { return hipErrorNotSupported; }
 int f32_chain_tile(const GemmDesc &) { return -1; }
+int force_gemm_split(int) { return -1; }
 bool f32_chain_tile_dims(int, int *bm, int *bn) { *bm = *bn = 64; return false; }
 hipError_t launch_f32_chain(int, const ChainArgs &, hipStream_t) { return hipErrorNotSupported; }
 const char *last_grouped_kernel() { return "fake_host_gemm"; }
-hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *it, int n, bool, bool, bool, hipStream_t s) {
+hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *it, int n, bool, bool, bool, int64_t, hipStream_t s) {
   for (int i = 0; i < n; ++i) (void)launch_gemm(d, it[i].A, it[i].B, it[i].C, it[i].D, it[i].br, s);
   return hipSuccess;
 }

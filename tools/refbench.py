@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+"""refbench - the reference's own benchmark SHAPE SET on the GPU path (VERDICT r4 row g / north_star "GFLOP/s on the
+benchmarks/mlir synthetic MLP/matmul shapes ... alongside the CPU baseline").
+
+The shapes are the IR-GEN rows of the reference's benchmark configs (the JSON files cannot travel to the GPU box; the table below
+restates their `mlir-gen` command lines and cites them):
+  benchmarks/config/matmul/<M>x<N>x<K>.json:37-51  mlir-gen --kernel=args --float-type=f32|bf16 [--vnni=2|4] --batch=M --layers=K,N --tiles=m,n,k
+  benchmarks/config/fc/<M>x<N>x<K>.json:40-64      the same + --bias --relu
+  benchmarks/config/base/base.json:34-111          mlir-gen --kernel=const --batch=256 --layers=1024,1024,1024,1024 --tiles=32,32,32 (gemm / mlp)
+mlir-gen's --tiles=a,b,c are (batch tile, OUTPUT-feature tile, INPUT-feature tile) = the (m, n, k) of the tile BRGEMM
+(tools/mlir-gen/MLIRGen.cpp:641-676); the file name <M>x<N>x<K> is (batch, out features, in features).
+
+Each row is replayed by tools/tpp_replay (the reference's timing loop: one timer around N calls of the kernel) in two forms:
+  tiles : as the compiler emits it - one fused_brgemm dispatch [m,n,k,k,n,n,m*k,k*n], (M/m)*(N/n) invokes with br = K/k on the packed
+          block layouts, through the runtime's tile queue (one grouped launch per layer)
+  whole : ONE whole-layer dispatch per layer on the flat tensors (k = 64 chunks, br = K/64)
+for f32, bf16 + VNNI-2 and bf16 + VNNI-4. GFLOP/s = BENCH_TOTAL_FLOPS / mean (MLIRGen.cpp:313-334). The CPU row is
+oracle/cpu_baseline.c (the reference's packed 32x32x32 call structure under OpenMP; libxsmm is not in the image) on the same shape.
+
+usage: python tools/refbench.py [--quick] [--no-cpu] [--only matmul|fc|base] [-n ITER] [--json out.json]
+"""
+import argparse
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PEAK = {"f32": 157.3e12, "bf16": 2500e12}
+
+# (M = batch, N = out features, K = in features, (tile m, n, k)) - benchmarks/config/matmul/*.json and fc/*.json (17 files each, same shapes)
+SHAPES = [
+    (1024, 1024, 512, (64, 64, 64)), (1024, 2560, 1024, (64, 64, 64)), (1024, 352, 512, (32, 32, 32)), (1024, 512, 256, (64, 64, 64)),
+    (128, 1024, 1024, (64, 64, 64)), (128, 1024, 4096, (64, 64, 64)), (128, 3072, 768, (64, 64, 64)), (128, 4096, 1024, (64, 64, 64)),
+    (128, 768, 2304, (64, 48, 64)), (128, 768, 3072, (32, 48, 32)), (128, 768, 768, (32, 64, 64)),
+    (256, 1024, 1024, (64, 64, 64)), (256, 1024, 4096, (64, 64, 64)), (256, 3072, 768, (64, 64, 64)), (256, 4096, 1024, (64, 64, 64)),
+    (256, 768, 3072, (64, 64, 64)), (256, 768, 768, (64, 64, 64)),
+]
+
+
+def cases(only):
+    out = []
+    for fam in ("matmul", "fc"):
+        if only and only != fam:
+            continue
+        for (M, N, K, t) in SHAPES:
+            for dt in ("f32", "bf16-vnni2", "bf16-vnni4"):
+                for form in ("tiles", "whole"):
+                    out.append({"family": fam, "name": "%s_%dx%dx%d" % (fam, M, N, K), "M": M, "layers": [K, N], "tiles": t, "dtype": dt,
+                                "form": form, "bias_relu": fam == "fc", "kernel": "args",
+                                "cite": "benchmarks/config/%s/%dx%dx%d.json" % (fam, M, N, K)})
+    if not only or only == "base":
+        for nm, br in (("gemm", False), ("mlp", True)):
+            for dt in ("f32", "bf16-vnni2", "bf16-vnni4"):
+                for form in ("tiles", "whole"):
+                    out.append({"family": "base", "name": "base_%s_256x1024x3" % nm, "M": 256, "layers": [1024] * 4, "tiles": (32, 32, 32),
+                                "dtype": dt, "form": form, "bias_relu": br, "kernel": "const", "cite": "benchmarks/config/base/base.json:34-111"})
+    return out
+
+
+def argv_of(c, n_iter):
+    a = ["--batch", str(c["M"]), "--layers", ",".join(map(str, c["layers"])), "--kernel", c["kernel"], "-n", str(n_iter), "--queue", "1"]
+    if c["form"] == "tiles":
+        a += ["--tiles", "%d,%d,%d" % c["tiles"]]
+    else:
+        a += ["--whole-layer"]
+    if c["bias_relu"]:
+        a += ["--bias", "--relu"]
+    if c["dtype"].startswith("bf16"):
+        a += ["--bf16", "--vnni", c["dtype"][-1]]
+    return a
+
+
+def flops_of(c):
+    f = 0.0
+    for l in range(len(c["layers"]) - 1):
+        f += 2.0 * c["M"] * c["layers"][l] * c["layers"][l + 1] + (2.0 * c["M"] * c["layers"][l + 1] if c["bias_relu"] else 0.0)
+    return f
+
+
+def cpu_rows(shapes, seconds=0.6):
+    """the CPU port (oracle/cpu_baseline.c: packed 32x32x32 blocks, OpenMP over the tile grid) on every (M, N, K): f32, plain matmul"""
+    import numpy as np
+    from oracle import pyoracle as orc
+    cb = orc.CpuBaseline(native=True)
+    cpus, _ = orc.usable_cpus()
+    team = cb.set_threads(cpus)
+    res = {}
+    rng = np.random.default_rng(5)
+    for (M, N, K) in shapes:
+        A = rng.uniform(-1, 1, M * K).astype(np.float32)
+        B = rng.uniform(-1, 1, K * N).astype(np.float32)
+        C = np.zeros(M * N, np.float32)
+        Ap, Bp, Cp = cb.pack(A, B, C, M, N, K)
+        cb.run(M, N, K, Ap, Bp, Cp, True, 2)
+        reps, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            cb.run(M, N, K, Ap, Bp, Cp, True, 10)
+            reps += 10
+        el = time.perf_counter() - t0
+        res[(M, N, K)] = {"us": el / reps * 1e6, "gflops": 2.0 * M * N * K * reps / el / 1e9, "threads": team}
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true", help="f32 only")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--only", default="")
+    ap.add_argument("-n", type=int, default=300)
+    ap.add_argument("--json", default="")
+    args = ap.parse_args()
+    replay = os.path.join(ROOT, "tools", "tpp_replay")
+    cs = [c for c in cases(args.only) if not (args.quick and c["dtype"] != "f32")]
+    with tempfile.NamedTemporaryFile("w", suffix=".cases", delete=False) as f:
+        for c in cs:
+            f.write(" ".join(argv_of(c, args.n)) + "\n")
+        path = f.name
+    r = subprocess.run([replay, "--cases", path], capture_output=True, text=True, timeout=3000)
+    os.unlink(path)
+    pat = re.compile(r"mean ([0-9.]+) us \(host side of the invokes ([0-9.]+) us\), ([0-9.]+) GFLOP/s \(BENCH_TOTAL_FLOPS ([0-9]+)\), kernel (.*)$")
+    got = [pat.search(l) for l in r.stderr.splitlines() if "GFLOP/s (BENCH_TOTAL_FLOPS" in l]
+    if len(got) != len(cs):
+        sys.stderr.write(r.stderr[-4000:])
+        raise SystemExit("refbench: %d cases, %d result lines (rc %d)" % (len(cs), len(got), r.returncode))
+    for c, m_ in zip(cs, got):
+        c["us"], c["host_us"], c["gflops"], c["kernel_name"] = float(m_.group(1)), float(m_.group(2)), float(m_.group(3)), m_.group(5).strip()
+        assert abs(float(m_.group(4)) - flops_of(c)) < 1, (c, m_.group(4))
+        c["frac_of_peak"] = c["gflops"] * 1e9 / PEAK["f32" if c["dtype"] == "f32" else "bf16"]
+    cpu = {}
+    if not args.no_cpu:
+        cpu = cpu_rows(sorted({(c["M"], c["layers"][1], c["layers"][0]) for c in cs if c["family"] != "base"} | {(256, 1024, 1024)}))
+    print("# refbench: %d rows, tpp_replay -n %d; GPU peaks f32 157.3 TF, bf16 2500 TF (dense MFMA); empty-launch floor ~2.5 us" % (len(cs), args.n))
+    print("# %-24s %-11s %-10s %-6s %9s %10s %7s %9s  %s" % ("benchmark", "tiles", "dtype", "form", "us", "GFLOP/s", "frac", "CPU GF/s", "kernel"))
+    for c in cs:
+        key = (c["M"], c["layers"][1], c["layers"][0])
+        cg = cpu.get(key if c["family"] != "base" else (256, 1024, 1024))
+        c["cpu_port_gflops_f32"] = round(cg["gflops"], 1) if cg else None
+        c["cpu_threads"] = cg["threads"] if cg else None
+        print("%-26s %-11s %-10s %-6s %9.2f %10.1f %7.4f %9s  %s" % (
+            c["name"], "%d,%d,%d" % c["tiles"], c["dtype"], c["form"], c["us"], c["gflops"], c["frac_of_peak"],
+            ("%.1f" % cg["gflops"]) if cg else "-", c["kernel_name"]), flush=True)
+    if args.json:
+        with open(args.json, "w") as f:
+            json.dump(cs, f, indent=0)
+
+
+if __name__ == "__main__":
+    main()

@@ -36,8 +36,35 @@ static std::vector<int64_t> parse_list(const char *s) {
   return v;
 }
 
+static int run_case(int argc, char **argv);
+
+// --cases FILE: one case per line (the flags of a single run), all in this process - the shape sweeps of tools/refbench.py
+// (benchmarks/config/matmul/*.json, fc/*.json) would otherwise pay a process start + HIP initialisation per row
 int main(int argc, char **argv) {
+  if (argc == 3 && std::string(argv[1]) == "--cases") {
+    FILE *f = fopen(argv[2], "r");
+    if (!f) { fprintf(stderr, "tpp_replay: cannot open %s\n", argv[2]); return 2; }
+    char line[1024];
+    int rc = 0;
+    while (fgets(line, sizeof line, f)) {
+      std::vector<char *> av{argv[0]};
+      for (char *t = strtok(line, " \t\r\n"); t; t = strtok(nullptr, " \t\r\n")) av.push_back(t);
+      if (av.size() < 2 || av[1][0] == '#') continue;
+      fprintf(stderr, "tpp_replay: case:");
+      for (size_t i = 1; i < av.size(); ++i) fprintf(stderr, " %s", av[i]);
+      fprintf(stderr, "\n");
+      rc |= run_case((int)av.size(), av.data());
+    }
+    fclose(f);
+    return rc;
+  }
+  return run_case(argc, argv);
+}
+
+static int run_case(int argc, char **argv) {
   int64_t batch = 256, tile = 32, tile_n = 0, tile_k = 0, n_iter = 100;
+  bool kernel_args = false; // mlir-gen --kernel=args: the output is an argument, the matmul accumulates into it (no BETA_0)
+  int vnni = 2, split = -1, variant = -1;
   std::vector<int64_t> layers = {1024, 1024, 1024, 1024};
   bool bias = false, relu = false, whole = false, chain = false, print = false, c1 = false, rnd = false, bf16 = false;
   int queue = 1, threads = 1;
@@ -61,6 +88,10 @@ int main(int argc, char **argv) {
     else if (a == "--print") print = true;
     else if (a == "--c1") c1 = true;
     else if (a == "--bf16") bf16 = true; // mlir-gen --float-type=bf16 --vnni=2: bf16 storage, W in VNNI-2 blocks
+    else if (a == "--vnni") vnni = atoi(next()); // --vnni=4 (benchmarks/config/*: the *_dp4_* rows): W in [K/4][N][4] blocks
+    else if (a == "--kernel") kernel_args = std::string(next()) == "args"; // const (default): zero fill folded into BETA_0; args: C += ...
+    else if (a == "--split") split = atoi(next());     // xsmm_hip_force_split for this case (-1: the runtime's model)
+    else if (a == "--variant") variant = atoi(next()); // xsmm_hip_force_variant at dispatch (-1: the runtime's choice)
     else if (a == "--random") rnd = true; // uniform [-1, 1) * fill instead of constant fills (switching power)
     else { fprintf(stderr, "unknown flag %s\n", a.c_str()); return 2; }
   }
@@ -111,7 +142,9 @@ int main(int argc, char **argv) {
     return 0;
   }
   const int L = (int)layers.size() - 1;
-  int64_t gflags = XSMM_GEMM_FLAG_BETA_0; // mlir-gen --kernel=const: zero fill folded into BETA_0
+  // mlir-gen --kernel=const: zero fill folded into BETA_0; --kernel=args: the output tensor is a function argument the contraction
+  // accumulates into (MLIRGen.cpp:249-253; test/Integration/mlir-gen.mlir:17,28: 10 * 1 + 1 = 11)
+  int64_t gflags = kernel_args ? 0 : XSMM_GEMM_FLAG_BETA_0;
   const int64_t ukind = relu ? XSMM_UNARY_RELU : XSMM_UNARY_NONE;
   const int64_t bkind = bias ? XSMM_BINARY_ADD : XSMM_BINARY_NONE, bflags = bias ? XSMM_BINARY_FLAG_BCAST_COL_IN_0 : 0;
   double flops = 0;
@@ -140,6 +173,9 @@ int main(int argc, char **argv) {
   for (int l = 0; l < L; ++l) { W[l] = dalloc((size_t)layers[l] * layers[l + 1], 1.0f / (float)layers[l]); B[l] = dalloc((size_t)layers[l + 1], 0.5f); }
 
   if (bf16) gflags |= XSMM_GEMM_WIRE_VNNI_B;
+  const int old_vf = xsmm_hip_set_vnni_factor(bf16 ? vnni : 2);
+  xsmm_hip_force_split(split);
+  xsmm_hip_force_variant(variant);
   xsmm_hip_set_async(1);
   xsmm_hip_set_tile_queue(queue);
   std::vector<int64_t> handle(L);
@@ -151,6 +187,7 @@ int main(int argc, char **argv) {
     else       // packed tiles: [MB][KB][t][t] x [NB][KB][t][t] -> [MB][NB][t][t]
       handle[l] = xsmm_fused_brgemm_dispatch(dt, tile, tn, tk, tk, tn, tn, tile * tk, tk * tn, gflags, 0, ukind, bflags, bkind);
   }
+  xsmm_hip_force_variant(-1);
   int chained = -1;
   std::vector<void *> pa(L), pb(L), pc(L), pd(L);
   std::vector<int64_t> z(L, 0), br(L);
@@ -218,5 +255,10 @@ int main(int argc, char **argv) {
     }
     printf("( %g, %g, %g, %g, %g, %g, %g, %g )\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
   }
+  xsmm_hip_set_vnni_factor(old_vf);
+  xsmm_hip_force_split(-1);
+  for (void *p : act) CHECK(hipFree(p));
+  for (void *p : W) CHECK(hipFree(p));
+  for (void *p : B) CHECK(hipFree(p));
   return 0;
 }

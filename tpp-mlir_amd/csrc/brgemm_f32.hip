@@ -716,7 +716,8 @@ static hipError_t launch_fast(const GemmArgs &a, hipStream_t s) {
 
 hipError_t launch_gemm_bf16_fast(int tile, const GemmArgs &a, hipStream_t s); // brgemm_bf16.hip
 hipError_t launch_f32_lw(int tile, const GemmArgs &a, hipStream_t s);         // brgemm_f32_lw.hip (tile 4: 128x64, forced variant 10 only - it measures within 2 % of brgemm_f32_fast<128x64>)
-hipError_t launch_f32_lw_grouped(int tile, const GemmArgs &a, const WorkItem *items, int n_items, hipStream_t s);
+hipError_t launch_f32_lw_grouped(int tile, const GemmArgs &a, const WorkItem *items, int n_items, int split, hipStream_t s);
+hipError_t launch_f32_lw_split(int tile, const GemmArgs &a, int split, hipStream_t s); // hipErrorOutOfMemory / InvalidValue: not launched
 int pick_bf16_tile(const GemmDesc &d);
 bool bf16_fast_eligible(const GemmDesc &d);
 
@@ -737,6 +738,7 @@ static hipError_t launch_grouped_t(const GemmArgs &a, const WorkItem *items, int
 }
 
 #define g_num_cus device_cu_count() /* compute units of the current device (gemm_common.h) */
+constexpr int SPLIT_MAX_WG = 16; // = SPLIT_MAX of split_scratch.h
 
 hipError_t launch_bf16_grouped64(const GemmArgs &a, const WorkItem *items, int n_items, hipStream_t s); // brgemm_bf16.hip
 hipError_t launch_bf16_small32(const GemmArgs &a, const WorkItem *items, int n_items, hipStream_t s); // brgemm_bf16_small.hip
@@ -776,6 +778,37 @@ int bf16_lw_b_kind(const GemmDesc &d) {
   return bf16_flat_eligible(d) ? 2 : -1;
 }
 
+// How many workgroups share the batch-reduce range of ONE output tile (SPLIT kernels of brgemm_f32_lw.hip) - 1 = no split.
+// tile: 1 = 64x64 + K2, 2 = 64x32 + K4, 3 = 32x32 + K4; tiles: output tiles of the whole launch; chunks: 64-k chunks per tile.
+// Fitted to profiles/r05_split_sweep.txt (whole-layer calls of the reference's skinny benchmark shapes over tile x split count):
+//  * a workgroup alone on a CU needs c(tile) us per chunk (the matrix pipes' rate: 0.213 us for a 32x32x64 chunk);
+//  * a split costs R = 2.6-2.7 us whatever the count - three dependent trips to the memory side: partial tile written through
+//    and acknowledged, arrival counter, the other partials read back - so it pays only where it takes more than that off the K loop;
+//  * more workgroups than CUs never paid: 128 x 1024 x 4096 on 32x32 tiles 17.1 us unsplit, 12.9 (S = 2: 256 workgroups), 13.6 (S = 4:
+//    512), 15.6 (6), 20.6 (8) - every further round of workgroups pays its own prologue and hand-off.
+// Hence: the largest S with tiles * S <= CUs, if the K-loop time it saves exceeds R by a margin. The answer depends on the
+// descriptor, the batch count and the number of tiles in the launch only: the same call pattern always adds in the same order.
+// xsmm_hip_force_split / TPP_HIP_SPLIT: 0 / 1 = never split, n > 1 = always n (clamped to the chunks), -1 = this model.
+static std::atomic<int> g_forced_split{[] {
+  const char *e = getenv("TPP_HIP_SPLIT");
+  return e ? atoi(e) : -1;
+}()};
+int force_gemm_split(int v) { return g_forced_split.exchange(v < -1 ? -1 : v); }
+static int choose_f32_split(int tile, long long tiles, long long chunks) {
+  const int forced = g_forced_split.load(std::memory_order_relaxed);
+  if (tile < 1 || tile > 3 || tiles <= 0 || chunks < 2) return 1;
+  const long long smax = chunks < SPLIT_MAX_WG ? chunks : SPLIT_MAX_WG;
+  if (forced >= 0) return forced <= 1 ? 1 : (int)(forced < smax ? forced : smax);
+  const double c = tile == 1 ? 0.92 : tile == 2 ? 0.46 : 0.213;
+  long long S = g_num_cus / tiles;
+  if (S > smax) S = smax;
+  if (S > chunks / 4) S = chunks / 4; // at least four chunks per workgroup
+  if (S < 2) return 1;
+  const long long per = (chunks + S - 1) / S;
+  const double saved = c * (double)(chunks - per);
+  return saved > 2.7 + 0.8 ? (int)S : 1;
+}
+
 static bool k32_pairs_on() {
   static const bool on = [] {
     const char *e = getenv("TPP_HIP_GROUPED_K32_PAIRS"); // A/B runs: 0 = 32-k tiles on the generic grouped kernel, as before round 4
@@ -794,7 +827,7 @@ static std::atomic<const char *> g_last_grouped{""};
 const char *last_grouped_kernel() { return g_last_grouped.load(std::memory_order_relaxed); }
 #define note_grouped(name, ...) (g_last_grouped.store(name, std::memory_order_relaxed), (__VA_ARGS__))
 hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_items, bool vec_ok, bool out_ok, bool pair_ok,
-                               hipStream_t stream) {
+                               int64_t br_hint, hipStream_t stream) {
   if (d.m <= 0 || d.n <= 0 || n_items <= 0) return hipSuccess;
   GemmArgs a;
   a.A = a.B = a.D = nullptr; a.C = nullptr;
@@ -803,6 +836,7 @@ hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_i
   a.ep = (d.beta0 ? EP_BETA0 : 0) | (d.bias ? EP_BIAS : 0) | (d.relu ? EP_RELU : 0) | (d.vnni_c ? EP_VNNI_C : 0);
   a.tiles_m = a.tiles_n = 0;
   a.vf = d.vnni_factor ? d.vnni_factor : 2;
+  a.split = 0; a.scratch = nullptr; a.split_cnt = nullptr;
   const bool tiles_ok = vec_ok && d.n % 4 == 0 && d.k % GK == 0; // 16-byte pieces; ragged m / n edges are predicated
   const bool vec = vec_ok && d.n % 4 == 0 && d.k % 4 == 0 && d.dtype == DT_F32 && !d.vnni_b && !((d.lda | d.ldb | d.stride_a | d.stride_b) & 3) &&
                    d.lda < (1 << 24) && d.ldb < (1 << 24); // (32-bit tile-relative lane offsets: 32 rows x ld x 4 B < 2^31)
@@ -812,10 +846,15 @@ hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_i
   // ... and 32-k tiles (--tiles=32,32,32, the reference's MLP benchmark) when every batch count is even: the loader waves build a
   // 64-k chunk from the blocks of two batch elements (brgemm_f32_lw.hip, pair mode)
   const bool k_pairs = k32_pairs_on() && d.k == 32 && pair_ok && d.stride_a >= 0 && d.stride_b >= 0 && d.stride_a < (1 << 26) && d.stride_b < (1 << 26);
-  if (vec && d.m % 32 == 0 && d.n % 32 == 0 && ((d.k % BK == 0 && d.variant != V_GENERIC) || (k_pairs && !d.generic_forced)) && d.lda < (1 << 22) && d.ldb < (1 << 22) && d.ldc < (1 << 22)) {
+  // (n that is not a multiple of 32 - the reference's --tiles=64,48,64 / 32,48,32 configs: the last 32-column tile of an item is
+  // ragged, the loader-wave kernels clamp its loads and mask its stores; needs the 16-byte output pieces of out_ok and ldc % 4)
+  const bool n_ragged = d.n % 32 != 0;
+  const bool fam_ok = n_ragged ? (!d.generic_forced && d.n > 32 && (d.k % BK == 0 || k_pairs)) // (plan_gemm knows no tile for such an n: variant = generic)
+                               : ((d.k % BK == 0 && d.variant != V_GENERIC) || (k_pairs && !d.generic_forced));
+  if (vec && d.m % 32 == 0 && fam_ok && d.lda < (1 << 22) && d.ldb < (1 << 22) && d.ldc < (1 << 22)) {
     const int64_t t64 = (d.m % 64 == 0 && d.n % 64 == 0) ? (int64_t)n_items * (d.m / 64) * (d.n / 64) : 0;
-    const int64_t t6432 = (d.m % 64 == 0) ? (int64_t)n_items * (d.m / 64) * (d.n / 32) : 0;
-    if (n_items <= 65535 * 32) { // grid.x carries the item index
+    const int64_t t6432 = (d.m % 64 == 0) ? (int64_t)n_items * (d.m / 64) * ((d.n + 31) / 32) : 0;
+    if (n_items <= 65535 * 2) { // grid.x carries the item index (x split)
       auto nm = [&](const char *plain, const char *pairs) { return d.k == 32 ? pairs : plain; };
       (void)nm;
       // the loader-wave kernels (brgemm_f32_lw.hip) in grouped mode; TPP_GROUPED_FAST builds the round-1 register-staged family for A/B runs
@@ -824,9 +863,18 @@ hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_i
       if (t6432 >= g_num_cus) return note_grouped("brgemm_f32_fast<64x32,k2> grouped", launch_fast_grouped_t<2, 1, 2, TPP_NACC, true>(a, items, n_items, stream));
       return note_grouped("brgemm_f32_fast<32x32,k4> grouped", launch_fast_grouped_t<1, 1, 4, TPP_NACC, false>(a, items, n_items, stream));
 #else
-      if (t64 >= g_num_cus) return note_grouped(t64 >= 2 * g_num_cus ? nm("brgemm_f32_lw<64x64> grouped", "brgemm_f32_lw<64x64> grouped, 32-k pairs") : nm("brgemm_f32_lw<64x64,k2> grouped", "brgemm_f32_lw<64x64,k2> grouped, 32-k pairs"), launch_f32_lw_grouped(t64 >= 2 * g_num_cus ? 0 : 1, a, items, n_items, stream));
-      if (t6432 >= g_num_cus) return note_grouped(nm("brgemm_f32_lw<64x32,k4> grouped", "brgemm_f32_lw<64x32,k4> grouped, 32-k pairs"), launch_f32_lw_grouped(2, a, items, n_items, stream));
-      return note_grouped(nm("brgemm_f32_lw<32x32,k4> grouped", "brgemm_f32_lw<32x32,k4> grouped, 32-k pairs"), launch_f32_lw_grouped(3, a, items, n_items, stream));
+      if (t64 >= g_num_cus) return note_grouped(t64 >= 2 * g_num_cus ? nm("brgemm_f32_lw<64x64> grouped", "brgemm_f32_lw<64x64> grouped, 32-k pairs") : nm("brgemm_f32_lw<64x64,k2> grouped", "brgemm_f32_lw<64x64,k2> grouped, 32-k pairs"), launch_f32_lw_grouped(t64 >= 2 * g_num_cus ? 0 : 1, a, items, n_items, 1, stream));
+      const int64_t t32 = (int64_t)n_items * (d.m / 32) * ((d.n + 31) / 32);
+      // (rounds of workgroups x per-chunk time, as pick_f32_variant: 1.5 rounds of 64x32 tiles lose to 3 half-rounds of 32x32 tiles)
+      if (t6432 >= g_num_cus && !(0.23 * 1.05 * (double)((t32 + g_num_cus - 1) / g_num_cus) < 0.46 * (double)((t6432 + g_num_cus - 1) / g_num_cus)))
+        return note_grouped(nm("brgemm_f32_lw<64x32,k4> grouped", "brgemm_f32_lw<64x32,k4> grouped, 32-k pairs"), launch_f32_lw_grouped(2, a, items, n_items, 1, stream));
+      // skinny groups (fewer 64x32 tiles than CUs): 32x32 tiles, and the batch-reduce range of a tile over several workgroups
+      // when the model says so (choose_f32_split: from the descriptor, the first item's batch count and the group's size)
+      const int64_t chunks = d.k == 32 ? br_hint / 2 : br_hint * (d.k / BK);
+      const int S = choose_f32_split(3, t32, chunks);
+      static const char *const split_names[2] = {"brgemm_f32_lw<32x32,k4> grouped, split", "brgemm_f32_lw<32x32,k4> grouped, 32-k pairs, split"};
+      if (S > 1) return note_grouped(split_names[d.k == 32], launch_f32_lw_grouped(3, a, items, n_items, S, stream));
+      return note_grouped(nm("brgemm_f32_lw<32x32,k4> grouped", "brgemm_f32_lw<32x32,k4> grouped, 32-k pairs"), launch_f32_lw_grouped(3, a, items, n_items, 1, stream));
 #endif
     }
   }
@@ -868,7 +916,14 @@ static int pick_f32_variant(const GemmDesc &d) {
     if (tiles(128, 64) > 0 && 1.85 * (double)r128 < (double)r64) return V_F32_128x64;
     return V_F32_LW_64x64K2;
   }
-  if (tiles(64, 32) >= g_num_cus) return V_F32_LW_64x32K2;
+  if (tiles(64, 32) >= g_num_cus) {
+    // one 64x32 workgroup per CU at a time (96 KiB of LDS), two 32x32 ones (64 KiB): rounds x per-chunk time. 256 x 3072 (384 tiles of
+    // 64x32 = 1.5 rounds) measured 15.9 us against 12.6 on 768 tiles of 32x32; where the rounds tie (C3: 256 / 512 tiles, 128 x 4096)
+    // the larger tile stays - same time, half the LDS traffic (profiles/r05_split_sweep.txt)
+    const int64_t r6432 = (tiles(64, 32) + g_num_cus - 1) / g_num_cus, r32 = (tiles(32, 32) + g_num_cus - 1) / g_num_cus;
+    if (tiles(32, 32) > 0 && 0.23 * 1.05 * (double)r32 < 0.46 * (double)r6432) return V_F32_LW_32x32K4;
+    return V_F32_LW_64x32K2;
+  }
   if (tiles(32, 32) > 0 && tiles(32, 32) >= tiles(64, 64) * 2 && tiles(64, 32) < g_num_cus) return V_F32_LW_32x32K4;
   if (tiles(64, 64) > 0) return V_F32_LW_64x64K2;
   if (tiles(64, 32) > 0) return V_F32_LW_64x32K2;
@@ -1026,6 +1081,7 @@ hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C,
   a.ep = (d.beta0 ? EP_BETA0 : 0) | (d.bias ? EP_BIAS : 0) | (d.relu ? EP_RELU : 0) | (d.vnni_c ? EP_VNNI_C : 0);
   a.tiles_m = a.tiles_n = 0;
   a.vf = d.vnni_factor ? d.vnni_factor : 2;
+  a.split = 0; a.scratch = nullptr; a.split_cnt = nullptr;
   int v = d.variant;
   const bool aligned16 = ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0;
   if (v != V_GENERIC && !aligned16) v = V_GENERIC;
@@ -1044,10 +1100,21 @@ hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C,
   case V_F32_32x32K4: return launch_fast<1, 1, 4, TPP_NACC, false>(a, stream);
   case V_F32_128x64: return launch_fast<4, 2, 1, TPP_NACC, true>(a, stream);
   case V_F32_64x64K2: return launch_fast<2, 2, 2, TPP_NACC, true>(a, stream);
-  case V_F32_LW_64x64:
+  case V_F32_LW_64x64: return launch_f32_lw(0, a, stream);
   case V_F32_LW_64x64K2:
-  case V_F32_LW_64x32K2: return launch_f32_lw(v - V_F32_LW_64x64, a, stream);
-  case V_F32_LW_32x32K4: return launch_f32_lw(3, a, stream);
+  case V_F32_LW_64x32K2:
+  case V_F32_LW_32x32K4: {
+    // skinny outputs (fewer tiles than CUs, a long batch-reduce): several workgroups per tile (choose_f32_split)
+    const int tile = v == V_F32_LW_32x32K4 ? 3 : v - V_F32_LW_64x64;
+    const int bm = tile == 3 ? 32 : 64, bn = tile == 1 ? 64 : 32;
+    const int S = choose_f32_split(tile, (long long)(d.m / bm) * (d.n / bn), (long long)a.br * (d.k / BK));
+    if (S > 1) {
+      const hipError_t e = launch_f32_lw_split(tile, a, S, stream);
+      if (e != hipErrorOutOfMemory && e != hipErrorInvalidValue) return e;
+      (void)hipGetLastError(); // no scratch block: the unsplit launch
+    }
+    return launch_f32_lw(tile, a, stream);
+  }
   case V_F32_LW_128x64: return launch_f32_lw(4, a, stream);
   case V_BF16_FAST:
   case V_BF16_DMA128:
@@ -1102,10 +1169,14 @@ hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C,
       d.stride_b >= 0 && d.stride_a < (1 << 26) && d.stride_b < (1 << 26) && d.lda < (1 << 22) && d.ldb < (1 << 22) && d.ldc < (1 << 22)) {
     const int64_t t64 = (d.m % 64 == 0 && d.n % 64 == 0) ? (d.m / 64) * (d.n / 64) : 0;
     const int64_t t6432 = (d.m % 64 == 0) ? (d.m / 64) * (d.n / 32) : 0;
-    if (t64 >= g_num_cus) return launch_f32_lw_grouped(t64 >= 2 * g_num_cus ? 0 : 1, a, nullptr, 1, stream);
-    if (t6432 >= g_num_cus) return launch_f32_lw_grouped(2, a, nullptr, 1, stream);
-    return launch_f32_lw_grouped(3, a, nullptr, 1, stream);
+    if (t64 >= g_num_cus) return launch_f32_lw_grouped(t64 >= 2 * g_num_cus ? 0 : 1, a, nullptr, 1, 1, stream);
+    if (t6432 >= g_num_cus) return launch_f32_lw_grouped(2, a, nullptr, 1, 1, stream);
+    return launch_f32_lw_grouped(3, a, nullptr, 1, choose_f32_split(3, (d.m / 32) * (d.n / 32), a.br / 2), stream);
   }
+  // a SINGLE invoke of a tile whose n ends inside a 32-column block (--tiles=64,48,64): the loader-wave kernel its group runs on
+  if (vec && !d.generic_forced && d.k % BK == 0 && a.br >= 1 && d.m % 32 == 0 && d.n > 32 && d.n % 32 != 0 && d.lda < (1 << 22) && d.ldb < (1 << 22) &&
+      d.ldc < (1 << 22))
+    return launch_f32_lw_grouped(3, a, nullptr, 1, choose_f32_split(3, (d.m / 32) * ((d.n + 31) / 32), (long long)a.br * (d.k / BK)), stream);
   if (d.dtype == DT_F32) return vec ? launch_grouped_t<float, false, true>(a, nullptr, 1, stream)
                                     : launch_grouped_t<float, false, false>(a, nullptr, 1, stream);
   if (d.vnni_b && vec16_4) return launch_grouped_t<unsigned short, true, true, 4>(a, nullptr, 1, stream);

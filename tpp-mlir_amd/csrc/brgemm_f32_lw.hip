@@ -19,6 +19,7 @@
 #include "gemm_common.h"
 #include "xsmm_desc.h"
 #include "chain_args.h"
+#include "split_scratch.h"
 #include <type_traits>
 
 namespace tpp {
@@ -28,10 +29,19 @@ constexpr int LW_NSLOT = 4; // LDS ring slots
 constexpr int LW_C_AUX = C_STORE_AUX; // write-through C stores (gemm_common.h)
 
 typedef __attribute__((address_space(3))) void lds_void_lw;
+typedef __attribute__((address_space(1))) unsigned int g_u32_lw;
 
 // NSLOT: ring depth (4; 3 for the 128x64 tile, whose 48 KiB slots would not fit four times)
 // NL loader waves for the A panel, NLB (default NL) for the B panel
-template <int WM, int WN, int WK, bool GROUPED, int NL = 1, int NSLOT = LW_NSLOT, int NLB = NL>
+// SPLIT (round 5): the batch-reduce dimension of ONE output tile is split over p.split workgroups - skinny outputs (the reference's
+// M = 128 / 256 benchmark shapes: 32 .. 128 tiles on a 256-CU chip) otherwise leave most CUs idle. Workgroup (tile, s) owns the
+// contiguous chunk range [T s / S, T (s + 1) / S), parks its partial tile in a scratch block (write-through stores), drains them
+// and adds 1 to the tile's arrival counter; the workgroup whose add returns S - 1 (the last to arrive, whichever it is) sums the S
+// partials IN SPLIT ORDER 0 .. S-1 - a fixed order of additions: results are bit-reproducible run to run, no float atomics -, adds
+// C (beta = 1), bias, relu, stores, and resets the counter. No workgroup ever waits for another one (no co-residency assumption).
+// GROUPED or SPLIT kernels also take n that is not a multiple of the tile width (the reference's --tiles=64,48,64 / 32,48,32):
+// the B loader clamps the column pieces, the epilogue masks its loads and stores; the plain kernel (C2, C3) carries none of this.
+template <int WM, int WN, int WK, bool GROUPED, int NL = 1, int NSLOT = LW_NSLOT, int NLB = NL, bool SPLIT = false>
 __global__ __launch_bounds__(64 * (WM * WN * WK + NL + NLB)) void brgemm_f32_lw(GemmArgs p, const WorkItem *__restrict__ items) {
   constexpr int NMW = WM * WN * WK; // MFMA waves
   constexpr int BM = 32 * WM, BN = 32 * WN;
@@ -55,13 +65,36 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NL + NLB)) void brgemm_f32_lw(
   // XCD-blocked (8, bn, bm) or plain (1, tiles_n, tiles_m) grid: see brgemm_f32.hip. GROUPED (tile queue): grid (items,
   // tiles_n, tiles_m), workgroup = one tile of one queued invoke, operands and batch count from its item. A template
   // parameter, not a run-time test: the plain kernel is the headline kernel and must not carry a second mode (measured: 0.6 %).
+  static_assert(!SPLIT || WK > 1, "the split epilogue is the K-split tiles' float4 epilogue");
+  constexpr bool RAGN = GROUPED || SPLIT; // n may end inside the tile's last 32-column block (a multiple of 4)
   WorkItem it{p.A, p.B, p.C, p.D, (int64_t)p.br};
-  if constexpr (GROUPED) {
-    if (items) it = items[blockIdx.x]; // (no list: a single invoke of the grouped kernel, operands in the arguments)
+  int tm, tn, sp = 0, tile_id = 0;
+  if constexpr (SPLIT && GROUPED) {
+    // grid (items * S, tiles_n, tiles_m): x = item * S + s (the two block rows of a layer that share a B panel then meet on one XCD)
+    const int item = (int)blockIdx.x / p.split;
+    sp = (int)blockIdx.x - item * p.split;
+    if (items) it = items[item];
+    tm = (int)blockIdx.z, tn = (int)blockIdx.y;
+    tile_id = (item * (int)gridDim.y + tn) * (int)gridDim.z + tm;
+  } else if constexpr (SPLIT) {
+    // linear grid of S * tiles units in [s][tn][tm] order; XCD x (= workgroup id mod 8) takes the x-th eighth of the list, so that
+    // one XCD's L2 sees ONE k range of A and B (every byte of the operands then comes out of HBM about once)
+    const int tiles = p.tiles_m * p.tiles_n, total = tiles * p.split;
+    int u = (int)blockIdx.x;
+    if ((total & 7) == 0) u = (u & 7) * (total >> 3) + (u >> 3);
+    sp = u / tiles;
+    tile_id = u - sp * tiles;
+    tn = tile_id / p.tiles_m;
+    tm = tile_id - tn * p.tiles_m;
+  } else {
+    if constexpr (GROUPED) {
+      if (items) it = items[blockIdx.x]; // (no list: a single invoke of the grouped kernel, operands in the arguments)
+    }
+    tm = GROUPED ? (int)blockIdx.z : (int)(blockIdx.x >> p.xn_shift) * p.tiles_m + (int)blockIdx.z;
+    tn = GROUPED ? (int)blockIdx.y : (int)(blockIdx.x & ((1u << p.xn_shift) - 1)) * p.tiles_n + (int)blockIdx.y;
   }
-  const int tm = GROUPED ? (int)blockIdx.z : (int)(blockIdx.x >> p.xn_shift) * p.tiles_m + (int)blockIdx.z;
-  const int tn = GROUPED ? (int)blockIdx.y : (int)(blockIdx.x & ((1u << p.xn_shift) - 1)) * p.tiles_n + (int)blockIdx.y;
   const int m0 = tm * BM, n0 = tn * BN;
+  const int nvalid = RAGN ? p.n - n0 : BN; // columns of this tile that exist (>= BN everywhere but in a ragged last tile)
   const float *__restrict__ A = (const float *)it.A;
   const float *__restrict__ B = (const float *)it.B;
   float *__restrict__ C = (float *)it.C;
@@ -70,7 +103,10 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NL + NLB)) void brgemm_f32_lw(
   // from element 2t+1. Only the loaders' source offsets know; the LDS images and the MFMA waves are the same.
   const bool pair = GROUPED && p.k == 32;
   const int kchunks = pair ? 1 : p.k / LW_BK;
-  const int T = pair ? (int)it.br / 2 : (int)it.br * kchunks;
+  const int Tall = pair ? (int)it.br / 2 : (int)it.br * kchunks;
+  // SPLIT: this workgroup's chunks [t_first, t_first + T) of the tile's Tall
+  const int t_first = SPLIT ? (int)(((long long)Tall * sp) / p.split) : 0;
+  const int T = SPLIT ? (int)(((long long)Tall * (sp + 1)) / p.split) - t_first : Tall;
 
   if (wave >= NMW) {
     // ---- loader waves --------------------------------------------------------------------
@@ -92,12 +128,20 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NL + NLB)) void brgemm_f32_lw(
       const int r = 4 * (part + 2 * j) + (lane >> 4), pc = (lane & 15) ^ r;
       voA2[j] = (unsigned)((r * (int)p.lda + (pair ? (pc >> 3) * (int)p.stride_a + 4 * (pc & 7) : 4 * pc)) * 4);
     }
-    const unsigned voB = (unsigned)(((lane / (BN / 4)) * (int)p.ldb + 4 * (lane % (BN / 4))) * 4);
+    // (a ragged last tile: the 16-byte column pieces beyond n re-read the tile's last valid piece - in bounds, and the columns
+    // they feed are never stored)
+    const int pieceB = RAGN && nvalid < BN ? (lane % (BN / 4) < nvalid / 4 ? lane % (BN / 4) : nvalid / 4 - 1) : lane % (BN / 4);
+    const unsigned voB = (unsigned)(((lane / (BN / 4)) * (int)p.ldb + 4 * pieceB) * 4);
     const unsigned stepA = (unsigned)(16 * (int)p.lda * 4), stepB = (unsigned)(RPI * (int)p.ldb * 4);
     const float *g = isA ? A + (int64_t)m0 * p.lda : B + n0; // panel base of the chunk being fetched
     int kc = 0;
     const int64_t d_in = isA ? (int64_t)LW_BK : (int64_t)LW_BK * p.ldb;
     const int64_t d_wrap = (isA ? p.stride_a : p.stride_b) * (pair ? 2 : 1) - (int64_t)(kchunks - 1) * d_in;
+    if constexpr (SPLIT) { // start at chunk t_first: batch element t_first / kchunks (pair mode: the pair t_first), k block t_first % kchunks
+      const int b0 = t_first / kchunks;
+      kc = t_first - b0 * kchunks;
+      g += (int64_t)b0 * (isA ? p.stride_a : p.stride_b) * (pair ? 2 : 1) + (int64_t)kc * d_in;
+    }
     const unsigned pairB = pair ? (unsigned)(((int)p.stride_b - 32 * (int)p.ldb) * 4) : 0u; // rows 32.. of a pair chunk: the second element
     auto issue = [&](int slot) __attribute__((always_inline)) {
       float *base = smem_lw + slot * SLOT + (isA ? 0 : A_STAGE);
@@ -166,7 +210,9 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NL + NLB)) void brgemm_f32_lw(
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
   float bias = 0.0f;
-  if (p.ep & EP_BIAS) bias = ((const float *)it.D)[ccol]; // (every K group: the groups share the epilogue)
+  if constexpr (WK == 1) { // (the K-split tiles' epilogue works on float4 pieces: bias4 below)
+    if ((p.ep & EP_BIAS) && (!RAGN || ccol < p.n)) bias = ((const float *)it.D)[ccol];
+  }
   // ... and the K-split tiles' float4 epilogue: its four bias values per lane (16-byte column piece lane & 7). With ONE MFMA wave
   // per SIMD (32x32 + K4) they come in here as well - behind the combine's second barrier the load was an exposed round trip:
   // the batch-256 layer of the reference's MLP 7.05 -> 6.82 us per launch, its tile-queue iteration 19.47 -> 19.25 us (same box,
@@ -174,11 +220,12 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NL + NLB)) void brgemm_f32_lw(
   // measured 0.02 us SLOWER on C3, so those tiles keep the load in the epilogue
   constexpr bool BIAS_EARLY = WK > 1 && WM * WN * WK <= 4;
   f32x4 bias4 = {0.0f, 0.0f, 0.0f, 0.0f};
+  const bool piece_ok = !RAGN || wn * 32 + 4 * (lane & 7) < nvalid; // this lane's 16-byte column piece of the float4 epilogue exists
   if constexpr (BIAS_EARLY) {
-    if (p.ep & EP_BIAS) bias4 = *(const f32x4 *)((const float *)it.D + n0 + wn * 32 + 4 * (lane & 7));
+    if ((p.ep & EP_BIAS) && piece_ok) bias4 = *(const f32x4 *)((const float *)it.D + n0 + wn * 32 + 4 * (lane & 7));
   }
-  if (wk == 0) {
-    if (!(p.ep & EP_BETA0)) {
+  if (wk == 0 && !SPLIT) { // (SPLIT: C joins the ordered sum of the partials in the last workgroup's epilogue)
+    if (!(p.ep & EP_BETA0) && (!RAGN || ccol < p.n)) {
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         acc[r] = __builtin_bit_cast(
@@ -278,8 +325,9 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NL + NLB)) void brgemm_f32_lw(
     constexpr int IPG = 4 / WK; // store instructions per lane per group
     const int c4 = lane & 7, rsel = lane >> 3; // 16-byte column piece, row within the instruction's 8 rows
     if constexpr (!BIAS_EARLY) {
-      if (p.ep & EP_BIAS) bias4 = *(const f32x4 *)((const float *)it.D + n0 + wn * 32 + 4 * c4);
+      if ((p.ep & EP_BIAS) && piece_ok) bias4 = *(const f32x4 *)((const float *)it.D + n0 + wn * 32 + 4 * c4);
     }
+    f32x4 part[IPG];
 #pragma unroll
     for (int j = 0; j < IPG; ++j) {
       const int q = 8 * (wk * IPG + j) + rsel;  // row of the 32x32 tile: q = (r & 3) + 4 * lh + 8 * (r >> 2)
@@ -288,13 +336,59 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NL + NLB)) void brgemm_f32_lw(
       f32x4 v = *(const f32x4 *)src;
 #pragma unroll
       for (int g = 1; g < WK; ++g) v += *(const f32x4 *)(src + g * (WM * WN) * 1024);
+      part[j] = v;
+    }
+    if constexpr (SPLIT) {
+      // park the partial tile: block [tile][split][piece], piece = (j * NMW + MFMA wave) * 64 + lane - every wave instruction writes
+      // 1 KiB contiguous; the last workgroup reads the S blocks with the same lane mapping
+      constexpr int TILE = BM * BN; // floats per partial
+      const int S = p.split;
+      float *scr = p.scratch + (size_t)tile_id * S * TILE;
+      const __amdgpu_buffer_rsrc_t rsrcS = __builtin_amdgcn_make_buffer_rsrc((void *)scr, 0, 0x7fffffff, 0x00020000);
+      const unsigned pvo = (unsigned)((wave * 64 + lane) * 16);
+#pragma unroll
+      for (int j = 0; j < IPG; ++j)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, part[j]), rsrcS, pvo, (unsigned)((sp * TILE + j * NMW * 256) * 4), 16);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the write-through stores of this wave have been acknowledged
+      __syncthreads();                                  // ... and those of every MFMA wave (red is free again)
+      unsigned *flag = (unsigned *)smem_lw;
+      if (wave == 0 && lane == 0)
+        *flag = __hip_atomic_fetch_add((g_u32_lw *)(p.split_cnt + tile_id), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      if (*flag != (unsigned)(S - 1)) return; // not the last to arrive: done
+      if (wave == 0 && lane == 0) __hip_atomic_store((g_u32_lw *)(p.split_cnt + tile_id), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // for the next launch
+      // the ordered sum: partial 0 + partial 1 + ... (sc1 loads: the blocks were written by workgroups behind other L2s)
+#pragma unroll
+      for (int j = 0; j < IPG; ++j) {
+        f32x4 acc4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcS, pvo, (unsigned)((j * NMW * 256) * 4), 16));
+        int s2 = 1;
+        for (; s2 + 4 <= S; s2 += 4) { // four loads in flight, added in order
+          f32x4 t[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            t[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcS, pvo, (unsigned)(((s2 + e) * TILE + j * NMW * 256) * 4), 16));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc4 += t[e];
+        }
+        for (; s2 < S; ++s2)
+          acc4 += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcS, pvo, (unsigned)((s2 * TILE + j * NMW * 256) * 4), 16));
+        part[j] = acc4;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < IPG; ++j) {
+      const int q = 8 * (wk * IPG + j) + rsel;
+      f32x4 v = part[j];
+      const unsigned co = (unsigned)(((wm * 32 + q) * (int)p.ldc + wn * 32 + 4 * c4) * 4);
+      if constexpr (SPLIT) {
+        if (!(p.ep & EP_BETA0) && piece_ok) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcC, co, 0, 0));
+      }
       v += bias4;
       if (p.ep & EP_RELU) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
       }
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrcC,
-                                             (unsigned)(((wm * 32 + q) * (int)p.ldc + wn * 32 + 4 * c4) * 4), 0, LW_C_AUX);
+      if (piece_ok) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrcC, co, 0, LW_C_AUX);
     }
     return;
   }
@@ -302,8 +396,9 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NL + NLB)) void brgemm_f32_lw(
   for (int r = 0; r < 16; ++r) {
     float v = acc[r] + bias;
     if (p.ep & EP_RELU) v = v > 0.0f ? v : 0.0f;
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrcC, voffC,
-                                          (unsigned)((r & 3) + 8 * (r >> 2)) * ldcb, LW_C_AUX);
+    if (!RAGN || ccol < p.n)
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrcC, voffC,
+                                            (unsigned)((r & 3) + 8 * (r >> 2)) * ldcb, LW_C_AUX);
   }
 }
 
@@ -362,17 +457,78 @@ static hipError_t launch_lw_grouped_t(const GemmArgs &a, const WorkItem *items, 
   GemmArgs args = a;
   args.tiles_m = args.tiles_n = 0;
   args.xn_shift = 0;
-  hipLaunchKernelGGL((brgemm_f32_lw<WM, WN, WK, true>), dim3((unsigned)n_items, a.n / BN, a.m / BM), dim3(NT), lds, s, args, items);
+  hipLaunchKernelGGL((brgemm_f32_lw<WM, WN, WK, true>), dim3((unsigned)n_items, (a.n + BN - 1) / BN, a.m / BM), dim3(NT), lds, s, args, items);
   return hipGetLastError();
 }
 
-// tile as in launch_f32_lw
-hipError_t launch_f32_lw_grouped(int tile, const GemmArgs &a, const WorkItem *items, int n_items, hipStream_t s) {
+// ---- SPLIT launches: S workgroups per output tile (kernel comment; scratch: split_scratch.h) ----------------------------------
+// whole-layer call: linear grid of S * tiles workgroups
+template <int WM, int WN, int WK> static hipError_t launch_lw_split_t(const GemmArgs &a, int S, hipStream_t s) {
+  constexpr int BM = 32 * WM, BN = 32 * WN, NT = 64 * (WM * WN * WK + 2);
+  constexpr size_t lds = (size_t)LW_NSLOT * (BM * LW_BK + LW_BK * BN) * sizeof(float);
+  const long long tiles = (long long)(a.m / BM) * ((a.n + BN - 1) / BN);
+  const SplitScratch *sc = split_scratch_for(s, tiles, tiles * S * BM * BN);
+  if (!sc) return hipErrorOutOfMemory; // the caller falls back to the unsplit launch
+  static std::atomic<unsigned long long> lds_set{0};
+  if (hipError_t e = ensure_dynamic_lds((const void *)brgemm_f32_lw<WM, WN, WK, false, 1, LW_NSLOT, 1, true>, (int)lds, lds_set); e != hipSuccess) return e;
+  GemmArgs args = a;
+  args.tiles_m = a.m / BM;
+  args.tiles_n = (a.n + BN - 1) / BN;
+  args.xn_shift = 0;
+  args.split = S;
+  args.scratch = sc->partial;
+  args.split_cnt = sc->cnt;
+  hipLaunchKernelGGL((brgemm_f32_lw<WM, WN, WK, false, 1, LW_NSLOT, 1, true>), dim3((unsigned)(tiles * S)), dim3(NT), lds, s, args, (const WorkItem *)nullptr);
+  return hipGetLastError();
+}
+// tile queue group: grid (items * S, tiles_n, tiles_m)
+template <int WM, int WN, int WK>
+static hipError_t launch_lw_grouped_split_t(const GemmArgs &a, const WorkItem *items, int n_items, int S, hipStream_t s) {
+  constexpr int BM = 32 * WM, BN = 32 * WN, NT = 64 * (WM * WN * WK + 2);
+  constexpr size_t lds = (size_t)LW_NSLOT * (BM * LW_BK + LW_BK * BN) * sizeof(float);
+  const int tiles_m = a.m / BM, tiles_n = (a.n + BN - 1) / BN;
+  const long long tiles = (long long)n_items * tiles_m * tiles_n;
+  const SplitScratch *sc = split_scratch_for(s, tiles, tiles * S * BM * BN);
+  if (!sc) return hipErrorOutOfMemory;
+  static std::atomic<unsigned long long> lds_set{0};
+  if (hipError_t e = ensure_dynamic_lds((const void *)brgemm_f32_lw<WM, WN, WK, true, 1, LW_NSLOT, 1, true>, (int)lds, lds_set); e != hipSuccess) return e;
+  GemmArgs args = a;
+  args.tiles_m = args.tiles_n = 0;
+  args.xn_shift = 0;
+  args.split = S;
+  args.scratch = sc->partial;
+  args.split_cnt = sc->cnt;
+  hipLaunchKernelGGL((brgemm_f32_lw<WM, WN, WK, true, 1, LW_NSLOT, 1, true>), dim3((unsigned)(n_items * S), tiles_n, tiles_m), dim3(NT), lds, s, args, items);
+  return hipGetLastError();
+}
+
+// tile as in launch_f32_lw; split > 1: that many workgroups per output tile (K-split tiles 1 .. 3 only); n may end inside the last tile
+hipError_t launch_f32_lw_grouped(int tile, const GemmArgs &a, const WorkItem *items, int n_items, int split, hipStream_t s) {
+  if (split > 1) {
+    hipError_t e = hipErrorInvalidValue;
+    switch (tile) {
+    case 1: e = launch_lw_grouped_split_t<2, 2, 2>(a, items, n_items, split, s); break;
+    case 2: e = launch_lw_grouped_split_t<2, 1, 4>(a, items, n_items, split, s); break;
+    case 3: e = launch_lw_grouped_split_t<1, 1, 4>(a, items, n_items, split, s); break;
+    default: break;
+    }
+    if (e != hipErrorOutOfMemory && e != hipErrorInvalidValue) return e;
+    (void)hipGetLastError(); // no scratch block (or a tile without a split instance): the unsplit launch
+  }
   switch (tile) {
   case 0: return launch_lw_grouped_t<2, 2, 1>(a, items, n_items, s);
   case 1: return launch_lw_grouped_t<2, 2, 2>(a, items, n_items, s);
   case 2: return launch_lw_grouped_t<2, 1, 4>(a, items, n_items, s);
   case 3: return launch_lw_grouped_t<1, 1, 4>(a, items, n_items, s);
+  default: return hipErrorInvalidValue;
+  }
+}
+// whole-layer call on S workgroups per tile; hipErrorOutOfMemory / hipErrorInvalidValue: not launched, use launch_f32_lw
+hipError_t launch_f32_lw_split(int tile, const GemmArgs &a, int split, hipStream_t s) {
+  switch (tile) {
+  case 1: return launch_lw_split_t<2, 2, 2>(a, split, s);
+  case 2: return launch_lw_split_t<2, 1, 4>(a, split, s);
+  case 3: return launch_lw_split_t<1, 1, 4>(a, split, s);
   default: return hipErrorInvalidValue;
   }
 }

@@ -24,6 +24,11 @@ struct GemmArgs {
   int tiles_m, tiles_n;
   int vf;              // VNNI blocking factor of B (2 or 4) when the operand is VNNI-packed
   int xn_shift;        // brgemm_f32_lw, XCD-blocked grid: log2 of the XCD blocks along N (set by its launcher; blockIdx.x = M block << xn_shift | N block)
+  // SPLIT kernels (the batch-reduce range of one output tile over `split` workgroups, set by their launchers): partial tiles
+  // [tile][split][BM * BN] and one arrival counter per tile, both in the launch stream's scratch block (split_scratch.h)
+  int split;
+  float *scratch;
+  unsigned *split_cnt;
 };
 
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short h) {

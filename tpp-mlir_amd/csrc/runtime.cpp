@@ -1024,7 +1024,7 @@ struct TileQueue {
     if (!pending.armed) return;
     pending.armed = false;
     Segment &S = segs[pending.seg];
-    if (pending.kind == KIND_GEMM) HIP_OK(launch_gemm_grouped(*(const GemmDesc *)pending.desc, S.list_dev, pending.n, pending.vec_ok, pending.out_ok, pending.pair_ok, pending.stream));
+    if (pending.kind == KIND_GEMM) HIP_OK(launch_gemm_grouped(*(const GemmDesc *)pending.desc, S.list_dev, pending.n, pending.vec_ok, pending.out_ok, pending.pair_ok, S.items[0].w.br, pending.stream));
     else if (pending.kind == KIND_UNARY) HIP_OK(launch_unary_grouped(*(const UnaryDesc *)pending.desc, S.list_dev, pending.n, pending.stream));
     else HIP_OK(launch_binary_grouped(*(const BinaryDesc *)pending.desc, S.list_dev, pending.n, pending.stream));
     S.list_used = true;
@@ -1109,7 +1109,7 @@ struct TileQueue {
       pending = Pending{true, kind, desc, rp, n, vec_ok, out_ok, pair_ok, stream};
       if (!defer) issue_pending();
     } else {
-      if (kind == KIND_GEMM) HIP_OK(launch_gemm_grouped(*(const GemmDesc *)desc, pinned[slot], n, vec_ok, out_ok, pair_ok, stream));
+      if (kind == KIND_GEMM) HIP_OK(launch_gemm_grouped(*(const GemmDesc *)desc, pinned[slot], n, vec_ok, out_ok, pair_ok, pinned[slot][0].br, stream));
       else if (kind == KIND_UNARY) HIP_OK(launch_unary_grouped(*(const UnaryDesc *)desc, pinned[slot], n, stream));
       else HIP_OK(launch_binary_grouped(*(const BinaryDesc *)desc, pinned[slot], n, stream));
       launched();
@@ -2481,6 +2481,7 @@ extern "C" const char *xsmm_hip_kernel_name(int64_t handle) {
 }
 extern "C" const char *xsmm_hip_last_grouped_kernel(void) { return last_grouped_kernel(); }
 extern "C" void xsmm_hip_force_variant(int v) { cfg().forced_variant.store(v); }
+extern "C" int xsmm_hip_force_split(int v) { return tpp::force_gemm_split(v); }
 // the VNNI blocking factor of bf16 B operands dispatched from now on (2 or 4); returns the previous one, -1 for an invalid factor
 extern "C" int xsmm_hip_set_vnni_factor(int v) {
   if (v != 2 && v != 4) return -1;

@@ -64,8 +64,11 @@ hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C,
 // n_items invokes of ONE descriptor in one launch (items: device array of WorkItem)
 // vec_ok: every item's A and B are 16-byte aligned; out_ok: every item's C is 16-byte and D 8-byte aligned;
 // pair_ok: every item's batch count is even (32-k tiles on the loader-wave kernels)
+// br_hint: the batch count of the first item - only a hint for how many workgroups share a tile's batch-reduce range (split
+// launches of skinny groups); the kernels take every item's own count from the list
 hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_items, bool vec_ok, bool out_ok, bool pair_ok,
-                               hipStream_t stream);
+                               int64_t br_hint, hipStream_t stream);
+int force_gemm_split(int workgroups_per_tile); // xsmm_hip_force_split (brgemm_f32.hip); returns the previous setting
 int f32_chain_tile(const GemmDesc &d); // 1 / 2 / 3 = the f32 chain tile the descriptor was planned on, -1 = none (brgemm_f32.hip)
 const char *last_grouped_kernel(); // kernel family of the most recent launch_gemm_grouped ("" before the first)
 // fills d.variant / d.name; returns false if no kernel can run the descriptor

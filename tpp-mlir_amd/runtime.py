@@ -100,6 +100,7 @@ _SIGNATURES = {
     "xsmm_hip_kernel_name": (ctypes.c_char_p, [I64]),
     "xsmm_hip_last_grouped_kernel": (ctypes.c_char_p, []),
     "xsmm_hip_force_variant": (None, [ctypes.c_int]),
+    "xsmm_hip_force_split": (ctypes.c_int, [ctypes.c_int]),
     "xsmm_hip_set_vnni_factor": (ctypes.c_int, [ctypes.c_int]),
     "xsmm_hip_get_vnni_factor": (ctypes.c_int, []),
     "xsmm_hip_version": (ctypes.c_char_p, []),
@@ -263,6 +264,10 @@ class XsmmRuntime:
 
     def force_variant(self, v):
         self.lib.xsmm_hip_force_variant(v)
+
+    def force_split(self, workgroups_per_tile):
+        """-1 the model, 0 / 1 never, n > 1: n workgroups share the batch-reduce range of one f32 output tile; returns the previous setting"""
+        return self.lib.xsmm_hip_force_split(workgroups_per_tile)
 
     def set_vnni_factor(self, v):
         """VNNI blocking factor (2 / 4) of bf16 B operands dispatched from now on; returns the previous one"""
