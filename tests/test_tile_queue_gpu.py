@@ -361,11 +361,12 @@ def test_f32_tiles_of_32_k_pair_their_batch_elements(rtq, tiles, layout, kb):
             assert ("32-k pairs" in ran) == (kb % 2 == 0), (ran, kb)
 
 
-@pytest.mark.parametrize("tm,tn,items,family", [(64, 64, 272, "64x64,k2"), (64, 64, 544, "64x64>"), (64, 32, 288, "64x32,k4"), (32, 32, 300, "32x32,k4")],
-                         ids=["64x64k2", "64x64", "64x32k4", "32x32k4"])
+@pytest.mark.parametrize("tm,tn,items,family", [(64, 64, 272, "64x64,k2"), (64, 64, 544, "64x64>"), (64, 32, 256, "64x32,k4"), (64, 32, 288, "32x32,k4"), (32, 32, 300, "32x32,k4")],
+                         ids=["64x64k2", "64x64", "64x32k4", "64x32-as-32x32k4", "32x32k4"])
 def test_f32_tiles_of_32_k_pairs_on_every_grouped_family(rtq, tm, tn, items, family):
     """many 32-k tile invokes in one group: the pair mode on each of the four loader-wave families the group size selects
-    (launch_gemm_grouped: the largest tile that still gives every CU a workgroup)"""
+    (launch_gemm_grouped: the largest tile that still gives every CU a workgroup; round 5: 288 tiles of 64x32 would be two rounds of
+    workgroups, the second nearly empty - they run as 576 tiles of 32x32, two per CU)"""
     rt = rtq
     kb = 4
     rng = np.random.default_rng(tm + tn + items)
@@ -616,3 +617,42 @@ def test_trace_cache_with_several_callers(rtq):
     # group that arrives at a complete group just terminates it - the results above are the check, the counters only say that
     # the cache was in use)
     assert replayed > 0 and abandoned + terminated > 0, (launches, checked, replayed, terminated, abandoned)
+
+
+def test_single_layer_timing_loop_replays_without_abandoning(rtq):
+    """the reference's one-layer benchmarks (benchmarks/config/matmul/*.json, fc/*.json): tpp-run calls the SAME group of tile invokes N
+    times with nothing in between; the invoke that ends an iteration's group is the group's own first member again. Round 5: that wrap
+    is a known way for a complete group to end (every iteration used to abandon its replay and rebuild the bookkeeping: the run was
+    host-bound). 20 iterations of C += A W on 48 tiles: result = 20 accumulated passes, and after the first few groups nothing is
+    abandoned any more."""
+    rt = rtq
+    M, N, K, tm, tn, tk = 128, 768, 768, 32, 64, 64
+    rng = np.random.default_rng(77)
+    MB, NB, KB = M // tm, N // tn, K // tk
+    A = rng.uniform(-1, 1, M * K).astype(np.float32)
+    W = rng.uniform(-0.05, 0.05, K * N).astype(np.float32)
+    C0 = rng.uniform(-1, 1, M * N).astype(np.float32)
+    h = rt.brgemm_dispatch(F32, tm, tn, tk, tk, tn, tn, tm * tk, tk * tn, 0)
+    dA, dW, dC = dev(A), dev(W), dev(C0)
+    iters = 20
+
+    def one_iteration():
+        for i in range(MB):
+            for j in range(NB):
+                rt.brgemm(F32, h, dA, i * KB * tm * tk, dW, j * KB * tk * tn, dC, (i * NB + j) * tm * tn, KB)
+
+    for _ in range(4):  # recorded, replayed, the wrap learnt
+        one_iteration()
+    stats0 = rt.tile_queue_stats()
+    for _ in range(iters - 4):
+        one_iteration()
+    rt.synchronize()
+    launches, checked, replayed, terminated, abandoned = (b - a for a, b in zip(stats0, rt.tile_queue_stats()))
+    # (lock-free arrivals are counted when their group's window closes: the last warm-up group may fall on either side of stats0)
+    assert abandoned == 0 and checked == 0 and abs(replayed - (iters - 4) * MB * NB) <= MB * NB, (launches, checked, replayed, terminated, abandoned)
+    ref = C0.copy()
+    for _ in range(iters):
+        for i in range(MB):
+            for j in range(NB):
+                orc.brgemm(F32, tm, tn, tk, tk, tn, tn, tm * tk, tk * tn, 0, A, i * KB * tm * tk, W, j * KB * tk * tn, ref, (i * NB + j) * tm * tn, KB)
+    close(host(dC, C0), ref, F32)

@@ -196,7 +196,9 @@ static int run_solo_handover(int reps, const char *what) {
   std::thread other;
   const int tiles_n = N / TS, tiles = (M / TS) * tiles_n;
   for (int rep = 0; rep < reps; ++rep) {
-    if (rep == reps / 2)
+    // the second thread is started from INSIDE the one caller's tile loop: its first invoke - the process's one
+    // solo -> two-sided switch - lands while the owner is marking members of a replayed group through the solo window
+    auto start_other = [&] {
       other = std::thread([&] {
         int k = 0; // (bounded: thousands of locked arrivals from two threads would hand the queue to the scheduler thread)
         while (!stop.load(std::memory_order_acquire) && k < 600) {
@@ -205,9 +207,11 @@ static int run_solo_handover(int reps, const char *what) {
           usleep(20);
         }
       });
+    };
     for (int l = 1; l <= LAYERS; ++l) memset(act[l], 0xff, (size_t)M * N * sizeof(float));
     for (int l = 0; l < LAYERS; ++l)
       for (int t = 0; t < tiles; ++t) {
+        if (rep == reps / 2 && l == 1 && t == tiles / 2) start_other();
         const int i = t / tiles_n, j = t % tiles_n;
         xsmm_fused_brgemm_invoke(XSMM_DTYPE_F32, hf, act[l], (int64_t)i * TS * K, w[l], j * TS, act[l + 1], (int64_t)i * TS * N + j * TS,
                                  nullptr, 0, K / KB);
