@@ -181,8 +181,15 @@ TPP_XSMM_EXPORT void xsmm_hip_flush(void);
  * RESIDENCY: the single launch needs every workgroup of its grid on a compute unit at the same time (one per CU). The grid is
  * checked against the CUs the stream may use (a CU mask is honoured); what cannot be checked is another process - or another
  * stream's LDS-heavy kernel - occupying CUs at that moment: the single-launch path needs the device to itself. Every wait inside
- * the kernel is bounded (50 ms): a starved launch is REPORTED at the next xsmm_hip_synchronize / perf_stop_timer (the runtime dies
- * loudly, its results are invalid), never hung. A harness that shares the GPU sets TPP_HIP_CHAIN=0.
+ * the kernel is bounded (50 ms): a starved launch never hangs, and since round 5 it does not end the process either - the library
+ * DEGRADES (the reference never aborts on a valid invoke): the FIRST single launch of every (stream, tile grid, layer count) is
+ * followed by a stream synchronisation and a look at its error word - a device that is shared from the start is found out before
+ * anyone could consume the launch's outputs, the call runs call by call at once (return value 0; the inputs are intact: beta 0,
+ * the outputs overlap no operand); later launches stay asynchronous and their calls are journaled - if the check at the next
+ * xsmm_hip_synchronize / perf_stop_timer finds a starved launch, the journaled calls are re-run call by call, in launch order,
+ * before that call returns. Either way one line goes to stderr and every later chain invoke of the process runs call by call.
+ * (What the re-run cannot repair: work that OTHERS enqueued between a starved asynchronous launch and the synchronisation has read
+ * invalid outputs.) A harness that knows it shares the GPU sets TPP_HIP_CHAIN=0 and spares itself the timeouts.
  * TPP_HIP_CHAIN=0 disables the single-launch path. */
 TPP_XSMM_EXPORT int xsmm_hip_fused_brgemm_chain_invoke(int64_t dtype, int64_t n, const int64_t *handles, void *const *a,
                                                        const int64_t *off_a, void *const *b, const int64_t *off_b,

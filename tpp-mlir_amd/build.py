@@ -126,6 +126,15 @@ def build_tools(verbose=False):
             if r.returncode != 0:
                 raise RuntimeError("building %s failed:\n%s" % (name, r.stderr))
         outs.append(out)
+    # test helper (tests/test_chain_starved_gpu.py): a kernel that holds compute units; never loaded by the product
+    src = os.path.join(root, "tools", "ubench", "cu_hog.hip")
+    out = os.path.join(root, "tools", "cu_hog.so")
+    if os.path.exists(src):
+        if not (os.path.exists(out) and os.path.getmtime(out) > os.path.getmtime(src)):
+            r = subprocess.run([hipcc(), "--offload-arch=" + ARCH, "-O2", "-shared", "-fPIC", src, "-o", out], capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("building cu_hog.so failed:\n%s" % r.stderr)
+        outs.append(out)
     return outs
 
 

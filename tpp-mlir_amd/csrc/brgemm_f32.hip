@@ -1066,6 +1066,7 @@ bool plan_gemm(GemmDesc &d, int forced_variant) {
   }
   d.variant = v;
   d.generic_forced = forced_variant == V_GENERIC;
+  d.variant_forced = forced_variant >= 0 && v == forced_variant;
   strncpy(d.name, variant_name(v), sizeof(d.name) - 1);
   d.name[sizeof(d.name) - 1] = 0;
   return true;
@@ -1088,6 +1089,16 @@ hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C,
   // the bf16 kernel stores 16-byte row pieces and reads the bias 8 bytes at a time
   if (v >= V_BF16_FAST && v != V_BF16_SMALL32 && ((((uintptr_t)C) & 15) || (d.bias && (((uintptr_t)D) & 7)))) v = V_GENERIC;
   if (v == V_BF16_SMALL32 && ((((uintptr_t)C) & 7) || (d.bias && (((uintptr_t)D) & 7)))) v = V_GENERIC;
+  // Small bf16 outputs with a LONG reduction: the 32x32 K-split kernel (fragments straight from global memory, two groups of loads
+  // in flight per wave) is latency-bound there - 128 x 1024 x 4096: 15.4 us against 9.8 on 64 loader-wave tiles of 32x64; at
+  // K = 1024 it still wins (4.9 against 5.1), the curves cross between 1024 and 2048 (profiles/r05_bf16_skinny_small_vs_lw.txt). The
+  // batch count arrives with the invoke, so this choice is made here and not at dispatch.
+  if (v == V_BF16_SMALL32 && d.variant == V_BF16_SMALL32 && !d.generic_forced && (int64_t)a.br * d.k >= 1536 && d.k % 64 == 0 && d.m % 32 == 0 && d.n % 64 == 0 &&
+      !(((uintptr_t)C) & 15) && !(d.bias && (((uintptr_t)D) & 7)) && !d.variant_forced) {
+    GemmDesc e = d;
+    e.m = (d.m + 63) / 64 * 64; // (bf16_fast_eligible asks for m % 64; the 32x64 tile needs m % 32 only)
+    if (bf16_fast_eligible(e)) v = V_BF16_LW_32x64;
+  }
   if (v >= V_BF16_LW_32x64 && v <= V_BF16_LW4_128x128 && a.br < 1) v = V_GENERIC; // empty batch (C = epilogue of nothing): the loader-wave kernels assume a chunk
   switch (v) {
   // LDS-DMA panels for every tile but the smallest: measured C2 +3 %, C3 +8 %, 4096^3 +3 %, 3 x 1024 MLP

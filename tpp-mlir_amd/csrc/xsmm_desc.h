@@ -26,6 +26,7 @@ struct GemmDesc {
                         // factor is not on the wire - the reference asks libxsmm_cpuid_dot_pack_factor, VNNIUtils.cpp:25-45)
   int variant;          // kernel variant chosen at dispatch (see gemm_variants.h), -1 = by invoke
   int generic_forced;   // variant = generic because it was asked for (xsmm_hip_force_variant / a VNNI C store), not because no fast tile fits
+  int variant_forced;   // variant is the one xsmm_hip_force_variant asked for: invoke-time refinements (batch-count dependent) leave it alone
   char name[64];        // kernel name for profiles
   char trace[160];      // dispatch tuple + kernel name as text (trace ranges)
 };
