@@ -46,17 +46,6 @@ typedef unsigned int u32x2_lw __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(1))) unsigned int g_u32_lw;
 
 constexpr int BLW_BK = 64; // k per chunk
-// COLUMN PAIRS (round 5; VNNI-2 B image, tiles with two column blocks per wave: 64x128 and 128x128). A dword of the image is one
-// column's k pair and neighbouring dwords are neighbouring COLUMNS, so no k permutation makes a wider read deliver one column's
-// k values - but WHICH column a lane's MFMA operand feeds is free: lane li of column block j takes column 2 li + j of the wave's 64
-// columns (instead of 32 j + li). One ds_read_b64 then holds the k pair of BOTH of the lane's columns - a k-step's B fragments
-// are 4 eight-byte reads (two ds_read2st64_b64, full LDS rate) instead of 8 four-byte reads (half rate) -, every element is the same
-// chain of products in the same order (bit-identical to the previous mapping, chain and single layer alike), and in the epilogue
-// the two blocks' accumulators pack straight into 16-byte pieces of 8 consecutive columns (no v_permlane32_swap).
-// -DTPP_BLW_COLPAIR=0: the previous mapping (A/B side builds).
-#ifndef TPP_BLW_COLPAIR
-#define TPP_BLW_COLPAIR 1
-#endif
 #ifndef TPP_BLW_INTERLEAVE
 #define TPP_BLW_INTERLEAVE 2 // fragment reads dealt between the MFMAs of a k-step: 1 = the four-accumulator tile (128x128), 2 = + 64x128; 0 = in front (A/B)
 #endif
@@ -425,14 +414,12 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
   constexpr int NFB = FULLPF ? 2 * KS : KS;
   static_assert(!FULLPF || NSLOT % 2 == 0, "chunk parity from the ring slot");
   static_assert(SUP == 1 || FULLPF, "two chunks per barrier: the tiles with two fragment sets");
-  constexpr bool CP = TPP_BLW_COLPAIR && FLATB == 0 && TN == 2; // column pairs (comment at TPP_BLW_COLPAIR)
   bf16x8_lw af[NFB][TM];
   u32x4 bw[NFB][TN]; // B fragments as dwords
   int b_lane[TN];   // dword index of this lane's column of tile j in pair-row 4*lh of a k-step
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     b_lane[j] = (4 * lh) * BN + (wn * TN + j) * 32 + li;
-    if constexpr (CP) b_lane[j] = (4 * lh) * BN + wn * 64 + 2 * li; // (both column blocks: the lane's 8-byte column pair)
     if constexpr (FLATB == 2) {
       // flat image [64 k][BN] (blw_loader FB = 2), fragments by ds_read_b64_tr_b16: in every 16 lanes, lane p names the 8-byte
       // piece (row p / 4, columns 4 (p % 4) ..) of a [4 k][16 n] block and receives COLUMN p of it - four consecutive k of
@@ -455,18 +442,6 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
       const int row = (wm * TM + i) * 32 + li;
       af[buf][i] = *(const bf16x8_lw *)(as + row * 128 + (((2 * ks + lh) ^ ((row >> 1) & 7)) << 4));
     }
-    if constexpr (CP) {
-      // pair-rows 8 ks + 4 lh + r, r = 0 .. 3: 8 bytes each = (column 2 li, column 2 li + 1); rows r, r + 1 are 512 B apart
-      const unsigned int *bp = bs + b_lane[0] + (8 * ks) * BN;
-      // kept as they arrive (rows r, r + 1 per ds_read2st64_b64: bw[buf][0] = rows 0, 1, bw[buf][1] = rows 2, 3, each row (column
-      // 2 li, column 2 li + 1)); the MFMA operands - one column's four k pairs - are put together right in front of their MFMAs, two
-      // k-steps after the read (building them here made the compiler wait for every read on the spot: 10.3 against 9.3 us per layer)
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const u32x2_lw q0 = *(const u32x2_lw *)(bp + (2 * r) * BN), q1 = *(const u32x2_lw *)(bp + (2 * r + 1) * BN);
-        bw[buf][r] = u32x4{q0[0], q0[1], q1[0], q1[1]};
-      }
-    } else
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       if constexpr (FLATB == 2) {
@@ -562,25 +537,14 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
       constexpr bool IL = TPP_BLW_INTERLEAVE >= 1 && (!FULLPF || (TPP_BLW_INTERLEAVE >= 2 && SUP == 1 && TM * TN >= 2));
       if constexpr (!IL) __builtin_amdgcn_sched_barrier(0);
       if (!skip_math) {
-        if constexpr (CP) {
-          const u32x4 r01 = bw[CUR + q][0], r23 = bw[CUR + q][1];
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            const u32x4 bj = {r01[j], r01[2 + j], r23[j], r23[2 + j]}; // column 2 li + j: its k pairs of rows 0 .. 3
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_lw, bj), af[CUR + q][i], acc[i][j], 0, 0, 0);
-          }
-        } else {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_lw, bw[CUR + q][j]), af[CUR + q][i], acc[i][j], 0, 0, 0);
-        }
       }
       if constexpr (IL && !FULLPF) {
-        constexpr int NRD = TM + (FLATB == 4 || CP ? TN : 2 * TN); // DS read instructions of a step (VNNI-4: one ds_read2_b64 per column tile; column pairs: two ds_read2st64_b64)
+        constexpr int NRD = TM + (FLATB == 4 ? TN : 2 * TN); // DS read instructions of a step (VNNI-4: one ds_read2_b64 per column tile)
         constexpr int PER = (NRD + TM * TN - 2) / (TM * TN - 1);
 #pragma unroll
         for (int g_ = 0; g_ < TM * TN - 1; ++g_) {
@@ -590,7 +554,7 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       } else if constexpr (IL) {
         // two fragment sets (64x128): the second half of a chunk reads TWO k-steps of the next chunk per step, behind every MFMA a share
-        constexpr int NRD = 2 * (TM + (FLATB == 4 || CP ? TN : 2 * TN)), PER = (NRD + TM * TN - 1) / (TM * TN);
+        constexpr int NRD = 2 * (TM + (FLATB == 4 ? TN : 2 * TN)), PER = (NRD + TM * TN - 1) / (TM * TN);
 #pragma unroll
         for (int g_ = 0; g_ < TM * TN; ++g_) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -623,19 +587,13 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     // bias: fetched here (8 bytes = 4 columns per register quad), used in the epilogue - its latency hides under the K loop
-    // (column pairs: the lane's columns of register quad g are the 8 consecutive columns 16 g + 8 lh .. of the wave's 64 - dword x of
-    // those 16 bytes is (column 2 (x + 8 g + 4 lh) of block 0, the next one of block 1): biasw[0][g] = dwords 0, 1, biasw[1][g] = 2, 3)
     u32x2_lw biasw[TN][4];
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         biasw[j][g] = u32x2_lw{0u, 0u};
-        if constexpr (CP) {
-          if (ep & EP_BIAS) biasw[j][g] = *(const u32x2_lw *)((const unsigned short *)Y.D + n0 + wn * 64 + 16 * g + 8 * lh + 4 * j);
-        } else {
-          if (ep & EP_BIAS) biasw[j][g] = *(const u32x2_lw *)((const unsigned short *)Y.D + n0 + (wn * TN + j) * 32 + 8 * g + 4 * lh);
-        }
+        if (ep & EP_BIAS) biasw[j][g] = *(const u32x2_lw *)((const unsigned short *)Y.D + n0 + (wn * TN + j) * 32 + 8 * g + 4 * lh);
       }
     if (MULTI && wave == 0) blw_stamp(p, l, 0, lane);
     if (MULTI && NLA > 1 && l > 0) __builtin_amdgcn_s_barrier(); // S2 (the loaders' rendezvous after the seam wait)
@@ -744,21 +702,7 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
       // columns 32*j + 8*g + 4*lh + (0..3)
       const __amdgpu_buffer_rsrc_t rsrcC = __builtin_amdgcn_make_buffer_rsrc(
           (void *)(C + (int64_t)(m0 + wm * 32 * TM) * Y.ldc + n0 + wn * 32 * TN), 0, 0x7fffffff, 0x00020000);
-      if constexpr (!MULTI && CP) {
-        if (!(ep & EP_BETA0)) { // beta = 1, column pairs: 16 bytes = the lane's 8 columns of quad g, dword x = (block 0, block 1) of register 4 g + x
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              const u32x4 c4 = __builtin_amdgcn_raw_buffer_load_b128(rsrcC, (unsigned)(32 * i + li) * ldcb + (unsigned)((16 * g + 8 * lh) * 2), 0, 0);
-#pragma unroll
-              for (int x = 0; x < 4; ++x) {
-                acc[i][0][4 * g + x] += __uint_as_float(c4[x] << 16);
-                acc[i][1][4 * g + x] += __uint_as_float(c4[x] & 0xffff0000u);
-              }
-            }
-        }
-      } else if constexpr (!MULTI) {
+      if constexpr (!MULTI) {
         if (!(ep & EP_BETA0)) { // beta = 1: add C before the single rounding (8-byte loads, rare path)
 #pragma unroll
           for (int i = 0; i < TM; ++i)
@@ -779,28 +723,6 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
       unsigned char *ot = smem_c + ((last_slot + 1 + wmn / WPS) % NSLOT) * SLOT + (wmn % WPS) * STAGE_W;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        if constexpr (CP) {
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            // dword x of the 16-byte piece = (acc[i][0][4g + x], acc[i][1][4g + x]) = columns 16 g + 8 lh + 2 x, + 1
-            const unsigned int bw_[4] = {biasw[0][g][0], biasw[0][g][1], biasw[1][g][0], biasw[1][g][1]};
-            u32x4 out;
-#pragma unroll
-            for (int x = 0; x < 4; ++x) {
-              float v0 = acc[i][0][4 * g + x] + __uint_as_float(bw_[x] << 16);
-              float v1 = acc[i][1][4 * g + x] + __uint_as_float(bw_[x] & 0xffff0000u);
-              if (relu) {
-                v0 = __builtin_fmaxf(v0, 0.0f);
-                v1 = __builtin_fmaxf(v1, 0.0f);
-              }
-              typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-              typedef float f32x2_t __attribute__((ext_vector_type(2)));
-              const f32x2_t vv = {v0, v1};
-              out[x] = __builtin_bit_cast(unsigned int, __builtin_convertvector(vv, bf16x2_t)); // one v_cvt_pk_bf16_f32 (RNE)
-            }
-            *(u32x4 *)(ot + li * ES + (16 * g + 8 * lh) * 2) = out;
-          }
-        } else
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           float bias[4][4];
