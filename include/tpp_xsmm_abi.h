@@ -263,7 +263,9 @@ TPP_XSMM_EXPORT int xsmm_hip_force_split(int workgroups_per_tile);
  * `--vnni=4` rows of benchmarks/config/omp/mlir-bf16.json:68-100): a harness that lowers with vnni = 4 sets 4 here before it
  * dispatches. k must then be a multiple of 4 (dispatch dies otherwise); ldb is the k-group row stride / v as the compiler passes it
  * (ConvertLinalgToXsmm.cpp:1144). xsmm.unary VNNI2 (kind 28) always packs pairs - there is no VNNI-4 pack kind at this revision
- * (XsmmEnum.td:34-45). set returns the previous factor, -1 for an invalid one. */
+ * (XsmmEnum.td:34-45). set returns the previous factor, -1 for an invalid one. The setting is process-wide and read once per
+ * dispatch: set it BEFORE dispatching (a handle keeps the factor it was dispatched with); a VNNI A operand (wire flag 4096) is
+ * checked against the same factor (k a multiple of it; [m][k/v][v] is byte-identical to the flat row). */
 TPP_XSMM_EXPORT int xsmm_hip_set_vnni_factor(int factor);
 TPP_XSMM_EXPORT int xsmm_hip_get_vnni_factor(void);
 /* Library version string. */

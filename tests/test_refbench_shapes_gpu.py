@@ -114,8 +114,8 @@ def test_one_layer_of_every_tile_shape_as_the_compiler_emits_it(rt, M, N, K, til
 
 SPLIT_CASES = [
     # m, n, k, br, forced variant, beta0, bias, relu
-    (128, 1024, 64, 64, None, True, False, False),   # matmul 128x1024x4096 as one dispatch
-    (128, 768, 64, 36, None, False, True, True),     # fc 128x768x2304: 36 chunks (uneven ranges for most split counts)
+    (128, 1024, 64, 64, 9, True, False, False),      # matmul 128x1024x4096 as one dispatch, on the 32x32 + K4 tile
+    (128, 768, 64, 36, 9, False, True, True),        # fc 128x768x2304: 36 chunks (uneven ranges for most split counts)
     (128, 256, 64, 7, 6, False, True, False),        # 64x64 + K2 tile, fewer chunks than the largest split counts (empty ranges)
     (64, 96, 64, 5, 7, True, False, True),           # 64x32 + K4 tile
     (96, 160, 128, 3, 9, False, False, False),       # 32x32 + K4 tile, k = 2 chunks per batch element: a range may start inside an element
@@ -199,3 +199,41 @@ def test_split_groups_through_the_tile_queue(rt):
         rt.set_async(old_async)
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
     check_close(unpack_c(outs[0], M, N, t, t).reshape(-1), ref, F32, "split group", mag=mag, K=K)
+
+
+# ---------------------------------------------------------------- the 32x16 tiles (brgemm_f32_lw16.hip, variant 11)
+LW16_CASES = [
+    # m, n, k, br, kwargs
+    (32, 16, 64, 1, dict(beta0=True)),
+    (32, 16, 64, 1, dict()),                                            # beta = 1
+    (64, 48, 64, 3, dict(bias=True, relu=True)),                        # n = 48: three column tiles
+    (128, 96, 128, 2, dict(beta0=True, bias=True, lda=300, ldb=100, ldc=104, offs=(4, 8, 4, 4))),   # two chunks per batch element, strides
+    (96, 160, 64, 5, dict(sa=64, sb=64 * 160, lda=64 * 5, relu=True)),  # batch-reduce along k of one row-major A (the whole-layer form)
+    (128, 1024, 64, 16, dict(sa=64, sb=64 * 1024, lda=1024, beta0=True, bias=True, relu=True)),      # fc 128x1024x1024: 256 tiles, XCD-blocked order
+    (128, 768, 64, 12, dict(sa=64, sb=64 * 768, lda=768)),              # matmul 128x768x768: 192 tiles
+    (32, 80, 64, 0, dict(bias=True)),                                   # empty batch: C = C + bias
+]
+
+
+@pytest.mark.parametrize("case", LW16_CASES, ids=lambda c: "m%d_n%d_k%d_br%d" % c[:4])
+def test_f32_lw16_tiles_against_the_oracle(rt, case):
+    from test_parity_gpu import gemm_case
+    m, n, k, br, kw = case
+    name = gemm_case(rt, F32, m, n, k, br, seed=m + n + k + br, force=11, **kw)
+    assert "lw16<32x16" in name, name
+
+
+@pytest.mark.parametrize("br", [1, 2, 3, 4, 5, 6, 7, 8, 9, 13])
+def test_f32_lw16_every_chunk_stream_length(rt, br):
+    """every position of the 4-slot ring (1 .. 13 chunks), both accumulator starts"""
+    from test_parity_gpu import gemm_case
+    for beta0 in (True, False):
+        name = gemm_case(rt, F32, 64, 32, 64, br, beta0=beta0, bias=not beta0, relu=beta0, seed=br, force=11, offs=(4, 4, 4, 4))
+        assert "lw16" in name, name
+
+
+def test_skinny_whole_layers_pick_the_half_width_tiles(rt):
+    """the reference's M = 128 shapes: at most one 32x16 tile per CU -> the half-width tiles; wider outputs keep theirs"""
+    for (m, n, want) in ((128, 1024, "lw16<32x16"), (128, 768, "lw16<32x16"), (128, 3072, "lw<32x32"), (256, 768, "lw<32x32"), (512, 1024, "lw<64x32"), (1024, 1024, "lw<64x64")):
+        h = rt.brgemm_dispatch(F32, m, n, 64, 1024, n, n, 64, 64 * n, 0)
+        assert want in rt.kernel_name(h), (m, n, rt.kernel_name(h))

@@ -655,4 +655,11 @@ def test_single_layer_timing_loop_replays_without_abandoning(rtq):
         for i in range(MB):
             for j in range(NB):
                 orc.brgemm(F32, tm, tn, tk, tk, tn, tn, tm * tk, tk * tn, 0, A, i * KB * tm * tk, W, j * KB * tk * tn, ref, (i * NB + j) * tm * tn, KB)
-    close(host(dC, C0), ref, F32)
+    # 20 accumulated passes: the two sides' summation orders differ in every pass - the element-wise bar per pass (1e-5 relative + the
+    # f32 dot-product floor (K + 2) eps sum |a||w|), times the number of passes
+    got = host(dC, C0).astype(np.float64)
+    Af = A.reshape(MB, KB, tm, tk).transpose(0, 2, 1, 3).reshape(M, K).astype(np.float64)
+    Wf = W.reshape(NB, KB, tk, tn).transpose(1, 2, 0, 3).reshape(K, N).astype(np.float64)
+    mag = (np.abs(Af) @ np.abs(Wf)).reshape(MB, tm, NB, tn).transpose(0, 2, 1, 3).reshape(-1)
+    bar = 1e-5 * np.abs(ref) + iters * (K + 2) * 2.0 ** -24 * (mag + np.abs(ref))
+    assert (np.abs(got - ref) <= bar).all(), float((np.abs(got - ref) / bar).max())

@@ -11,16 +11,16 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SHAPES = [(128, 1024, 1024), (128, 1024, 4096), (128, 3072, 768), (128, 4096, 1024), (128, 768, 2304), (128, 768, 3072), (128, 768, 768),
           (256, 1024, 1024), (256, 768, 3072), (256, 768, 768), (256, 3072, 768), (1024, 352, 512), (1024, 512, 256), (512, 1024, 1024)]
-VARIANTS = {6: "64x64k2", 7: "64x32k4", 9: "32x32k4"}
+VARIANTS = {6: "64x64k2", 7: "64x32k4", 9: "32x32k4", 11: "32x16k4"}
 SPLITS = [1, 2, 3, 4, 6, 8, 12, 16]
 n_iter = int(sys.argv[sys.argv.index("-n") + 1]) if "-n" in sys.argv else 300
 cases = [("warm", 0, 0, ["--batch", "1024", "--layers", "1024,1024", "--whole-layer", "-n", "2000"])]
 for (M, N, K) in SHAPES:
     for v, vn in VARIANTS.items():
-        bm, bn = (64, 64) if v == 6 else (64, 32) if v == 7 else (32, 32)
+        bm, bn = (64, 64) if v == 6 else (64, 32) if v == 7 else (32, 16) if v == 11 else (32, 32)
         if M % bm or N % bn:
             continue
-        for S in SPLITS:
+        for S in ([1] if v == 11 else SPLITS):  # (the 32x16 tiles have no split launch)
             if S > 1 and K // 64 // S < 2:
                 continue
             cases.append(((M, N, K), vn, S, ["--batch", str(M), "--layers", "%d,%d" % (K, N), "--whole-layer", "--kernel", "args", "-n", str(n_iter),

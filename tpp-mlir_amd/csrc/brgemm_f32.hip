@@ -655,6 +655,7 @@ enum GemmVariant : int {
   V_GENERIC = 8,     // chosen per invoke when the fast preconditions fail
   V_F32_LW_32x32K4 = 9,   // 4 MFMA waves 1x1x4 + 2 loader waves
   V_F32_LW_128x64 = 10,   // 8 MFMA waves 4x2x1 + 2 x 2 loader waves, 3-slot ring (large outputs)
+  V_F32_LW16_32x16 = 11,  // brgemm_f32_lw16.hip: 32x16 tiles on v_mfma_f32_16x16x4_f32, 4 MFMA waves (K split) + 3 loader waves: outputs of at most one 32x16 tile per CU
   V_BF16_FAST = 16,  // brgemm_bf16.hip: 64x64 register-staged
   V_BF16_DMA128 = 17, // brgemm_bf16.hip: 128x128, LDS-DMA + loader waves
   V_BF16_DMA256 = 18, // brgemm_bf16_dma256.hip: 256x256, LDS-DMA
@@ -718,6 +719,7 @@ hipError_t launch_gemm_bf16_fast(int tile, const GemmArgs &a, hipStream_t s); //
 hipError_t launch_f32_lw(int tile, const GemmArgs &a, hipStream_t s);         // brgemm_f32_lw.hip (tile 4: 128x64, forced variant 10 only - it measures within 2 % of brgemm_f32_fast<128x64>)
 hipError_t launch_f32_lw_grouped(int tile, const GemmArgs &a, const WorkItem *items, int n_items, int split, hipStream_t s);
 hipError_t launch_f32_lw_split(int tile, const GemmArgs &a, int split, hipStream_t s); // hipErrorOutOfMemory / InvalidValue: not launched
+hipError_t launch_f32_lw16(const GemmArgs &a, const WorkItem *items, int n_items, bool grouped, hipStream_t s); // brgemm_f32_lw16.hip
 int pick_bf16_tile(const GemmDesc &d);
 bool bf16_fast_eligible(const GemmDesc &d);
 
@@ -809,6 +811,13 @@ static int choose_f32_split(int tile, long long tiles, long long chunks) {
   return saved > 2.7 + 0.8 ? (int)S : 1;
 }
 
+static bool lw16_on() {
+  static const bool on = [] {
+    const char *e = getenv("TPP_HIP_F32_LW16"); // A/B runs: 0 = never the 32x16 tiles
+    return !e || atoi(e) != 0;
+  }();
+  return on;
+}
 static bool k32_pairs_on() {
   static const bool on = [] {
     const char *e = getenv("TPP_HIP_GROUPED_K32_PAIRS"); // A/B runs: 0 = 32-k tiles on the generic grouped kernel, as before round 4
@@ -848,6 +857,18 @@ hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_i
   const bool k_pairs = k32_pairs_on() && d.k == 32 && pair_ok && d.stride_a >= 0 && d.stride_b >= 0 && d.stride_a < (1 << 26) && d.stride_b < (1 << 26);
   // (n that is not a multiple of 32 - the reference's --tiles=64,48,64 / 32,48,32 configs: the last 32-column tile of an item is
   // ragged, the loader-wave kernels clamp its loads and mask its stores; needs the 16-byte output pieces of out_ok and ldc % 4)
+  // skinny groups - at most one 32x16 tile per CU over the whole work list: the half-width tiles (brgemm_f32_lw16.hip), every CU a
+  // workgroup without a hand-off. 64-k tiles, or 32-k tiles whose n is not a multiple of 32 with even batch counts (--tiles=32,48,32);
+  // plain 32x32x32 tiles stay on the pair kernel whatever the group size (a single invoke and its group add in the same order:
+  // what tools/queue_fuzz.py checks bit for bit)
+  {
+    const int64_t t16 = (d.m % 32 == 0 && d.n % 16 == 0) ? (int64_t)n_items * (d.m / 32) * (d.n / 16) : 0;
+    const bool k_ok = (d.k % BK == 0 && d.k > 0) || (k_pairs && d.n % 32 != 0);
+    if (vec && out_ok && lw16_on() && !d.generic_forced && t16 > 0 && t16 <= g_num_cus && k_ok && d.ldc % 4 == 0 && n_items <= 65535 && d.lda < (1 << 22) &&
+        d.ldb < (1 << 22) && d.ldc < (1 << 22) && (!d.bias || out_ok) &&
+        !((d.k == 32 ? br_hint / 2 : br_hint * (d.k / BK)) >= 48 && d.n % 32 == 0 && d.k % BK == 0)) // (long reductions: the split 32x32 tiles below, as launch_gemm)
+      return note_grouped(d.k == 32 ? "brgemm_f32_lw16<32x16,k4> grouped, 32-k pairs" : "brgemm_f32_lw16<32x16,k4> grouped", launch_f32_lw16(a, items, n_items, true, stream));
+  }
   const bool n_ragged = d.n % 32 != 0;
   const bool fam_ok = n_ragged ? (!d.generic_forced && d.n > 32 && (d.k % BK == 0 || k_pairs)) // (plan_gemm knows no tile for such an n: variant = generic)
                                : ((d.k % BK == 0 && d.variant != V_GENERIC) || (k_pairs && !d.generic_forced));
@@ -911,6 +932,10 @@ static int pick_f32_variant(const GemmDesc &d) {
   // of workgroups (one per CU at a time). A 128x64 round takes ~1.85x a 64x64 round (measured, K = 1024: 32.7 vs
   // 17.6 us), so 128x64 wins at 1280-2048 x 1024 (one round instead of two) and for large outputs (0.93x), and
   // loses e.g. at 3072 x 1024 (two rounds against three; tools/sessions/mid_probe.py).
+  // Skinny outputs - at most one 32x16 tile per CU (the reference's M = 128 shapes: 128 x 1024 = 256 tiles, 128 x 768 = 192): the
+  // half-width tiles of brgemm_f32_lw16.hip put a workgroup on every CU where 32x32 tiles would leave half the chip idle, and need
+  // no hand-off between workgroups (the SPLIT launches pay 2.6-2.7 us for one); profiles/r05_lw16_vs_split.txt
+  if (tiles(32, 16) > 0 && tiles(32, 16) <= g_num_cus && d.ldc % 4 == 0 && lw16_on()) return V_F32_LW16_32x16;
   if (tiles(64, 64) >= g_num_cus) {
     const int64_t r64 = (tiles(64, 64) + g_num_cus - 1) / g_num_cus, r128 = (tiles(128, 64) + g_num_cus - 1) / g_num_cus;
     if (tiles(128, 64) > 0 && 1.85 * (double)r128 < (double)r64) return V_F32_128x64;
@@ -974,6 +999,7 @@ static const char *variant_name(int v) {
   case V_F32_LW_64x32K2: return "brgemm_f32_fast_lw<64x32,k4>";
   case V_F32_LW_32x32K4: return "brgemm_f32_fast_lw<32x32,k4>";
   case V_F32_LW_128x64: return "brgemm_f32_fast_lw<128x64,k1>";
+  case V_F32_LW16_32x16: return "brgemm_f32_lw16<32x16,k4>";
   case V_BF16_FAST: return "brgemm_bf16_fast<64x64>";
   case V_BF16_DMA128: return "brgemm_bf16_dma<128x128>";
   case V_BF16_DMA256: return "brgemm_bf16_dma<256x256>";
@@ -1060,6 +1086,7 @@ bool plan_gemm(GemmDesc &d, int forced_variant) {
     if (forced_variant <= 7 && d.m % bm[forced_variant] == 0 && d.n % bn[forced_variant] == 0) v = forced_variant;
     if (forced_variant == V_F32_LW_32x32K4 && d.m % 32 == 0 && d.n % 32 == 0) v = forced_variant;
     if (forced_variant == V_F32_LW_128x64 && d.m % 128 == 0 && d.n % 64 == 0) v = forced_variant;
+    if (forced_variant == V_F32_LW16_32x16 && d.m % 32 == 0 && d.n % 16 == 0 && d.ldc % 4 == 0) v = forced_variant;
     if (forced_variant == V_GENERIC) v = V_GENERIC;
   } else if (forced_variant == V_GENERIC) {
     v = V_GENERIC;
@@ -1127,6 +1154,22 @@ hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C,
     return launch_f32_lw(tile, a, stream);
   }
   case V_F32_LW_128x64: return launch_f32_lw(4, a, stream);
+  case V_F32_LW16_32x16: {
+    if (((uintptr_t)C) & 15 || (d.bias && (((uintptr_t)D) & 15))) break; // 16-byte pieces of C and of the bias row: else the generic kernel below
+    // LONG reductions (K >= 3072): every XCD streams all of A besides its share of B on the half-width tiles and their chunk time
+    // rises by 40 % (128 x 1024 x 4096: 14.6 us); the 32x32 tiles with the k range shared between XCD-aligned workgroups fetch every
+    // byte once (12.8 us). The batch count arrives with the invoke, so this is decided here. (profiles/r05_lw16_vs_split.txt)
+    const long long chunks = (long long)a.br * (d.k / BK);
+    if (chunks >= 48 && !d.variant_forced && d.n % 32 == 0) {
+      const int S = choose_f32_split(3, (long long)(d.m / 32) * (d.n / 32), chunks);
+      if (S > 1) {
+        const hipError_t e = launch_f32_lw_split(3, a, S, stream);
+        if (e != hipErrorOutOfMemory && e != hipErrorInvalidValue) return e;
+        (void)hipGetLastError();
+      }
+    }
+    return launch_f32_lw16(a, nullptr, 1, false, stream);
+  }
   case V_BF16_FAST:
   case V_BF16_DMA128:
   case V_BF16_DMA256: return launch_gemm_bf16_fast(v - V_BF16_FAST, a, stream);

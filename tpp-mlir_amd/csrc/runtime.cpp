@@ -421,9 +421,21 @@ int64_t gemm_dispatch_common(const char *who, int has_batch, int fused, int64_t 
   // The blocking factor of a VNNI B operand is not on the wire: the reference's compiler and its runtime library both ask
   // libxsmm_cpuid_dot_pack_factor (VNNIUtils.cpp:25-45; `--vnni=4` in benchmarks/config/omp/mlir-bf16.json:68-100). Its stand-in
   // here is a process-wide setting read at dispatch time (xsmm_hip_set_vnni_factor / TPP_HIP_VNNI_FACTOR, default 2).
-  const int vf = vnni_b ? cfg().vnni_factor.load(std::memory_order_relaxed) : 2;
+  //  The setting is read ONCE per dispatch, here; the handle keeps the factor it was dispatched with (it is part of the
+  // descriptor key). A harness sets it before it dispatches - a thread that changes it while another one dispatches gets whichever
+  // value is current; with TPP_HIP_TRACE a change between two VNNI dispatches is reported.
+  const int vf_now = cfg().vnni_factor.load(std::memory_order_relaxed);
+  const int vf = vnni_b ? vf_now : 2;
   if (vnni_b && (k % vf)) die("%s: VNNI-%d B operand needs k to be a multiple of %d, got %ld", who, vf, vf, (long)k);
-  if ((flags & XSMM_GEMM_WIRE_VNNI_A) && (k & 1)) die("%s: VNNI-2 A operand needs an even k, got %ld", who, (long)k);
+  // a VNNI A operand [m][k/v][v] is byte-identical to the flat row for every v that divides k: the same factor as B's
+  if ((flags & XSMM_GEMM_WIRE_VNNI_A) && (k % vf_now)) die("%s: VNNI-%d A operand needs k to be a multiple of %d, got %ld", who, vf_now, vf_now, (long)k);
+  if (flags & (XSMM_GEMM_WIRE_VNNI_B | XSMM_GEMM_WIRE_VNNI_A)) {
+    static std::atomic<int> last_vf{0};
+    const int prev = last_vf.exchange(vf_now, std::memory_order_relaxed);
+    if (prev && prev != vf_now && cfg().trace)
+      fprintf(stderr, "[tpp-xsmm-hip] %s: the VNNI factor changed from %d to %d between two VNNI dispatches (handles keep the factor they were "
+                      "dispatched with)\n", who, prev, vf_now);
+  }
   if (vnni_c && (m & 1)) die("%s: VNNI-2 C operand needs an even m, got %ld", who, (long)m);
   if (fused) {
     if (unary_flags != 0) die("%s: unsupported unary flags %ld on a fused brgemm", who, (long)unary_flags);
@@ -1771,7 +1783,13 @@ struct CallerState;
 // One pointer in the static TLS block (initial-exec: a %fs-relative load; the general-dynamic model of a shared library calls
 // __tls_get_addr on every access - 10-15 cycles of an invoke), the state itself behind the usual thread_local so that it is
 // destroyed with its thread. 8 bytes of the loader's static-TLS reserve: dlopen-safe.
+// -DTPP_TLS_DEFAULT_MODEL: the compiler's default model for a shared object instead - for a process whose static-TLS
+// surplus is already spent by other initial-exec libraries when this one is dlopen'ed ("cannot allocate memory in static TLS block").
+#ifdef TPP_TLS_DEFAULT_MODEL
+static __thread CallerState *tl_fast = nullptr;
+#else
 static __thread CallerState *tl_fast __attribute__((tls_model("initial-exec"))) = nullptr;
+#endif
 struct CallerState {
   DeviceRanges devmem; // per caller: no sharing, no lock
   DirectWindow::Caller *me = nullptr;
@@ -2142,7 +2160,7 @@ bool try_chain_launch(int n, const GemmDesc *const *d, void *const *pa, void *co
   // with the same loader-wave tile and that tile fits, use it - the launch is then bit-identical to the separate launches; else
   // the smallest tile that fits (most CUs busy).
   int tile = -1, bm = 0, bn = 0;
-  const int64_t cus = stream_cus(cfg().stream.load(std::memory_order_relaxed));
+  const int64_t cus = stream_cus(s); // (the stream the launch goes to: ADVICE r4)
   auto fits = [&](int t) {
     if (f32) (void)f32_chain_tile_dims(t, &bm, &bn);
     else blw_tile_dims(t, &bm, &bn);
