@@ -243,6 +243,11 @@ TPP_XSMM_EXPORT const char *xsmm_hip_kernel_name(int64_t handle);
  * invokes may run on a faster family than a single invoke of its handle would (xsmm_hip_kernel_name), e.g. 32-k f32 tiles with even
  * batch counts on the loader-wave kernels. A static string; diagnostics only. */
 TPP_XSMM_EXPORT const char *xsmm_hip_last_grouped_kernel(void);
+/* The kernel of the most recent NON-queued gemm / brgemm / fused_brgemm invoke when it was refined at invoke time - the batch count
+ * arrives with the invoke, so two choices are made there: f32 outputs with fewer tiles than CUs and a long reduction run with the
+ * batch-reduce range of a tile split over several workgroups (xsmm_hip_force_split), small bf16 outputs with K >= 1536 on the 32x64
+ * loader-wave tile. "" = the kernel xsmm_hip_kernel_name(handle) names ran. For tests, tools and profiles. */
+TPP_XSMM_EXPORT const char *xsmm_hip_last_refined_kernel(void);
 /* Force a GEMM tile variant for A/B benchmarking and tests (-1 = automatic): f32 0..4 (64x64,
  * 64x32+K2, 32x32+K4, 128x64, 64x64+K2), 5..7 the loader-wave kernels (64x64, 64x64+K2, 64x32+K4), 8 generic, 9 / 10 loader-wave 32x32+K4 / 128x64, bf16 16 / 17 / 18 / 19 (64x64, 128x128, 256x256, 32x32 + K split),
  * 20 .. 23 the bf16 loader-wave tiles for mid-size outputs (32x64 + K split, 64x64, 64x128, 128x128).

@@ -234,6 +234,6 @@ def test_f32_lw16_every_chunk_stream_length(rt, br):
 
 def test_skinny_whole_layers_pick_the_half_width_tiles(rt):
     """the reference's M = 128 shapes: at most one 32x16 tile per CU -> the half-width tiles; wider outputs keep theirs"""
-    for (m, n, want) in ((128, 1024, "lw16<32x16"), (128, 768, "lw16<32x16"), (128, 3072, "lw<32x32"), (256, 768, "lw<32x32"), (512, 1024, "lw<64x32"), (1024, 1024, "lw<64x64")):
+    for (m, n, want) in ((128, 1024, "lw16<32x16"), (128, 768, "lw16<32x16"), (128, 3072, "lw<32x32"), (256, 768, "lw<32x32"), (256, 1024, "lw<32x32"), (512, 1024, "lw<64x32"), (1024, 1024, "lw<64x64")):
         h = rt.brgemm_dispatch(F32, m, n, 64, 1024, n, n, 64, 64 * n, 0)
         assert want in rt.kernel_name(h), (m, n, rt.kernel_name(h))

@@ -134,6 +134,7 @@ int force_gemm_split(int) { return -1; }
 bool f32_chain_tile_dims(int, int *bm, int *bn) { *bm = *bn = 64; return false; }
 hipError_t launch_f32_chain(int, const ChainArgs &, hipStream_t) { return hipErrorNotSupported; }
 const char *last_grouped_kernel() { return "fake_host_gemm"; }
+const char *last_refined_kernel() { return ""; }
 hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *it, int n, bool, bool, bool, int64_t, hipStream_t s) {
   for (int i = 0; i < n; ++i) (void)launch_gemm(d, it[i].A, it[i].B, it[i].C, it[i].D, it[i].br, s);
   return hipSuccess;

@@ -20,7 +20,7 @@ for (M, N, K) in SHAPES:
         bm, bn = (64, 64) if v == 6 else (64, 32) if v == 7 else (32, 16) if v == 11 else (32, 32)
         if M % bm or N % bn:
             continue
-        for S in ([1] if v == 11 else SPLITS):  # (the 32x16 tiles have no split launch)
+        for S in ([1] if v == 11 else SPLITS):  # (the 16x16-block tiles have no split launch)
             if S > 1 and K // 64 // S < 2:
                 continue
             cases.append(((M, N, K), vn, S, ["--batch", str(M), "--layers", "%d,%d" % (K, N), "--whole-layer", "--kernel", "args", "-n", str(n_iter),

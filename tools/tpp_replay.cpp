@@ -237,7 +237,9 @@ static int run_case(int argc, char **argv) {
   fprintf(stderr, "tpp_replay: %s, batch %ld, %d layer(s), queue %d: mean %.3f us (host side of the invokes %.3f us), %.1f GFLOP/s (BENCH_TOTAL_FLOPS %.0f), kernel %s\n",
           chain ? (chained == 1 ? "whole-layer calls as ONE chain launch" : "whole-layer calls handed over together, run call by call") : whole ? "whole-layer dispatch" : "packed tile invokes", (long)batch, L, queue, mean * 1e6,
           host_dt / (double)n_iter * 1e6, flops / mean / 1e9, flops,
-          (queue && !whole && xsmm_hip_last_grouped_kernel()[0]) ? xsmm_hip_last_grouped_kernel() : xsmm_hip_kernel_name(handle[0]));
+          (queue && !whole && xsmm_hip_last_grouped_kernel()[0]) ? xsmm_hip_last_grouped_kernel()
+          : (whole && !chain && xsmm_hip_last_refined_kernel()[0])  ? xsmm_hip_last_refined_kernel()
+                                                                    : xsmm_hip_kernel_name(handle[0]));
   if (queue) {
     int64_t qs[5];
     xsmm_hip_tile_queue_stats(qs);

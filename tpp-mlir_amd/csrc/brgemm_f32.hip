@@ -719,7 +719,7 @@ hipError_t launch_gemm_bf16_fast(int tile, const GemmArgs &a, hipStream_t s); //
 hipError_t launch_f32_lw(int tile, const GemmArgs &a, hipStream_t s);         // brgemm_f32_lw.hip (tile 4: 128x64, forced variant 10 only - it measures within 2 % of brgemm_f32_fast<128x64>)
 hipError_t launch_f32_lw_grouped(int tile, const GemmArgs &a, const WorkItem *items, int n_items, int split, hipStream_t s);
 hipError_t launch_f32_lw_split(int tile, const GemmArgs &a, int split, hipStream_t s); // hipErrorOutOfMemory / InvalidValue: not launched
-hipError_t launch_f32_lw16(const GemmArgs &a, const WorkItem *items, int n_items, bool grouped, hipStream_t s); // brgemm_f32_lw16.hip
+hipError_t launch_f32_lw16(int tile, const GemmArgs &a, const WorkItem *items, int n_items, bool grouped, hipStream_t s); // brgemm_f32_lw16.hip: tile 0 = 32x16
 int pick_bf16_tile(const GemmDesc &d);
 bool bf16_fast_eligible(const GemmDesc &d);
 
@@ -834,6 +834,10 @@ static bool k32_pairs_on() {
 // report which kernel a tile-queue group ran on - the descriptor's own name is what a SINGLE invoke would run on)
 static std::atomic<const char *> g_last_grouped{""};
 const char *last_grouped_kernel() { return g_last_grouped.load(std::memory_order_relaxed); }
+// the same for single launches whose kernel was refined at INVOKE time (the batch count arrives with the invoke): "" = the
+// descriptor's own kernel (xsmm_hip_kernel_name) ran
+static std::atomic<const char *> g_last_refined{""};
+const char *last_refined_kernel() { return g_last_refined.load(std::memory_order_relaxed); }
 #define note_grouped(name, ...) (g_last_grouped.store(name, std::memory_order_relaxed), (__VA_ARGS__))
 hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_items, bool vec_ok, bool out_ok, bool pair_ok,
                                int64_t br_hint, hipStream_t stream) {
@@ -862,12 +866,14 @@ hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_i
   // plain 32x32x32 tiles stay on the pair kernel whatever the group size (a single invoke and its group add in the same order:
   // what tools/queue_fuzz.py checks bit for bit)
   {
+    const int l16_tile = 0;
     const int64_t t16 = (d.m % 32 == 0 && d.n % 16 == 0) ? (int64_t)n_items * (d.m / 32) * (d.n / 16) : 0;
     const bool k_ok = (d.k % BK == 0 && d.k > 0) || (k_pairs && d.n % 32 != 0);
+    static const char *const l16_names[1][2] = {{"brgemm_f32_lw16<32x16,k4> grouped", "brgemm_f32_lw16<32x16,k4> grouped, 32-k pairs"}};
     if (vec && out_ok && lw16_on() && !d.generic_forced && t16 > 0 && t16 <= g_num_cus && k_ok && d.ldc % 4 == 0 && n_items <= 65535 && d.lda < (1 << 22) &&
         d.ldb < (1 << 22) && d.ldc < (1 << 22) && (!d.bias || out_ok) &&
         !((d.k == 32 ? br_hint / 2 : br_hint * (d.k / BK)) >= 48 && d.n % 32 == 0 && d.k % BK == 0)) // (long reductions: the split 32x32 tiles below, as launch_gemm)
-      return note_grouped(d.k == 32 ? "brgemm_f32_lw16<32x16,k4> grouped, 32-k pairs" : "brgemm_f32_lw16<32x16,k4> grouped", launch_f32_lw16(a, items, n_items, true, stream));
+      return note_grouped(l16_names[l16_tile][d.k == 32], launch_f32_lw16(l16_tile, a, items, n_items, true, stream));
   }
   const bool n_ragged = d.n % 32 != 0;
   const bool fam_ok = n_ragged ? (!d.generic_forced && d.n > 32 && (d.k % BK == 0 || k_pairs)) // (plan_gemm knows no tile for such an n: variant = generic)
@@ -906,7 +912,10 @@ hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_i
                      d.lda < (1 << 21) && d.ldb < (1 << 21); // (32-bit lane offsets)
   // bf16 tiles of 64x64 with k a multiple of 64: the 64x64 bf16 family in grouped mode (it stores 16-byte
   // row pieces and reads the bias 8 bytes at a time: checked per item by the queue through out_ok)
-  if (vec16 && out_ok && d.variant >= V_BF16_FAST && d.variant != V_BF16_SMALL32 && bf16_fast_eligible(d) &&
+  // (whatever a SINGLE invoke of the handle would run on - a lone 64x64 tile is planned on the 32x32 K-split kernel -, the GROUP is
+  // what fills the chip: round 5, the reference's fc / matmul shapes as 64,64,64 tile invokes: 1024 x 2560 x 1024 30.4 us on 32x32
+  // tiles against 15 us whole-layer)
+  if (vec16 && out_ok && d.variant >= V_BF16_FAST && (d.variant != V_BF16_SMALL32 || !d.variant_forced) && !d.generic_forced && bf16_fast_eligible(d) &&
       (int64_t)n_items * (d.m / 64) * (d.n / 64) >= (3 * g_num_cus) / 4)
     return note_grouped("brgemm_bf16_fast<64x64> grouped", launch_bf16_grouped64(a, items, n_items, stream));
   if (vec_ok && out_ok && d.variant != V_GENERIC && bf16_small_eligible(d)) return note_grouped("brgemm_bf16_small32 grouped", launch_bf16_small32(a, items, n_items, stream));
@@ -935,7 +944,10 @@ static int pick_f32_variant(const GemmDesc &d) {
   // Skinny outputs - at most one 32x16 tile per CU (the reference's M = 128 shapes: 128 x 1024 = 256 tiles, 128 x 768 = 192): the
   // half-width tiles of brgemm_f32_lw16.hip put a workgroup on every CU where 32x32 tiles would leave half the chip idle, and need
   // no hand-off between workgroups (the SPLIT launches pay 2.6-2.7 us for one); profiles/r05_lw16_vs_split.txt
-  if (tiles(32, 16) > 0 && tiles(32, 16) <= g_num_cus && d.ldc % 4 == 0 && lw16_on()) return V_F32_LW16_32x16;
+  // (a 16x48 tile of the same family - 256 x 768 outputs are exactly 256 of them - was built and measured: 256 x 768 x 768 5.59 us
+  // against 5.48 on 192 tiles of 32x32, x 3072 14.9 against 13.7: 16 KiB of panel per 98 kflop chunk, the launch is bound by the
+  // L2 -> LDS traffic of all CUs together, ~16 TB/s; removed. profiles/r05_lw16_vs_split.txt)
+  if (d.ldc % 4 == 0 && lw16_on() && tiles(32, 16) > 0 && tiles(32, 16) <= g_num_cus) return V_F32_LW16_32x16;
   if (tiles(64, 64) >= g_num_cus) {
     const int64_t r64 = (tiles(64, 64) + g_num_cus - 1) / g_num_cus, r128 = (tiles(128, 64) + g_num_cus - 1) / g_num_cus;
     if (tiles(128, 64) > 0 && 1.85 * (double)r128 < (double)r64) return V_F32_128x64;
@@ -1111,6 +1123,7 @@ hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C,
   a.vf = d.vnni_factor ? d.vnni_factor : 2;
   a.split = 0; a.scratch = nullptr; a.split_cnt = nullptr;
   int v = d.variant;
+  g_last_refined.store("", std::memory_order_relaxed);
   const bool aligned16 = ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0;
   if (v != V_GENERIC && !aligned16) v = V_GENERIC;
   // the bf16 kernel stores 16-byte row pieces and reads the bias 8 bytes at a time
@@ -1124,7 +1137,10 @@ hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C,
       !(((uintptr_t)C) & 15) && !(d.bias && (((uintptr_t)D) & 7)) && !d.variant_forced) {
     GemmDesc e = d;
     e.m = (d.m + 63) / 64 * 64; // (bf16_fast_eligible asks for m % 64; the 32x64 tile needs m % 32 only)
-    if (bf16_fast_eligible(e)) v = V_BF16_LW_32x64;
+    if (bf16_fast_eligible(e)) {
+      v = V_BF16_LW_32x64;
+      g_last_refined.store("brgemm_bf16_lw<32x64,k2> (long reduction)", std::memory_order_relaxed);
+    }
   }
   if (v >= V_BF16_LW_32x64 && v <= V_BF16_LW4_128x128 && a.br < 1) v = V_GENERIC; // empty batch (C = epilogue of nothing): the loader-wave kernels assume a chunk
   switch (v) {
@@ -1148,7 +1164,10 @@ hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C,
     const int S = choose_f32_split(tile, (long long)(d.m / bm) * (d.n / bn), (long long)a.br * (d.k / BK));
     if (S > 1) {
       const hipError_t e = launch_f32_lw_split(tile, a, S, stream);
-      if (e != hipErrorOutOfMemory && e != hipErrorInvalidValue) return e;
+      if (e != hipErrorOutOfMemory && e != hipErrorInvalidValue) {
+        g_last_refined.store(tile == 1 ? "brgemm_f32_lw<64x64,k2>, split" : tile == 2 ? "brgemm_f32_lw<64x32,k4>, split" : "brgemm_f32_lw<32x32,k4>, split", std::memory_order_relaxed);
+        return e;
+      }
       (void)hipGetLastError(); // no scratch block: the unsplit launch
     }
     return launch_f32_lw(tile, a, stream);
@@ -1164,11 +1183,14 @@ hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C,
       const int S = choose_f32_split(3, (long long)(d.m / 32) * (d.n / 32), chunks);
       if (S > 1) {
         const hipError_t e = launch_f32_lw_split(3, a, S, stream);
-        if (e != hipErrorOutOfMemory && e != hipErrorInvalidValue) return e;
+        if (e != hipErrorOutOfMemory && e != hipErrorInvalidValue) {
+          g_last_refined.store("brgemm_f32_lw<32x32,k4>, split (long reduction)", std::memory_order_relaxed);
+          return e;
+        }
         (void)hipGetLastError();
       }
     }
-    return launch_f32_lw16(a, nullptr, 1, false, stream);
+    return launch_f32_lw16(0, a, nullptr, 1, false, stream);
   }
   case V_BF16_FAST:
   case V_BF16_DMA128:

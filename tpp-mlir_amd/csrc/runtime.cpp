@@ -2609,6 +2609,7 @@ extern "C" const char *xsmm_hip_kernel_name(int64_t handle) {
   return (d && d->kind == KIND_GEMM) ? d->name : "";
 }
 extern "C" const char *xsmm_hip_last_grouped_kernel(void) { return last_grouped_kernel(); }
+extern "C" const char *xsmm_hip_last_refined_kernel(void) { return last_refined_kernel(); }
 extern "C" void xsmm_hip_force_variant(int v) { cfg().forced_variant.store(v); }
 extern "C" int xsmm_hip_force_split(int v) { return tpp::force_gemm_split(v); }
 // the VNNI blocking factor of bf16 B operands dispatched from now on (2 or 4); returns the previous one, -1 for an invalid factor

@@ -72,6 +72,7 @@ hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_i
 int force_gemm_split(int workgroups_per_tile); // xsmm_hip_force_split (brgemm_f32.hip); returns the previous setting
 int f32_chain_tile(const GemmDesc &d); // 1 / 2 / 3 = the f32 chain tile the descriptor was planned on, -1 = none (brgemm_f32.hip)
 const char *last_grouped_kernel(); // kernel family of the most recent launch_gemm_grouped ("" before the first)
+const char *last_refined_kernel(); // most recent launch_gemm: the kernel an invoke-time refinement chose, "" = the descriptor's own
 // fills d.variant / d.name; returns false if no kernel can run the descriptor
 bool plan_gemm(GemmDesc &d, int forced_variant);
 constexpr int GEMM_VARIANT_BF16_LW0 = 20; // = V_BF16_LW_32x64: first of the four loader-wave bf16 tiles (brgemm_bf16_lw.hip)

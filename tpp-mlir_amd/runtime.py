@@ -99,6 +99,7 @@ _SIGNATURES = {
     "xsmm_hip_device_count": (ctypes.c_int, []),
     "xsmm_hip_kernel_name": (ctypes.c_char_p, [I64]),
     "xsmm_hip_last_grouped_kernel": (ctypes.c_char_p, []),
+    "xsmm_hip_last_refined_kernel": (ctypes.c_char_p, []),
     "xsmm_hip_force_variant": (None, [ctypes.c_int]),
     "xsmm_hip_force_split": (ctypes.c_int, [ctypes.c_int]),
     "xsmm_hip_set_vnni_factor": (ctypes.c_int, [ctypes.c_int]),
@@ -261,6 +262,10 @@ class XsmmRuntime:
 
     def last_grouped_kernel(self):
         return self.lib.xsmm_hip_last_grouped_kernel().decode()
+
+    def last_refined_kernel(self):
+        """the kernel an invoke-time refinement chose for the most recent non-queued GEMM invoke, "" = the handle's own kernel"""
+        return self.lib.xsmm_hip_last_refined_kernel().decode()
 
     def force_variant(self, v):
         self.lib.xsmm_hip_force_variant(v)
