@@ -937,6 +937,38 @@ def main():
                 if mm:
                     others.append({"workload": "mlir-gen mlp 3x1024 bs=256 bias+relu (fp32 unless noted), " + label + " (tools/tpp_replay)",
                                    "value": float(mm.group(2)), "unit": "GFLOP/s", "us_per_step": float(mm.group(1))})
+            # the plain gemm row of the reference's headline config (base.json:34 gemm_fp32_mlir: no bias, no relu) - the shape the CPU
+            # row's `headline_shape` quotes - as the compiler emits it
+            r = subprocess.run([replay, "--batch", "256", "--layers", "1024,1024,1024,1024", "--tiles", "32", "--queue", "1", "-n", "200"],
+                               capture_output=True, text=True, timeout=300)
+            mm = re.search(r"mean ([0-9.]+) us[^,]*, ([0-9.]+) GFLOP/s", r.stderr)
+            if mm:
+                others.append({"workload": "mlir-gen gemm 3x1024 bs=256 fp32 (base.json gemm_fp32_mlir: no bias / relu), tile queue, tiles 32,32,32 (tools/tpp_replay)",
+                               "value": float(mm.group(2)), "unit": "GFLOP/s", "us_per_step": float(mm.group(1)),
+                               "frac_of_f32_mfma_peak": round(float(mm.group(2)) / 1e3 / PEAK_F32_MFMA_TFLOPS, 4)})
+            # the reference's own benchmark SHAPE SET (benchmarks/config/matmul/*.json, fc/*.json, base/base.json: 17 + 17 + 2 rows),
+            # f32, each as the compiler emits it (tile invokes through the tile queue) and as one whole-layer dispatch, with the CPU
+            # port on the same shape: tools/refbench.py (the full table incl. bf16 VNNI-2 / VNNI-4: profiles/r05_refbench.txt).
+            # Here: the three worst and the three best rows by fraction of the f32 MFMA peak.
+            try:
+                with tempfile.TemporaryDirectory() as td:
+                    jf = os.path.join(td, "refbench.json")
+                    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "refbench.py"), "--quick", "-n", "200", "--json", jf],
+                                   capture_output=True, text=True, timeout=600, check=True)
+                    rows = json.load(open(jf))
+                rows.sort(key=lambda r_: r_["frac_of_peak"])
+                keep = lambda r_: {"benchmark": r_["name"], "tiles": "%d,%d,%d" % tuple(r_["tiles"]), "form": r_["form"], "us": r_["us"],  # noqa: E731
+                                   "value": r_["gflops"], "unit": "GFLOP/s", "frac_of_f32_mfma_peak": round(r_["frac_of_peak"], 4),
+                                   "kernel": r_["kernel_name"], "cpu_port_gflops": r_["cpu_port_gflops_f32"], "cpu_threads": r_["cpu_threads"],
+                                   "reference_config": r_["cite"]}
+                met = [r_ for r_ in rows if r_["frac_of_peak"] >= 0.45 or r_["us"] / (len(r_["layers"]) - 1) <= 5.0]
+                others.append({"workload": "the reference's benchmark shape set, f32 (tools/refbench.py: %d rows = 36 benchmarks x {tile invokes, whole layer})" % len(rows),
+                               "rows": len(rows), "rows_at_0.45_of_peak_or_within_2x_the_launch_floor": len(met),
+                               "median_frac_of_f32_mfma_peak": round(rows[len(rows) // 2]["frac_of_peak"], 4),
+                               "worst3": [keep(r_) for r_ in rows[:3]], "best3": [keep(r_) for r_ in rows[-3:]],
+                               "full_table": "profiles/r05_refbench.txt"})
+            except Exception as ex:
+                others.append({"workload": "the reference's benchmark shape set (tools/refbench.py)", "error": str(ex)[:300]})
             # the same fp32 MLP at batch 512 as whole-layer calls: three launches, and handed over together (ONE launch of the f32
             # layer chain, bit-identical to the three: tests/test_chain_f32_gpu.py)
             for label, extra in (("three whole-layer launches", ["--whole-layer"]), ("ONE chain launch (xsmm_hip_fused_brgemm_chain_invoke)", ["--chain"])):
@@ -1012,6 +1044,15 @@ def main():
             "per_launch": per_launch,
             "cpu_baseline": cpu,
         }
+        if others:
+            hp = [o for o in others if str(o.get("workload", "")).startswith("C2 through HOST pointers")]
+            line["deployment"] = {
+                "headline_needs": "device-resident operands (hipMalloc) + asynchronous mode (TPP_HIP_ASYNC=1 / xsmm_hip_set_async): a HARNESS change "
+                                  "(tpp-run allocates memref globals / malloc: lib/TPP/Runner/MLIRBench.cpp:176-246), not a compiler or IR change",
+                "unmodified_harness_host_pointers_gflops": hp[0]["value"] if hp else None,
+                "unmodified_harness_us_per_invoke": hp[0]["us_per_step"] if hp else None,
+                "note": "through HOST pointers every synchronous invoke mirrors its operands over PCIe (12 MiB up, 4 MiB down for C2): the same "
+                        "BRGEMM then runs at the rate above - about 1/17 of the headline value and ~1.5x the CPU row (INTEGRATION.md section 3)"}
         if mlp is not None:
             line["mlp"] = mlp
         if others:

@@ -208,7 +208,7 @@ F32_FAST = [
 def test_brgemm_f32_fast_variants(rt, case):
     m, n, k, br, kw = case
     name = gemm_case(rt, F32, m, n, k, br, seed=m + n + k + br, **kw)
-    assert "fast" in name, name
+    assert "fast" in name or "lw16" in name, name  # (round 5: outputs of at most one 32x16 tile per CU run on the half-width tiles)
 
 
 @pytest.mark.parametrize("variant,m,n", [(0, 128, 128), (1, 128, 96), (2, 96, 96), (3, 256, 128), (4, 128, 128),
