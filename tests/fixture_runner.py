@@ -20,7 +20,7 @@ F32, BF16 = 1, 2
 
 def fixtures():
     names = sorted(glob.glob(os.path.join(GOLDEN, "*.json")))
-    return [n for n in names if os.path.basename(n) not in ("flops.json", "xsmm_to_func_wire.json")]
+    return [n for n in names if os.path.basename(n) not in ("flops.json", "xsmm_to_func_wire.json", "benchmark_configs.json")]
 
 
 def load(path):

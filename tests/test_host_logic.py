@@ -121,3 +121,25 @@ def test_bench_gpus_n_without_world_size_launches_n_ranks():
     if not torch.cuda.is_available():
         assert r.returncode != 0 and r.stderr.count("needs an MI355X") >= 2, r.stderr[-3000:]
         assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_refbench_restates_the_reference_benchmark_configs():
+    """tools/refbench.py's shape table = the IR-GEN rows of benchmarks/config/matmul/*.json and fc/*.json (harvested into
+    tests/golden/benchmark_configs.json by tests/golden/harvest_benchmarks.py): same (batch, out, in) shapes, same --tiles, the fc
+    rows with --bias --relu, --kernel=args, f32 / bf16 vnni 2 / bf16 vnni 4 each; base.json's tiled gemm / mlp rows 256 x 1024 x 3"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("refbench", os.path.join(ROOT, "tools", "refbench.py"))
+    rb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rb)
+    with open(os.path.join(GOLDEN, "benchmark_configs.json")) as f:
+        cfg = json.load(f)
+    for fam in ("matmul", "fc"):
+        want = {(r["batch"], r["layers"][1], r["layers"][0], tuple(r["tiles"])) for r in cfg[fam]}
+        assert want == set(rb.SHAPES), (fam, want ^ set(rb.SHAPES))
+        assert all(r["kernel"] == "args" and r["bias"] == (fam == "fc") and r["relu"] == (fam == "fc") for r in cfg[fam])
+        assert {(r["float_type"], r["vnni"]) for r in cfg[fam]} == {("f32", 0), ("bf16", 2), ("bf16", 4)}
+    tiled = [r for r in cfg["base"] if r["tiles"]]
+    assert tiled and all(r["batch"] == 256 and r["layers"] == [1024] * 4 and r["tiles"] == [32, 32, 32] and r["kernel"] == "const" for r in tiled)
+    got = rb.cases("")
+    assert len(got) == (17 + 17) * 3 * 2 + 2 * 3 * 2
+    assert {c["kernel"] for c in got if c["family"] == "base"} == {"const"} and {c["kernel"] for c in got if c["family"] != "base"} == {"args"}
