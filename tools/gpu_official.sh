@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round deliverable session: full parity suite, smoke, the driver's bench command, rocprofv3 kernel stats of the SAME bench
+# Round deliverable session (round 5 adds: refbench table, split sweep, the N = 2 rig bench, PMC of the skinny-shape kernels): full parity suite, smoke, the driver's bench command, rocprofv3 kernel stats of the SAME bench
 # command, default bench, MFMA-busy PMC passes, the per-rank MLP step probe + in-kernel stamps, shape sweeps, tile-queue replays,
 # eltwise bandwidth. Results in gpurun_out/<tag>/.   usage: gpurun --timeout 2400 -- 'bash tools/gpu_official.sh r03_official1'
 TAG=${1:-official}; OUT=gpurun_out/$TAG; mkdir -p $OUT
@@ -14,7 +14,8 @@ timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 find /tmp/prof_stats -name "*kernel_stats.csv" -exec cp {} $OUT/rocprof_kernel_stats.csv \;
 # MFMA-busy passes (PMC alone) + kernel stats of the same commands: C2, C3, the C4 layer kernel, the chain kernels
 ( cd /tmp
-for what in "c2:$R/tools/c2_probe --iters 40 --init reference" "c3:$R/tools/c2_probe --c3 --iters 40 --init reference" "c4layer:$R/tools/mlp_probe --rows 4096 --only layers --iters 40" "c4chain:$R/tools/mlp_probe --rows 4096,2048,1024,512 --only chain --iters 40"; do
+printf -- "--batch 128 --layers 1024,1024 --kernel args --whole-layer -n 40\n--batch 128 --layers 4096,1024 --kernel args --whole-layer -n 40\n--batch 128 --layers 2304,768 --kernel args --tiles 64,48,64 -n 40\n" > /tmp/skinny_cases.txt
+for what in "c2:$R/tools/c2_probe --iters 40 --init reference" "c3:$R/tools/c2_probe --c3 --iters 40 --init reference" "c4layer:$R/tools/mlp_probe --rows 4096 --only layers --iters 40" "c4chain:$R/tools/mlp_probe --rows 4096,2048,1024,512 --only chain --iters 40" "skinny:$R/tools/tpp_replay --cases /tmp/skinny_cases.txt"; do
   tag=${what%%:*}; cmd=${what#*:}
   timeout 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES --output-format csv -d /tmp/mf_$tag -o p -- $cmd > /dev/null 2>&1
   f=$(find /tmp/mf_$tag -name "*counter_collection.csv" | head -1)
@@ -43,6 +44,10 @@ if [ -f tools/_abl/libtpp_xsmm_runner_utils.so ]; then
 for dbg in 0 16 32 48 2 6 7; do echo "dbg=$dbg"; lib=tools/_abl; [ $((dbg & 32)) -ne 0 ] && lib=tools/_abl_nomath
   LD_LIBRARY_PATH=$lib TPP_HIP_CHAIN_DBG=$dbg timeout 100 tools/mlp_probe 2>&1; done > $OUT/chain_ablation.txt
 fi
+# round 5: the reference's benchmark shape set (full table + json), the split / half-width-tile sweep, the self-launching N = 2 bench on the one-device rig
+timeout 600 python tools/refbench.py -n 300 --json $OUT/refbench.json > $OUT/refbench.txt 2> $OUT/refbench.err
+timeout 300 python tools/split_sweep.py > $OUT/split_sweep.txt 2>&1
+TPP_BENCH_ONE_DEVICE=1 timeout 600 python bench.py --gpus 2 --steps 6 --warmup 3 > $OUT/bench_gpus2_rig.json 2> $OUT/bench_gpus2_rig.err
 python tools/sweep.py 2>/dev/null | grep -E "^(f32|bf16)" > $OUT/sweep.txt
 python tools/sweep.py big 2>/dev/null | grep -E "^(f32|bf16)" >> $OUT/sweep.txt
 python tools/sweep.py shards 2>/dev/null | grep -E "^bf16" >> $OUT/sweep.txt
