@@ -237,3 +237,24 @@ def test_skinny_whole_layers_pick_the_half_width_tiles(rt):
     for (m, n, want) in ((128, 1024, "lw16<32x16"), (128, 768, "lw16<32x16"), (128, 3072, "lw<32x32"), (256, 768, "lw<32x32"), (256, 1024, "lw<32x32"), (512, 1024, "lw<64x32"), (1024, 1024, "lw<64x64")):
         h = rt.brgemm_dispatch(F32, m, n, 64, 1024, n, n, 64, 64 * n, 0)
         assert want in rt.kernel_name(h), (m, n, rt.kernel_name(h))
+
+
+@pytest.mark.parametrize("m,n,br,beta0,bias,relu", [(128, 256, 32, True, True, True), (64, 96, 24, False, False, False), (256, 1024, 64, True, False, True),
+                                                    (32, 32, 25, False, True, False)])
+def test_bf16_small_outputs_with_a_long_reduction_switch_tiles_at_invoke_time(rt, m, n, br, beta0, bias, relu):
+    """bf16 VNNI-2 layers planned on the 32x32 K-split kernel (small outputs) run on the loader-wave tiles when K = br * 64 >= 1536 -
+    the batch count arrives with the invoke: 32x32 + K2 when the output is at most one 32x32 tile per CU, else 32x64 + K2; against the
+    oracle, and a short reduction on the same handle stays on the handle's own kernel"""
+    from test_parity_gpu import gemm_case
+    k = 64
+    K = k * br
+    name = gemm_case(rt, BF16, m, n, k, br, lda=K + 8, sa=k, sb=k * n, vnni=True, beta0=beta0, bias=bias, relu=relu, seed=m + n + br, offs=(8, 8, 8, 4))
+    assert "small<32x32" in name, name  # the dispatch-time plan
+    want = "32x32,k2" if (m // 32) * (n // 32) <= 256 and n % 64 == 0 or n % 64 else "32x64,k2"
+    ran = rt.last_refined_kernel()
+    if n % 64 == 0:
+        assert "long reduction" in ran and ("32x32,k2" in ran if (m // 32) * (n // 32) <= 256 else "32x64,k2" in ran), ran
+    else:
+        assert ran == "", ran  # (n = 96 / 32: the loader-wave tiles need n % 64 == 0 - the handle's own kernel)
+    gemm_case(rt, BF16, m, n, k, 4, lda=K + 8, sa=k, sb=k * n, vnni=True, beta0=beta0, bias=bias, relu=relu, seed=m + n, offs=(8, 8, 8, 4))
+    assert rt.last_refined_kernel() == ""

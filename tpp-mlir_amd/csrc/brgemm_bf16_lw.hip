@@ -876,9 +876,13 @@ static bool blw_sup2(const ChainArgs &a) {
 }
 
 // one layer (a.nlayers == 1): any chunk stream of at least one chunk, both accumulator starts
+// tile 4 (round 5, VNNI-2 only, single layers only): 32x32 + K2 - two MFMA waves, one loader wave per panel. For SMALL outputs with a
+// LONG reduction (the reference's M = 128 / 256 shapes at K >= 1536: launch_gemm routes here): twice the workgroups of the 32x64 tile,
+// each streaming 8 KiB per chunk - the layer is bound by how many CUs pull panels, not by the matrix pipes
 hipError_t launch_bf16_lw(int tile, const ChainArgs &a, hipStream_t s) {
-  if (a.L[0].br < 1 || a.L[0].k < BLW_BK || tile < 0 || tile > 3) return hipErrorInvalidValue;
+  if (a.L[0].br < 1 || a.L[0].k < BLW_BK || tile < 0 || tile > 4) return hipErrorInvalidValue;
   const bool sup2 = blw_sup2(a);
+  if (tile == 4) return sup2 ? launch_blw_t<1, 1, 2, 1, 1, 8, 1, 1, 2, false, 0>(a, s) : launch_blw_t<1, 1, 2, 1, 1, 8, 1, 1, 1, false, 0>(a, s);
   BLW_DISPATCH(false, 0)
 }
 

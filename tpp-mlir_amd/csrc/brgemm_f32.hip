@@ -818,6 +818,20 @@ static bool lw16_on() {
   }();
   return on;
 }
+static int64_t bf16_long_k() {
+  static const int64_t v = [] {
+    const char *e = getenv("TPP_HIP_BF16_LONG_K"); // A/B runs: the reduction length from which small bf16 outputs leave the 32x32 K-split kernel
+    return e ? (int64_t)atoll(e) : (int64_t)1536;
+  }();
+  return v;
+}
+static bool bf16_lw32_on() {
+  static const bool on = [] {
+    const char *e = getenv("TPP_HIP_BF16_LW32"); // A/B runs: 0 = long-reduction bf16 layers stay on the 32x64 tile
+    return !e || atoi(e) != 0;
+  }();
+  return on;
+}
 static bool k32_pairs_on() {
   static const bool on = [] {
     const char *e = getenv("TPP_HIP_GROUPED_K32_PAIRS"); // A/B runs: 0 = 32-k tiles on the generic grouped kernel, as before round 4
@@ -1130,16 +1144,23 @@ hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C,
   if (v >= V_BF16_FAST && v != V_BF16_SMALL32 && ((((uintptr_t)C) & 15) || (d.bias && (((uintptr_t)D) & 7)))) v = V_GENERIC;
   if (v == V_BF16_SMALL32 && ((((uintptr_t)C) & 7) || (d.bias && (((uintptr_t)D) & 7)))) v = V_GENERIC;
   // Small bf16 outputs with a LONG reduction: the 32x32 K-split kernel (fragments straight from global memory, two groups of loads
-  // in flight per wave) is latency-bound there - 128 x 1024 x 4096: 15.4 us against 9.8 on 64 loader-wave tiles of 32x64; at
-  // K = 1024 it still wins (4.9 against 5.1), the curves cross between 1024 and 2048 (profiles/r05_bf16_skinny_small_vs_lw.txt). The
-  // batch count arrives with the invoke, so this choice is made here and not at dispatch.
-  if (v == V_BF16_SMALL32 && d.variant == V_BF16_SMALL32 && !d.generic_forced && (int64_t)a.br * d.k >= 1536 && d.k % 64 == 0 && d.m % 32 == 0 && d.n % 64 == 0 &&
-      !(((uintptr_t)C) & 15) && !(d.bias && (((uintptr_t)D) & 7)) && !d.variant_forced) {
+  // in flight per wave) is latency-bound there - 128 x 1024 x 4096: 15.4 us against 9.8 on 64 loader-wave tiles of 32x64 and 8.1 on
+  // 128 tiles of 32x32 + K2 (the same kernel, twice the workgroups pulling panels). Crossovers (profiles/r05_bf16_skinny_small_vs_lw.txt):
+  // against the 32x32 + K2 instance - usable when the output is at most one 32x32 tile per CU - at K = 1024 (256 x 1024 x 1024: 4.78
+  // against 5.05 us, the reference's bs = 256 bf16 MLP as whole-layer calls 14.3 against 15.7; at K = 768 the K-split kernel still
+  // wins by 0.06-0.2 us), against the 32x64 tile between 1024 and 2048. The batch count arrives with the invoke, so this choice is
+  // made here and not at dispatch.
+  bool bf16_lw_32x32 = false;
+  if (v == V_BF16_SMALL32 && d.variant == V_BF16_SMALL32 && !d.generic_forced && d.k % 64 == 0 && d.m % 32 == 0 && d.n % 64 == 0 && !(((uintptr_t)C) & 15) &&
+      !(d.bias && (((uintptr_t)D) & 7)) && !d.variant_forced) {
+    const bool t32 = (d.m / 32) * (d.n / 32) <= (int64_t)g_num_cus && bf16_lw32_on();
+    const int64_t thr = t32 && bf16_long_k() > 1024 ? 1024 : bf16_long_k();
     GemmDesc e = d;
-    e.m = (d.m + 63) / 64 * 64; // (bf16_fast_eligible asks for m % 64; the 32x64 tile needs m % 32 only)
-    if (bf16_fast_eligible(e)) {
+    e.m = (d.m + 63) / 64 * 64; // (bf16_fast_eligible asks for m % 64; these tiles need m % 32 only)
+    if ((int64_t)a.br * d.k >= thr && bf16_fast_eligible(e)) {
       v = V_BF16_LW_32x64;
-      g_last_refined.store("brgemm_bf16_lw<32x64,k2> (long reduction)", std::memory_order_relaxed);
+      bf16_lw_32x32 = t32;
+      g_last_refined.store(t32 ? "brgemm_bf16_lw<32x32,k2> (long reduction)" : "brgemm_bf16_lw<32x64,k2> (long reduction)", std::memory_order_relaxed);
     }
   }
   if (v >= V_BF16_LW_32x64 && v <= V_BF16_LW4_128x128 && a.br < 1) v = V_GENERIC; // empty batch (C = epilogue of nothing): the loader-wave kernels assume a chunk
@@ -1205,7 +1226,7 @@ hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C,
     c.m = a.m; c.n = a.n; c.nlayers = 1; c.tiles_m = c.tiles_n = 0; c.xm = 0; c.stamps = nullptr;
     c.dbg = chain_ablation_bits();
     c.L[0] = ChainLayer{a.B, a.D, a.C, a.ldb, a.ldc, a.stride_a, a.stride_b, a.k, a.br, a.ep, 0};
-    return launch_bf16_lw(v - V_BF16_LW_32x64, c, stream);
+    return launch_bf16_lw(bf16_lw_32x32 ? 4 : v - V_BF16_LW_32x64, c, stream);
   }
   case V_BF16_LW4_32x64:
   case V_BF16_LW4_64x64:
