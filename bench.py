@@ -62,6 +62,11 @@ def parse():
                     help="all-gather of the MLP output at N > 1: peer = every rank stores its rows into every peer's buffer through "
                          "IPC-mapped pointers (csrc/peer_gather.hip), falling back to RCCL if the buffers cannot be mapped; rccl = "
                          "dist.all_gather_into_tensor")
+    ap.add_argument("--refbench", action="store_true",
+                    help="N = 1 only: print the reference's whole benchmark shape set (tools/refbench.py: 216 rows, f32 / bf16 VNNI-2 / VNNI-4, tile "
+                         "invokes and whole layer) with the CPU port's figure per shape beside it (this file's cpu_baseline leg) and exit: what "
+                         "profiles/r05_refbench.txt is made with")
+    ap.add_argument("--refbench-json", default="", help="with --refbench: also write the rows as JSON")
     ap.add_argument("--no-pmc", action="store_true",
                     help="do not run the rocprofv3 PMC passes for roofline.traffic (use when bench.py itself runs under a profiler)")
     return ap.parse_args()
@@ -301,6 +306,48 @@ def parity_figures(got, A, B, C0, m, n, k, br):
             "pass": bool(normwise <= 1e-5 and used <= 1.0 and hip64["normwise"] <= 2.0 * orc64["normwise"] + 2.0 ** -22)}
 
 
+REFBENCH_SHAPES = [(1024, 1024, 512), (1024, 2560, 1024), (1024, 352, 512), (1024, 512, 256), (128, 1024, 1024), (128, 1024, 4096), (128, 3072, 768),
+                   (128, 4096, 1024), (128, 768, 2304), (128, 768, 3072), (128, 768, 768), (256, 1024, 1024), (256, 1024, 4096), (256, 3072, 768),
+                   (256, 4096, 1024), (256, 768, 3072), (256, 768, 768)]  # (M, N, K) of benchmarks/config/matmul/*.json = fc/*.json (tools/refbench.py)
+
+
+def cpu_refbench_rows(seconds_per_shape=0.5):
+    """cpu_baseline leg, second part: the CPU port (oracle/cpu_baseline.c: the reference's packed 32x32x32 call structure under OpenMP,
+    the container's usable CPUs) on every (M, N, K) of the reference's benchmark shape set - the column beside the GPU rows of
+    tools/refbench.py. ~10 s in all. Returns {"MxNxK": {"gflops", "us", "threads"}}."""
+    from oracle import pyoracle as orc
+    cb = orc.CpuBaseline(native=True)
+    cpus, _ = orc.usable_cpus()
+    team = cb.set_threads(cpus)
+    rng = np.random.default_rng(5)
+    res = {}
+    for (M, N, K) in REFBENCH_SHAPES:
+        A = rng.uniform(-1, 1, M * K).astype(np.float32)
+        B = rng.uniform(-1, 1, K * N).astype(np.float32)
+        Ap, Bp, Cp = cb.pack(A, B, np.zeros(M * N, np.float32), M, N, K)
+        cb.run(M, N, K, Ap, Bp, Cp, True, 2)
+        reps, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds_per_shape:
+            cb.run(M, N, K, Ap, Bp, Cp, True, 10)
+            reps += 10
+        el = time.perf_counter() - t0
+        res["%dx%dx%d" % (M, N, K)] = {"gflops": round(2.0 * M * N * K * reps / el / 1e9, 1), "us": round(el / reps * 1e6, 2), "threads": team}
+    return res
+
+
+def refbench_mode(args):
+    """--refbench: the whole table, CPU column included; prints it and exits"""
+    cpu = cpu_refbench_rows()
+    with tempfile.TemporaryDirectory() as td:
+        cj = os.path.join(td, "cpu.json")
+        with open(cj, "w") as f:
+            json.dump(cpu, f)
+        cmd = [sys.executable, os.path.join(ROOT, "tools", "refbench.py"), "-n", "300", "--cpu-json", cj]
+        if args.refbench_json:
+            cmd += ["--json", args.refbench_json]
+        return subprocess.call(cmd)
+
+
 def cpu_baseline(seconds, A, B, C):
     """The CPU row: the reference's packed 32x32x32-tile batch-reduce call structure under OpenMP
     (oracle/cpu_baseline.c, compiled here with -O3 -march=native) on the same C2 inputs, checked against the
@@ -449,6 +496,10 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch one rank per GPU (python bench.py --gpus N starts them itself)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no HIP device visible); there is no CPU fallback")
+    if args.refbench:
+        if world != 1:
+            raise SystemExit("--refbench is an N = 1 mode")
+        sys.exit(refbench_mode(args))
     # TEST SWITCH (tests/test_bench_multi_gpu.py): TPP_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and runs the process group on
     # gloo (RCCL cannot place two ranks on one device) - the whole N > 1 code path of this file, the peer-store gather over real IPC
     # handles included, on a one-GPU box. The numbers of such a run are meaningless (the ranks time-slice one GPU) and say so.
@@ -954,12 +1005,12 @@ def main():
                 with tempfile.TemporaryDirectory() as td:
                     jf = os.path.join(td, "refbench.json")
                     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "refbench.py"), "--quick", "-n", "200", "--json", jf],
-                                   capture_output=True, text=True, timeout=600, check=True)
+                                   capture_output=True, text=True, timeout=600, check=True)  # (GPU side only; the CPU column joins below)
                     rows = json.load(open(jf))
                 rows.sort(key=lambda r_: r_["frac_of_peak"])
                 keep = lambda r_: {"benchmark": r_["name"], "tiles": "%d,%d,%d" % tuple(r_["tiles"]), "form": r_["form"], "us": r_["us"],  # noqa: E731
                                    "value": r_["gflops"], "unit": "GFLOP/s", "frac_of_f32_mfma_peak": round(r_["frac_of_peak"], 4),
-                                   "kernel": r_["kernel_name"], "cpu_port_gflops": r_["cpu_port_gflops_f32"], "cpu_threads": r_["cpu_threads"],
+                                   "kernel": r_["kernel_name"], "shape": "%dx%dx%d" % (r_["M"], r_["layers"][1], r_["layers"][0]),
                                    "reference_config": r_["cite"]}
                 met = [r_ for r_ in rows if r_["frac_of_peak"] >= 0.45 or r_["us"] / (len(r_["layers"]) - 1) <= 5.0]
                 others.append({"workload": "the reference's benchmark shape set, f32 (tools/refbench.py: %d rows = 36 benchmarks x {tile invokes, whole layer})" % len(rows),
@@ -996,6 +1047,16 @@ def main():
         if not args.no_cpu_baseline:
             hA, hB, hC = inputs(args.init)
             cpu = cpu_baseline(args.cpu_seconds, hA, hB, hC)
+            if others:  # the CPU port on the shapes of the reference's benchmark set, beside the GPU rows of other_configs
+                try:
+                    cpu["refbench_shapes"] = cpu_refbench_rows()
+                    for o_ in others:
+                        for r_ in o_.get("worst3", []) + o_.get("best3", []):
+                            cr = cpu["refbench_shapes"].get(r_["shape"])
+                            if cr:
+                                r_["cpu_port_gflops"], r_["cpu_threads"] = cr["gflops"], cr["threads"]
+                except Exception as ex:
+                    cpu["refbench_shapes"] = {"error": str(ex)[:200]}
 
     # who took part: the process group's own count and every rank's device (N distinct GPUs, or the one-device test rig)
     group_info = None

@@ -142,4 +142,9 @@ def test_refbench_restates_the_reference_benchmark_configs():
     assert tiled and all(r["batch"] == 256 and r["layers"] == [1024] * 4 and r["tiles"] == [32, 32, 32] and r["kernel"] == "const" for r in tiled)
     got = rb.cases("")
     assert len(got) == (17 + 17) * 3 * 2 + 2 * 3 * 2
+    # ... and bench.py's cpu_baseline leg (the CPU column of the table) runs the same (M, N, K) list
+    spec_b = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bm = importlib.util.module_from_spec(spec_b)
+    spec_b.loader.exec_module(bm)
+    assert bm.REFBENCH_SHAPES == [(M, N, K) for (M, N, K, _) in rb.SHAPES]
     assert {c["kernel"] for c in got if c["family"] == "base"} == {"const"} and {c["kernel"] for c in got if c["family"] != "base"} == {"args"}

@@ -45,7 +45,7 @@ for dbg in 0 16 32 48 2 6 7; do echo "dbg=$dbg"; lib=tools/_abl; [ $((dbg & 32))
   LD_LIBRARY_PATH=$lib TPP_HIP_CHAIN_DBG=$dbg timeout 100 tools/mlp_probe 2>&1; done > $OUT/chain_ablation.txt
 fi
 # round 5: the reference's benchmark shape set (full table + json), the split / half-width-tile sweep, the self-launching N = 2 bench on the one-device rig
-timeout 600 python tools/refbench.py -n 300 --json $OUT/refbench.json > $OUT/refbench.txt 2> $OUT/refbench.err
+timeout 900 python bench.py --refbench --refbench-json $OUT/refbench.json > $OUT/refbench.txt 2> $OUT/refbench.err
 timeout 300 python tools/split_sweep.py > $OUT/split_sweep.txt 2>&1
 TPP_BENCH_ONE_DEVICE=1 timeout 600 python bench.py --gpus 2 --steps 6 --warmup 3 > $OUT/bench_gpus2_rig.json 2> $OUT/bench_gpus2_rig.err
 python tools/sweep.py 2>/dev/null | grep -E "^(f32|bf16)" > $OUT/sweep.txt

@@ -14,10 +14,11 @@ Each row is replayed by tools/tpp_replay (the reference's timing loop: one timer
   tiles : as the compiler emits it - one fused_brgemm dispatch [m,n,k,k,n,n,m*k,k*n], (M/m)*(N/n) invokes with br = K/k on the packed
           block layouts, through the runtime's tile queue (one grouped launch per layer)
   whole : ONE whole-layer dispatch per layer on the flat tensors (k = 64 chunks, br = K/64)
-for f32, bf16 + VNNI-2 and bf16 + VNNI-4. GFLOP/s = BENCH_TOTAL_FLOPS / mean (MLIRGen.cpp:313-334). The CPU row is
-oracle/cpu_baseline.c (the reference's packed 32x32x32 call structure under OpenMP; libxsmm is not in the image) on the same shape.
+for f32, bf16 + VNNI-2 and bf16 + VNNI-4. GFLOP/s = BENCH_TOTAL_FLOPS / mean (MLIRGen.cpp:313-334). This tool measures the GPU side
+only; the CPU column (the reference's packed 32x32x32 call structure under OpenMP on the same shape: the `cpu_baseline` leg of
+bench.py, which alone may use oracle/) is read from --cpu-json when given - `python bench.py --refbench` produces the whole table.
 
-usage: python tools/refbench.py [--quick] [--no-cpu] [--only matmul|fc|base] [-n ITER] [--json out.json]
+usage: python tools/refbench.py [--quick] [--only matmul|fc|base] [-n ITER] [--json out.json] [--cpu-json cpu_rows.json]
 """
 import argparse
 import json
@@ -26,10 +27,8 @@ import re
 import subprocess
 import sys
 import tempfile
-import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
 PEAK = {"f32": 157.3e12, "bf16": 2500e12}
 
 # (M = batch, N = out features, K = in features, (tile m, n, k)) - benchmarks/config/matmul/*.json and fc/*.json (17 files each, same shapes)
@@ -82,34 +81,11 @@ def flops_of(c):
     return f
 
 
-def cpu_rows(shapes, seconds=0.6):
-    """the CPU port (oracle/cpu_baseline.c: packed 32x32x32 blocks, OpenMP over the tile grid) on every (M, N, K): f32, plain matmul"""
-    import numpy as np
-    from oracle import pyoracle as orc
-    cb = orc.CpuBaseline(native=True)
-    cpus, _ = orc.usable_cpus()
-    team = cb.set_threads(cpus)
-    res = {}
-    rng = np.random.default_rng(5)
-    for (M, N, K) in shapes:
-        A = rng.uniform(-1, 1, M * K).astype(np.float32)
-        B = rng.uniform(-1, 1, K * N).astype(np.float32)
-        C = np.zeros(M * N, np.float32)
-        Ap, Bp, Cp = cb.pack(A, B, C, M, N, K)
-        cb.run(M, N, K, Ap, Bp, Cp, True, 2)
-        reps, t0 = 0, time.perf_counter()
-        while time.perf_counter() - t0 < seconds:
-            cb.run(M, N, K, Ap, Bp, Cp, True, 10)
-            reps += 10
-        el = time.perf_counter() - t0
-        res[(M, N, K)] = {"us": el / reps * 1e6, "gflops": 2.0 * M * N * K * reps / el / 1e9, "threads": team}
-    return res
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true", help="f32 only")
-    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true", help="(accepted for older command lines; the CPU column comes from --cpu-json only)")
+    ap.add_argument("--cpu-json", default="", help='{"MxNxK": {"gflops": g, "threads": t}, ...} from bench.py\'s cpu_baseline leg')
     ap.add_argument("--only", default="")
     ap.add_argument("-n", type=int, default=300)
     ap.add_argument("--json", default="")
@@ -132,8 +108,9 @@ def main():
         assert abs(float(m_.group(4)) - flops_of(c)) < 1, (c, m_.group(4))
         c["frac_of_peak"] = c["gflops"] * 1e9 / PEAK["f32" if c["dtype"] == "f32" else "bf16"]
     cpu = {}
-    if not args.no_cpu:
-        cpu = cpu_rows(sorted({(c["M"], c["layers"][1], c["layers"][0]) for c in cs if c["family"] != "base"} | {(256, 1024, 1024)}))
+    if args.cpu_json:
+        with open(args.cpu_json) as f:
+            cpu = {tuple(int(x) for x in k.split("x")): v for k, v in json.load(f).items()}
     print("# refbench: %d rows, tpp_replay -n %d; GPU peaks f32 157.3 TF, bf16 2500 TF (dense MFMA); empty-launch floor ~2.5 us" % (len(cs), args.n))
     print("# %-24s %-11s %-10s %-6s %9s %10s %7s %9s  %s" % ("benchmark", "tiles", "dtype", "form", "us", "GFLOP/s", "frac", "CPU GF/s", "kernel"))
     for c in cs:

@@ -30,14 +30,14 @@ static inline const SplitScratch *split_scratch_for(hipStream_t s, long long til
     (void)hipGetLastError();
     return nullptr;
   }
-  std::lock_guard<std::mutex> lk(mu);
-  for (const SplitScratch *b : blocks)
-    if (b->device == dev && b->stream == s) return b;
-  // a stream that is being captured into a graph: no allocation, no device synchronisation now - the launch runs unsplit (a harness
-  // that captures warms up first, like bench.py, and then finds the block)
+  // a stream that is being captured into a graph: the launch runs unsplit - a captured split launch would carry this stream's block
+  // into every replay of the graph, on whatever stream and next to whatever other launch (and nothing may be allocated now anyway)
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(s, &cs) != hipSuccess) (void)hipGetLastError();
   if (cs != hipStreamCaptureStatusNone) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  for (const SplitScratch *b : blocks)
+    if (b->device == dev && b->stream == s) return b;
   SplitScratch *b = new SplitScratch{dev, s, nullptr, nullptr};
   if (hipMalloc((void **)&b->cnt, SPLIT_MAX_TILES * sizeof(unsigned)) != hipSuccess ||
       hipMalloc((void **)&b->partial, SPLIT_SCRATCH_FLOATS * sizeof(float)) != hipSuccess ||
