@@ -258,3 +258,40 @@ def test_bf16_small_outputs_with_a_long_reduction_switch_tiles_at_invoke_time(rt
         assert ran == "", ran  # (n = 96 / 32: the loader-wave tiles need n % 64 == 0 - the handle's own kernel)
     gemm_case(rt, BF16, m, n, k, 4, lda=K + 8, sa=k, sb=k * n, vnni=True, beta0=beta0, bias=bias, relu=relu, seed=m + n, offs=(8, 8, 8, 4))
     assert rt.last_refined_kernel() == ""
+
+
+@pytest.mark.parametrize("forced", [-1, 2, 3, 5, 16])
+def test_bf16_split_groups_through_the_tile_queue(rt, forced):
+    """a skinny bf16 layer as tile invokes (matmul 128x1024x2048 as 32 invokes of 64x64x64, br = 32, VNNI-2 W, C += ...): the group runs
+    on the 32x32 K-split kernel with the K steps of a tile over several workgroups (the model's count, and forced counts incl. more
+    workgroups than a tile has 64-step shares); one bf16 ulp + the f32 floor against the oracle, the same bits on every run"""
+    M, N, K, t = 128, 1024, 2048, 64
+    rng = np.random.default_rng(21)
+    X = orc.bf16_to_f32(orc.f32_to_bf16(rng.uniform(-1, 1, M * K).astype(np.float32))).reshape(M, K)
+    W = orc.bf16_to_f32(orc.f32_to_bf16((rng.uniform(-1, 1, K * N) / 32).astype(np.float32))).reshape(K, N)
+    C0 = orc.bf16_to_f32(orc.f32_to_bf16(rng.uniform(-1, 1, M * N).astype(np.float32))).reshape(M, N)
+    ref = orc.f32_to_bf16(C0.reshape(-1).copy())
+    Wv = np.ascontiguousarray(W.reshape(K // 2, 2, N).transpose(0, 2, 1)).reshape(-1)
+    orc.brgemm(BF16, M, N, K, K, N, N, 0, 0, VB, orc.f32_to_bf16(X.reshape(-1)), 0, orc.f32_to_bf16(Wv), 0, ref, 0, 1)
+    dA, dW = dev(orc.f32_to_bf16(pack_a(X, M, K, t, t))), dev(orc.f32_to_bf16(pack_w(W, K, N, t, t, 2)))
+    h = rt.brgemm_dispatch(BF16, t, t, t, t, t, t, t * t, t * t, VB)
+    MB, NB, KB = M // t, N // t, K // t
+    old_async, old_q = rt.set_async(True), rt.set_tile_queue(1)
+    rt.force_split(forced)
+    outs = []
+    try:
+        for rep in range(3):
+            dC = dev(orc.f32_to_bf16(pack_c(C0, M, N, t, t)))
+            for i in range(MB):
+                for j in range(NB):
+                    rt.brgemm(BF16, h, dA, i * KB * t * t, dW, j * KB * t * t, dC, (i * NB + j) * t * t, KB)
+            rt.synchronize()
+            outs.append(host(dC, ref))
+            assert "small32 grouped, split" in rt.last_grouped_kernel(), rt.last_grouped_kernel()
+    finally:
+        rt.force_split(-1)
+        rt.set_tile_queue(old_q)
+        rt.set_async(old_async)
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    got = unpack_c(orc.bf16_to_f32(outs[0]), M, N, t, t).reshape(-1)
+    check_close(orc.f32_to_bf16(got), ref, BF16, "bf16 split group (forced %d)" % forced)

@@ -15,6 +15,7 @@
 // compiler-native bf16 tiles (32 x 32 x 32, 32 x 64 x 64 ...), where a batch element is 2-4 K steps.
 #include "gemm_common.h"
 #include "xsmm_desc.h"
+#include "split_scratch.h"
 
 namespace tpp {
 
@@ -28,20 +29,32 @@ typedef __attribute__((address_space(1))) unsigned short g_u16;
 
 constexpr int SG = 8; // K steps (of 16) per register set
 
+// SPLIT (round 5): grid (items * p.split, tiles_n, tiles_m) - the K steps of ONE output tile shared by p.split workgroups (skinny
+// groups with a long reduction: 128 x 1024 x 4096 as 64x64x64 tile invokes is 128 tiles of 32x32 on 256 CUs, each a latency-bound
+// stream of 256 K steps). Same hand-off as the f32 SPLIT kernels (brgemm_f32_lw.hip): the f32 partial tile parked write-through in
+// the stream's scratch block, arrival counter, the LAST workgroup sums the partials in split order (fixed order of additions), adds
+// C / bias, relu, rounds ONCE to bf16 and stores. No workgroup waits for another.
+typedef __attribute__((address_space(1))) unsigned int g_u32_s32;
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void brgemm_bf16_small32(GemmArgs p, const WorkItem *__restrict__ items) {
+  const int item = SPLIT ? (int)blockIdx.x / p.split : (int)blockIdx.x;
+  const int sp = SPLIT ? (int)blockIdx.x - item * p.split : 0;
   if (items) {
-    const WorkItem it = items[blockIdx.x];
+    const WorkItem it = items[item];
     p.A = it.A; p.B = it.B; p.C = it.C; p.D = it.D; p.br = (int)it.br;
   }
   __shared__ float red[4 * 16 * 64];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
-  const int tm = items ? (int)blockIdx.z : (int)(blockIdx.x >> 1) * p.tiles_m + (int)blockIdx.z;
-  const int tn = items ? (int)blockIdx.y : (int)(blockIdx.x & 1) * p.tiles_n + (int)blockIdx.y;
+  const int tm = (items || SPLIT) ? (int)blockIdx.z : (int)(blockIdx.x >> 1) * p.tiles_m + (int)blockIdx.z;
+  const int tn = (items || SPLIT) ? (int)blockIdx.y : (int)(blockIdx.x & 1) * p.tiles_n + (int)blockIdx.y;
   const int m0 = tm * 32, n0 = tn * 32;
   const int spb = p.k >> 4;                // K steps per batch element
-  const int S = p.br * spb;                // K steps in total
+  const int S_all = p.br * spb;            // K steps in total
+  // SPLIT: this workgroup's steps [s_lo, s_lo + S) of the tile's S_all
+  const int s_lo = SPLIT ? (int)(((long long)S_all * sp) / p.split) : 0;
+  const int S = SPLIT ? (int)(((long long)S_all * (sp + 1)) / p.split) - s_lo : S_all;
   const int per = (S + 3) >> 2;            // contiguous share of each wave (consecutive steps walk along cache lines)
   int s = wave * per;
   const int s_end = s + per < S ? s + per : S;
@@ -50,7 +63,7 @@ __global__ __launch_bounds__(256) void brgemm_bf16_small32(GemmArgs p, const Wor
   g_cu16 *a_lane = (g_cu16 *)p.A + (int64_t)(m0 + li) * p.lda + 8 * lh;
   g_cu32 *b_lane = (g_cu32 *)p.B + (int64_t)(4 * lh) * p.ldb + (n0 + li); // dwords: pair-row stride = ldb
   // position of step s: batch element b, step kk inside it
-  int b = spb ? s / spb : 0, kk = s - b * spb;
+  int b = spb ? (s_lo + s) / spb : 0, kk = (s_lo + s) - b * spb;
 
   f32x16 acc;
 #pragma unroll
@@ -121,6 +134,27 @@ __global__ __launch_bounds__(256) void brgemm_bf16_small32(GemmArgs p, const Wor
 #pragma unroll
       for (int w = 1; w < 4; ++w) v[x] += red[w * 1024 + (4 * g + x) * 64 + lane];
     }
+    if constexpr (SPLIT) {
+      // park the partial tile ([tile][split][wave][lane] float4: 1 KiB per wave instruction), arrive, and only the last workgroup goes on
+      const int nsp = p.split;
+      const int tile_id = (item * (int)gridDim.y + tn) * (int)gridDim.z + tm;
+      float *scr = p.scratch + (size_t)tile_id * nsp * 1024;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)scr, 0, 0x7fffffff, 0x00020000);
+      const unsigned pvo = (unsigned)((wave * 64 + lane) * 16);
+      const f32x4 part = {v[0], v[1], v[2], v[3]};
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, part), rs, pvo, (unsigned)(sp * 4096), 16);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      unsigned *flag = (unsigned *)red;
+      if (wave == 0 && lane == 0) *flag = __hip_atomic_fetch_add((g_u32_s32 *)(p.split_cnt + tile_id), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      if (*flag != (unsigned)(nsp - 1)) return;
+      if (wave == 0 && lane == 0) __hip_atomic_store((g_u32_s32 *)(p.split_cnt + tile_id), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      f32x4 acc4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, pvo, 0, 16));
+      for (int s2 = 1; s2 < nsp; ++s2) acc4 += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, pvo, (unsigned)(s2 * 4096), 16));
+#pragma unroll
+      for (int x = 0; x < 4; ++x) v[x] = acc4[x];
+    }
     if (!(p.ep & EP_BETA0)) {
       const u32x2d c2 = *(g_cu32x2 *)(crow + 8 * g);
       v[0] += __uint_as_float(c2[0] << 16);
@@ -150,9 +184,21 @@ __global__ __launch_bounds__(256) void brgemm_bf16_small32(GemmArgs p, const Wor
 
 // preconditions (checked by the callers): bf16, VNNI-2 B, m % 32 == 0, n % 32 == 0, k % 16 == 0, lda % 8 == 0,
 // stride_a % 8 == 0, stride_b % 2 == 0, ldc % 4 == 0; A 16-byte, B 4-byte, C / D 8-byte aligned
-hipError_t launch_bf16_small32(const GemmArgs &a, const WorkItem *items, int n_items, hipStream_t s) {
+// split > 1: that many workgroups per output tile (grouped launches and single invokes in the grouped grid form)
+hipError_t launch_bf16_small32(const GemmArgs &a, const WorkItem *items, int n_items, hipStream_t s, int split) {
   GemmArgs args = a;
   const int tiles_m = a.m / 32, tiles_n = a.n / 32;
+  if (split > 1 && tiles_n <= 65535 && tiles_m <= 65535) {
+    const long long tiles = (long long)n_items * tiles_m * tiles_n;
+    if (const SplitScratch *sc = split_scratch_for(s, tiles, tiles * split * 1024)) {
+      args.tiles_m = args.tiles_n = 0;
+      args.split = split;
+      args.scratch = sc->partial;
+      args.split_cnt = sc->cnt;
+      hipLaunchKernelGGL(brgemm_bf16_small32<true>, dim3((unsigned)(n_items * split), tiles_n, tiles_m), dim3(256), 0, s, args, items);
+      return hipGetLastError();
+    } // (no scratch block: the unsplit launch)
+  }
   dim3 grid;
   if (items) {
     args.tiles_m = args.tiles_n = 0;
@@ -166,7 +212,7 @@ hipError_t launch_bf16_small32(const GemmArgs &a, const WorkItem *items, int n_i
     if (tiles_m > 65535 || tiles_n > 65535) return hipErrorInvalidValue;
     grid = dim3(1, tiles_n, tiles_m);
   }
-  hipLaunchKernelGGL(brgemm_bf16_small32, grid, dim3(256), 0, s, args, items);
+  hipLaunchKernelGGL(brgemm_bf16_small32<false>, grid, dim3(256), 0, s, args, items);
   return hipGetLastError();
 }
 

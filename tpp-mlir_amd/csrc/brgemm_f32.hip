@@ -743,7 +743,7 @@ static hipError_t launch_grouped_t(const GemmArgs &a, const WorkItem *items, int
 constexpr int SPLIT_MAX_WG = 16; // = SPLIT_MAX of split_scratch.h
 
 hipError_t launch_bf16_grouped64(const GemmArgs &a, const WorkItem *items, int n_items, hipStream_t s); // brgemm_bf16.hip
-hipError_t launch_bf16_small32(const GemmArgs &a, const WorkItem *items, int n_items, hipStream_t s); // brgemm_bf16_small.hip
+hipError_t launch_bf16_small32(const GemmArgs &a, const WorkItem *items, int n_items, hipStream_t s, int split = 1); // brgemm_bf16_small.hip
 // flat-B bf16 for the loader-wave tiles: 16-byte row pieces of A, B and C, 64-k chunks, 32-bit lane offsets
 static bool bf16_flat_eligible(const GemmDesc &d) {
   return d.dtype == DT_BF16 && !d.vnni_b && !d.vnni_c && d.k > 0 && d.k % 64 == 0 && d.m % 32 == 0 && d.n % 64 == 0 &&
@@ -932,7 +932,26 @@ hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_i
   if (vec16 && out_ok && d.variant >= V_BF16_FAST && (d.variant != V_BF16_SMALL32 || !d.variant_forced) && !d.generic_forced && bf16_fast_eligible(d) &&
       (int64_t)n_items * (d.m / 64) * (d.n / 64) >= (3 * g_num_cus) / 4)
     return note_grouped("brgemm_bf16_fast<64x64> grouped", launch_bf16_grouped64(a, items, n_items, stream));
-  if (vec_ok && out_ok && d.variant != V_GENERIC && bf16_small_eligible(d)) return note_grouped("brgemm_bf16_small32 grouped", launch_bf16_small32(a, items, n_items, stream));
+  if (vec_ok && out_ok && d.variant != V_GENERIC && bf16_small_eligible(d)) {
+    // skinny groups with a long reduction: the K steps of a tile over several workgroups (the kernel is a latency-bound stream: 0.047 us
+    // per 16-k step of a workgroup). Measured (profiles/r05_bf16_skinny_small_vs_lw.txt): it pays only while every workgroup still has
+    // a CU to itself - 128 x 1024 x 4096 as 64x64x64 tile invokes 12.0 -> 9.8 us at S = 2 (10.3 at 4, 13.1 at 8), 256 x 1024 x 4096
+    // 12.3 -> 14.2 at S = 2. Hence the largest count with tiles x S <= CUs and at least 32 steps per workgroup, if it saves more
+    // than the hand-off costs. xsmm_hip_force_split overrides.
+    const long long t32 = (long long)n_items * (d.m / 32) * (d.n / 32), steps = (long long)br_hint * (d.k / 16);
+    int S = 1;
+    const int forced = g_forced_split.load(std::memory_order_relaxed);
+    if (forced >= 0) S = forced <= 1 ? 1 : (int)(forced < 16 ? forced : 16);
+    else if (t32 > 0) {
+      long long c = (long long)g_num_cus / t32;
+      if (c > 16) c = 16;
+      if (c > steps / 32) c = steps / 32;
+      if (c >= 2 && 0.047 * (double)(steps - (steps + c - 1) / c) > 2.7 + 0.8) S = (int)c;
+    }
+    if (S > (int)steps) S = steps > 1 ? (int)steps : 1;
+    if (S > 1) return note_grouped("brgemm_bf16_small32 grouped, split", launch_bf16_small32(a, items, n_items, stream, S));
+    return note_grouped("brgemm_bf16_small32 grouped", launch_bf16_small32(a, items, n_items, stream));
+  }
   if (d.dtype == DT_F32) return note_grouped("brgemm_grouped<f32>", vec ? launch_grouped_t<float, false, true>(a, items, n_items, stream)
                                                                         : launch_grouped_t<float, false, false>(a, items, n_items, stream));
   if (d.vnni_b && vec16_4) return note_grouped("brgemm_grouped<bf16,vnni4>", launch_grouped_t<unsigned short, true, true, 4>(a, items, n_items, stream)); // VNNI-4 on the bf16 MFMA path
