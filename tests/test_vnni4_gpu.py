@@ -258,3 +258,49 @@ def test_chain_launch_on_vnni4_and_flat_b_layers(rt, kind, m, tile):
     ref = np.zeros(32 * N, np.uint16)
     orc.fused_brgemm(BF16, 32, N, 64, N, N, N, 64, 64 * N, 4, 0, 5, 4, 1, X, 0, Wf[0], 0, ref, 0, bs[0], 0, N // 64)
     check_close(outs[kind + "_layer0"], ref, BF16, "%s chain layer 0 (rows 0-31)" % kind)
+
+
+def test_vnni4_groups_of_64x64_tiles_run_on_the_64x64_family(rt):
+    """round 5: `mlir-gen --tiles=64,64,64 --vnni=4` (the *_dp4_* rows of benchmarks/config/matmul|fc/*.json) as tile invokes - a group
+    that fills the chip (here 16 x 16 tiles of 64x64, br = 3) runs on the register-staged 64x64 bf16 kernel with the VNNI-4 source image
+    (four 16-byte loads per 4-column x 8-k piece, the in-register transpose selects differently): bit-identical to the same matrix as a
+    VNNI-2 operand through the same family, and against the oracle; with bias + relu and with C += ..."""
+    MB, NB, KB, t = 16, 16, 3, 64
+    rng = np.random.default_rng(4)
+    X = rand(rng, MB * KB * t * t, BF16)
+    Wf = rand(rng, NB * KB * t * t, BF16, -0.3, 0.3).reshape(NB, KB, t, t)  # [NB][KB][k][n] flat blocks
+    W2 = np.ascontiguousarray(Wf.reshape(NB, KB, t // 2, 2, t).transpose(0, 1, 2, 4, 3)).reshape(-1)
+    W4 = np.ascontiguousarray(Wf.reshape(NB, KB, t // 4, 4, t).transpose(0, 1, 2, 4, 3)).reshape(-1)
+    bias = rand(rng, NB * t, BF16)
+    C0 = rand(rng, MB * NB * t * t, BF16)
+    outs = {}
+    for flags, fused in ((4 | VB, (0, 5, 4, 1)), (VB, (0, 0, 0, 0))):
+        for v, W in ((2, W2), (4, W4)):
+            old, old_o = rt.set_vnni_factor(v), orc.set_vnni_factor(v)
+            try:
+                disp = (BF16, t, t, t, t, t, t, t * t, t * t, flags) + fused
+                h = rt.fused_brgemm_dispatch(*disp)
+                ref = C0.copy()
+                for i in range(0, MB, 5):  # (the oracle on a sample of tile rows: rows are independent)
+                    for j in range(NB):
+                        orc.fused_brgemm(*disp, X, i * KB * t * t, W, j * KB * t * t, ref, (i * NB + j) * t * t, bias, j * t, KB)
+            finally:
+                rt.set_vnni_factor(old)
+                orc.set_vnni_factor(old_o)
+            prev_async, prev_q = rt.set_async(True), rt.set_tile_queue(1)
+            try:
+                dX, dW, db, dC = dev(X), dev(W), dev(bias), dev(C0)
+                for i in range(MB):
+                    for j in range(NB):
+                        rt.fused_brgemm(BF16, h, dX, i * KB * t * t, dW, j * KB * t * t, dC, (i * NB + j) * t * t, db, j * t, KB)
+                rt.synchronize()
+                ran = rt.last_grouped_kernel()
+            finally:
+                rt.set_tile_queue(prev_q)
+                rt.set_async(prev_async)
+            assert ("fast_vnni4<64x64> grouped" if v == 4 else "fast<64x64> grouped") in ran, ran
+            got = host(dC, C0)
+            sel = np.concatenate([np.arange((i * NB) * t * t, (i * NB + NB) * t * t) for i in range(0, MB, 5)])
+            check_close(got[sel], ref[sel], BF16, "64x64 tiles vnni %d flags %d" % (v, flags))
+            outs[(flags, v)] = got
+        assert np.array_equal(outs[(flags, 2)], outs[(flags, 4)]), "VNNI-4 and VNNI-2 images of one matrix must give the same bits"

@@ -39,7 +39,10 @@ constexpr int NSTAGE_H = 3;
 constexpr int NSET_H = 3;  // staging register sets (chunks of global loads in flight per lane)
 
 // items != nullptr: grouped mode (tile queue), grid (items, tiles_n, tiles_m) - see brgemm_f32.hip
-template <int WM, int WN, int TM, int TN>
+// VF = 4 (round 5; grouped launches of --vnni=4 tile invokes): B is [k/4][n][4] - a B piece is still a 4-column x 8-k block fetched
+// with four 16-byte loads (k-group rows 2g, 2g + 1 x column pairs) and written as four per-column 16-byte LDS pieces; only the
+// source offsets and the register selection of the in-register transpose differ, the LDS image and everything behind it are the same.
+template <int WM, int WN, int TM, int TN, int VF = 2>
 __global__ __launch_bounds__(64 * WM * WN) void brgemm_bf16_fast(GemmArgs p, const WorkItem *__restrict__ items) {
   if (items) {
     const WorkItem it = items[blockIdx.x];
@@ -84,10 +87,11 @@ __global__ __launch_bounds__(64 * WM * WN) void brgemm_bf16_fast(GemmArgs p, con
 #pragma unroll
   for (int u = 0; u < LB; ++u) {
     const int q = tid + u * NT, g = q & 7, jq = q >> 3;
-    voffB[u] = (unsigned)((4 * g * 2 * (int)p.ldb + 8 * jq) * 2);
+    voffB[u] = VF == 4 ? (unsigned)((2 * g * 4 * (int)p.ldb + 16 * jq) * 2)  // k-group row 2g, columns 4 jq ..: 8 bytes per column
+                       : (unsigned)((4 * g * 2 * (int)p.ldb + 8 * jq) * 2);
   }
-  const unsigned rowB = (unsigned)(2 * (int)p.ldb * 2); // bytes between pair-rows
-  const unsigned short *gA = A + (int64_t)m0 * p.lda, *gB = B + 2 * (int64_t)n0;
+  const unsigned rowB = VF == 4 ? (unsigned)(4 * (int)p.ldb * 2) : (unsigned)(2 * (int)p.ldb * 2); // bytes between k-group rows / pair-rows
+  const unsigned short *gA = A + (int64_t)m0 * p.lda, *gB = B + VF * (int64_t)n0;
   int kc = 0;
   const int64_t dA_wrap = p.stride_a - (int64_t)(kchunks - 1) * BKH;
   const int64_t dB_in = (int64_t)(BKH / 2) * 2 * p.ldb, dB_wrap = p.stride_b - (int64_t)(kchunks - 1) * dB_in;
@@ -102,7 +106,8 @@ __global__ __launch_bounds__(64 * WM * WN) void brgemm_bf16_fast(GemmArgs p, con
       const int u = (it - LA) >> 2, rr = (it - LA) & 3;
       if (B_ITEMS % NT == 0 || tid + u * NT < B_ITEMS) {
         const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)gB, 0, 0x7fffffff, 0x00020000);
-        rb[set][u][rr] = __builtin_amdgcn_raw_buffer_load_b128(r, voffB[u] + rr * rowB, 0, 0);
+        // VNNI-2: pair-row 4g + rr, 4 columns; VNNI-4: k-group row 2g + rr / 2, column pair rr % 2
+        rb[set][u][rr] = __builtin_amdgcn_raw_buffer_load_b128(r, VF == 4 ? voffB[u] + (rr >> 1) * rowB + (rr & 1) * 16u : voffB[u] + rr * rowB, 0, 0);
       }
     }
   };
@@ -116,6 +121,10 @@ __global__ __launch_bounds__(64 * WM * WN) void brgemm_bf16_fast(GemmArgs p, con
       const int q = tid + u * NT, g = q & 7, jq = q >> 3;
       if (B_ITEMS % NT == 0 || q < B_ITEMS) { // column 4*jq+e: its 4 pair-rows, transposed in registers
         u32x4 v = {rb[stage][u][0][e], rb[stage][u][1][e], rb[stage][u][2][e], rb[stage][u][3][e]};
+        if constexpr (VF == 4) { // column 4 jq + e = column e % 2 of pair e / 2: its k 0..3 from row 2g, k 4..7 from row 2g + 1
+          const int c2 = e >> 1, o = 2 * (e & 1);
+          v = u32x4{rb[stage][u][c2][o], rb[stage][u][c2][o + 1], rb[stage][u][2 + c2][o], rb[stage][u][2 + c2][o + 1]};
+        }
         if (TPP_ABLATE & HABL_NO_TRANSPOSE) v = rb[stage][u][e];
         *(u32x4 *)(bs + g * B_GROW + ((4 * jq + e) << 4)) = v;
       }
@@ -363,11 +372,18 @@ static hipError_t launch_bf16(const GemmArgs &a, hipStream_t s) {
 // grouped launch of the 64x64 bf16 tile: one workgroup per (item, 64x64 tile of the item)
 hipError_t launch_bf16_grouped64(const GemmArgs &a, const WorkItem *items, int n_items, hipStream_t s) {
   constexpr size_t lds = (size_t)NSTAGE_H * (64 * BKH * 2 + 8 * (64 + 1) * 16);
+  GemmArgs args = a;
+  args.tiles_m = args.tiles_n = 0;
+  if (a.vf == 4) { // VNNI-4 B operands (xsmm_hip_set_vnni_factor(4))
+    auto kern4 = brgemm_bf16_fast<2, 2, 1, 1, 4>;
+    static std::atomic<unsigned long long> lds_set4{0};
+    if (hipError_t e = ensure_dynamic_lds((const void *)kern4, (int)lds, lds_set4); e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern4, dim3((unsigned)n_items, a.n / 64, a.m / 64), dim3(256), lds, s, args, items);
+    return hipGetLastError();
+  }
   auto kern = brgemm_bf16_fast<2, 2, 1, 1>;
   static std::atomic<unsigned long long> lds_set{0};
   if (hipError_t e = ensure_dynamic_lds((const void *)kern, (int)lds, lds_set); e != hipSuccess) return e;
-  GemmArgs args = a;
-  args.tiles_m = args.tiles_n = 0;
   hipLaunchKernelGGL(kern, dim3((unsigned)n_items, a.n / 64, a.m / 64), dim3(256), lds, s, args, items);
   return hipGetLastError();
 }

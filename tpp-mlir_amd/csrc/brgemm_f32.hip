@@ -932,6 +932,11 @@ hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_i
   if (vec16 && out_ok && d.variant >= V_BF16_FAST && (d.variant != V_BF16_SMALL32 || !d.variant_forced) && !d.generic_forced && bf16_fast_eligible(d) &&
       (int64_t)n_items * (d.m / 64) * (d.n / 64) >= (3 * g_num_cus) / 4)
     return note_grouped("brgemm_bf16_fast<64x64> grouped", launch_bf16_grouped64(a, items, n_items, stream));
+  // ... and the same family on a VNNI-4 B operand (--vnni=4 tile invokes: benchmarks/config/*/*_dp4_*; the generic kernel's MFMA path
+  // took 30 us for 1024 x 2560 x 1024 against 19.5 on VNNI-2)
+  if (vec16_4 && out_ok && !d.generic_forced && !d.vnni_c && d.k % BK == 0 && d.m % 64 == 0 && d.n % 64 == 0 && !((d.ldc | d.stride_b) & 7) && d.ldc < (1 << 22) &&
+      d.lda < (1 << 22) && d.ldb < (1 << 20) && (int64_t)n_items * (d.m / 64) * (d.n / 64) >= (3 * g_num_cus) / 4)
+    return note_grouped("brgemm_bf16_fast_vnni4<64x64> grouped", launch_bf16_grouped64(a, items, n_items, stream));
   if (vec_ok && out_ok && d.variant != V_GENERIC && bf16_small_eligible(d)) {
     // skinny groups with a long reduction: the K steps of a tile over several workgroups (the kernel is a latency-bound stream: 0.047 us
     // per 16-k step of a workgroup). Measured (profiles/r05_bf16_skinny_small_vs_lw.txt): it pays only while every workgroup still has
