@@ -35,7 +35,11 @@ constexpr int SG = 8; // K steps (of 16) per register set
 // the stream's scratch block, arrival counter, the LAST workgroup sums the partials in split order (fixed order of additions), adds
 // C / bias, relu, rounds ONCE to bf16 and stores. No workgroup waits for another.
 typedef __attribute__((address_space(1))) unsigned int g_u32_s32;
-template <bool SPLIT>
+// VF = 4: B is VNNI-4 [k/4][n][4] - a lane's 8 consecutive k of its column are two 8-byte loads (k-group rows 2 h, 2 h + 1 of the step)
+// instead of four 4-byte loads; everything else is the same (bit-identical results on the same matrix).
+typedef unsigned int u32x2s __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) const u32x2s g_cu32x2s;
+template <bool SPLIT, int VF = 2>
 __global__ __launch_bounds__(256) void brgemm_bf16_small32(GemmArgs p, const WorkItem *__restrict__ items) {
   const int item = SPLIT ? (int)blockIdx.x / p.split : (int)blockIdx.x;
   const int sp = SPLIT ? (int)blockIdx.x - item * p.split : 0;
@@ -62,6 +66,7 @@ __global__ __launch_bounds__(256) void brgemm_bf16_small32(GemmArgs p, const Wor
   // per-lane operand addresses of K step 0 of batch element 0
   g_cu16 *a_lane = (g_cu16 *)p.A + (int64_t)(m0 + li) * p.lda + 8 * lh;
   g_cu32 *b_lane = (g_cu32 *)p.B + (int64_t)(4 * lh) * p.ldb + (n0 + li); // dwords: pair-row stride = ldb
+  g_cu32x2s *b_lane4 = (g_cu32x2s *)p.B + (int64_t)(2 * lh) * p.ldb + (n0 + li); // VF = 4, 8-byte units: k-group row stride = ldb
   // position of step s: batch element b, step kk inside it
   int b = spb ? (s_lo + s) / spb : 0, kk = (s_lo + s) - b * spb;
 
@@ -77,6 +82,11 @@ __global__ __launch_bounds__(256) void brgemm_bf16_small32(GemmArgs p, const Wor
         g_cu16 *ap = a_lane + (int64_t)b * p.stride_a + 16 * kk;
         g_cu32 *bp = b_lane + (((int64_t)b * p.stride_b) >> 1) + (int64_t)(8 * kk) * p.ldb;
         fa[set][g] = *(g_cu32x4 *)ap;
+        if constexpr (VF == 4) {
+          g_cu32x2s *bq = b_lane4 + (((int64_t)b * p.stride_b) >> 2) + (int64_t)(4 * kk) * p.ldb;
+          const u32x2s q0 = bq[0], q1 = bq[p.ldb];
+          fb[set][g] = u32x4{q0[0], q0[1], q1[0], q1[1]};
+        } else
         fb[set][g] = u32x4{bp[0], bp[p.ldb], bp[2 * p.ldb], bp[3 * p.ldb]};
         if (++kk == spb) {
           kk = 0;
@@ -182,8 +192,8 @@ __global__ __launch_bounds__(256) void brgemm_bf16_small32(GemmArgs p, const Wor
   }
 }
 
-// preconditions (checked by the callers): bf16, VNNI-2 B, m % 32 == 0, n % 32 == 0, k % 16 == 0, lda % 8 == 0,
-// stride_a % 8 == 0, stride_b % 2 == 0, ldc % 4 == 0; A 16-byte, B 4-byte, C / D 8-byte aligned
+// preconditions (checked by the callers): bf16, VNNI-2 B (a.vf == 4: VNNI-4 B), m % 32 == 0, n % 32 == 0, k % 16 == 0, lda % 8 == 0,
+// stride_a % 8 == 0, stride_b % 2 == 0 (VNNI-4: % 4), ldc % 4 == 0; A 16-byte, B 4-byte (VNNI-4: 8-byte), C / D 8-byte aligned
 // split > 1: that many workgroups per output tile (grouped launches and single invokes in the grouped grid form)
 hipError_t launch_bf16_small32(const GemmArgs &a, const WorkItem *items, int n_items, hipStream_t s, int split) {
   GemmArgs args = a;
@@ -195,7 +205,8 @@ hipError_t launch_bf16_small32(const GemmArgs &a, const WorkItem *items, int n_i
       args.split = split;
       args.scratch = sc->partial;
       args.split_cnt = sc->cnt;
-      hipLaunchKernelGGL(brgemm_bf16_small32<true>, dim3((unsigned)(n_items * split), tiles_n, tiles_m), dim3(256), 0, s, args, items);
+      if (a.vf == 4) hipLaunchKernelGGL((brgemm_bf16_small32<true, 4>), dim3((unsigned)(n_items * split), tiles_n, tiles_m), dim3(256), 0, s, args, items);
+      else hipLaunchKernelGGL((brgemm_bf16_small32<true>), dim3((unsigned)(n_items * split), tiles_n, tiles_m), dim3(256), 0, s, args, items);
       return hipGetLastError();
     } // (no scratch block: the unsplit launch)
   }
@@ -212,7 +223,8 @@ hipError_t launch_bf16_small32(const GemmArgs &a, const WorkItem *items, int n_i
     if (tiles_m > 65535 || tiles_n > 65535) return hipErrorInvalidValue;
     grid = dim3(1, tiles_n, tiles_m);
   }
-  hipLaunchKernelGGL(brgemm_bf16_small32<false>, grid, dim3(256), 0, s, args, items);
+  if (a.vf == 4) hipLaunchKernelGGL((brgemm_bf16_small32<false, 4>), grid, dim3(256), 0, s, args, items);
+  else hipLaunchKernelGGL((brgemm_bf16_small32<false>), grid, dim3(256), 0, s, args, items);
   return hipGetLastError();
 }
 

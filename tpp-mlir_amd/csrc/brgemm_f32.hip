@@ -937,7 +937,11 @@ hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_i
   if (vec16_4 && out_ok && !d.generic_forced && !d.vnni_c && d.k % BK == 0 && d.m % 64 == 0 && d.n % 64 == 0 && !((d.ldc | d.stride_b) & 7) && d.ldc < (1 << 22) &&
       d.lda < (1 << 22) && d.ldb < (1 << 20) && (int64_t)n_items * (d.m / 64) * (d.n / 64) >= (3 * g_num_cus) / 4)
     return note_grouped("brgemm_bf16_fast_vnni4<64x64> grouped", launch_bf16_grouped64(a, items, n_items, stream));
-  if (vec_ok && out_ok && d.variant != V_GENERIC && bf16_small_eligible(d)) {
+  // (VNNI-4 tile invokes - the compiler-native 32x32x32 tiles of a --vnni=4 pipeline, small groups of 64x64x64 tiles - on the same
+  // kernel: its B fragment is then two 8-byte loads; a single invoke of such a handle stays on the generic kernel's MFMA path)
+  const bool small4 = d.dtype == DT_BF16 && d.vnni_b && d.vnni_factor == 4 && !d.vnni_c && !d.generic_forced && d.m % 32 == 0 && d.n % 32 == 0 && d.k > 0 &&
+                      d.k % 16 == 0 && !(d.lda & 7) && !(d.stride_a & 7) && !(d.stride_b & 3) && !(d.ldc & 3);
+  if (vec_ok && out_ok && ((d.variant != V_GENERIC && bf16_small_eligible(d)) || small4)) {
     // skinny groups with a long reduction: the K steps of a tile over several workgroups (the kernel is a latency-bound stream: 0.047 us
     // per 16-k step of a workgroup). Measured (profiles/r05_bf16_skinny_small_vs_lw.txt): it pays only while every workgroup still has
     // a CU to itself - 128 x 1024 x 4096 as 64x64x64 tile invokes 12.0 -> 9.8 us at S = 2 (10.3 at 4, 13.1 at 8), 256 x 1024 x 4096
@@ -954,8 +958,8 @@ hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_i
       if (c >= 2 && 0.047 * (double)(steps - (steps + c - 1) / c) > 2.7 + 0.8) S = (int)c;
     }
     if (S > (int)steps) S = steps > 1 ? (int)steps : 1;
-    if (S > 1) return note_grouped("brgemm_bf16_small32 grouped, split", launch_bf16_small32(a, items, n_items, stream, S));
-    return note_grouped("brgemm_bf16_small32 grouped", launch_bf16_small32(a, items, n_items, stream));
+    if (S > 1) return note_grouped(small4 ? "brgemm_bf16_small32_vnni4 grouped, split" : "brgemm_bf16_small32 grouped, split", launch_bf16_small32(a, items, n_items, stream, S));
+    return note_grouped(small4 ? "brgemm_bf16_small32_vnni4 grouped" : "brgemm_bf16_small32 grouped", launch_bf16_small32(a, items, n_items, stream));
   }
   if (d.dtype == DT_F32) return note_grouped("brgemm_grouped<f32>", vec ? launch_grouped_t<float, false, true>(a, items, n_items, stream)
                                                                         : launch_grouped_t<float, false, false>(a, items, n_items, stream));
