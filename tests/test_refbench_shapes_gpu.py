@@ -296,3 +296,42 @@ def test_bf16_split_groups_through_the_tile_queue(rt, forced):
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
     got = unpack_c(orc.bf16_to_f32(outs[0]), M, N, t, t).reshape(-1)
     check_close(orc.f32_to_bf16(got), ref, BF16, "bf16 split group (forced %d)" % forced)
+
+
+def test_f32_32k_pair_tiles_with_a_long_batch_split_in_the_group(rt):
+    """the compiler-native 32x32x32 f32 tile with a LONG batch (br = 128: 64 pair chunks) in a small group (6 invokes): the pair mode of
+    the loader-wave kernel AND the split of a tile's batch-reduce range over several workgroups in one launch - a range then starts at
+    an arbitrary PAIR of batch elements; against the oracle, same bits on every run, and bias + relu behind the ordered sum"""
+    t, br, items = 32, 128, 6
+    rng = np.random.default_rng(8)
+    A = rng.uniform(-1, 1, 2 * br * t * t).astype(np.float32)       # two A tile rows
+    B = (rng.uniform(-1, 1, 3 * br * t * t) / 8).astype(np.float32)  # three B tile columns
+    bias = rng.uniform(-1, 1, 3 * t).astype(np.float32)
+    C0 = rng.uniform(-1, 1, items * t * t).astype(np.float32)
+    disp = (F32, t, t, t, t, t, t, t * t, t * t, 0, 0, 5, 4, 1)  # beta = 1, bias + relu
+    ref = C0.copy()
+    for it in range(items):
+        orc.fused_brgemm(*disp, A, (it // 3) * br * t * t, B, (it % 3) * br * t * t, ref, it * t * t, bias, (it % 3) * t, br)
+    h = rt.fused_brgemm_dispatch(*disp)
+    dA, dB, db = dev(A), dev(B), dev(bias)
+    old_async, old_q = rt.set_async(True), rt.set_tile_queue(1)
+    outs = []
+    try:
+        for rep in range(3):
+            dC = dev(C0)
+            for it in range(items):
+                rt.fused_brgemm(F32, h, dA, (it // 3) * br * t * t, dB, (it % 3) * br * t * t, dC, it * t * t, db, (it % 3) * t, br)
+            rt.synchronize()
+            outs.append(host(dC, C0))
+            ran = rt.last_grouped_kernel()
+            assert "32-k pairs" in ran and "split" in ran, ran
+    finally:
+        rt.set_tile_queue(old_q)
+        rt.set_async(old_async)
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    mag = np.abs(C0).astype(np.float64)
+    for it in range(items):
+        a2 = np.abs(A[(it // 3) * br * t * t:][:br * t * t]).reshape(br, t, t).astype(np.float64)
+        b2 = np.abs(B[(it % 3) * br * t * t:][:br * t * t]).reshape(br, t, t).astype(np.float64)
+        mag[it * t * t:(it + 1) * t * t] += (np.einsum("bik,bkj->ij", a2, b2) + np.abs(bias[(it % 3) * t:(it % 3 + 1) * t])[None, :]).reshape(-1)
+    check_close(outs[0], ref, F32, "32-k pairs + split", mag=mag, K=br * t)
