@@ -65,8 +65,11 @@ __global__ __launch_bounds__(256) void brgemm_bf16_small32(GemmArgs p, const Wor
 
   // per-lane operand addresses of K step 0 of batch element 0
   g_cu16 *a_lane = (g_cu16 *)p.A + (int64_t)(m0 + li) * p.lda + 8 * lh;
-  g_cu32 *b_lane = (g_cu32 *)p.B + (int64_t)(4 * lh) * p.ldb + (n0 + li); // dwords: pair-row stride = ldb
-  g_cu32x2s *b_lane4 = (g_cu32x2s *)p.B + (int64_t)(2 * lh) * p.ldb + (n0 + li); // VF = 4, 8-byte units: k-group row stride = ldb
+  // (n that ends inside this 32-column tile - the reference's --tiles=64,48,64 / 32,48,32: the lanes of the missing columns re-read the
+  // last existing one, in bounds; their results are never stored - the epilogue masks by the quad's first column, n % 4 == 0)
+  const int bcol = n0 + li < p.n ? n0 + li : p.n - 1;
+  g_cu32 *b_lane = (g_cu32 *)p.B + (int64_t)(4 * lh) * p.ldb + bcol; // dwords: pair-row stride = ldb
+  g_cu32x2s *b_lane4 = (g_cu32x2s *)p.B + (int64_t)(2 * lh) * p.ldb + bcol; // VF = 4, 8-byte units: k-group row stride = ldb
   // position of step s: batch element b, step kk inside it
   int b = spb ? (s_lo + s) / spb : 0, kk = (s_lo + s) - b * spb;
 
@@ -165,6 +168,8 @@ __global__ __launch_bounds__(256) void brgemm_bf16_small32(GemmArgs p, const Wor
 #pragma unroll
       for (int x = 0; x < 4; ++x) v[x] = acc4[x];
     }
+    const bool quad_ok = n0 + 8 * g + 4 * lh < p.n; // this lane's four columns exist
+    if (!quad_ok) return;
     if (!(p.ep & EP_BETA0)) {
       const u32x2d c2 = *(g_cu32x2 *)(crow + 8 * g);
       v[0] += __uint_as_float(c2[0] << 16);
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(256) void brgemm_bf16_small32(GemmArgs p, const Wor
 // split > 1: that many workgroups per output tile (grouped launches and single invokes in the grouped grid form)
 hipError_t launch_bf16_small32(const GemmArgs &a, const WorkItem *items, int n_items, hipStream_t s, int split) {
   GemmArgs args = a;
-  const int tiles_m = a.m / 32, tiles_n = a.n / 32;
+  const int tiles_m = a.m / 32, tiles_n = (a.n + 31) / 32; // (a ragged last column tile: grouped launches only, n % 4 == 0)
   if (split > 1 && tiles_n <= 65535 && tiles_m <= 65535) {
     const long long tiles = (long long)n_items * tiles_m * tiles_n;
     if (const SplitScratch *sc = split_scratch_for(s, tiles, tiles * split * 1024)) {

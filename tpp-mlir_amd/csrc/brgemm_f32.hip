@@ -938,16 +938,19 @@ hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_i
       d.lda < (1 << 22) && d.ldb < (1 << 20) && (int64_t)n_items * (d.m / 64) * (d.n / 64) >= (3 * g_num_cus) / 4)
     return note_grouped("brgemm_bf16_fast_vnni4<64x64> grouped", launch_bf16_grouped64(a, items, n_items, stream));
   // (VNNI-4 tile invokes - the compiler-native 32x32x32 tiles of a --vnni=4 pipeline, small groups of 64x64x64 tiles - on the same
-  // kernel: its B fragment is then two 8-byte loads; a single invoke of such a handle stays on the generic kernel's MFMA path)
-  const bool small4 = d.dtype == DT_BF16 && d.vnni_b && d.vnni_factor == 4 && !d.vnni_c && !d.generic_forced && d.m % 32 == 0 && d.n % 32 == 0 && d.k > 0 &&
-                      d.k % 16 == 0 && !(d.lda & 7) && !(d.stride_a & 7) && !(d.stride_b & 3) && !(d.ldc & 3);
-  if (vec_ok && out_ok && ((d.variant != V_GENERIC && bf16_small_eligible(d)) || small4)) {
+  // kernel: its B fragment is then two 8-byte loads; a single invoke of such a handle stays on the generic kernel's MFMA path.
+  // And tiles whose n is a multiple of 4 but not of 32 (--tiles=64,48,64): a masked last column tile instead of the generic kernel.)
+  const bool small_base = d.dtype == DT_BF16 && d.vnni_b && !d.vnni_c && !d.generic_forced && d.m % 32 == 0 && d.n >= 32 && d.n % 4 == 0 && d.k > 0 &&
+                          d.k % 16 == 0 && !(d.lda & 7) && !(d.stride_a & 7) && !(d.ldc & 3);
+  const bool small4 = small_base && d.vnni_factor == 4 && !(d.stride_b & 3);
+  const bool small_ragged = small_base && d.vnni_factor == 2 && d.n % 32 != 0 && !(d.stride_b & 1);
+  if (vec_ok && out_ok && ((d.variant != V_GENERIC && bf16_small_eligible(d)) || small_ragged || small4)) {
     // skinny groups with a long reduction: the K steps of a tile over several workgroups (the kernel is a latency-bound stream: 0.047 us
     // per 16-k step of a workgroup). Measured (profiles/r05_bf16_skinny_small_vs_lw.txt): it pays only while every workgroup still has
     // a CU to itself - 128 x 1024 x 4096 as 64x64x64 tile invokes 12.0 -> 9.8 us at S = 2 (10.3 at 4, 13.1 at 8), 256 x 1024 x 4096
     // 12.3 -> 14.2 at S = 2. Hence the largest count with tiles x S <= CUs and at least 32 steps per workgroup, if it saves more
     // than the hand-off costs. xsmm_hip_force_split overrides.
-    const long long t32 = (long long)n_items * (d.m / 32) * (d.n / 32), steps = (long long)br_hint * (d.k / 16);
+    const long long t32 = (long long)n_items * (d.m / 32) * ((d.n + 31) / 32), steps = (long long)br_hint * (d.k / 16);
     int S = 1;
     const int forced = g_forced_split.load(std::memory_order_relaxed);
     if (forced >= 0) S = forced <= 1 ? 1 : (int)(forced < 16 ? forced : 16);
