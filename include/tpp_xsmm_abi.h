@@ -262,6 +262,21 @@ TPP_XSMM_EXPORT void xsmm_hip_force_variant(int variant);
  * measurement switch): -1 = the model (default), 0 or 1 = never split, n > 1 = n workgroups per tile (at most 16 and at most the
  * number of 64-k chunks). Also TPP_HIP_SPLIT. Returns the previous setting. */
 TPP_XSMM_EXPORT int xsmm_hip_force_split(int workgroups_per_tile);
+/* Transposes folded into the gemm they feed (tile queue on, asynchronous mode, device operands, f32). A contraction with a
+ * transposed B operand reaches the runtime as xsmm.unary transpose into a small temporary + xsmm.gemm reading it, per tile and with
+ * ONE temporary per caller (test/Conversion/LinalgToXsmm/linalg-to-gemm.mlir:46-62, the lowering of
+ * benchmarks/mlir/fp32-query-times-key.mlir): a dependence chain through the temporary that no queue can batch. So a transpose of a
+ * tile of at most 64x64 into a dense destination (ldo = m) is remembered instead of launched; a gemm of the same thread whose B
+ * operand is exactly that destination (k, n, ldb matching, one batch element) reads B transposed from the transpose's SOURCE (all
+ * such gemms of a loop are one queue group = one launch); a later transpose of the same handle into the same destination replaces
+ * the remembered one (it is dead: fully overwritten, its readers were served); any other invoke of any thread, xsmm_hip_flush and
+ * every synchronisation point launch the remembered transpose first - whenever anything can look at the destination it holds what
+ * the program wrote. Results of a folded gemm are those of the generic kernel on the same values. One transposing thread per process
+ * (a second one switches the folding off until it is enabled again: 1 re-arms it). 0 turns it off (also TPP_HIP_FOLD_TRANSPOSE=0);
+ * returns the previous setting.
+ * stats: [0] gemm invokes served from a transpose's source, [1] remembered transposes dropped as dead, [2] launched after all. */
+TPP_XSMM_EXPORT int xsmm_hip_set_fold_transpose(int enable);
+TPP_XSMM_EXPORT void xsmm_hip_fold_transpose_stats(int64_t out[3]);
 /* The VNNI blocking factor v of bf16 B operands ([k/v][ldb][v]) of gemm / brgemm / fused_brgemm handles dispatched FROM NOW ON with
  * the VNNI_B wire flag: 2 (default) or 4; also TPP_HIP_VNNI_FACTOR. The factor is not on the wire - the reference's compiler and its
  * runtime library both ask libxsmm_cpuid_dot_pack_factor(LIBXSMM_DATATYPE_BF16) (lib/TPP/Transforms/Utils/VNNIUtils.cpp:25-45; the

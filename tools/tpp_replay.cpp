@@ -21,6 +21,8 @@
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
+#include <functional>
+#include <omp.h>
 #include <string>
 #include <vector>
 
@@ -37,6 +39,7 @@ static std::vector<int64_t> parse_list(const char *s) {
 }
 
 static int run_case(int argc, char **argv);
+static int run_script(const std::string &name, int queue, int64_t n_iter, int threads);
 
 // --cases FILE: one case per line (the flags of a single run), all in this process - the shape sweeps of tools/refbench.py
 // (benchmarks/config/matmul/*.json, fc/*.json) would otherwise pay a process start + HIP initialisation per row
@@ -68,6 +71,7 @@ static int run_case(int argc, char **argv) {
   std::vector<int64_t> layers = {1024, 1024, 1024, 1024};
   bool bias = false, relu = false, whole = false, chain = false, print = false, c1 = false, rnd = false, bf16 = false;
   int queue = 1, threads = 1;
+  std::string script;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
     auto next = [&]() { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(2); } return argv[++i]; };
@@ -87,6 +91,7 @@ static int run_case(int argc, char **argv) {
     else if (a == "--chain") whole = chain = true; // the whole-layer calls of an iteration handed over together (xsmm_hip_fused_brgemm_chain_invoke)
     else if (a == "--print") print = true;
     else if (a == "--c1") c1 = true;
+    else if (a == "--script") script = next(); // the call scripts of benchmarks/mlir/*.mlir (base/mha.json, base/pack.json): see run_script
     else if (a == "--bf16") bf16 = true; // mlir-gen --float-type=bf16 --vnni=2: bf16 storage, W in VNNI-2 blocks
     else if (a == "--vnni") vnni = atoi(next()); // --vnni=4 (benchmarks/config/*: the *_dp4_* rows): W in [K/4][N][4] blocks
     else if (a == "--kernel") kernel_args = std::string(next()) == "args"; // const (default): zero fill folded into BETA_0; args: C += ...
@@ -96,6 +101,7 @@ static int run_case(int argc, char **argv) {
     else { fprintf(stderr, "unknown flag %s\n", a.c_str()); return 2; }
   }
   if (xsmm_hip_device_count() < 1) { fprintf(stderr, "tpp_replay: no HIP device (there is no CPU fallback)\n"); return 1; }
+  if (!script.empty()) return run_script(script, queue, n_iter, threads);
   if (c1) {
     // A, W, C: 256x256 f32 filled 1.0; packed copies [8][8][32][32]; result 257 everywhere (C += A W)
     const int64_t N = 256, T = 32, NB = N / T, tt = T * T;
@@ -262,5 +268,132 @@ static int run_case(int argc, char **argv) {
   for (void *p : act) CHECK(hipFree(p));
   for (void *p : W) CHECK(hipFree(p));
   for (void *p : B) CHECK(hipFree(p));
+  return 0;
+}
+
+// --script NAME: the xsmm call scripts of the reference's hand-written benchmark files (benchmarks/config/base/mha.json, pack.json ->
+// benchmarks/mlir/*.mlir), f32. The calls per tile are the ones test/Conversion/LinalgToXsmm/linalg-to-gemm.mlir pins for exactly these
+// functions (mha_projection :132-145, mha_query_times_key :46-62, mha_out_softmax_times_value :91-104), with the zero fill folded into
+// BETA_0 as the default pipeline does (FoldXsmmFlags, lib/TPP/PassBundles/LinalgLowering.cpp:56; test/Passes/fold-xsmm-flags.mlir:3-20);
+// the pack files are per-block 2-D copies (LowerPacksAndUnpacks.cpp:45-49,112-121 -> xsmm.unary identity). GFLOP/s uses each file's
+// own BENCH_TOTAL_FLOPS line (for the pack files that number is the tensor's byte count).
+//   mha_projection  fp32-projection.mlir            forall (64, 8): gemm [32,64,512,512,512,512] beta_0
+//   mha_qk          fp32-query-times-key.mlir       forall (64, 8): unary transpose [32,64,512,32] into a 64x32 temporary (memref.alloc in
+//                                                   the loop body: one per calling thread here), gemm [32,32,64,512,32,32] beta_0
+//   mha_sv          fp32-out-softmax-times-value.mlir  forall (64, 8): gemm [32,64,32,32,512,512] beta_0
+//   pack_a / pack_b / unpack_c   fp32-pack-gemm-operand-a-512x1024.mlir, -b-512x1024.mlir, fp32-unpack-gemm-operand-a-512x512.mlir
+// Constant / index fills with closed-form results, checked on the first run (parity against the oracle: tests/test_mha_scripts_gpu.py).
+static int run_script(const std::string &name, int queue, int64_t n_iter, int threads) {
+  xsmm_hip_set_async(1);
+  xsmm_hip_set_tile_queue(queue);
+  auto dfill = [&](size_t n, auto gen) {
+    float *d; CHECK(hipMalloc((void **)&d, n * 4));
+    std::vector<float> h(n);
+    for (size_t i = 0; i < n; ++i) h[i] = gen(i);
+    CHECK(hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice));
+    return d;
+  };
+  auto cst = [](float v) { return [v](size_t) { return v; }; };
+  const int64_t Bt = 64, S = 32, H = 8, D = 64, E = H * D; // batch, sequence, heads, head size, embedding (512)
+  std::vector<float *> bufs;
+  std::function<void()> kernel;
+  std::function<bool(const std::vector<float> &)> check;
+  float *out = nullptr;
+  size_t out_n = 0;
+  double flops = 0;
+  int invokes = 0;
+  if (threads < 1) threads = 1;
+  auto par2 = [threads](int64_t n0, int64_t n1, auto body) { // the lowered scf.forall (n0, n1): nested loops, or OpenMP over the flat grid
+    if (threads <= 1) {
+      for (int64_t i = 0; i < n0; ++i)
+        for (int64_t j = 0; j < n1; ++j) body(i, j, 0);
+    } else {
+#pragma omp parallel for schedule(static) num_threads(threads)
+      for (int64_t t = 0; t < n0 * n1; ++t) body(t / n1, t % n1, omp_get_thread_num());
+    }
+  };
+  if (name == "mha_projection") {
+    float *in = dfill(Bt * S * E, cst(1.0f)), *W = dfill(E * E, cst(0.5f));
+    out = dfill(out_n = Bt * S * E, cst(-1.0f));
+    bufs = {in, W, out};
+    const int64_t h = xsmm_gemm_dispatch(1, S, D, E, E, E, E, XSMM_GEMM_FLAG_BETA_0);
+    kernel = [=]() { par2(Bt, H, [=](int64_t b, int64_t hd, int) { xsmm_gemm_invoke(1, h, in, b * S * E, W, hd * D, out, b * S * E + hd * D); }); };
+    check = [=](const std::vector<float> &r) { for (float v : r) if (v != 256.0f) return false; return true; };
+    flops = 1073741824.0, invokes = 512;
+  } else if (name == "mha_qk") {
+    float *Q = dfill(Bt * S * E, cst(1.0f)), *K = dfill(Bt * S * E, cst(0.5f));
+    out = dfill(out_n = Bt * H * S * S, cst(-1.0f));
+    float *tmp = dfill((size_t)threads * D * S, cst(0.0f));
+    bufs = {Q, K, out, tmp};
+    const int64_t ht = xsmm_unary_dispatch(XSMM_UNARY_TRANSPOSE, 1, S, D, E, S, 0);
+    const int64_t hg = xsmm_gemm_dispatch(1, S, S, D, E, S, S, XSMM_GEMM_FLAG_BETA_0);
+    kernel = [=]() {
+      par2(Bt, H, [=](int64_t b, int64_t hd, int th) {
+        xsmm_unary_invoke(1, ht, Q, b * S * E + hd * D, tmp, th * D * S);
+        xsmm_gemm_invoke(1, hg, K, b * S * E + hd * D, tmp, th * D * S, out, (b * H + hd) * S * S);
+      });
+    };
+    check = [=](const std::vector<float> &r) { for (float v : r) if (v != 32.0f) return false; return true; };
+    flops = 67108864.0, invokes = 1024;
+  } else if (name == "mha_sv") {
+    float *P = dfill(Bt * H * S * S, cst(1.0f)), *V = dfill(Bt * S * E, cst(0.5f));
+    out = dfill(out_n = Bt * S * E, cst(-1.0f));
+    bufs = {P, V, out};
+    const int64_t h = xsmm_gemm_dispatch(1, S, D, S, S, E, E, XSMM_GEMM_FLAG_BETA_0);
+    kernel = [=]() {
+      par2(Bt, H, [=](int64_t b, int64_t hd, int) { xsmm_gemm_invoke(1, h, P, (b * H + hd) * S * S, V, b * S * E + hd * D, out, b * S * E + hd * D); });
+    };
+    check = [=](const std::vector<float> &r) { for (float v : r) if (v != 16.0f) return false; return true; };
+    flops = 67108864.0, invokes = 512;
+  } else if (name == "pack_a" || name == "pack_b" || name == "unpack_c") {
+    // pack_a: [512][1024] -> [16][32][32][32];  pack_b: [1024][512] -> (outer_dims_perm [1,0]) [16 (n)][32 (k)][32][32];  unpack_c: [16][16][32][32] -> [512][512]
+    const int64_t T = 32, R = name == "pack_b" ? 1024 : 512, Ccols = name == "pack_a" ? 1024 : 512;
+    const int64_t RB = R / T, CB = Ccols / T, tt = T * T;
+    float *in = dfill(R * Ccols, [](size_t i) { return (float)i; });
+    out = dfill(out_n = R * Ccols, cst(-1.0f));
+    bufs = {in, out};
+    const bool un = name == "unpack_c", pb = name == "pack_b";
+    const int64_t h = un ? xsmm_unary_dispatch(XSMM_UNARY_IDENTITY, 1, T, T, T, Ccols, 0) : xsmm_unary_dispatch(XSMM_UNARY_IDENTITY, 1, T, T, Ccols, T, 0);
+    float *o = out;
+    kernel = [=]() {
+      if (pb) par2(CB, RB, [=](int64_t nb, int64_t kb, int) { xsmm_unary_invoke(1, h, in, kb * T * Ccols + nb * T, o, (nb * RB + kb) * tt); });
+      else if (un) par2(RB, CB, [=](int64_t i, int64_t j, int) { xsmm_unary_invoke(1, h, in, (i * CB + j) * tt, o, i * T * Ccols + j * T); });
+      else par2(RB, CB, [=](int64_t i, int64_t j, int) { xsmm_unary_invoke(1, h, in, i * T * Ccols + j * T, o, (i * CB + j) * tt); });
+    };
+    check = [=](const std::vector<float> &r) {
+      for (int64_t i = 0; i < R; ++i)
+        for (int64_t j = 0; j < Ccols; ++j) {
+          const int64_t flat = i * Ccols + j, bi = i / T, bj = j / T, blk = ((pb ? bj * RB + bi : bi * CB + bj) * T + i % T) * T + j % T;
+          if (un ? r[flat] != (float)blk : r[blk] != (float)flat) return false;
+        }
+      return true;
+    };
+    flops = (double)(R * Ccols * 4), invokes = (int)(RB * CB);
+  } else {
+    fprintf(stderr, "tpp_replay: unknown script %s\n", name.c_str());
+    return 2;
+  }
+  kernel();
+  xsmm_hip_synchronize();
+  std::vector<float> res(out_n);
+  CHECK(hipMemcpy(res.data(), out, out_n * 4, hipMemcpyDeviceToHost));
+  if (!check(res)) { fprintf(stderr, "tpp_replay --script %s: WRONG RESULT\n", name.c_str()); return 1; }
+  const int64_t warm = n_iter / 100 < 1 ? 1 : (n_iter / 100 > 50 ? 50 : n_iter / 100);
+  for (int64_t i = 0; i < warm; ++i) kernel();
+  xsmm_hip_synchronize();
+  int64_t q0[5] = {0, 0, 0, 0, 0}, q1[5] = {0, 0, 0, 0, 0};
+  if (queue) xsmm_hip_tile_queue_stats(q0);
+  const int64_t t0 = perf_start_timer();
+  for (int64_t i = 0; i < n_iter; ++i) kernel();
+  const double host_dt = (double)(perf_start_timer() - t0) * 1e-9;
+  const double mean = perf_stop_timer(t0) / (double)n_iter;
+  if (queue) xsmm_hip_tile_queue_stats(q1);
+  printf("%g\n", mean);
+  fprintf(stderr, "tpp_replay: script %s (%d invokes per call, %d calling thread(s)), queue %d: mean %.3f us (host side of the invokes %.3f us), %.1f GFLOP/s (BENCH_TOTAL_FLOPS %.0f), kernel %s; result checked; %.1f launches per call (per call: %.1f invokes with full bookkeeping, %.1f replayed, %.2f replays abandoned)\n",
+          name.c_str(), invokes, threads, queue, mean * 1e6, host_dt / (double)n_iter * 1e6, flops / mean / 1e9, flops,
+          queue && xsmm_hip_last_grouped_kernel()[0] ? xsmm_hip_last_grouped_kernel() : "(one launch per invoke)",
+          queue ? (double)(q1[0] - q0[0]) / (double)n_iter : (double)invokes, (double)(q1[1] - q0[1]) / (double)n_iter,
+          (double)(q1[2] - q0[2]) / (double)n_iter, (double)(q1[4] - q0[4]) / (double)n_iter);
+  for (float *p : bufs) CHECK(hipFree(p));
   return 0;
 }

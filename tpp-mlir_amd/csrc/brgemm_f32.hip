@@ -465,8 +465,10 @@ __global__ __launch_bounds__(256) void brgemm_grouped(GemmArgs p, const WorkItem
           float v = 0.0f;
           if (bk < p.k && bj < p.n) {
             // VNNI-v B [k/v][ldb][v] (v = p.vf: 2 or 4; the oracle's b_index)
+            // (b_trans: the operand is the SOURCE of a transpose the runtime folded into this gemm - element [bk][bj] of B is
+            // element [bj][bk] of the source)
             const int64_t idx = VNNI ? (int64_t)(bk / p.vf) * (p.vf * p.ldb) + p.vf * (int64_t)bj + (bk % p.vf)
-                                     : (int64_t)bk * p.ldb + bj;
+                                     : p.b_trans ? (int64_t)bj * p.ldb + bk : (int64_t)bk * p.ldb + bj;
             v = Elem<T>::load(gB, bbase + idx);
           }
           rb[u][e] = v;
@@ -864,6 +866,11 @@ hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_i
   a.tiles_m = a.tiles_n = 0;
   a.vf = d.vnni_factor ? d.vnni_factor : 2;
   a.split = 0; a.scratch = nullptr; a.split_cnt = nullptr;
+  a.b_trans = d.b_trans;
+  if (d.b_trans) { // B read transposed (a folded xsmm.unary transpose): the generic kernel's element-wise loads
+    if (d.dtype != DT_F32 || d.vnni_b) return hipErrorInvalidValue;
+    return note_grouped("brgemm_grouped<f32>, B read transposed", launch_grouped_t<float, false, false>(a, items, n_items, stream));
+  }
   const bool tiles_ok = vec_ok && d.n % 4 == 0 && d.k % GK == 0; // 16-byte pieces; ragged m / n edges are predicated
   const bool vec = vec_ok && d.n % 4 == 0 && d.k % 4 == 0 && d.dtype == DT_F32 && !d.vnni_b && !((d.lda | d.ldb | d.stride_a | d.stride_b) & 3) &&
                    d.lda < (1 << 24) && d.ldb < (1 << 24); // (32-bit tile-relative lane offsets: 32 rows x ld x 4 B < 2^31)
@@ -1167,8 +1174,13 @@ hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C,
   a.tiles_m = a.tiles_n = 0;
   a.vf = d.vnni_factor ? d.vnni_factor : 2;
   a.split = 0; a.scratch = nullptr; a.split_cnt = nullptr;
+  a.b_trans = d.b_trans;
   int v = d.variant;
   g_last_refined.store("", std::memory_order_relaxed);
+  if (d.b_trans) {
+    if (d.dtype != DT_F32 || d.vnni_b) return hipErrorInvalidValue;
+    return launch_grouped_t<float, false, false>(a, nullptr, 1, stream);
+  }
   const bool aligned16 = ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0;
   if (v != V_GENERIC && !aligned16) v = V_GENERIC;
   // the bf16 kernel stores 16-byte row pieces and reads the bias 8 bytes at a time

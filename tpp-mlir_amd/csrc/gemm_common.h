@@ -29,6 +29,7 @@ struct GemmArgs {
   int split;
   float *scratch;
   unsigned *split_cnt;
+  int b_trans;         // generic kernel: B[k][j] = B_ptr[j * ldb + k] (GemmDesc::b_trans)
 };
 
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short h) {

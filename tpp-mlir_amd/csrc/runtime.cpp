@@ -69,7 +69,9 @@ struct Config {
   std::atomic<int> tile_queue{0};
   std::atomic<int> vnni_factor{2}; // blocking factor of VNNI B operands dispatched from now on (xsmm_hip_set_vnni_factor / TPP_HIP_VNNI_FACTOR)
   int trace = 0; // TPP_HIP_TRACE: 1 = one stderr line per dispatch + a roctx range per invoke, 2 = also one stderr line per invoke
+  std::atomic<int> fold_transpose{1}; // TPP_HIP_FOLD_TRANSPOSE / xsmm_hip_set_fold_transpose: transposes that feed a gemm's B operand are folded into it
   Config() {
+    if (const char *e = getenv("TPP_HIP_FOLD_TRANSPOSE")) fold_transpose = atoi(e) != 0;
     if (const char *e = getenv("TPP_HIP_ASYNC")) async = atoi(e) != 0;
     if (const char *e = getenv("TPP_HIP_TRACE")) trace = atoi(e);
     if (const char *e = getenv("TPP_HIP_VARIANT")) forced_variant = atoi(e);
@@ -512,7 +514,7 @@ __attribute__((always_inline)) inline void gemm_operands(const GemmDesc *d, void
   if (br > 0 && d->k > 0) {
     A.bytes = ((size_t)(br - 1) * d->stride_a + span(d->m, d->lda, d->k)) * es;
     const int64_t vf = d->vnni_factor;
-    const size_t bspan = d->vnni_b ? span((d->k + vf - 1) / vf, vf * d->ldb, vf * d->n) : span(d->k, d->ldb, d->n);
+    const size_t bspan = d->vnni_b ? span((d->k + vf - 1) / vf, vf * d->ldb, vf * d->n) : d->b_trans ? span(d->n, d->ldb, d->k) : span(d->k, d->ldb, d->n);
     B.bytes = ((size_t)(br - 1) * d->stride_b + bspan) * es;
   }
 }
@@ -1743,7 +1745,10 @@ InlineQueue &inl() {
   static InlineQueue i;
   return i;
 }
+std::atomic<int> g_dt_pending{0}; // a deferred transpose exists (see "deferred transposes" below)
+void dt_materialize();
 void flush_tile_queue() {
+  if (g_dt_pending.load(std::memory_order_acquire)) dt_materialize();
   if (!cfg().tile_queue.load(std::memory_order_relaxed)) return;
   InlineQueue &iq = inl();
   if (!iq.scheduled.load(std::memory_order_acquire)) {
@@ -1915,6 +1920,133 @@ bool try_enqueue(const GemmDesc *d, void *a, void *b, void *c, void *dp, int64_t
   return enqueue_item(d, WorkItem{a, b, c, dp, br}, ptrs, 4, s);
 }
 
+// ---- deferred transposes (round 5) ------------------------------------------------------------------------------------
+// A contraction whose B operand is transposed in memory reaches the runtime as TWO invokes per tile: xsmm.unary transpose into a
+// small temporary, then xsmm.gemm reading it (ConvertLinalgToXsmm; test/Conversion/LinalgToXsmm/linalg-to-gemm.mlir:46-62 has the
+// query-times-key benchmark lowered exactly so: transpose [32,64,512,32] + gemm [32,32,64,512,32,32] per (batch, head), ONE
+// temporary for every tile of a caller). Through the tile queue that is a chain of true and anti dependences on the temporary:
+// every invoke its own launch (1024 launches for benchmarks/mlir/fp32-query-times-key.mlir, 3.7 ms; the queue cannot help).
+// So a transpose of a small tile into a DENSE destination (ldo = m) is not launched when it is invoked but REMEMBERED (one record
+// per process, owned by the calling thread), and
+//   * a gemm of the same thread whose B operand is exactly that destination (k = the transpose's n, n = its m, ldb = ldo, one batch
+//     element, f32, no operand of it overlapping the destination, C not overlapping the transpose's source) runs on a SIBLING
+//     descriptor that reads B transposed straight from the transpose's source (GemmDesc::b_trans - the generic kernel). All such
+//     gemms of a loop share that sibling: the queue groups them into one launch;
+//   * a second transpose of the same descriptor into the same destination REPLACES the record: the remembered one is dead - fully
+//     overwritten, and its only readers were served from its source;
+//   * any other invoke (of any thread), a flush and every synchronisation point first launches the remembered transpose the
+//     ordinary way (dt_materialize), so the destination holds what the program wrote whenever anything can look at it.
+// Between a transpose's invoke and its launch only folded gemms of its own thread run, and those do not write its source: the
+// deferred launch reads what the immediate one would have read. Only while ONE thread transposes (a second transposing thread
+// switches this off for the process: the reference's OpenMP callers own a temporary each, their chains are per thread anyway).
+// Summation order of a folded gemm = the generic kernel's (what a single invoke of the same gemm on the generic kernel adds).
+struct DeferredTranspose {
+  const UnaryDesc *d = nullptr;
+  void *src = nullptr, *dst = nullptr;
+  hipStream_t stream = nullptr;
+  uintptr_t owner = 0;
+  const GemmDesc *sib_of = nullptr, *sib = nullptr; // the last gemm descriptor folded and its sibling
+};
+SpinLock g_dt_mu;
+DeferredTranspose g_dt;                  // valid while g_dt_pending (under g_dt_mu)
+std::atomic<uintptr_t> g_dt_first{0};    // the first thread that invoked a foldable transpose
+std::atomic<bool> g_dt_multi{false};     // ... and another one did too: no more deferring
+std::atomic<int64_t> g_dt_folded{0}, g_dt_dropped{0}, g_dt_launched{0}; // statistics (xsmm_hip_fold_transpose_stats)
+void unary_invoke_core(const UnaryDesc *d, void *pi, float scalar, bool use_scalar, void *po, bool may_defer);
+// launches the remembered transpose, if there is one (any thread)
+void dt_materialize() {
+  DeferredTranspose r;
+  {
+    std::lock_guard<SpinLock> lk(g_dt_mu);
+    if (!g_dt_pending.load(std::memory_order_relaxed)) return;
+    r = g_dt;
+    g_dt_pending.store(0, std::memory_order_release);
+  }
+  g_dt_launched.fetch_add(1, std::memory_order_relaxed);
+  const hipStream_t cur = cfg().stream.load(std::memory_order_relaxed);
+  if (cur != r.stream) die("tpp-xsmm-hip: a deferred transpose outlived its stream"); // (xsmm_hip_set_stream flushes first: cannot happen)
+  unary_invoke_core(r.d, r.src, 0.0f, false, r.dst, false);
+}
+inline bool dt_overlap(const void *a, size_t na, const void *b, size_t nb) {
+  return a && b && (uintptr_t)a < (uintptr_t)b + nb && (uintptr_t)b < (uintptr_t)a + na;
+}
+const GemmDesc *dt_sibling(const GemmDesc *d, int64_t ld_src) {
+  std::vector<int64_t> key = {KIND_GEMM, -29, (int64_t)(uintptr_t)d, ld_src};
+  return (const GemmDesc *)intern(key, [&]() {
+    GemmDesc *e = new GemmDesc(*d);
+    e->b_trans = 1;
+    e->ldb = ld_src;
+    e->variant = GEMM_VARIANT_GENERIC;
+    e->generic_forced = 1;
+    snprintf(e->name, sizeof(e->name), "brgemm_grouped(generic), B read transposed");
+    snprintf(e->trace, sizeof(e->trace), "gemm[%ld,%ld,%ld,%ld,(%ld)^T,%ld] dt%ld flags%ld %s (transpose folded)", (long)d->m, (long)d->n, (long)d->k,
+             (long)d->lda, (long)ld_src, (long)d->ldc, (long)d->dtype, (long)d->wire_flags, e->name);
+    return (void *)e;
+  });
+}
+// a gemm invoke while a transpose is remembered: the sibling descriptor + the transpose's source if it folds (the record stays),
+// else the transpose is launched and nullptr comes back
+const GemmDesc *dt_fold_or_materialize(const GemmDesc *d, void *pa, void *pb, void *pc, void *pd, int64_t br, hipStream_t s, void **src) {
+  {
+    std::lock_guard<SpinLock> lk(g_dt_mu);
+    if (!g_dt_pending.load(std::memory_order_relaxed)) return nullptr;
+    DeferredTranspose &r = g_dt;
+    const UnaryDesc *t = r.d;
+    const size_t dst_bytes = (size_t)t->n * t->m * 4, src_bytes = span(t->m, t->ldi, t->n) * 4;
+    if (r.owner == thread_token() && pb == r.dst && br == 1 && d->dtype == DT_F32 && !d->vnni_b && !d->vnni_c && !d->b_trans && d->k == t->n &&
+        d->n == t->m && d->ldb == t->ldo && s == r.stream && d->m <= 64 && d->n <= 64 && queue_active() &&
+        !dt_overlap(pa, span(d->m, d->lda, d->k) * 4, r.dst, dst_bytes) && !dt_overlap(pc, span(d->m, d->ldc, d->n) * 4, r.dst, dst_bytes) &&
+        !dt_overlap(pd, d->bias ? (size_t)d->n * 4 : 0, r.dst, dst_bytes) && !dt_overlap(pc, span(d->m, d->ldc, d->n) * 4, r.src, src_bytes)) {
+      if (r.sib_of != d) {
+        r.sib = dt_sibling(d, t->ldi);
+        r.sib_of = d;
+      }
+      *src = r.src;
+      g_dt_folded.fetch_add(1, std::memory_order_relaxed);
+      return r.sib;
+    }
+  }
+  dt_materialize();
+  return nullptr;
+}
+// a transpose invoke: true = remembered (nothing launched)
+bool dt_defer(const UnaryDesc *d, void *pi, void *po, hipStream_t s) {
+  if (d->dtype != DT_F32 || d->m > 64 || d->n > 64 || d->ldo != d->m || !cfg().fold_transpose.load(std::memory_order_relaxed) || !queue_active()) return false;
+  if (g_dt_multi.load(std::memory_order_relaxed)) return false;
+  const uintptr_t me = thread_token();
+  uintptr_t first = g_dt_first.load(std::memory_order_relaxed);
+  if (first == 0 && g_dt_first.compare_exchange_strong(first, me)) first = me;
+  if (first != me) {
+    g_dt_multi.store(true, std::memory_order_release);
+    return false;
+  }
+  DeviceRanges &devmem = caller_state().devmem;
+  if (devmem.refresh()) check_queue_device();
+  if (!devmem.is_device(pi, 0) || !devmem.is_device(po, 1)) return false;
+  const size_t dst_bytes = (size_t)d->n * d->m * 4, src_bytes = span(d->m, d->ldi, d->n) * 4;
+  if (dt_overlap(pi, src_bytes, po, dst_bytes)) return false;
+  bool launch_old = false;
+  {
+    std::lock_guard<SpinLock> lk(g_dt_mu);
+    if (g_dt_pending.load(std::memory_order_relaxed)) {
+      DeferredTranspose &r = g_dt;
+      const size_t r_dst = (size_t)r.d->n * r.d->m * 4;
+      if (r.owner == me && r.d == d && r.dst == po && r.stream == s && !dt_overlap(pi, src_bytes, r.dst, r_dst)) {
+        r.src = pi; // the remembered transpose is dead: fully overwritten, its readers were served from its source
+        g_dt_dropped.fetch_add(1, std::memory_order_relaxed);
+        return true;
+      }
+      launch_old = true;
+    }
+  }
+  if (launch_old) dt_materialize();
+  std::lock_guard<SpinLock> lk(g_dt_mu);
+  if (g_dt_pending.load(std::memory_order_relaxed)) return false; // (another thread got in between: not deferred)
+  g_dt = DeferredTranspose{d, pi, po, s, me, nullptr, nullptr};
+  g_dt_pending.store(1, std::memory_order_release);
+  return true;
+}
+
 void gemm_invoke_common(const char *who, bool want_fused, int64_t dtype, int64_t handle, void *a, int64_t off_a,
                         void *b, int64_t off_b, void *c, int64_t off_c, void *dptr, int64_t off_d, int64_t br) {
   const GemmDesc *d = as_desc<GemmDesc>(handle, KIND_GEMM, who);
@@ -1928,6 +2060,13 @@ void gemm_invoke_common(const char *who, bool want_fused, int64_t dtype, int64_t
   void *pd = dptr ? (char *)dptr + off_d * es : nullptr;
   if (d->bias && !dptr) die("%s: fused bias operand is null", who);
   hipStream_t s = cfg().stream.load(std::memory_order_relaxed);
+  if (g_dt_pending.load(std::memory_order_acquire)) { // a remembered transpose: this gemm reads its source instead, or it is launched now
+    void *src = nullptr;
+    if (const GemmDesc *sib = dt_fold_or_materialize(d, pa, pb, pc, pd, br, s, &src)) {
+      d = sib;
+      pb = src;
+    }
+  }
   if (cfg().tile_queue.load(std::memory_order_relaxed)) {
     if (cfg().async.load(std::memory_order_relaxed) && try_enqueue(d, pa, pb, pc, pd, br, s)) return;
     flush_tile_queue();
@@ -2392,7 +2531,15 @@ static void unary_invoke_common(const char *who, int64_t dtype, int64_t handle, 
   if (use_scalar && (d->op == XSMM_UNARY_TRANSPOSE || d->op == XSMM_UNARY_VNNI2))
     die("%s: scalar input is meaningless for op %ld", who, (long)d->op);
   void *pi = use_scalar || d->op == XSMM_UNARY_ZERO ? nullptr : (char *)in + off_in * es, *po = (char *)out + off_out * es;
+  unary_invoke_core(d, pi, scalar, use_scalar, po, true);
+}
+namespace {
+void unary_invoke_core(const UnaryDesc *d, void *pi, float scalar, bool use_scalar, void *po, bool may_defer) {
   hipStream_t s = cfg().stream.load(std::memory_order_relaxed);
+  if (may_defer) {
+    if (d->op == XSMM_UNARY_TRANSPOSE && pi && dt_defer(d, pi, po, s)) return;
+    if (g_dt_pending.load(std::memory_order_acquire)) dt_materialize();
+  }
   if (cfg().tile_queue.load(std::memory_order_relaxed)) {
     // small tiles of tensor.pack / unpack lowering and bias broadcasts: queued like the GEMM tiles
     if (queue_active() && !use_scalar && d->m <= 64 && d->n <= 64) {
@@ -2409,6 +2556,7 @@ static void unary_invoke_common(const char *who, int64_t dtype, int64_t handle, 
   HIP_OK(launch_unary(*d, I.dev, scalar, use_scalar, O.dev, s));
   finish(ops, s);
 }
+} // namespace
 
 extern "C" void xsmm_unary_invoke(int64_t dtype, int64_t handle, void *in, int64_t off_in, void *out,
                                   int64_t off_out) {
@@ -2429,6 +2577,7 @@ extern "C" void xsmm_binary_invoke(int64_t dtype, int64_t handle, void *lhs, int
   const size_t es = esize(dtype);
   void *pl = (char *)lhs + off_lhs * es, *pr = (char *)rhs + off_rhs * es, *po = (char *)out + off_out * es;
   hipStream_t s = cfg().stream.load(std::memory_order_relaxed);
+  if (g_dt_pending.load(std::memory_order_acquire)) dt_materialize();
   if (cfg().tile_queue.load(std::memory_order_relaxed)) {
     if (queue_active() && d->m <= 64 && d->n <= 64) {
       const void *ptrs[3] = {pl, pr, po};
@@ -2611,6 +2760,19 @@ extern "C" const char *xsmm_hip_kernel_name(int64_t handle) {
 extern "C" const char *xsmm_hip_last_grouped_kernel(void) { return last_grouped_kernel(); }
 extern "C" const char *xsmm_hip_last_refined_kernel(void) { return last_refined_kernel(); }
 extern "C" void xsmm_hip_force_variant(int v) { cfg().forced_variant.store(v); }
+extern "C" int xsmm_hip_set_fold_transpose(int enable) {
+  flush_tile_queue(); // (launches a remembered transpose)
+  if (enable) { // (re-)armed: the next thread that transposes is "the one transposing thread"
+    g_dt_first.store(0, std::memory_order_relaxed);
+    g_dt_multi.store(false, std::memory_order_release);
+  }
+  return cfg().fold_transpose.exchange(enable != 0);
+}
+extern "C" void xsmm_hip_fold_transpose_stats(int64_t out[3]) {
+  out[0] = g_dt_folded.load(std::memory_order_relaxed);   // gemm invokes that read a remembered transpose's source
+  out[1] = g_dt_dropped.load(std::memory_order_relaxed);  // remembered transposes that were overwritten before anything else could read them
+  out[2] = g_dt_launched.load(std::memory_order_relaxed); // remembered transposes that were launched after all
+}
 extern "C" int xsmm_hip_force_split(int v) { return tpp::force_gemm_split(v); }
 // the VNNI blocking factor of bf16 B operands dispatched from now on (2 or 4); returns the previous one, -1 for an invalid factor
 extern "C" int xsmm_hip_set_vnni_factor(int v) {

@@ -27,6 +27,8 @@ struct GemmDesc {
   int variant;          // kernel variant chosen at dispatch (see gemm_variants.h), -1 = by invoke
   int generic_forced;   // variant = generic because it was asked for (xsmm_hip_force_variant / a VNNI C store), not because no fast tile fits
   int variant_forced;   // variant is the one xsmm_hip_force_variant asked for: invoke-time refinements (batch-count dependent) leave it alone
+  int b_trans;          // runtime-made sibling of a dispatched descriptor (never on the wire): B is read TRANSPOSED, B[k][j] = ptr[j * ldb + k] -
+                        // the source of an xsmm.unary transpose that fed this gemm's B operand (runtime.cpp, deferred transposes); generic kernel only
   char name[64];        // kernel name for profiles
   char trace[160];      // dispatch tuple + kernel name as text (trace ranges)
 };

@@ -102,6 +102,8 @@ _SIGNATURES = {
     "xsmm_hip_last_refined_kernel": (ctypes.c_char_p, []),
     "xsmm_hip_force_variant": (None, [ctypes.c_int]),
     "xsmm_hip_force_split": (ctypes.c_int, [ctypes.c_int]),
+    "xsmm_hip_set_fold_transpose": (ctypes.c_int, [ctypes.c_int]),
+    "xsmm_hip_fold_transpose_stats": (None, [ctypes.POINTER(ctypes.c_int64)]),
     "xsmm_hip_set_vnni_factor": (ctypes.c_int, [ctypes.c_int]),
     "xsmm_hip_get_vnni_factor": (ctypes.c_int, []),
     "xsmm_hip_version": (ctypes.c_char_p, []),
@@ -273,6 +275,16 @@ class XsmmRuntime:
     def force_split(self, workgroups_per_tile):
         """-1 the model, 0 / 1 never, n > 1: n workgroups share the batch-reduce range of one f32 output tile; returns the previous setting"""
         return self.lib.xsmm_hip_force_split(workgroups_per_tile)
+
+    def set_fold_transpose(self, enable):
+        """transposes that feed a gemm's B operand folded into the gemm (default on); returns the previous setting"""
+        return self.lib.xsmm_hip_set_fold_transpose(1 if enable else 0)
+
+    def fold_transpose_stats(self):
+        """(gemm invokes served from a transpose's source, remembered transposes dropped as dead, remembered transposes launched)"""
+        out = (ctypes.c_int64 * 3)()
+        self.lib.xsmm_hip_fold_transpose_stats(out)
+        return tuple(int(v) for v in out)
 
     def set_vnni_factor(self, v):
         """VNNI blocking factor (2 / 4) of bf16 B operands dispatched from now on; returns the previous one"""
