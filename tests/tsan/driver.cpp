@@ -277,6 +277,74 @@ static int run_chain(int rounds, const char *what) {
   return bad.load();
 }
 
+// Transposes folded into the gemm they feed (runtime.cpp, deferred transposes): ONE thread runs transpose -> temporary -> gemm per
+// tile (the lowering of benchmarks/mlir/fp32-query-times-key.mlir, one temporary for all tiles) while three other threads keep
+// invoking unrelated copies - every one of their invokes launches the remembered transpose if there is one, under the first
+// thread's feet - and a fourth one flushes. In the second half of the repetitions a second thread transposes as well (its own
+// temporary): the folding switches itself off, the results stay.
+static int run_transposes(int reps, const char *what) {
+  const int TILES = 48, T = 32, KQ = 64, LD = 512;
+  float *Q = dev_alloc((size_t)T * LD), *Km = dev_alloc((size_t)T * LD), *out = dev_alloc((size_t)2 * TILES * T * T), *tmp = dev_alloc((size_t)2 * KQ * T);
+  float *other_src = dev_alloc((size_t)8 * T * T), *other_dst = dev_alloc((size_t)8 * T * T);
+  std::vector<float> ref((size_t)TILES * T * T);
+  fill(Q, (size_t)T * LD, 91u, 2);
+  fill(Km, (size_t)T * LD, 92u, 2);
+  fill(other_src, (size_t)8 * T * T, 93u, 2);
+  // tile t: columns 8 (t % 56) .. + 63 of Q and K (overlapping windows of one 32 x 512 matrix); out[t] = K_t Q_t^T
+  for (int t = 0; t < TILES; ++t)
+    for (int i = 0; i < T; ++i)
+      for (int j = 0; j < T; ++j) {
+        float acc = 0.0f;
+        for (int kk = 0; kk < KQ; ++kk) acc += Km[i * LD + 8 * (t % 56) + kk] * Q[j * LD + 8 * (t % 56) + kk];
+        ref[((size_t)t * T + i) * T + j] = acc;
+      }
+  const int64_t ht = xsmm_unary_dispatch(XSMM_UNARY_TRANSPOSE, XSMM_DTYPE_F32, T, KQ, LD, T, 0);
+  const int64_t hg = xsmm_gemm_dispatch(XSMM_DTYPE_F32, T, T, KQ, LD, T, T, XSMM_GEMM_FLAG_BETA_0);
+  const int64_t hc = xsmm_unary_dispatch(XSMM_UNARY_IDENTITY, XSMM_DTYPE_F32, T, T, T, T, 0);
+  int bad = 0;
+  int64_t st0[3], st1[3];
+  xsmm_hip_fold_transpose_stats(st0);
+  for (int rep = 0; rep < reps; ++rep) {
+    const bool two = rep >= reps / 2;
+    xsmm_hip_set_fold_transpose(1); // re-armed: the first thread below that transposes is the one whose transposes are folded
+    memset(out, 0xff, (size_t)2 * TILES * T * T * sizeof(float));
+    std::atomic<int> done{0};
+    std::vector<std::thread> th;
+    auto qk = [&](int which) {
+      for (int t = 0; t < TILES; ++t) {
+        xsmm_unary_invoke(XSMM_DTYPE_F32, ht, Q, 8 * (t % 56), tmp, (int64_t)which * KQ * T);
+        xsmm_gemm_invoke(XSMM_DTYPE_F32, hg, Km, 8 * (t % 56), tmp, (int64_t)which * KQ * T, out, ((int64_t)which * TILES + t) * T * T);
+      }
+      done.fetch_add(1, std::memory_order_release);
+    };
+    th.emplace_back(qk, 0);
+    if (two) th.emplace_back(qk, 1);
+    for (int o = 0; o < 3; ++o)
+      th.emplace_back([&, o] {
+        int k = 0;
+        while (done.load(std::memory_order_acquire) < (two ? 2 : 1) && k < 4000) {
+          xsmm_unary_invoke(XSMM_DTYPE_F32, hc, other_src, (int64_t)((o + k) & 7) * T * T, other_dst, (int64_t)o * T * T);
+          if (o == 2 && (++k & 7) == 0) xsmm_hip_flush();
+          else ++k;
+          usleep(5);
+        }
+      });
+    for (auto &t : th) t.join();
+    xsmm_hip_synchronize();
+    if (memcmp(out, ref.data(), ref.size() * sizeof(float))) ++bad;
+    if (two && memcmp(out + (size_t)TILES * T * T, ref.data(), ref.size() * sizeof(float))) ++bad;
+    // the temporary holds the last transpose
+    for (int i = 0; i < T && !bad; ++i)
+      for (int kk = 0; kk < KQ; ++kk)
+        if (tmp[kk * T + i] != Q[i * LD + 8 * ((TILES - 1) % 56) + kk]) { ++bad; break; }
+  }
+  xsmm_hip_fold_transpose_stats(st1);
+  printf("%-46s reps %d: %s (%ld gemms served from a transpose's source, %ld transposes dropped, %ld launched late)\n", what, reps,
+         bad ? "MISMATCH" : "identical to the serial run", (long)(st1[0] - st0[0]), (long)(st1[1] - st0[1]), (long)(st1[2] - st0[2]));
+  hipFree(Q); hipFree(Km); hipFree(out); hipFree(tmp); hipFree(other_src); hipFree(other_dst);
+  return bad;
+}
+
 int main(int argc, char **argv) {
   int bad = 0;
   const int chain_rounds = argc > 1 ? atoi(argv[1]) : 200;
@@ -303,6 +371,7 @@ int main(int argc, char **argv) {
     ++bad;
   }
   bad += run_mlp(true, 2, "tile queue, zero/brgemm/relu tiles, 8 callers");
+  bad += run_transposes(8, "tile queue, transposes folded into gemms");
   // 3b. mode 2: several callers hand their invokes to the ring + scheduler thread
   xsmm_hip_set_tile_queue(2);
   bad += run_mlp(true, 6, "tile queue, device operands, 8 callers");
@@ -333,6 +402,7 @@ int main(int argc, char **argv) {
   xsmm_hip_set_async(1);
   bad += run_mlp(true, 2, "async again");
   bad += run_fused(4, "fused tiles through the scheduler thread");
+  bad += run_transposes(4, "transposes + gemms through the scheduler thread");
   xsmm_hip_set_tile_queue(0);
   bad += run_mlp(true, 1, "async, queue off");
   printf("%s\n", bad ? "FAILED" : "OK");

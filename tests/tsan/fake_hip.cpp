@@ -117,7 +117,8 @@ hipError_t launch_gemm(const GemmDesc &d, const void *A_, const void *B_, void *
     for (int64_t j = 0; j < d.n; ++j) {
       float acc = d.beta0 ? 0.0f : C[i * d.ldc + j];
       for (int64_t b = 0; b < br; ++b)
-        for (int64_t kk = 0; kk < d.k; ++kk) acc += A[b * d.stride_a + i * d.lda + kk] * B[b * d.stride_b + kk * d.ldb + j];
+        for (int64_t kk = 0; kk < d.k; ++kk)
+          acc += A[b * d.stride_a + i * d.lda + kk] * (d.b_trans ? B[b * d.stride_b + j * d.ldb + kk] : B[b * d.stride_b + kk * d.ldb + j]);
       if (d.bias) acc += D[j];
       if (d.relu && !(acc > 0.0f)) acc = 0.0f;
       C[i * d.ldc + j] = acc;
@@ -143,6 +144,11 @@ hipError_t launch_unary(const UnaryDesc &d, const void *in_, float scalar, bool 
   const float *in = (const float *)in_;
   float *out = (float *)out_;
   if (!g_compute) return hipSuccess;
+  if (d.op == 29) { // transpose: m x n in, n x m out
+    for (int64_t i = 0; i < d.m; ++i)
+      for (int64_t j = 0; j < d.n; ++j) out[j * d.ldo + i] = in[i * d.ldi + j];
+    return hipSuccess;
+  }
   for (int64_t i = 0; i < d.m; ++i)
     for (int64_t j = 0; j < d.n; ++j) {
       float v = d.op == 2 ? 0.0f : (use_scalar ? scalar : in[i * d.ldi + j]);

@@ -27,14 +27,26 @@ add = rt.binary_dispatch(1, F32, 32, 32, 32, 32, 32, 0)
 mul = rt.binary_dispatch(2, F32, 32, 32, 32, 32, 32, 0)
 gemm = rt.brgemm_dispatch(F32, 32, 32, 32, 32, 32, 32, 1024, 1024, 0)
 gemm0 = rt.brgemm_dispatch(F32, 32, 32, 32, 32, 32, 32, 1024, 1024, 4)
+# transposes feeding a gemm's B operand through a temporary (kinds 7, 8): with one calling thread the runtime folds them into the gemm
+# (deferred transposes, runtime.cpp) - the queued run reads B from the transpose's source, the unqueued run from the temporary
+transp = rt.unary_dispatch(29, F32, 32, 32, 32, 32, 0)
+gemm1 = rt.gemm_dispatch(F32, 32, 32, 32, 32, 32, 32, 4)
+tls = threading.local()
 
 
 BR = [1]
 
 
 def issue(op, bufs):
-    kind, s, st, s2, s2t, d, dt = op
+    kind, s, st, s2, s2t, d, dt = op[:7]
     S, S2, D = bufs[s], bufs[s2], bufs[d]
+    if kind in (7, 8):
+        # 7: the temporary is the op's own tile of a fourth buffer (every transpose is launched: the next one goes elsewhere);
+        # 8: ONE temporary per calling thread in a scratch buffer that is not compared (transposes are dropped as dead)
+        X, xt = (bufs[op[7]], dt) if kind == 7 else (bufs[NBUF], getattr(tls, "tid", 0))
+        rt.unary(F32, transp, S, st * 1024, X, xt * 1024)
+        rt.gemm(F32, gemm1, S2, s2t * 1024, X, xt * 1024, D, dt * 1024)
+        return
     if kind == 0:
         rt.unary(F32, copy, S, st * 1024, D, dt * 1024)
     elif kind == 1:
@@ -57,12 +69,12 @@ def make_program(rng):
     op writes its own tile of a buffer no op of the phase reads), so any interleaving gives the same result"""
     phases = []
     for _ in range(int(rng.integers(2, 7))):
-        kind = int(rng.integers(0, 7))
+        kind = int(rng.integers(0, 9))
         perm = rng.permutation(NBUF)
         s, s2, d = int(perm[0]), int(perm[1]), int(perm[2])
         n = int(rng.integers(4, NTILE))
         tiles = rng.permutation(NTILE)[:n]
-        phases.append([(kind, s, int(rng.integers(0, NTILE)), s2, int(rng.integers(0, NTILE)), d, int(t)) for t in tiles])
+        phases.append([(kind, s, int(rng.integers(0, NTILE)), s2, int(rng.integers(0, NTILE)), d, int(t), int(perm[3])) for t in tiles])
     return phases
 
 
@@ -77,6 +89,7 @@ def run(phases, bufs, nthr, sync_after):
     barrier = threading.Barrier(nthr)
 
     def worker(tid):
+        tls.tid = tid
         for pi, ph in enumerate(phases):
             for op in ph[tid::nthr]:
                 issue(op, bufs)
@@ -101,13 +114,14 @@ while time.time() < t_end:
     init = [(rng.uniform(-1, 1, NTILE * 1024) * 0.2).astype(np.float32) for _ in range(NBUF)]
     phases = make_program(rng)
     BR[0] = int(rng.choice([1, 2, 4]))
-    q_bufs = [torch.from_numpy(b.copy()).cuda() for b in init]
-    r_bufs = [torch.from_numpy(b.copy()).cuda() for b in init]
+    q_bufs = [torch.from_numpy(b.copy()).cuda() for b in init] + [torch.zeros(8 * 1024, dtype=torch.float32, device="cuda")]
+    r_bufs = [torch.from_numpy(b.copy()).cuda() for b in init] + [torch.zeros(8 * 1024, dtype=torch.float32, device="cuda")]
     for rep in range(int(rng.integers(2, 6))):
         nthr = int(rng.choice([1, 1, 2, 3, 4, 6]))
         sync_after = set(int(x) for x in rng.integers(0, len(phases), int(rng.integers(0, 2))))
         rt.set_async(True)
         rt.set_tile_queue(True)
+        rt.set_fold_transpose(True)  # re-armed: the first thread of this run that transposes is the one whose transposes are folded
         run(phases, q_bufs, nthr, sync_after)
         rt.synchronize()
         rt.set_tile_queue(False)
@@ -123,10 +137,11 @@ while time.time() < t_end:
             if len(phases[pi]) > 2 and rng.integers(0, 2):
                 del phases[pi][int(rng.integers(0, len(phases[pi])))]
             else:
-                k, s, st, s2, s2t, d, dt = phases[pi][0]
-                phases[pi] = [(k, s, int(rng.integers(0, NTILE)), s2, s2t, d, t[6]) for t in phases[pi]]
+                k, s, st, s2, s2t, d, dt, x = phases[pi][0]
+                phases[pi] = [(k, s, int(rng.integers(0, NTILE)), s2, s2t, d, t[6], x) for t in phases[pi]]
     rounds += 1
     seed += 1
 st = tuple(b - a for a, b in zip(stats0, rt.tile_queue_stats()))
 print("queue_fuzz: %d programs (%d invokes through the queue) identical to the unqueued runs; queue launches %d, full bookkeeping %d, "
-      "replayed %d, terminated %d, abandoned %d" % ((rounds, ops) + st))
+      "replayed %d, terminated %d, abandoned %d; transposes: %d gemms served from a transpose's source, %d dropped as dead, %d launched late"
+      % ((rounds, ops) + st + rt.fold_transpose_stats()))

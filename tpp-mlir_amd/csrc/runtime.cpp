@@ -1954,18 +1954,22 @@ std::atomic<bool> g_dt_multi{false};     // ... and another one did too: no more
 std::atomic<int64_t> g_dt_folded{0}, g_dt_dropped{0}, g_dt_launched{0}; // statistics (xsmm_hip_fold_transpose_stats)
 void unary_invoke_core(const UnaryDesc *d, void *pi, float scalar, bool use_scalar, void *po, bool may_defer);
 // launches the remembered transpose, if there is one (any thread)
+// The record stays "pending" until the transpose HAS BEEN handed to the queue / launched, and the lock is held across that: a
+// thread that sees pending = 0 (and goes on to queue an invoke that reads the destination) is ordered behind the transpose.
+std::atomic<uintptr_t> g_dt_busy{0}; // the thread inside the hand-over below (its own flush_tile_queue calls must not re-enter)
 void dt_materialize() {
-  DeferredTranspose r;
-  {
-    std::lock_guard<SpinLock> lk(g_dt_mu);
-    if (!g_dt_pending.load(std::memory_order_relaxed)) return;
-    r = g_dt;
-    g_dt_pending.store(0, std::memory_order_release);
-  }
+  const uintptr_t me = thread_token();
+  if (g_dt_busy.load(std::memory_order_relaxed) == me) return;
+  std::lock_guard<SpinLock> lk(g_dt_mu);
+  if (!g_dt_pending.load(std::memory_order_relaxed)) return;
+  const DeferredTranspose r = g_dt;
   g_dt_launched.fetch_add(1, std::memory_order_relaxed);
   const hipStream_t cur = cfg().stream.load(std::memory_order_relaxed);
   if (cur != r.stream) die("tpp-xsmm-hip: a deferred transpose outlived its stream"); // (xsmm_hip_set_stream flushes first: cannot happen)
+  g_dt_busy.store(me, std::memory_order_relaxed);
   unary_invoke_core(r.d, r.src, 0.0f, false, r.dst, false);
+  g_dt_busy.store(0, std::memory_order_relaxed);
+  g_dt_pending.store(0, std::memory_order_release);
 }
 inline bool dt_overlap(const void *a, size_t na, const void *b, size_t nb) {
   return a && b && (uintptr_t)a < (uintptr_t)b + nb && (uintptr_t)b < (uintptr_t)a + na;
