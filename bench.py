@@ -1007,6 +1007,8 @@ def main():
                     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "refbench.py"), "--quick", "-n", "200", "--json", jf],
                                    capture_output=True, text=True, timeout=600, check=True)  # (GPU side only; the CPU column joins below)
                     rows = json.load(open(jf))
+                scripts = [r_ for r_ in rows if r_["family"] == "mlir"]
+                rows = [r_ for r_ in rows if r_["family"] != "mlir"]
                 rows.sort(key=lambda r_: r_["frac_of_peak"])
                 keep = lambda r_: {"benchmark": r_["name"], "tiles": "%d,%d,%d" % tuple(r_["tiles"]), "form": r_["form"], "us": r_["us"],  # noqa: E731
                                    "value": r_["gflops"], "unit": "GFLOP/s", "frac_of_f32_mfma_peak": round(r_["frac_of_peak"], 4),
@@ -1018,6 +1020,17 @@ def main():
                                "median_frac_of_f32_mfma_peak": round(rows[len(rows) // 2]["frac_of_peak"], 4),
                                "worst3": [keep(r_) for r_ in rows[:3]], "best3": [keep(r_) for r_ in rows[-3:]],
                                "full_table": "profiles/r05_refbench.txt"})
+                # the hand-written benchmark files (benchmarks/config/base/mha.json, pack.json -> benchmarks/mlir/*.mlir) as the xsmm call
+                # scripts the reference's conversion test pins for them (tools/tpp_replay --script; GFLOP/s from each file's own
+                # BENCH_TOTAL_FLOPS line - the pack files count bytes there)
+                if scripts:
+                    others.append({"workload": "benchmarks/mlir/*.mlir as xsmm call scripts through the tile queue, f32 (mha pieces: 512 (batch, head) tiles each; "
+                                               "pack / unpack: per-block copies)",
+                                   "rows": [{"file": r_["cite"], "invokes_per_call": r_["invokes"], "us": r_["us"], "host_side_us": r_["host_us"], "value": r_["gflops"],
+                                             "unit": "GB/s moved one way (the file's BENCH_TOTAL_FLOPS counts bytes)" if r_["script"].startswith(("pack", "unpack")) else "GFLOP/s",
+                                             "kernel": r_["kernel_name"]} for r_ in scripts],
+                                   "note": "fp32-query-times-key.mlir = transpose + gemm per tile through ONE temporary: the transposes are folded into the gemms "
+                                           "(xsmm_hip_set_fold_transpose; 3.6 ms as 1024 launches without)"})
             except Exception as ex:
                 others.append({"workload": "the reference's benchmark shape set (tools/refbench.py)", "error": str(ex)[:300]})
             # the same fp32 MLP at batch 512 as whole-layer calls: three launches, and handed over together (ONE launch of the f32

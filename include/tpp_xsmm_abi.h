@@ -269,11 +269,11 @@ TPP_XSMM_EXPORT int xsmm_hip_force_split(int workgroups_per_tile);
  * tile of at most 64x64 into a dense destination (ldo = m) is remembered instead of launched; a gemm of the same thread whose B
  * operand is exactly that destination (k, n, ldb matching, one batch element) reads B transposed from the transpose's SOURCE (all
  * such gemms of a loop are one queue group = one launch); a later transpose of the same handle into the same destination replaces
- * the remembered one (it is dead: fully overwritten, its readers were served); any other invoke of any thread, xsmm_hip_flush and
+ * the remembered one (it is dead: fully overwritten, its readers were served); any other invoke of the thread, xsmm_hip_flush and
  * every synchronisation point launch the remembered transpose first - whenever anything can look at the destination it holds what
- * the program wrote. Results of a folded gemm are those of the generic kernel on the same values. One transposing thread per process
- * (a second one switches the folding off until it is enabled again: 1 re-arms it). 0 turns it off (also TPP_HIP_FOLD_TRANSPOSE=0);
- * returns the previous setting.
+ * the program wrote. Results of a folded gemm are those of the generic kernel on the same values. One remembered transpose per
+ * calling thread (the reference's OpenMP callers own a temporary each); an invoke of another thread launches it first only if it
+ * touches the destination or writes the source. 0 turns it off (also TPP_HIP_FOLD_TRANSPOSE=0); returns the previous setting.
  * stats: [0] gemm invokes served from a transpose's source, [1] remembered transposes dropped as dead, [2] launched after all. */
 TPP_XSMM_EXPORT int xsmm_hip_set_fold_transpose(int enable);
 TPP_XSMM_EXPORT void xsmm_hip_fold_transpose_stats(int64_t out[3]);

@@ -29,8 +29,35 @@ def rows_of(path):
     return out
 
 
+def mlir_files():
+    """the hand-written benchmark files of base/mha.json and base/pack.json: file, its BENCH_TOTAL_FLOPS line, its -n flag; and the xsmm
+    dispatches the reference's conversion test pins for the three mha functions (test/Conversion/LinalgToXsmm/linalg-to-gemm.mlir CHECK lines)"""
+    out = {"files": [], "lowered_calls": {}}
+    for cfgf in ("mha.json", "pack.json"):
+        for grp in json.load(open(os.path.join(REF, "base", cfgf))):
+            for suite, rows in grp.items():
+                for name, row in rows.items():
+                    if row.get("type") != "MLIR":
+                        continue
+                    f = os.path.join("/root/reference/benchmarks/mlir", row["benchmark"])
+                    m = re.search(r"BENCH_TOTAL_FLOPS:\s*(\d+)", open(f).read()) if os.path.exists(f) else None  # (mha.json also names a file the tree does not hold)
+                    out["files"].append({"config": "benchmarks/config/base/%s" % cfgf, "suite": suite, "name": name, "file": "benchmarks/mlir/" + row["benchmark"],
+                                         "flags": row.get("flags"), "in_tree": os.path.exists(f), "bench_total_flops": int(m.group(1)) if m else None})
+    test = "/root/reference/test/Conversion/LinalgToXsmm/linalg-to-gemm.mlir"
+    cur = None
+    for ln, line in enumerate(open(test).read().splitlines(), 1):
+        m = re.search(r"CHECK-LABEL:\s*(\w+)", line)
+        if m:
+            cur = m.group(1) if m.group(1).startswith("mha_") else None
+        m = re.search(r"CHECK:.*xsmm\.(gemm|unary|brgemm)\.dispatch\s*(\w+)?\s*\[([0-9, ]+)\]\s*flags = \(([a-z_0-9, ]*)\)", line)
+        if m and cur:
+            out["lowered_calls"].setdefault(cur, []).append({"where": "test/Conversion/LinalgToXsmm/linalg-to-gemm.mlir:%d" % ln, "op": m.group(1),
+                                                             "kind": m.group(2), "dims": [int(x) for x in m.group(3).split(",")], "flags": m.group(4)})
+    return out
+
+
 def main():
-    data = {"matmul": [], "fc": [], "base": rows_of(os.path.join(REF, "base", "base.json"))}
+    data = {"matmul": [], "fc": [], "base": rows_of(os.path.join(REF, "base", "base.json")), "mlir": mlir_files()}
     for fam in ("matmul", "fc"):
         for f in sorted(glob.glob(os.path.join(REF, fam, "*.json"))):
             data[fam] += rows_of(f)

@@ -141,10 +141,27 @@ def test_refbench_restates_the_reference_benchmark_configs():
     tiled = [r for r in cfg["base"] if r["tiles"]]
     assert tiled and all(r["batch"] == 256 and r["layers"] == [1024] * 4 and r["tiles"] == [32, 32, 32] and r["kernel"] == "const" for r in tiled)
     got = rb.cases("")
-    assert len(got) == (17 + 17) * 3 * 2 + 2 * 3 * 2
+    assert len([c for c in got if c["family"] != "mlir"]) == (17 + 17) * 3 * 2 + 2 * 3 * 2
+    # the hand-written files of base/mha.json and pack.json (benchmarks/mlir/*.mlir) as call scripts: every file the tree holds, its own
+    # BENCH_TOTAL_FLOPS, and per tile the dispatches the reference's conversion test pins (linalg-to-gemm.mlir; zero fills folded into BETA_0)
+    files = {r["file"]: r for r in cfg["mlir"]["files"] if r["in_tree"]}
+    scripts = [c for c in got if c["family"] == "mlir"]
+    assert {c["cite"] for c in scripts} == set(files) and len(scripts) == 6
+    assert all(c["flops"] == files[c["cite"]]["bench_total_flops"] for c in scripts)
+    fn = {"mha_projection": "mha_projection", "mha_qk": "mha_query_times_key", "mha_sv": "mha_out_softmax_times_value"}
+    for script, calls in rb.SCRIPT_CALLS.items():
+        pinned = [(("%s %s" % (c["op"], c["kind"])) if c["kind"] else c["op"], c["dims"]) for c in cfg["mlir"]["lowered_calls"][fn[script]] if c["kind"] != "zero"]
+        assert pinned == [(op, dims) for op, dims in calls], (script, pinned)
+        assert all(c["flags"] == "none" for c in cfg["mlir"]["lowered_calls"][fn[script]] if c["kind"] != "zero")
+    # ... and tools/tpp_replay.cpp issues exactly those tuples (S = 32, D = 64, E = 512 in its --script mode)
+    src = open(os.path.join(ROOT, "tools", "tpp_replay.cpp")).read()
+    for needle in ("xsmm_gemm_dispatch(1, S, D, E, E, E, E, XSMM_GEMM_FLAG_BETA_0)", "xsmm_unary_dispatch(XSMM_UNARY_TRANSPOSE, 1, S, D, E, S, 0)",
+                   "xsmm_gemm_dispatch(1, S, S, D, E, S, S, XSMM_GEMM_FLAG_BETA_0)", "xsmm_gemm_dispatch(1, S, D, S, S, E, E, XSMM_GEMM_FLAG_BETA_0)",
+                   "Bt = 64, S = 32, H = 8, D = 64, E = H * D"):
+        assert needle in src, needle
     # ... and bench.py's cpu_baseline leg (the CPU column of the table) runs the same (M, N, K) list
     spec_b = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
     bm = importlib.util.module_from_spec(spec_b)
     spec_b.loader.exec_module(bm)
     assert bm.REFBENCH_SHAPES == [(M, N, K) for (M, N, K, _) in rb.SHAPES]
-    assert {c["kernel"] for c in got if c["family"] == "base"} == {"const"} and {c["kernel"] for c in got if c["family"] != "base"} == {"args"}
+    assert {c["kernel"] for c in got if c["family"] == "base"} == {"const"} and {c["kernel"] for c in got if c["family"] in ("matmul", "fc")} == {"args"}

@@ -26,7 +26,7 @@ ZERO, TRANSPOSE, IDENTITY, BCAST_SCALAR, BETA0 = 2, 29, 1, 8, 4
 def rt():
     r = pkg.get_runtime()
     assert r.device_count() >= 1, "no HIP device visible: the gpu tests need an MI355X"
-    r.set_fold_transpose(True)  # (re-)armed for this thread: earlier test modules may have transposed from other threads
+    r.set_fold_transpose(True)
     return r
 
 
@@ -300,8 +300,9 @@ def test_gemm_behind_a_transpose_folded_or_not_same_results(rt, case):
 
 
 def test_another_thread_reads_the_temporary_after_a_join(rt):
-    """thread 1: transpose + folded gemm; joined; the main thread copies the temporary: it must hold the transpose (any invoke of any
-    thread launches a remembered transpose first). A second TRANSPOSING thread then switches the folding off for the process."""
+    """thread 1: transpose + folded gemm; joined; the main thread copies the temporary: it must hold the transpose (an invoke of another
+    thread that touches a remembered transpose's destination launches it first). Every thread has its own record: the main thread's
+    transposes fold as well."""
     import threading
     rng = np.random.default_rng(24)
     X = rng.uniform(-1, 1, S * E).astype(np.float32)
@@ -319,7 +320,6 @@ def test_another_thread_reads_the_temporary_after_a_join(rt):
             rt.unary(F32, ht, dX, 0, dT, 0)
             rt.gemm(F32, hg, dK, 0, dT, 0, dO, 0)
 
-        rt.set_fold_transpose(True)  # re-armed: the worker is the transposing thread
         f0 = rt.fold_transpose_stats()
         t = threading.Thread(target=worker)
         t.start()
@@ -330,13 +330,27 @@ def test_another_thread_reads_the_temporary_after_a_join(rt):
         assert rt.fold_transpose_stats()[2] - f0[2] == 1
         assert np.array_equal(host(dC, tX), tX)
         check_close(host(dO, ref), ref, F32, "gemm of the worker thread", K=D)
-        # a second transposing thread (this one): folding is off from here on, results unchanged
-        rt.unary(F32, ht, dX, 0, dT, 0)
+        # an invoke of another thread that touches neither the destination nor (writing) the source leaves the record alone
+        dT2, dC2 = dev(np.zeros(D * S, np.float32)), dev(np.zeros(D * S, np.float32))
+        f1 = rt.fold_transpose_stats()
+
+        def worker2():
+            rt.unary(F32, ht, dX, 0, dT2, 0)
+
+        t = threading.Thread(target=worker2)
+        t.start()
+        t.join()
+        rt.unary(F32, hc, dC, 0, dC2, 0)  # reads dC, writes dC2: unrelated to dT2 and dX
+        assert rt.fold_transpose_stats()[2] == f1[2], "still remembered"
+        rt.unary(F32, hc, dC, 0, dX, 0)  # WRITES (the first 64 x 32 floats of) the transpose's source: the transpose must read the old bytes, so it is launched first
+        assert rt.fold_transpose_stats()[2] - f1[2] == 1
+        rt.synchronize()
+        assert np.array_equal(host(dT2, tX), tX)
+        # this thread's own transposes fold too (one record per thread)
+        rt.unary(F32, ht, dK, 0, dT, 0)
         rt.gemm(F32, hg, dK, 0, dT, 0, dO, 0)
         rt.synchronize()
-        assert rt.fold_transpose_stats()[0] - f0[0] == 1
-        check_close(host(dO, ref), ref, F32, "gemm behind an unfolded transpose", K=D)
+        assert rt.fold_transpose_stats()[0] - f0[0] == 2
     finally:
-        rt.set_fold_transpose(True)
         rt.set_tile_queue(old_q)
         rt.set_async(old_async)

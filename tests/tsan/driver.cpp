@@ -280,8 +280,8 @@ static int run_chain(int rounds, const char *what) {
 // Transposes folded into the gemm they feed (runtime.cpp, deferred transposes): ONE thread runs transpose -> temporary -> gemm per
 // tile (the lowering of benchmarks/mlir/fp32-query-times-key.mlir, one temporary for all tiles) while three other threads keep
 // invoking unrelated copies - every one of their invokes launches the remembered transpose if there is one, under the first
-// thread's feet - and a fourth one flushes. In the second half of the repetitions a second thread transposes as well (its own
-// temporary): the folding switches itself off, the results stay.
+// thread's feet when it touches the record's destination or source (here: never; the flushes launch it) - and one of them flushes. In
+// the second half of the repetitions a second thread runs the same script on its own temporary: one record per thread, both fold.
 static int run_transposes(int reps, const char *what) {
   const int TILES = 48, T = 32, KQ = 64, LD = 512;
   float *Q = dev_alloc((size_t)T * LD), *Km = dev_alloc((size_t)T * LD), *out = dev_alloc((size_t)2 * TILES * T * T), *tmp = dev_alloc((size_t)2 * KQ * T);
@@ -306,7 +306,6 @@ static int run_transposes(int reps, const char *what) {
   xsmm_hip_fold_transpose_stats(st0);
   for (int rep = 0; rep < reps; ++rep) {
     const bool two = rep >= reps / 2;
-    xsmm_hip_set_fold_transpose(1); // re-armed: the first thread below that transposes is the one whose transposes are folded
     memset(out, 0xff, (size_t)2 * TILES * T * T * sizeof(float));
     std::atomic<int> done{0};
     std::vector<std::thread> th;

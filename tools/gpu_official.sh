@@ -47,6 +47,8 @@ fi
 # round 5: the reference's benchmark shape set (full table + json), the split / half-width-tile sweep, the self-launching N = 2 bench on the one-device rig
 timeout 900 python bench.py --refbench --refbench-json $OUT/refbench.json > $OUT/refbench.txt 2> $OUT/refbench.err
 timeout 300 python tools/split_sweep.py > $OUT/split_sweep.txt 2>&1
+# benchmarks/mlir/*.mlir (base/mha.json, pack.json) as xsmm call scripts: queue on / off, transpose folding on / off, 8 callers
+timeout 300 tools/tpp_replay --cases tools/scripts.cases 2>&1 | grep -v "^[0-9.e-]*$" > $OUT/mlir_scripts.txt
 TPP_BENCH_ONE_DEVICE=1 timeout 600 python bench.py --gpus 2 --steps 6 --warmup 3 > $OUT/bench_gpus2_rig.json 2> $OUT/bench_gpus2_rig.err
 python tools/sweep.py 2>/dev/null | grep -E "^(f32|bf16)" > $OUT/sweep.txt
 python tools/sweep.py big 2>/dev/null | grep -E "^(f32|bf16)" >> $OUT/sweep.txt

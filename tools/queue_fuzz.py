@@ -27,8 +27,9 @@ add = rt.binary_dispatch(1, F32, 32, 32, 32, 32, 32, 0)
 mul = rt.binary_dispatch(2, F32, 32, 32, 32, 32, 32, 0)
 gemm = rt.brgemm_dispatch(F32, 32, 32, 32, 32, 32, 32, 1024, 1024, 0)
 gemm0 = rt.brgemm_dispatch(F32, 32, 32, 32, 32, 32, 32, 1024, 1024, 4)
-# transposes feeding a gemm's B operand through a temporary (kinds 7, 8): with one calling thread the runtime folds them into the gemm
-# (deferred transposes, runtime.cpp) - the queued run reads B from the transpose's source, the unqueued run from the temporary
+# transposes feeding a gemm's B operand through a temporary (kinds 7, 8): the runtime folds them into the gemm (deferred transposes,
+# runtime.cpp: one remembered transpose per calling thread) - the queued run reads B from the transpose's source, the unqueued run
+# from the temporary
 transp = rt.unary_dispatch(29, F32, 32, 32, 32, 32, 0)
 gemm1 = rt.gemm_dispatch(F32, 32, 32, 32, 32, 32, 32, 4)
 tls = threading.local()
@@ -121,7 +122,6 @@ while time.time() < t_end:
         sync_after = set(int(x) for x in rng.integers(0, len(phases), int(rng.integers(0, 2))))
         rt.set_async(True)
         rt.set_tile_queue(True)
-        rt.set_fold_transpose(True)  # re-armed: the first thread of this run that transposes is the one whose transposes are folded
         run(phases, q_bufs, nthr, sync_after)
         rt.synchronize()
         rt.set_tile_queue(False)

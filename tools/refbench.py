@@ -18,7 +18,11 @@ for f32, bf16 + VNNI-2 and bf16 + VNNI-4. GFLOP/s = BENCH_TOTAL_FLOPS / mean (ML
 only; the CPU column (the reference's packed 32x32x32 call structure under OpenMP on the same shape: the `cpu_baseline` leg of
 bench.py, which alone may use oracle/) is read from --cpu-json when given - `python bench.py --refbench` produces the whole table.
 
-usage: python tools/refbench.py [--quick] [--only matmul|fc|base] [-n ITER] [--json out.json] [--cpu-json cpu_rows.json]
+Plus (round 5) the hand-written files of benchmarks/config/base/mha.json and pack.json - benchmarks/mlir/fp32-projection.mlir,
+fp32-query-times-key.mlir, fp32-out-softmax-times-value.mlir, the pack / unpack files - as the xsmm call scripts of tools/tpp_replay --script
+(form "script"; the pack rows' "GFLOP/s" counts bytes as their BENCH_TOTAL_FLOPS lines do, their fraction is of the HBM peak).
+
+usage: python tools/refbench.py [--quick] [--only matmul|fc|base|mlir] [-n ITER] [--json out.json] [--cpu-json cpu_rows.json]
 """
 import argparse
 import json
@@ -41,8 +45,37 @@ SHAPES = [
 ]
 
 
+# the hand-written benchmark files (benchmarks/config/base/mha.json:1-40, pack.json): benchmarks/mlir/*.mlir as the xsmm call scripts the
+# reference's own conversion test pins for them (test/Conversion/LinalgToXsmm/linalg-to-gemm.mlir:46-62,91-104,132-145; tools/tpp_replay
+# --script): name, file, BENCH_TOTAL_FLOPS of the file (the pack files count bytes), invokes per call
+SCRIPTS = [
+    ("mha_projection", "fp32-projection.mlir", 1073741824.0, 512),
+    ("mha_qk", "fp32-query-times-key.mlir", 67108864.0, 1024),
+    ("mha_sv", "fp32-out-softmax-times-value.mlir", 67108864.0, 512),
+    ("pack_a", "fp32-pack-gemm-operand-a-512x1024.mlir", 2097152.0, 512),
+    ("pack_b", "fp32-pack-gemm-operand-b-512x1024.mlir", 2097152.0, 512),
+    ("unpack_c", "fp32-unpack-gemm-operand-a-512x512.mlir", 1048576.0, 256),
+]
+
+
+# the xsmm dispatches per (batch, head) tile of the three mha files, as the reference's conversion test has them (the zero fill of the
+# output tile that precedes each gemm there is folded into BETA_0 by the default pipeline: FoldXsmmFlags, LinalgLowering.cpp:56)
+SCRIPT_CALLS = {
+    "mha_projection": [("gemm", [32, 64, 512, 512, 512, 512])],
+    "mha_qk": [("unary transpose", [32, 64, 512, 32]), ("gemm", [32, 32, 64, 512, 32, 32])],
+    "mha_sv": [("gemm", [32, 64, 32, 32, 512, 512])],
+}
+
+
 def cases(only):
     out = []
+    if not only or only == "mlir":
+        for nm, f, fl, inv in SCRIPTS:
+            out.append({"family": "mlir", "name": "mlir_" + nm, "script": nm, "M": 0, "layers": [0, 0], "tiles": (32, 64 if nm != "mha_qk" else 32, 0),
+                        "dtype": "f32", "form": "script", "bias_relu": False, "kernel": "const", "flops": fl, "invokes": inv,
+                        "cite": "benchmarks/mlir/" + f})
+    if only == "mlir":
+        return out
     for fam in ("matmul", "fc"):
         if only and only != fam:
             continue
@@ -62,6 +95,8 @@ def cases(only):
 
 
 def argv_of(c, n_iter):
+    if c.get("script"):
+        return ["--script", c["script"], "--queue", "1", "-n", str(n_iter)]
     a = ["--batch", str(c["M"]), "--layers", ",".join(map(str, c["layers"])), "--kernel", c["kernel"], "-n", str(n_iter), "--queue", "1"]
     if c["form"] == "tiles":
         a += ["--tiles", "%d,%d,%d" % c["tiles"]]
@@ -75,6 +110,8 @@ def argv_of(c, n_iter):
 
 
 def flops_of(c):
+    if c.get("script"):
+        return c["flops"]
     f = 0.0
     for l in range(len(c["layers"]) - 1):
         f += 2.0 * c["M"] * c["layers"][l] * c["layers"][l + 1] + (2.0 * c["M"] * c["layers"][l + 1] if c["bias_relu"] else 0.0)
@@ -92,6 +129,9 @@ def main():
     args = ap.parse_args()
     replay = os.path.join(ROOT, "tools", "tpp_replay")
     cs = [c for c in cases(args.only) if not (args.quick and c["dtype"] != "f32")]
+    # the script rows last: they run from a second calling context only in their own cases, and the multi-caller state of the tile
+    # queue is process-wide
+    cs = [c for c in cs if not c.get("script")] + [c for c in cs if c.get("script")]
     with tempfile.NamedTemporaryFile("w", suffix=".cases", delete=False) as f:
         for c in cs:
             f.write(" ".join(argv_of(c, args.n)) + "\n")
@@ -104,9 +144,13 @@ def main():
         sys.stderr.write(r.stderr[-4000:])
         raise SystemExit("refbench: %d cases, %d result lines (rc %d)" % (len(cs), len(got), r.returncode))
     for c, m_ in zip(cs, got):
-        c["us"], c["host_us"], c["gflops"], c["kernel_name"] = float(m_.group(1)), float(m_.group(2)), float(m_.group(3)), m_.group(5).strip()
+        c["us"], c["host_us"], c["gflops"], c["kernel_name"] = float(m_.group(1)), float(m_.group(2)), float(m_.group(3)), m_.group(5).split("; result checked")[0].strip()
+        if c.get("script", "").startswith(("pack", "unpack")):
+            c["kernel_name"] = "unary_grouped_kernel<f32>"  # (the line names the last grouped GEMM launch; these scripts run none)
         assert abs(float(m_.group(4)) - flops_of(c)) < 1, (c, m_.group(4))
         c["frac_of_peak"] = c["gflops"] * 1e9 / PEAK["f32" if c["dtype"] == "f32" else "bf16"]
+        if c.get("script", "").startswith(("pack", "unpack")):  # bytes: read + written once each against the HBM peak (8 TB/s)
+            c["frac_of_peak"] = 2.0 * c["gflops"] * 1e9 / 8e12
     cpu = {}
     if args.cpu_json:
         with open(args.cpu_json) as f:
@@ -115,7 +159,7 @@ def main():
     print("# %-24s %-11s %-10s %-6s %9s %10s %7s %9s  %s" % ("benchmark", "tiles", "dtype", "form", "us", "GFLOP/s", "frac", "CPU GF/s", "kernel"))
     for c in cs:
         key = (c["M"], c["layers"][1], c["layers"][0])
-        cg = cpu.get(key if c["family"] != "base" else (256, 1024, 1024))
+        cg = cpu.get(key if c["family"] != "base" else (256, 1024, 1024)) if not c.get("script") else None
         c["cpu_port_gflops_f32"] = round(cg["gflops"], 1) if cg else None
         c["cpu_threads"] = cg["threads"] if cg else None
         print("%-26s %-11s %-10s %-6s %9.2f %10.1f %7.4f %9s  %s" % (

@@ -39,7 +39,7 @@ static std::vector<int64_t> parse_list(const char *s) {
 }
 
 static int run_case(int argc, char **argv);
-static int run_script(const std::string &name, int queue, int64_t n_iter, int threads);
+static int run_script(const std::string &name, int queue, int64_t n_iter, int threads, int fold);
 
 // --cases FILE: one case per line (the flags of a single run), all in this process - the shape sweeps of tools/refbench.py
 // (benchmarks/config/matmul/*.json, fc/*.json) would otherwise pay a process start + HIP initialisation per row
@@ -72,6 +72,7 @@ static int run_case(int argc, char **argv) {
   bool bias = false, relu = false, whole = false, chain = false, print = false, c1 = false, rnd = false, bf16 = false;
   int queue = 1, threads = 1;
   std::string script;
+  int fold = 1;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
     auto next = [&]() { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(2); } return argv[++i]; };
@@ -92,6 +93,7 @@ static int run_case(int argc, char **argv) {
     else if (a == "--print") print = true;
     else if (a == "--c1") c1 = true;
     else if (a == "--script") script = next(); // the call scripts of benchmarks/mlir/*.mlir (base/mha.json, base/pack.json): see run_script
+    else if (a == "--fold") fold = atoi(next()); // --script: xsmm_hip_set_fold_transpose (1 = default: transposes folded into the gemm they feed)
     else if (a == "--bf16") bf16 = true; // mlir-gen --float-type=bf16 --vnni=2: bf16 storage, W in VNNI-2 blocks
     else if (a == "--vnni") vnni = atoi(next()); // --vnni=4 (benchmarks/config/*: the *_dp4_* rows): W in [K/4][N][4] blocks
     else if (a == "--kernel") kernel_args = std::string(next()) == "args"; // const (default): zero fill folded into BETA_0; args: C += ...
@@ -101,7 +103,7 @@ static int run_case(int argc, char **argv) {
     else { fprintf(stderr, "unknown flag %s\n", a.c_str()); return 2; }
   }
   if (xsmm_hip_device_count() < 1) { fprintf(stderr, "tpp_replay: no HIP device (there is no CPU fallback)\n"); return 1; }
-  if (!script.empty()) return run_script(script, queue, n_iter, threads);
+  if (!script.empty()) return run_script(script, queue, n_iter, threads, fold);
   if (c1) {
     // A, W, C: 256x256 f32 filled 1.0; packed copies [8][8][32][32]; result 257 everywhere (C += A W)
     const int64_t N = 256, T = 32, NB = N / T, tt = T * T;
@@ -283,9 +285,10 @@ static int run_case(int argc, char **argv) {
 //   mha_sv          fp32-out-softmax-times-value.mlir  forall (64, 8): gemm [32,64,32,32,512,512] beta_0
 //   pack_a / pack_b / unpack_c   fp32-pack-gemm-operand-a-512x1024.mlir, -b-512x1024.mlir, fp32-unpack-gemm-operand-a-512x512.mlir
 // Constant / index fills with closed-form results, checked on the first run (parity against the oracle: tests/test_mha_scripts_gpu.py).
-static int run_script(const std::string &name, int queue, int64_t n_iter, int threads) {
+static int run_script(const std::string &name, int queue, int64_t n_iter, int threads, int fold) {
   xsmm_hip_set_async(1);
   xsmm_hip_set_tile_queue(queue);
+  xsmm_hip_set_fold_transpose(fold);
   auto dfill = [&](size_t n, auto gen) {
     float *d; CHECK(hipMalloc((void **)&d, n * 4));
     std::vector<float> h(n);
@@ -394,6 +397,14 @@ static int run_script(const std::string &name, int queue, int64_t n_iter, int th
           queue && xsmm_hip_last_grouped_kernel()[0] ? xsmm_hip_last_grouped_kernel() : "(one launch per invoke)",
           queue ? (double)(q1[0] - q0[0]) / (double)n_iter : (double)invokes, (double)(q1[1] - q0[1]) / (double)n_iter,
           (double)(q1[2] - q0[2]) / (double)n_iter, (double)(q1[4] - q0[4]) / (double)n_iter);
+  if (name == "mha_qk") {
+    int64_t f[3];
+    xsmm_hip_fold_transpose_stats(f);
+    fprintf(stderr, "tpp_replay: transposes (process totals): %ld gemms served from a transpose's source, %ld transposes dropped as dead, %ld launched late; folding %s\n",
+            (long)f[0], (long)f[1], (long)f[2], fold ? "on" : "off");
+  }
+  xsmm_hip_synchronize();
   for (float *p : bufs) CHECK(hipFree(p));
+  xsmm_hip_set_fold_transpose(1);
   return 0;
 }

@@ -1745,7 +1745,7 @@ InlineQueue &inl() {
   static InlineQueue i;
   return i;
 }
-std::atomic<int> g_dt_pending{0}; // a deferred transpose exists (see "deferred transposes" below)
+std::atomic<int> g_dt_pending{0}; // number of remembered transposes (see "deferred transposes" below)
 void dt_materialize();
 void flush_tile_queue() {
   if (g_dt_pending.load(std::memory_order_acquire)) dt_materialize();
@@ -1795,13 +1795,16 @@ static __thread CallerState *tl_fast = nullptr;
 #else
 static __thread CallerState *tl_fast __attribute__((tls_model("initial-exec"))) = nullptr;
 #endif
+void dt_release_slot(int slot);
 struct CallerState {
   DeviceRanges devmem; // per caller: no sharing, no lock
   DirectWindow::Caller *me = nullptr;
   bool claimed = false;
+  int dt_slot = -1; // this thread's slot of remembered transposes ("deferred transposes" below)
   ~CallerState() {
     tl_fast = nullptr;
     if (me) me->owned.store(0, std::memory_order_release);
+    if (dt_slot >= 0) dt_release_slot(dt_slot);
   }
 };
 
@@ -1925,54 +1928,110 @@ bool try_enqueue(const GemmDesc *d, void *a, void *b, void *c, void *dp, int64_t
 // small temporary, then xsmm.gemm reading it (ConvertLinalgToXsmm; test/Conversion/LinalgToXsmm/linalg-to-gemm.mlir:46-62 has the
 // query-times-key benchmark lowered exactly so: transpose [32,64,512,32] + gemm [32,32,64,512,32,32] per (batch, head), ONE
 // temporary for every tile of a caller). Through the tile queue that is a chain of true and anti dependences on the temporary:
-// every invoke its own launch (1024 launches for benchmarks/mlir/fp32-query-times-key.mlir, 3.7 ms; the queue cannot help).
-// So a transpose of a small tile into a DENSE destination (ldo = m) is not launched when it is invoked but REMEMBERED (one record
-// per process, owned by the calling thread), and
+// every invoke its own launch (1024 launches for benchmarks/mlir/fp32-query-times-key.mlir, 3.6 ms; the queue cannot help).
+// So a transpose of a small tile into a DENSE destination (ldo = m) is not launched when it is invoked but REMEMBERED - one record
+// per calling thread (the reference's OpenMP callers own a temporary each) - and
 //   * a gemm of the same thread whose B operand is exactly that destination (k = the transpose's n, n = its m, ldb = ldo, one batch
 //     element, f32, no operand of it overlapping the destination, C not overlapping the transpose's source) runs on a SIBLING
 //     descriptor that reads B transposed straight from the transpose's source (GemmDesc::b_trans - the generic kernel). All such
-//     gemms of a loop share that sibling: the queue groups them into one launch;
-//   * a second transpose of the same descriptor into the same destination REPLACES the record: the remembered one is dead - fully
-//     overwritten, and its only readers were served from its source;
-//   * any other invoke (of any thread), a flush and every synchronisation point first launches the remembered transpose the
-//     ordinary way (dt_materialize), so the destination holds what the program wrote whenever anything can look at it.
-// Between a transpose's invoke and its launch only folded gemms of its own thread run, and those do not write its source: the
-// deferred launch reads what the immediate one would have read. Only while ONE thread transposes (a second transposing thread
-// switches this off for the process: the reference's OpenMP callers own a temporary each, their chains are per thread anyway).
+//     gemms of a loop, of every thread, share that sibling: the queue groups them into one launch;
+//   * a second transpose of the same thread, the same descriptor and the same destination REPLACES the record: the remembered one is
+//     dead - fully overwritten, and its only readers were served from its source;
+//   * any other invoke of the owning thread launches the remembered transpose first, the ordinary way (dt_launch); an invoke of
+//     ANOTHER thread does so if one of its operands overlaps the record's destination, or if it writes into the record's source (a
+//     race-free program orders such an invoke behind the transpose's invoke: it then sees the record); a flush and every
+//     synchronisation point launch every record - the destination holds what the program wrote whenever anything can look at it.
+// Between a transpose's invoke and its launch only folded gemms of its own thread and invokes that touch neither its destination
+// nor (writing) its source run: the deferred launch reads what the immediate one would have read.
 // Summation order of a folded gemm = the generic kernel's (what a single invoke of the same gemm on the generic kernel adds).
 struct DeferredTranspose {
   const UnaryDesc *d = nullptr;
   void *src = nullptr, *dst = nullptr;
   hipStream_t stream = nullptr;
-  uintptr_t owner = 0;
   const GemmDesc *sib_of = nullptr, *sib = nullptr; // the last gemm descriptor folded and its sibling
 };
-SpinLock g_dt_mu;
-DeferredTranspose g_dt;                  // valid while g_dt_pending (under g_dt_mu)
-std::atomic<uintptr_t> g_dt_first{0};    // the first thread that invoked a foldable transpose
-std::atomic<bool> g_dt_multi{false};     // ... and another one did too: no more deferring
-std::atomic<int64_t> g_dt_folded{0}, g_dt_dropped{0}, g_dt_launched{0}; // statistics (xsmm_hip_fold_transpose_stats)
+struct alignas(64) DtSlot {
+  // line 0 - what EVERY thread reads per invoke while records exist; written when a record appears or goes, not per tile:
+  std::atomic<uintptr_t> owner{0};   // thread_token() of the thread that owns the slot (0: free)
+  std::atomic<int> live{0};          // a record is remembered
+  // the record's destination, and the hull of the sources it has had (the source changes with every tile of a loop - the next
+  // transpose replaces the record -, the hull stops growing after one pass: eight callers that each rewrote a line the seven others
+  // read per invoke took 2.5 us per tile). For the other threads' overlap test: written under mu before live = 1 (release), read after live
+  // (acquire). A reader that races with a replacement may see either record's source range - both belong to invokes it is not ordered with.
+  std::atomic<uintptr_t> d_lo{0}, d_hi{0}, s_lo{0}, s_hi{0};
+  // line 1 - the owner's (and, rarely, of a thread that launches the record):
+  alignas(64) SpinLock mu;           // the record and its hand-over
+  DeferredTranspose r;               // under mu
+  std::atomic<int64_t> folded{0}, dropped{0}; // statistics (the owner's relaxed adds)
+};
+constexpr int DT_SLOTS = 64;
+DtSlot g_dt_slots[DT_SLOTS];
+std::atomic<int> g_dt_top{0}; // slots [0, top) have been claimed at some time
+std::atomic<int64_t> g_dt_launched{0}; // statistics (xsmm_hip_fold_transpose_stats; folded / dropped: per slot)
+static __thread bool tl_dt_busy = false; // this thread is inside dt_launch's hand-over (its own flush_tile_queue calls must not re-enter)
 void unary_invoke_core(const UnaryDesc *d, void *pi, float scalar, bool use_scalar, void *po, bool may_defer);
-// launches the remembered transpose, if there is one (any thread)
-// The record stays "pending" until the transpose HAS BEEN handed to the queue / launched, and the lock is held across that: a
-// thread that sees pending = 0 (and goes on to queue an invoke that reads the destination) is ordered behind the transpose.
-std::atomic<uintptr_t> g_dt_busy{0}; // the thread inside the hand-over below (its own flush_tile_queue calls must not re-enter)
-void dt_materialize() {
-  const uintptr_t me = thread_token();
-  if (g_dt_busy.load(std::memory_order_relaxed) == me) return;
-  std::lock_guard<SpinLock> lk(g_dt_mu);
-  if (!g_dt_pending.load(std::memory_order_relaxed)) return;
-  const DeferredTranspose r = g_dt;
+// Launches the slot's remembered transpose, if there is one (any thread). The record stays live until the transpose HAS BEEN handed to
+// the queue / launched, and the lock is held across that: a thread that then sees live = 0 (and goes on to queue an invoke that reads
+// the destination) is ordered behind the transpose.
+void dt_launch(DtSlot &sl) {
+  if (tl_dt_busy) return;
+  std::lock_guard<SpinLock> lk(sl.mu);
+  if (!sl.live.load(std::memory_order_relaxed)) return;
+  const DeferredTranspose r = sl.r;
   g_dt_launched.fetch_add(1, std::memory_order_relaxed);
-  const hipStream_t cur = cfg().stream.load(std::memory_order_relaxed);
-  if (cur != r.stream) die("tpp-xsmm-hip: a deferred transpose outlived its stream"); // (xsmm_hip_set_stream flushes first: cannot happen)
-  g_dt_busy.store(me, std::memory_order_relaxed);
+  if (cfg().stream.load(std::memory_order_relaxed) != r.stream) die("tpp-xsmm-hip: a deferred transpose outlived its stream"); // (xsmm_hip_set_stream flushes first)
+  tl_dt_busy = true;
   unary_invoke_core(r.d, r.src, 0.0f, false, r.dst, false);
-  g_dt_busy.store(0, std::memory_order_relaxed);
-  g_dt_pending.store(0, std::memory_order_release);
+  tl_dt_busy = false;
+  sl.live.store(0, std::memory_order_release);
+  g_dt_pending.fetch_sub(1, std::memory_order_release);
 }
+void dt_materialize() { // every record (flush, synchronisation points)
+  if (tl_dt_busy) return;
+  const int top = g_dt_top.load(std::memory_order_acquire);
+  for (int i = 0; i < top; ++i)
+    if (g_dt_slots[i].live.load(std::memory_order_acquire)) dt_launch(g_dt_slots[i]);
+}
+struct DtRange {
+  uintptr_t lo, hi;
+};
+inline DtRange dt_range(const void *p, size_t bytes) { return DtRange{(uintptr_t)p, p ? (uintptr_t)p + bytes : 0}; }
 inline bool dt_overlap(const void *a, size_t na, const void *b, size_t nb) {
-  return a && b && (uintptr_t)a < (uintptr_t)b + nb && (uintptr_t)b < (uintptr_t)a + na;
+  return a && b && na && nb && (uintptr_t)a < (uintptr_t)b + nb && (uintptr_t)b < (uintptr_t)a + na;
+}
+// the records of OTHER threads that this invoke (reads rd[0..nr), writes wr[0..nw)) must see launched
+void dt_scan_foreign(const DtSlot *mine, const DtRange *rd, int nr, const DtRange *wr, int nw) {
+  const int top = g_dt_top.load(std::memory_order_acquire);
+  for (int i = 0; i < top; ++i) {
+    DtSlot &sl = g_dt_slots[i];
+    if (&sl == mine || !sl.live.load(std::memory_order_acquire)) continue;
+    const uintptr_t dl = sl.d_lo.load(std::memory_order_relaxed), dh = sl.d_hi.load(std::memory_order_relaxed);
+    const uintptr_t slo = sl.s_lo.load(std::memory_order_relaxed), shi = sl.s_hi.load(std::memory_order_relaxed);
+    bool hit = false;
+    for (int k = 0; k < nr && !hit; ++k) hit = rd[k].lo < dh && dl < rd[k].hi;
+    for (int k = 0; k < nw && !hit; ++k) hit = (wr[k].lo < dh && dl < wr[k].hi) || (wr[k].lo < shi && slo < wr[k].hi);
+    if (hit) dt_launch(sl);
+  }
+}
+// the owning thread ends: the slot is free for another thread once its record (if any) has been launched by a flush
+void dt_release_slot(int slot) { g_dt_slots[slot].owner.store(0, std::memory_order_release); }
+DtSlot *dt_my_slot(bool claim) {
+  CallerState &tl = caller_state();
+  if (tl.dt_slot >= 0) return &g_dt_slots[tl.dt_slot];
+  if (!claim) return nullptr;
+  const uintptr_t me = thread_token();
+  for (int i = 0; i < DT_SLOTS; ++i) {
+    DtSlot &sl = g_dt_slots[i];
+    uintptr_t none = 0;
+    if (sl.owner.load(std::memory_order_relaxed) == 0 && !sl.live.load(std::memory_order_acquire) && sl.owner.compare_exchange_strong(none, me)) {
+      int top = g_dt_top.load(std::memory_order_relaxed);
+      while (top < i + 1 && !g_dt_top.compare_exchange_weak(top, i + 1, std::memory_order_release)) {
+      }
+      tl.dt_slot = i;
+      return &sl;
+    }
+  }
+  return nullptr; // more transposing threads than slots: this one's transposes are launched as they come
 }
 const GemmDesc *dt_sibling(const GemmDesc *d, int64_t ld_src) {
   std::vector<int64_t> key = {KIND_GEMM, -29, (int64_t)(uintptr_t)d, ld_src};
@@ -1988,66 +2047,102 @@ const GemmDesc *dt_sibling(const GemmDesc *d, int64_t ld_src) {
     return (void *)e;
   });
 }
-// a gemm invoke while a transpose is remembered: the sibling descriptor + the transpose's source if it folds (the record stays),
-// else the transpose is launched and nullptr comes back
-const GemmDesc *dt_fold_or_materialize(const GemmDesc *d, void *pa, void *pb, void *pc, void *pd, int64_t br, hipStream_t s, void **src) {
-  {
-    std::lock_guard<SpinLock> lk(g_dt_mu);
-    if (!g_dt_pending.load(std::memory_order_relaxed)) return nullptr;
-    DeferredTranspose &r = g_dt;
-    const UnaryDesc *t = r.d;
-    const size_t dst_bytes = (size_t)t->n * t->m * 4, src_bytes = span(t->m, t->ldi, t->n) * 4;
-    if (r.owner == thread_token() && pb == r.dst && br == 1 && d->dtype == DT_F32 && !d->vnni_b && !d->vnni_c && !d->b_trans && d->k == t->n &&
-        d->n == t->m && d->ldb == t->ldo && s == r.stream && d->m <= 64 && d->n <= 64 && queue_active() &&
-        !dt_overlap(pa, span(d->m, d->lda, d->k) * 4, r.dst, dst_bytes) && !dt_overlap(pc, span(d->m, d->ldc, d->n) * 4, r.dst, dst_bytes) &&
-        !dt_overlap(pd, d->bias ? (size_t)d->n * 4 : 0, r.dst, dst_bytes) && !dt_overlap(pc, span(d->m, d->ldc, d->n) * 4, r.src, src_bytes)) {
-      if (r.sib_of != d) {
-        r.sib = dt_sibling(d, t->ldi);
-        r.sib_of = d;
+// a gemm invoke while transposes are remembered: the sibling descriptor + the transpose's source if it folds into this thread's record
+// (which stays), else nullptr - this thread's record, and every other thread's record the gemm's operands touch, launched first
+const GemmDesc *dt_gemm(const GemmDesc *d, void *pa, void *pb, void *pc, void *pd, int64_t br, hipStream_t s, void **src) {
+  const size_t es = esize(d->dtype);
+  DtSlot *mine = dt_my_slot(false);
+  const GemmDesc *sib = nullptr;
+  if (mine && mine->live.load(std::memory_order_acquire)) {
+    {
+      std::lock_guard<SpinLock> lk(mine->mu);
+      if (mine->live.load(std::memory_order_relaxed)) {
+        DeferredTranspose &r = mine->r;
+        const UnaryDesc *t = r.d;
+        const size_t dst_bytes = (size_t)t->n * t->m * 4, src_bytes = span(t->m, t->ldi, t->n) * 4;
+        if (pb == r.dst && br == 1 && d->dtype == DT_F32 && !d->vnni_b && !d->vnni_c && !d->b_trans && d->k == t->n && d->n == t->m && d->ldb == t->ldo &&
+            s == r.stream && d->m <= 64 && d->n <= 64 && queue_active() && !dt_overlap(pa, span(d->m, d->lda, d->k) * 4, r.dst, dst_bytes) &&
+            !dt_overlap(pc, span(d->m, d->ldc, d->n) * 4, r.dst, dst_bytes) && !dt_overlap(pd, d->bias ? (size_t)d->n * 4 : 0, r.dst, dst_bytes) &&
+            !dt_overlap(pc, span(d->m, d->ldc, d->n) * 4, r.src, src_bytes)) {
+          if (r.sib_of != d) {
+            r.sib = dt_sibling(d, t->ldi);
+            r.sib_of = d;
+          }
+          *src = r.src;
+          sib = r.sib;
+          mine->folded.store(mine->folded.load(std::memory_order_relaxed) + 1, std::memory_order_relaxed);
+        }
       }
-      *src = r.src;
-      g_dt_folded.fetch_add(1, std::memory_order_relaxed);
-      return r.sib;
     }
+    if (!sib) dt_launch(*mine);
   }
-  dt_materialize();
-  return nullptr;
+  if (g_dt_pending.load(std::memory_order_relaxed) > (sib ? 1 : 0)) { // other threads' records
+    const GemmDesc *e = sib ? sib : d;
+    const void *b = sib ? *src : pb;
+    const int64_t vf = e->vnni_factor ? e->vnni_factor : 2;
+    const size_t bspan = e->vnni_b ? span((e->k + vf - 1) / vf, vf * e->ldb, vf * e->n) : e->b_trans ? span(e->n, e->ldb, e->k) : span(e->k, e->ldb, e->n);
+    const size_t nb = br > 0 ? (size_t)(br - 1) : 0;
+    const DtRange rd[4] = {dt_range(pa, (nb * e->stride_a + span(e->m, e->lda, e->k)) * es), dt_range(b, (nb * e->stride_b + bspan) * es),
+                           dt_range(pd, e->bias ? (size_t)e->n * es : 0), dt_range(pc, span(e->m, e->ldc, e->n) * es * (e->vnni_c ? 2 : 1))};
+    dt_scan_foreign(mine, rd, 4, rd + 3, 1);
+  }
+  return sib;
+}
+// any other invoke while transposes are remembered: this thread's record first, then the other threads' records it touches
+void dt_other(const void *const *reads, const size_t *read_bytes, int nr, const void *out, size_t out_bytes) {
+  if (DtSlot *mine = dt_my_slot(false)) {
+    if (mine->live.load(std::memory_order_acquire)) dt_launch(*mine);
+  }
+  if (g_dt_pending.load(std::memory_order_relaxed) == 0) return;
+  DtRange rd[3], wr[1] = {dt_range(out, out_bytes)};
+  for (int i = 0; i < nr && i < 3; ++i) rd[i] = dt_range(reads[i], read_bytes[i]);
+  dt_scan_foreign(nullptr, rd, nr < 3 ? nr : 3, wr, 1);
 }
 // a transpose invoke: true = remembered (nothing launched)
 bool dt_defer(const UnaryDesc *d, void *pi, void *po, hipStream_t s) {
   if (d->dtype != DT_F32 || d->m > 64 || d->n > 64 || d->ldo != d->m || !cfg().fold_transpose.load(std::memory_order_relaxed) || !queue_active()) return false;
-  if (g_dt_multi.load(std::memory_order_relaxed)) return false;
-  const uintptr_t me = thread_token();
-  uintptr_t first = g_dt_first.load(std::memory_order_relaxed);
-  if (first == 0 && g_dt_first.compare_exchange_strong(first, me)) first = me;
-  if (first != me) {
-    g_dt_multi.store(true, std::memory_order_release);
-    return false;
-  }
   DeviceRanges &devmem = caller_state().devmem;
   if (devmem.refresh()) check_queue_device();
   if (!devmem.is_device(pi, 0) || !devmem.is_device(po, 1)) return false;
   const size_t dst_bytes = (size_t)d->n * d->m * 4, src_bytes = span(d->m, d->ldi, d->n) * 4;
   if (dt_overlap(pi, src_bytes, po, dst_bytes)) return false;
-  bool launch_old = false;
-  {
-    std::lock_guard<SpinLock> lk(g_dt_mu);
-    if (g_dt_pending.load(std::memory_order_relaxed)) {
-      DeferredTranspose &r = g_dt;
-      const size_t r_dst = (size_t)r.d->n * r.d->m * 4;
-      if (r.owner == me && r.d == d && r.dst == po && r.stream == s && !dt_overlap(pi, src_bytes, r.dst, r_dst)) {
+  DtSlot *mine = dt_my_slot(true);
+  if (!mine) return false;
+  const uintptr_t s_lo = (uintptr_t)pi, s_hi = (uintptr_t)pi + src_bytes;
+  bool replaced = false, launch_old = false;
+  if (mine->live.load(std::memory_order_acquire)) {
+    std::lock_guard<SpinLock> lk(mine->mu);
+    if (mine->live.load(std::memory_order_relaxed)) {
+      DeferredTranspose &r = mine->r;
+      if (r.d == d && r.dst == po && r.stream == s) {
         r.src = pi; // the remembered transpose is dead: fully overwritten, its readers were served from its source
-        g_dt_dropped.fetch_add(1, std::memory_order_relaxed);
-        return true;
+        // (the published source range only GROWS while the record lives: the hull of the sources of the loop's transposes - after one
+        // pass over the source tensor the line the other threads read is not written any more)
+        if (s_lo < mine->s_lo.load(std::memory_order_relaxed)) mine->s_lo.store(s_lo, std::memory_order_relaxed);
+        if (s_hi > mine->s_hi.load(std::memory_order_relaxed)) mine->s_hi.store(s_hi, std::memory_order_relaxed);
+        mine->dropped.store(mine->dropped.load(std::memory_order_relaxed) + 1, std::memory_order_relaxed);
+        replaced = true;
+      } else {
+        launch_old = true;
       }
-      launch_old = true;
     }
   }
-  if (launch_old) dt_materialize();
-  std::lock_guard<SpinLock> lk(g_dt_mu);
-  if (g_dt_pending.load(std::memory_order_relaxed)) return false; // (another thread got in between: not deferred)
-  g_dt = DeferredTranspose{d, pi, po, s, me, nullptr, nullptr};
-  g_dt_pending.store(1, std::memory_order_release);
+  if (launch_old) dt_launch(*mine);
+  // the other threads' records this transpose touches (it will read its source and write its destination when it is launched)
+  if (g_dt_pending.load(std::memory_order_relaxed) > (replaced ? 1 : 0)) {
+    const DtRange rd[1] = {dt_range(pi, src_bytes)}, wr[1] = {dt_range(po, dst_bytes)};
+    dt_scan_foreign(mine, rd, 1, wr, 1);
+  }
+  if (replaced) return true;
+  std::lock_guard<SpinLock> lk(mine->mu);
+  if (mine->live.load(std::memory_order_relaxed)) return false; // (cannot happen: only the owner makes a record live)
+  mine->r = DeferredTranspose{d, pi, po, s, nullptr, nullptr};
+  mine->d_lo.store((uintptr_t)po, std::memory_order_relaxed);
+  mine->d_hi.store((uintptr_t)po + dst_bytes, std::memory_order_relaxed);
+  mine->s_lo.store(s_lo, std::memory_order_relaxed);
+  mine->s_hi.store(s_hi, std::memory_order_relaxed);
+  g_dt_pending.fetch_add(1, std::memory_order_relaxed);
+  mine->live.store(1, std::memory_order_release);
   return true;
 }
 
@@ -2066,7 +2161,7 @@ void gemm_invoke_common(const char *who, bool want_fused, int64_t dtype, int64_t
   hipStream_t s = cfg().stream.load(std::memory_order_relaxed);
   if (g_dt_pending.load(std::memory_order_acquire)) { // a remembered transpose: this gemm reads its source instead, or it is launched now
     void *src = nullptr;
-    if (const GemmDesc *sib = dt_fold_or_materialize(d, pa, pb, pc, pd, br, s, &src)) {
+    if (const GemmDesc *sib = dt_gemm(d, pa, pb, pc, pd, br, s, &src)) {
       d = sib;
       pb = src;
     }
@@ -2542,7 +2637,13 @@ void unary_invoke_core(const UnaryDesc *d, void *pi, float scalar, bool use_scal
   hipStream_t s = cfg().stream.load(std::memory_order_relaxed);
   if (may_defer) {
     if (d->op == XSMM_UNARY_TRANSPOSE && pi && dt_defer(d, pi, po, s)) return;
-    if (g_dt_pending.load(std::memory_order_acquire)) dt_materialize();
+    if (g_dt_pending.load(std::memory_order_acquire)) {
+      Operand I, O;
+      unary_operands(d, pi, po, I, O);
+      const void *rd[1] = {I.ptr};
+      const size_t rb[1] = {I.bytes};
+      dt_other(rd, rb, 1, po, O.bytes);
+    }
   }
   if (cfg().tile_queue.load(std::memory_order_relaxed)) {
     // small tiles of tensor.pack / unpack lowering and bias broadcasts: queued like the GEMM tiles
@@ -2581,7 +2682,13 @@ extern "C" void xsmm_binary_invoke(int64_t dtype, int64_t handle, void *lhs, int
   const size_t es = esize(dtype);
   void *pl = (char *)lhs + off_lhs * es, *pr = (char *)rhs + off_rhs * es, *po = (char *)out + off_out * es;
   hipStream_t s = cfg().stream.load(std::memory_order_relaxed);
-  if (g_dt_pending.load(std::memory_order_acquire)) dt_materialize();
+  if (g_dt_pending.load(std::memory_order_acquire)) {
+    Operand L, R, O;
+    binary_operands(d, pl, pr, po, L, R, O);
+    const void *rd[2] = {L.ptr, R.ptr};
+    const size_t rb[2] = {L.bytes, R.bytes};
+    dt_other(rd, rb, 2, po, O.bytes);
+  }
   if (cfg().tile_queue.load(std::memory_order_relaxed)) {
     if (queue_active() && d->m <= 64 && d->n <= 64) {
       const void *ptrs[3] = {pl, pr, po};
@@ -2766,15 +2873,14 @@ extern "C" const char *xsmm_hip_last_refined_kernel(void) { return last_refined_
 extern "C" void xsmm_hip_force_variant(int v) { cfg().forced_variant.store(v); }
 extern "C" int xsmm_hip_set_fold_transpose(int enable) {
   flush_tile_queue(); // (launches a remembered transpose)
-  if (enable) { // (re-)armed: the next thread that transposes is "the one transposing thread"
-    g_dt_first.store(0, std::memory_order_relaxed);
-    g_dt_multi.store(false, std::memory_order_release);
-  }
   return cfg().fold_transpose.exchange(enable != 0);
 }
 extern "C" void xsmm_hip_fold_transpose_stats(int64_t out[3]) {
-  out[0] = g_dt_folded.load(std::memory_order_relaxed);   // gemm invokes that read a remembered transpose's source
-  out[1] = g_dt_dropped.load(std::memory_order_relaxed);  // remembered transposes that were overwritten before anything else could read them
+  out[0] = out[1] = 0;
+  for (int i = 0; i < DT_SLOTS; ++i) {
+    out[0] += g_dt_slots[i].folded.load(std::memory_order_relaxed);  // gemm invokes that read a remembered transpose's source
+    out[1] += g_dt_slots[i].dropped.load(std::memory_order_relaxed); // remembered transposes that were overwritten before anything else could read them
+  }
   out[2] = g_dt_launched.load(std::memory_order_relaxed); // remembered transposes that were launched after all
 }
 extern "C" int xsmm_hip_force_split(int v) { return tpp::force_gemm_split(v); }
