@@ -63,7 +63,7 @@ def parse():
                          "IPC-mapped pointers (csrc/peer_gather.hip), falling back to RCCL if the buffers cannot be mapped; rccl = "
                          "dist.all_gather_into_tensor")
     ap.add_argument("--refbench", action="store_true",
-                    help="N = 1 only: print the reference's whole benchmark shape set (tools/refbench.py: 216 rows, f32 / bf16 VNNI-2 / VNNI-4, tile "
+                    help="N = 1 only: print the reference's whole benchmark shape set (tools/refbench.py: 222 rows, f32 / bf16 VNNI-2 / VNNI-4, tile "
                          "invokes and whole layer) with the CPU port's figure per shape beside it (this file's cpu_baseline leg) and exit: what "
                          "profiles/r05_refbench.txt is made with")
     ap.add_argument("--refbench-json", default="", help="with --refbench: also write the rows as JSON")

@@ -163,7 +163,7 @@ def main():
         c["cpu_port_gflops_f32"] = round(cg["gflops"], 1) if cg else None
         c["cpu_threads"] = cg["threads"] if cg else None
         print("%-26s %-11s %-10s %-6s %9.2f %10.1f %7.4f %9s  %s" % (
-            c["name"], "%d,%d,%d" % c["tiles"], c["dtype"], c["form"], c["us"], c["gflops"], c["frac_of_peak"],
+            c["name"], "-" if c.get("script") else "%d,%d,%d" % c["tiles"], c["dtype"], c["form"], c["us"], c["gflops"], c["frac_of_peak"],
             ("%.1f" % cg["gflops"]) if cg else "-", c["kernel_name"]), flush=True)
     if args.json:
         with open(args.json, "w") as f:
