@@ -354,3 +354,70 @@ def test_another_thread_reads_the_temporary_after_a_join(rt):
     finally:
         rt.set_tile_queue(old_q)
         rt.set_async(old_async)
+
+
+# ---- tile grids over flat operands merged into one launch (runtime.cpp "GRID MERGE") ----
+
+@pytest.mark.parametrize("case", ["grid", "grid_bias_relu_br2", "hole", "swapped_outputs", "columns_wider_than_ldb"])
+def test_flat_tile_grid_replayed_as_one_merged_launch(rt, case):
+    """tile invokes that tile ONE flat problem (A by tile row, B by tile column, C by both): the first pass collects the group (grouped
+    kernel), complete replays of it run as one launch of the merged problem - every pass against the oracle on the program as written.
+    Groups that are not exactly a grid (a missing tile, outputs that do not follow the grid, B tiles that are not columns of one row)
+    stay on the grouped kernel."""
+    rng = np.random.default_rng(31)
+    M, N, K, tm, tn = 256, 256, 128, 32, 64
+    br = 2 if case == "grid_bias_relu_br2" else 1
+    k = K // br
+    fused = case == "grid_bias_relu_br2"
+    X = rng.uniform(-1, 1, M * K).astype(np.float32)
+    W = (rng.uniform(-1, 1, K * N) / np.sqrt(K)).astype(np.float32)
+    bias = rng.uniform(-1, 1, N).astype(np.float32)
+    ldb = N
+    if case == "columns_wider_than_ldb":  # B tiles 64 columns apart in memory but ldb = 64: consecutive "columns" are really other rows
+        ldb = tn
+    if fused:
+        h = rt.fused_brgemm_dispatch(F32, tm, tn, k, K, ldb, N, k, k * ldb, BETA0, 0, 5, 4, 1)
+    else:
+        h = rt.brgemm_dispatch(F32, tm, tn, k, K, ldb, N, k, k * ldb, BETA0)
+    grid = [(i, j) for i in range(M // tm) for j in range(N // tn)]
+    if case == "hole":
+        grid = grid[:-1]
+    out_of = {t: t for t in grid}
+    if case == "swapped_outputs":
+        out_of[grid[3]], out_of[grid[4]] = grid[4], grid[3]
+    C0 = rng.uniform(-1, 1, M * N).astype(np.float32)
+    ref = C0.copy()
+    for (i, j) in grid:
+        oi, oj = out_of[(i, j)]
+        if fused:
+            orc.fused_brgemm(F32, tm, tn, k, K, ldb, N, k, k * ldb, BETA0, 0, 5, 4, 1, X, i * tm * K, W, j * tn, ref, oi * tm * N + oj * tn, bias, j * tn, br)
+        else:
+            orc.brgemm(F32, tm, tn, k, K, ldb, N, k, k * ldb, BETA0, X, i * tm * K, W, j * tn, ref, oi * tm * N + oj * tn, br)
+    dX, dW, dB = dev(X), dev(W), dev(bias)
+    old_async, old_q = rt.set_async(True), rt.set_tile_queue(1)
+    try:
+        names = []
+        for rep in range(4):
+            dC = dev(C0)
+            # (a fresh output tensor per pass would be another group: the passes write the same one, re-initialised through a copy)
+            if rep == 0:
+                dOut = dC
+            else:
+                dOut.copy_(dC)
+            for (i, j) in grid:
+                oi, oj = out_of[(i, j)]
+                if fused:
+                    rt.fused_brgemm(F32, h, dX, i * tm * K, dW, j * tn, dOut, oi * tm * N + oj * tn, dB, j * tn, br)
+                else:
+                    rt.brgemm(F32, h, dX, i * tm * K, dW, j * tn, dOut, oi * tm * N + oj * tn, br)
+            rt.synchronize()
+            names.append(rt.last_grouped_kernel())
+            check_close(host(dOut, ref), ref, F32, "%s pass %d [%s]" % (case, rep, names[-1]), K=K)
+    finally:
+        rt.set_tile_queue(old_q)
+        rt.set_async(old_async)
+    merged = ["merged" in nm for nm in names]
+    if case in ("grid", "grid_bias_relu_br2"):
+        assert not merged[0] and all(merged[2:]), names
+    else:
+        assert not any(merged), names

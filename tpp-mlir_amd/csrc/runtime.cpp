@@ -741,6 +741,11 @@ struct Segment {
   size_t list_cap = 0;
   bool list_valid = false, list_used = false; // holds items[] of THIS recording / a launch may still be reading it
   hipStream_t list_stream = nullptr;           // ... on this stream
+  // GRID (round 5, detect_grid below): the group's gemm invokes tile ONE flat problem - a complete replay is then ONE launch of the
+  // merged problem's own kernel. 0: not looked at yet, 1: grid_desc / grid_w hold the merged problem, -1: not a grid
+  int grid_state = 0;
+  const GemmDesc *grid_desc = nullptr;
+  WorkItem grid_w{};
   // Called with the inline queue's lock held, once per RECORDING (a steady-state replay never comes here). The buffers are sized
   // for the largest group (TileQueue::CAP) the first time a segment needs them and then travel with it (store_recording swaps
   // segments, so at most NSEG + 1 sets exist per queue: allocation is a start-up cost, not a per-recording one); they live as long
@@ -843,6 +848,7 @@ struct Segment {
     list_valid = false;
     n_alloc = -1;
     dev_epoch = 0;
+    grid_state = 0;
   }
   int index_of(const void *d, const WorkItem &w, hipStream_t st) const {
     if (table.empty()) return -1;
@@ -857,6 +863,80 @@ struct Segment {
     return false;
   }
 };
+
+// GRID MERGE (round 5). The compiler tiles a contraction over FLAT operands into one gemm invoke per output tile (the mha projection,
+// benchmarks/mlir/fp32-projection.mlir: 64 x 8 invokes of [32,64,512,512,512,512] = one 2048 x 512 x 512 problem with lda = ldb = ldc =
+// 512). When a recorded group is exactly such a grid - every item the same f32 descriptor and batch count, A a function of the tile row
+// only (A0 + r m lda), B of the tile column only (B0 + c n, all columns inside one row of B: cols n <= ldb), C = C0 + r m ldc + c n, the
+// bias D0 + c n, every (r, c) once - a complete replay of it is launched as ONE invoke of the merged problem (rows m, cols n) on the
+// kernel plan_gemm picks for THAT shape (64x64 tiles instead of 1024 workgroups of 32x32 with 8 chunks each: 13.0 -> ~10.5 us). Same
+// reads, same writes, the same sums per element in a different (fixed) order: like every kernel choice that depends on the group.
+// Packed block layouts (mlir-gen's tiles) are never grids: their B tiles are not columns of one row. TPP_HIP_GRID_MERGE=0: off.
+static bool grid_merge_on() {
+  static const bool on = [] {
+    const char *e = getenv("TPP_HIP_GRID_MERGE");
+    return !e || atoi(e) != 0;
+  }();
+  return on;
+}
+std::atomic<const char *> g_last_merged{nullptr}; // trace text of the merged descriptor if the most recent group launch was a merged one
+inline void detect_grid(Segment &S) {
+  S.grid_state = -1;
+  const size_t n = S.items.size();
+  if (!grid_merge_on() || n < 4) return;
+  const void *desc = S.items[0].desc;
+  if (*(const int *)desc != KIND_GEMM) return;
+  const GemmDesc *d = (const GemmDesc *)desc;
+  if (d->dtype != DT_F32 || d->vnni_b || d->vnni_c || d->b_trans || d->generic_forced || d->variant_forced || d->m <= 0 || d->n <= 0 || d->k <= 0) return;
+  const int64_t br = S.items[0].w.br;
+  std::vector<uintptr_t> ua, ub;
+  ua.reserve(n);
+  ub.reserve(n);
+  for (const TraceItem &t : S.items) {
+    if (t.desc != desc || t.w.br != br || t.stream != S.items[0].stream) return;
+    ua.push_back((uintptr_t)t.w.A);
+    ub.push_back((uintptr_t)t.w.B);
+  }
+  std::sort(ua.begin(), ua.end());
+  ua.erase(std::unique(ua.begin(), ua.end()), ua.end());
+  std::sort(ub.begin(), ub.end());
+  ub.erase(std::unique(ub.begin(), ub.end()), ub.end());
+  const size_t R = ua.size(), Cn = ub.size();
+  if (R * Cn != n || br < 1) return;
+  const uintptr_t sa = (uintptr_t)d->m * (uintptr_t)d->lda * 4, sb = (uintptr_t)d->n * 4;
+  for (size_t r = 0; r < R; ++r)
+    if (ua[r] != ua[0] + r * sa) return;
+  for (size_t c = 0; c < Cn; ++c)
+    if (ub[c] != ub[0] + c * sb) return;
+  if ((int64_t)Cn * d->n > d->ldb || (int64_t)Cn * d->n > d->ldc) return;
+  uintptr_t c0 = 0, d0 = 0;
+  for (const TraceItem &t : S.items)
+    if ((uintptr_t)t.w.A == ua[0] && (uintptr_t)t.w.B == ub[0]) c0 = (uintptr_t)t.w.C, d0 = (uintptr_t)t.w.D;
+  if (!c0) return;
+  std::vector<char> seen(n, 0);
+  for (const TraceItem &t : S.items) {
+    const size_t r = ((uintptr_t)t.w.A - ua[0]) / sa, c = ((uintptr_t)t.w.B - ub[0]) / sb;
+    if ((uintptr_t)t.w.C != c0 + ((uintptr_t)r * d->m * d->ldc + (uintptr_t)c * d->n) * 4) return;
+    if (d->bias && (uintptr_t)t.w.D != d0 + (uintptr_t)c * d->n * 4) return;
+    if (seen[r * Cn + c]++) return;
+  }
+  const int64_t M = (int64_t)R * d->m, N = (int64_t)Cn * d->n;
+  std::vector<int64_t> key = {KIND_GEMM, -31, (int64_t)(uintptr_t)d, M, N};
+  bool ok = true;
+  const GemmDesc *e = (const GemmDesc *)intern(key, [&]() {
+    GemmDesc *g = new GemmDesc(*d);
+    g->m = M;
+    g->n = N;
+    ok = plan_gemm(*g, -1);
+    snprintf(g->trace, sizeof(g->trace), "tile grid %zu x %zu of gemm[%ld,%ld,%ld] merged -> [%ld,%ld,%ld,%ld,%ld,%ld] %s", R, Cn, (long)d->m, (long)d->n,
+             (long)d->k, (long)M, (long)N, (long)d->k, (long)d->lda, (long)d->ldb, (long)d->ldc, g->name);
+    return (void *)g;
+  });
+  if (!ok || e->variant == GEMM_VARIANT_GENERIC) return; // (no fast tile for the merged shape: the grouped launch stays)
+  S.grid_desc = e;
+  S.grid_w = WorkItem{(const void *)ua[0], (const void *)ub[0], (void *)c0, d->bias ? (const void *)d0 : nullptr, br};
+  S.grid_state = 1;
+}
 
 // DIRECT WINDOW: replayed members arrive without a lock. While the inline queue replays a recorded group, `cur` names it
 // (generation << 7 | segment index + 1) and a caller whose invoke is a member marks it in the segment (Segment::mark) and counts it
@@ -1038,6 +1118,13 @@ struct TileQueue {
     if (!pending.armed) return;
     pending.armed = false;
     Segment &S = segs[pending.seg];
+    if (pending.kind == KIND_GEMM && S.grid_state == 0) detect_grid(S);
+    if (pending.kind == KIND_GEMM && S.grid_state == 1) {
+      HIP_OK(launch_gemm(*S.grid_desc, S.grid_w.A, S.grid_w.B, S.grid_w.C, S.grid_w.D, S.grid_w.br, pending.stream));
+      g_last_merged.store(S.grid_desc->trace, std::memory_order_relaxed);
+      return;
+    }
+    g_last_merged.store(nullptr, std::memory_order_relaxed);
     if (pending.kind == KIND_GEMM) HIP_OK(launch_gemm_grouped(*(const GemmDesc *)pending.desc, S.list_dev, pending.n, pending.vec_ok, pending.out_ok, pending.pair_ok, S.items[0].w.br, pending.stream));
     else if (pending.kind == KIND_UNARY) HIP_OK(launch_unary_grouped(*(const UnaryDesc *)pending.desc, S.list_dev, pending.n, pending.stream));
     else HIP_OK(launch_binary_grouped(*(const BinaryDesc *)pending.desc, S.list_dev, pending.n, pending.stream));
@@ -1123,6 +1210,7 @@ struct TileQueue {
       pending = Pending{true, kind, desc, rp, n, vec_ok, out_ok, pair_ok, stream};
       if (!defer) issue_pending();
     } else {
+      if (kind == KIND_GEMM) g_last_merged.store(nullptr, std::memory_order_relaxed);
       if (kind == KIND_GEMM) HIP_OK(launch_gemm_grouped(*(const GemmDesc *)desc, pinned[slot], n, vec_ok, out_ok, pair_ok, pinned[slot][0].br, stream));
       else if (kind == KIND_UNARY) HIP_OK(launch_unary_grouped(*(const UnaryDesc *)desc, pinned[slot], n, stream));
       else HIP_OK(launch_binary_grouped(*(const BinaryDesc *)desc, pinned[slot], n, stream));
@@ -2868,7 +2956,10 @@ extern "C" const char *xsmm_hip_kernel_name(int64_t handle) {
   const GemmDesc *d = reinterpret_cast<const GemmDesc *>(handle);
   return (d && d->kind == KIND_GEMM) ? d->name : "";
 }
-extern "C" const char *xsmm_hip_last_grouped_kernel(void) { return last_grouped_kernel(); }
+extern "C" const char *xsmm_hip_last_grouped_kernel(void) {
+  const char *m = g_last_merged.load(std::memory_order_relaxed);
+  return m ? m : last_grouped_kernel();
+}
 extern "C" const char *xsmm_hip_last_refined_kernel(void) { return last_refined_kernel(); }
 extern "C" void xsmm_hip_force_variant(int v) { cfg().forced_variant.store(v); }
 extern "C" int xsmm_hip_set_fold_transpose(int enable) {
