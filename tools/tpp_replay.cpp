@@ -397,6 +397,12 @@ static int run_script(const std::string &name, int queue, int64_t n_iter, int th
           queue && xsmm_hip_last_grouped_kernel()[0] ? xsmm_hip_last_grouped_kernel() : "(one launch per invoke)",
           queue ? (double)(q1[0] - q0[0]) / (double)n_iter : (double)invokes, (double)(q1[1] - q0[1]) / (double)n_iter,
           (double)(q1[2] - q0[2]) / (double)n_iter, (double)(q1[4] - q0[4]) / (double)n_iter);
+  // ... and the result once more behind the timed calls (every caller count, every replayed / merged / folded launch form)
+  CHECK(hipMemset(out, 0xff, out_n * 4));
+  kernel();
+  xsmm_hip_synchronize();
+  CHECK(hipMemcpy(res.data(), out, out_n * 4, hipMemcpyDeviceToHost));
+  if (!check(res)) { fprintf(stderr, "tpp_replay --script %s: WRONG RESULT after the timed calls\n", name.c_str()); return 1; }
   if (name == "mha_qk") {
     int64_t f[3];
     xsmm_hip_fold_transpose_stats(f);
