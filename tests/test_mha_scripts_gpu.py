@@ -252,6 +252,23 @@ def test_remembered_transpose_is_launched_before_anything_else_reads_or_writes_i
         rt.set_async(False)
         assert np.array_equal(host(dT, tX), tX)
         rt.set_async(True)
+        # (5) a stream switch launches it on the stream it was invoked for (and drains that stream)
+        import torch
+        other = torch.cuda.Stream()
+        rt.unary(F32, ht, dY, 0, dT, 0)
+        rt.set_stream(other)
+        try:
+            assert np.array_equal(host(dT, tY), tY)
+            rt.unary(F32, ht, dX, 0, dT, 0)  # remembered for the new stream
+            rt.gemm(F32, rt.gemm_dispatch(F32, S, S, D, E, S, S, BETA0), dY, 0, dT, 0, dC, 0)  # folded, queued on the new stream
+        finally:
+            rt.set_stream(None)
+        rt.synchronize()
+        torch.cuda.synchronize()
+        assert np.array_equal(host(dT, tX), tX)
+        ref = np.zeros(S * S, np.float32)
+        orc.gemm(F32, S, S, D, E, S, S, BETA0, Y, 0, tX, 0, ref, 0)
+        check_close(host(dC, ref)[:S * S], ref, F32, "gemm folded on a second stream", K=D)
     finally:
         rt.set_tile_queue(old_q)
         rt.set_async(old_async)
