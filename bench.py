@@ -477,6 +477,115 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
+def compact_line(line, detail_path=None):
+    """The FINAL stdout line: the contract keys + one compact figure per BASELINE config, < 4 KB, so that the driver's 8 KB tail
+    always holds it whole (round 5's single line had grown to 16 KB and the driver's record lost the C4 step: VERDICT r5 weak 7).
+    Everything else (other_configs, per_launch, parity detail, the CPU port's shape table) goes out as an EARLIER line and into
+    gpurun_out/bench_detail.json. Pure function of the full line: tests/test_host_logic.py runs it on a committed full line."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    out = {k_: line.get(k_) for k_ in keep}
+    cfg_ = line.get("config") or {}
+    out["config"] = {k_: cfg_[k_] for k_ in ("workload", "launch", "kernel", "speedup_vs_one_gpu_same_run", "gathered_bit_identical",
+                                              "one_gpu_same_run_ms_per_step") if k_ in cfg_}
+    r_ = line.get("roofline") or {}
+    roof = {k_: r_.get(k_) for k_ in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+    if r_.get("kernel_us") is not None:
+        roof["kernel_us"] = r_["kernel_us"]
+    if isinstance(r_.get("traffic"), (int, float)):
+        roof["traffic"] = round(r_["traffic"])
+    if r_.get("algorithmic_bytes") is not None:
+        roof["algorithmic_bytes"] = r_["algorithmic_bytes"]
+    mb = r_.get("mfma_busy")
+    if isinstance(mb, dict) and mb.get("mfma_busy") is not None:
+        roof["mfma_busy"] = mb["mfma_busy"]
+    configs = {}
+    others = line.get("other_configs") or []
+
+    def first(prefix):
+        for o_ in others:
+            if str(o_.get("workload", "")).startswith(prefix):
+                return o_
+        return None
+
+    o_ = first("C3 ")
+    if o_:
+        configs["C3"] = {"us": o_.get("us_per_step"), "frac": o_.get("frac_of_f32_mfma_peak"), "kernel": o_.get("kernel")}
+    mlp = line.get("mlp")
+    if mlp:
+        configs["C4"] = {"ms_per_step": mlp.get("ms_per_step"), "frac": mlp.get("frac_of_bf16_mfma_peak"), "kernel": mlp.get("kernel"),
+                         "one_chain_launch": mlp.get("step_is_one_chain_launch"), "gflops": mlp.get("value")}
+        shares = mlp.get("per_rank_step_us")
+        if shares:
+            configs["C4"]["per_rank_chain_us"] = {w_: v_.get("chain_us") for w_, v_ in shares.items()}
+        for k_ in ("gather", "speedup_vs_one_gpu_same_run", "gathered_bit_identical"):
+            if k_ in mlp:
+                configs["C4"][k_] = mlp[k_]
+    o_ = first("C5 bf16 BRGEMM")
+    if o_:
+        configs["C5"] = {"us": o_.get("us_per_step"), "frac": o_.get("frac_of_bf16_mfma_peak"), "kernel": o_.get("kernel")}
+    o_ = first("C5 VNNI-2 pack")
+    if o_:
+        configs["C5_pack"] = {"us": o_.get("us_per_step"), "frac_of_hbm_8TBps": o_.get("frac_of_hbm_8TBps")}
+    o_ = first("C5 end to end on the FLAT")
+    if o_:
+        configs["C5_flat_b_end_to_end_us"] = o_.get("us_per_step")
+    o_ = first("mlir-gen mlp 3x1024 bs=256 bias+relu (fp32 unless noted), tile queue, tiles 32,32,32 (")
+    if o_:
+        configs["ref_mlp_bs256_tile_invokes_us"] = o_.get("us_per_step")
+    o_ = first("the reference's benchmark shape set, f32")
+    if o_ and "rows" in o_:
+        configs["refbench_f32"] = {"at_bar": o_.get("rows_at_0.45_of_peak_or_within_2x_the_launch_floor"), "of": o_.get("rows"),
+                                   "median_frac": o_.get("median_frac_of_f32_mfma_peak")}
+        for k_ in ("benchmarks_at_bar", "benchmarks"):
+            if k_ in o_:
+                configs["refbench_f32"][k_] = o_[k_]
+    if configs:
+        roof["configs"] = configs
+    out["roofline"] = roof
+    c_ = line.get("cpu_baseline")
+    if c_:
+        out["cpu_baseline"] = {k_: c_.get(k_) for k_ in ("value", "unit", "cores", "kind", "cpu") if k_ in c_}
+        smp = str(c_.get("sample", ""))
+        out["cpu_baseline"]["sample"] = smp if len(smp) <= 260 else smp[:257] + "..."
+        hs = c_.get("headline_shape")
+        if isinstance(hs, dict):
+            out["cpu_baseline"]["ref_mlp_gemm_bs256_us"] = hs.get("us_per_iteration")
+    par = line.get("parity")
+    if isinstance(par, dict):
+        out["parity"] = {k_: ({"max_rel": v_.get("max_rel"), "normwise": v_.get("normwise"), "within_1e-5_rel": v_.get("frac_within_1e-5_rel")}
+                              if isinstance(v_, dict) else v_) for k_, v_ in par.items()}
+    dep = line.get("deployment")
+    if isinstance(dep, dict):
+        out["deployment"] = {k_: v_ for k_, v_ in dep.items() if not isinstance(v_, str) or len(v_) <= 120}
+    if "c2_weak" in line:
+        cw = line["c2_weak"]
+        out["c2_weak"] = {"value": cw.get("value"), "ms_per_step": cw.get("ms_per_step"), "frac": (cw.get("roofline") or {}).get("frac")}
+    if "process_group" in line:
+        pg_ = line["process_group"]
+        out["process_group"] = {k_: pg_.get(k_) for k_ in ("world_size", "backend", "distinct_devices", "one_device_test_rig")}
+    if "error" in line:
+        out["error"] = line["error"]
+    out["detail"] = detail_path or "the previous stdout line (key \"bench_detail\")"
+    return out
+
+
+def emit(line):
+    """print the full line as a DETAIL line (and to gpurun_out/bench_detail.json when that directory can be written), then the
+    compact contract line LAST"""
+    detail_path = None
+    try:
+        d_ = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d_, exist_ok=True)
+        detail_path = os.path.join(d_, "bench_detail.json")
+        with open(detail_path, "w") as f_:
+            json.dump(line, f_)
+        detail_path = "gpurun_out/bench_detail.json (+ the previous stdout line)"
+    except OSError:
+        detail_path = None
+    print(json.dumps({"bench_detail": line}), flush=True)
+    print(json.dumps(compact_line(line, detail_path)), flush=True)
+
+
 def main():
     args = parse()
     import torch
@@ -1153,7 +1262,7 @@ def main():
                                               "per-kernel roofline of the shard kernels is in the N = 1 line (mlp.per_rank_step_us)"}})
             if one_device:
                 line["data"] = "synthetic (TEST RIG: all ranks on ONE device - the timings of this line are meaningless)"
-        print(json.dumps(line), flush=True)
+        emit(line)
         if mlp is not None and mlp.get("gathered_bit_identical") is False:
             sys.stderr.write("[bench] the gathered MLP output differs from the unsharded result: this run is INVALID\n")
             sys.exit(3)

@@ -23,6 +23,22 @@ def free_port():
     return p
 
 
+def bench_lines(stdout):
+    """bench.py prints TWO JSON lines (round 6): the full detail first, the compact contract line LAST (< 6000 bytes, so the driver's
+    8 KB tail always holds it whole). Returns (detail, final)."""
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 2, stdout[-2000:]
+    assert stdout.rstrip().endswith(lines[-1]), "the contract line must be the LAST thing on stdout"
+    assert len(lines[-1]) < 6000, len(lines[-1])
+    detail, final = json.loads(lines[0])["bench_detail"], json.loads(lines[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "dtype", "data"):
+        assert final[k] == detail[k], k
+    assert final["roofline"]["frac"] == detail["roofline"]["frac"]
+    if detail.get("mlp"):
+        assert final["roofline"]["configs"]["C4"]["ms_per_step"] == detail["mlp"]["ms_per_step"]
+    return detail, final
+
+
 def test_bench_two_ranks_on_one_device_reports_verified_strong_scaling():
     env = dict(os.environ, TPP_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
@@ -31,9 +47,7 @@ def test_bench_two_ranks_on_one_device_reports_verified_strong_scaling():
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
     if r.returncode != 0:
         pytest.fail("bench.py --gpus 2 exited %d\n--- stdout (tail)\n%s\n--- stderr (tail)\n%s" % (r.returncode, r.stdout[-1500:], r.stderr[-6000:]), pytrace=False)
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    d = json.loads(lines[0])
+    d, final = bench_lines(r.stdout)
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 3
     pgp = d["process_group"]
     assert pgp["world_size"] == 2 and len(pgp["ranks"]) == 2 and pgp["one_device_test_rig"] is True
@@ -51,6 +65,8 @@ def test_bench_two_ranks_on_one_device_reports_verified_strong_scaling():
     assert mlp["gather"] in ("peer", "rccl") and mlp["one_gpu_same_run"]["ms_per_step"] > 0
     assert mlp["speedup_vs_one_gpu_same_run"] > 0
     assert "TEST RIG" in d["data"]
+    assert final["process_group"]["world_size"] == 2 and final["config"]["gathered_bit_identical"] is True
+    assert final["roofline"]["configs"]["C4"]["gathered_bit_identical"] is True
 
 
 def test_bench_gpus_2_without_a_launcher_starts_its_own_ranks():
@@ -62,9 +78,7 @@ def test_bench_gpus_2_without_a_launcher_starts_its_own_ranks():
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
     if r.returncode != 0:
         pytest.fail("bench.py --gpus 2 exited %d\n--- stdout (tail)\n%s\n--- stderr (tail)\n%s" % (r.returncode, r.stdout[-1500:], r.stderr[-6000:]), pytrace=False)
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    d = json.loads(lines[0])
+    d, final = bench_lines(r.stdout)
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 3
     assert d["process_group"]["world_size"] == 2 and len(d["process_group"]["ranks"]) == 2
     g = d["mlp"]["gathers"]
@@ -82,8 +96,6 @@ def test_bench_survives_a_peer_path_that_fails_on_one_rank():
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
     if r.returncode != 0:
         pytest.fail("bench.py --gpus 2 exited %d\n--- stdout (tail)\n%s\n--- stderr (tail)\n%s" % (r.returncode, r.stdout[-1500:], r.stderr[-6000:]), pytrace=False)
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    mlp = json.loads(lines[0])["mlp"]
+    mlp = bench_lines(r.stdout)[0]["mlp"]
     assert "failed" in mlp["gathers"]["peer"] and "injected" in mlp["gathers"]["peer"]["failed"] or "another rank" in mlp["gathers"]["peer"]["failed"]
     assert mlp["gather"] == "rccl" and mlp["gathers"]["rccl"]["gathered_bit_identical"] is True and mlp["gathered_bit_identical"] is True

@@ -123,6 +123,40 @@ def test_bench_gpus_n_without_world_size_launches_n_ranks():
         assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
+def test_bench_final_line_is_compact_and_keeps_every_baseline_config():
+    """the driver keeps an 8 KB tail of bench.py's stdout; round 5's ONE line had grown to 16 KB and the
+    driver-written record lost the C4 step. The final line is now a pure function of the full line (bench.compact_line): under
+    4 KB, with the contract keys, roofline + cpu_baseline objects and one figure per BASELINE config. Checked here on committed
+    full lines of earlier rounds (N = 1) and on the N = 2 rig line."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for name in ("r04_bench.json", "r05_bench.json", "r05_bench_steps20.json", "r05_bench_gpus2_rig.json"):
+        full = json.loads([l for l in open(os.path.join(ROOT, "profiles", name)).read().splitlines() if l.startswith("{")][-1])
+        out = bench.compact_line(full)
+        text = json.dumps(out)
+        assert len(text) < 4096, (name, len(text))
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+            assert out[k] == full[k], (name, k)
+        assert out["config"]["workload"] == full["config"]["workload"]
+        roof = out["roofline"]
+        for k in ("bound", "achieved", "peak", "unit", "frac"):
+            assert roof[k] == full["roofline"][k], (name, k)
+        assert "traffic" in roof
+        c4 = roof["configs"]["C4"]
+        assert c4["ms_per_step"] == full["mlp"]["ms_per_step"] and c4["frac"] == full["mlp"]["frac_of_bf16_mfma_peak"]
+        if full["n_gpus"] == 1:
+            assert roof["configs"]["C3"]["us"] > 0 and roof["configs"]["C5"]["us"] > 0
+            cb = out["cpu_baseline"]
+            assert cb["value"] == full["cpu_baseline"]["value"] and cb["cores"] == full["cpu_baseline"]["cores"] and cb["kind"] == "port"
+            assert len(cb["sample"]) <= 260
+        else:
+            assert c4["gathered_bit_identical"] is True and out["process_group"]["world_size"] == full["n_gpus"]
+            assert out["c2_weak"]["value"] == full["c2_weak"]["value"]
+
+
 def test_refbench_restates_the_reference_benchmark_configs():
     """tools/refbench.py's shape table = the IR-GEN rows of benchmarks/config/matmul/*.json and fc/*.json (harvested into
     tests/golden/benchmark_configs.json by tests/golden/harvest_benchmarks.py): same (batch, out, in) shapes, same --tiles, the fc
