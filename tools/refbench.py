@@ -94,10 +94,12 @@ def cases(only):
     return out
 
 
-def argv_of(c, n_iter):
+def argv_of(c, n_iter, repeats=1):
     if c.get("script"):
         return ["--script", c["script"], "--queue", "1", "-n", str(n_iter)]
     a = ["--batch", str(c["M"]), "--layers", ",".join(map(str, c["layers"])), "--kernel", c["kernel"], "-n", str(n_iter), "--queue", "1"]
+    if repeats > 1:
+        a += ["--repeats", str(repeats)]
     if c["form"] == "tiles":
         a += ["--tiles", "%d,%d,%d" % c["tiles"]]
     else:
@@ -126,6 +128,8 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("-n", type=int, default=300)
     ap.add_argument("--json", default="")
+    ap.add_argument("--repeats", type=int, default=3, help="timed loops per row (own timer each): the row gets us_min / us_median / us_max and "
+                    "the tile queue's abandoned-replay count (VERDICT r5 weak 9: a row must say whether its mean is typical)")
     args = ap.parse_args()
     replay = os.path.join(ROOT, "tools", "tpp_replay")
     cs = [c for c in cases(args.only) if not (args.quick and c["dtype"] != "f32")]
@@ -134,16 +138,25 @@ def main():
     cs = [c for c in cs if not c.get("script")] + [c for c in cs if c.get("script")]
     with tempfile.NamedTemporaryFile("w", suffix=".cases", delete=False) as f:
         for c in cs:
-            f.write(" ".join(argv_of(c, args.n)) + "\n")
+            f.write(" ".join(argv_of(c, args.n, args.repeats)) + "\n")
         path = f.name
     r = subprocess.run([replay, "--cases", path], capture_output=True, text=True, timeout=3000)
     os.unlink(path)
     pat = re.compile(r"mean ([0-9.]+) us \(host side of the invokes ([0-9.]+) us\), ([0-9.]+) GFLOP/s \(BENCH_TOTAL_FLOPS ([0-9]+)\), kernel (.*)$")
-    got = [pat.search(l) for l in r.stderr.splitlines() if "GFLOP/s (BENCH_TOTAL_FLOPS" in l]
+    got, reps = [], {}
+    rpat = re.compile(r"repeats (\d+) x \d+ calls: min ([0-9.]+) median ([0-9.]+) max ([0-9.]+) us; replays abandoned in the repeats (-?\d+)")
+    for l in r.stderr.splitlines():
+        if "GFLOP/s (BENCH_TOTAL_FLOPS" in l:
+            got.append(pat.search(l))
+        elif rpat.search(l) and got:
+            reps[len(got) - 1] = rpat.search(l)
     if len(got) != len(cs):
         sys.stderr.write(r.stderr[-4000:])
         raise SystemExit("refbench: %d cases, %d result lines (rc %d)" % (len(cs), len(got), r.returncode))
-    for c, m_ in zip(cs, got):
+    for i_, (c, m_) in enumerate(zip(cs, got)):
+        if i_ in reps:
+            c["repeats"], c["us_min"], c["us_median"], c["us_max"], c["replays_abandoned"] = (int(reps[i_].group(1)), float(reps[i_].group(2)),
+                                                                                               float(reps[i_].group(3)), float(reps[i_].group(4)), int(reps[i_].group(5)))
         c["us"], c["host_us"], c["gflops"], c["kernel_name"] = float(m_.group(1)), float(m_.group(2)), float(m_.group(3)), m_.group(5).split("; result checked")[0].strip()
         if c.get("script", "").startswith(("pack", "unpack")):
             c["kernel_name"] = "unary_grouped_kernel<f32>"  # (the line names the last grouped GEMM launch; these scripts run none)
@@ -156,14 +169,18 @@ def main():
         with open(args.cpu_json) as f:
             cpu = {tuple(int(x) for x in k.split("x")): v for k, v in json.load(f).items()}
     print("# refbench: %d rows, tpp_replay -n %d; GPU peaks f32 157.3 TF, bf16 2500 TF (dense MFMA); empty-launch floor ~2.5 us" % (len(cs), args.n))
-    print("# %-24s %-11s %-10s %-6s %9s %10s %7s %9s  %s" % ("benchmark", "tiles", "dtype", "form", "us", "GFLOP/s", "frac", "CPU GF/s", "kernel"))
+    print("# us = mean of the FIRST timed loop (the reference's figure: one timer around N calls); median / max = over --repeats loops of the same "
+          "N calls; ab = replays the tile queue abandoned in the repeats (0 = every iteration replayed its recorded group)")
+    print("# %-24s %-11s %-10s %-6s %9s %8s %8s %3s %10s %7s %9s  %s" % ("benchmark", "tiles", "dtype", "form", "us", "median", "max", "ab", "GFLOP/s", "frac", "CPU GF/s", "kernel"))
     for c in cs:
         key = (c["M"], c["layers"][1], c["layers"][0])
         cg = cpu.get(key if c["family"] != "base" else (256, 1024, 1024)) if not c.get("script") else None
         c["cpu_port_gflops_f32"] = round(cg["gflops"], 1) if cg else None
         c["cpu_threads"] = cg["threads"] if cg else None
-        print("%-26s %-11s %-10s %-6s %9.2f %10.1f %7.4f %9s  %s" % (
-            c["name"], "-" if c.get("script") else "%d,%d,%d" % c["tiles"], c["dtype"], c["form"], c["us"], c["gflops"], c["frac_of_peak"],
+        print("%-26s %-11s %-10s %-6s %9.2f %8s %8s %3s %10.1f %7.4f %9s  %s" % (
+            c["name"], "-" if c.get("script") else "%d,%d,%d" % c["tiles"], c["dtype"], c["form"], c["us"],
+            ("%.2f" % c["us_median"]) if "us_median" in c else "-", ("%.2f" % c["us_max"]) if "us_max" in c else "-",
+            c.get("replays_abandoned", "-"), c["gflops"], c["frac_of_peak"],
             ("%.1f" % cg["gflops"]) if cg else "-", c["kernel_name"]), flush=True)
     if args.json:
         with open(args.json, "w") as f:

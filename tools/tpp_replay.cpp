@@ -67,7 +67,7 @@ int main(int argc, char **argv) {
 static int run_case(int argc, char **argv) {
   int64_t batch = 256, tile = 32, tile_n = 0, tile_k = 0, n_iter = 100;
   bool kernel_args = false; // mlir-gen --kernel=args: the output is an argument, the matmul accumulates into it (no BETA_0)
-  int vnni = 2, split = -1, variant = -1;
+  int vnni = 2, split = -1, variant = -1, repeats = 1;
   std::vector<int64_t> layers = {1024, 1024, 1024, 1024};
   bool bias = false, relu = false, whole = false, chain = false, print = false, c1 = false, rnd = false, bf16 = false;
   int queue = 1, threads = 1;
@@ -99,6 +99,7 @@ static int run_case(int argc, char **argv) {
     else if (a == "--kernel") kernel_args = std::string(next()) == "args"; // const (default): zero fill folded into BETA_0; args: C += ...
     else if (a == "--split") split = atoi(next());     // xsmm_hip_force_split for this case (-1: the runtime's model)
     else if (a == "--variant") variant = atoi(next()); // xsmm_hip_force_variant at dispatch (-1: the runtime's choice)
+    else if (a == "--repeats") repeats = atoi(next()); // the timed loop R times (own timer each): min / median / max + the queue's abandon counter per case
     else if (a == "--random") rnd = true; // uniform [-1, 1) * fill instead of constant fills (switching power)
     else { fprintf(stderr, "unknown flag %s\n", a.c_str()); return 2; }
   }
@@ -242,6 +243,24 @@ static int run_case(int argc, char **argv) {
   const double elapsed = perf_stop_timer(t0); // flushes the tile queue and drains the stream
   const double mean = elapsed / (double)n_iter;
   printf("%g\n", mean); // tpp-run prints the mean seconds (MLIRBench.cpp:297-300)
+  // --repeats R: R - 1 more timed loops of the same N calls, each behind its own timer: a table row then says whether its mean is a
+  // typical loop or one hiccup (a 51 us row among 4.2 us ones), and how many replays the tile queue abandoned
+  std::vector<double> loops{mean * 1e6};
+  int64_t q_before[5] = {0, 0, 0, 0, 0};
+  xsmm_hip_tile_queue_stats(q_before);
+  for (int r = 1; r < repeats; ++r) {
+    const int64_t t1 = perf_start_timer();
+    for (int64_t i = 0; i < n_iter; ++i) kernel();
+    loops.push_back(perf_stop_timer(t1) / (double)n_iter * 1e6);
+  }
+  if (repeats > 1) {
+    int64_t q_after[5];
+    xsmm_hip_tile_queue_stats(q_after);
+    std::vector<double> sl(loops);
+    std::sort(sl.begin(), sl.end());
+    fprintf(stderr, "tpp_replay: repeats %d x %ld calls: min %.3f median %.3f max %.3f us; replays abandoned in the repeats %ld\n", repeats, (long)n_iter,
+            sl.front(), sl[sl.size() / 2], sl.back(), (long)(q_after[4] - q_before[4]));
+  }
   fprintf(stderr, "tpp_replay: %s, batch %ld, %d layer(s), queue %d: mean %.3f us (host side of the invokes %.3f us), %.1f GFLOP/s (BENCH_TOTAL_FLOPS %.0f), kernel %s\n",
           chain ? (chained == 1 ? "whole-layer calls as ONE chain launch" : "whole-layer calls handed over together, run call by call") : whole ? "whole-layer dispatch" : "packed tile invokes", (long)batch, L, queue, mean * 1e6,
           host_dt / (double)n_iter * 1e6, flops / mean / 1e9, flops,

@@ -1030,13 +1030,34 @@ static int pick_bf16_lw_tile(const GemmDesc &d) {
     return e ? atoi(e) : 1;
   }();
   if (!enabled) return -1;
+  // Gate (unchanged since round 3): some tile of the family gives at least 3/4 of the CUs a workgroup. Which tile, round 6 - fitted to the
+  // sweep of the reference's whole shape set over every tile (tools/bf16_sweep.py, profiles/r06_bf16_sweep.txt): a launch costs
+  // rounds x (a + b x chunks), rounds = ceil(tiles / CUs) (one workgroup per CU: a second round is a second kernel's worth), with
+  // (a, b) in us from the K = 1024 / K = 4096 pairs of the sweep: 32x64 (3.56, 0.098), 64x64 (3.75, 0.135), 64x128 (4.66, 0.204), 128x128
+  // (6.06, 0.236). The old rule - the LARGEST tile that still reaches 3/4 of the CUs - put 1024 x 2560 on 320 tiles of 64x128 (two
+  // rounds: 15.1 us) instead of 160 tiles of 128x128 (one round: 10.2 us). The batch count arrives with the invoke: priced at 16 chunks
+  // (K = 1024; the order of two candidates flips with K only when their round counts differ AND the sums are within a few percent).
+  static const int legacy = [] {
+    const char *e = getenv("TPP_HIP_BF16_LW_PICK");
+    return e ? atoi(e) == 0 : 0; // TPP_HIP_BF16_LW_PICK=0: the round-3 rule (A/B runs)
+  }();
+  static const double ca[4] = {3.56, 3.75, 4.66, 6.06}, cb[4] = {0.098, 0.135, 0.204, 0.236};
+  bool gate = false;
+  int best = -1;
+  double best_t = 0;
   for (int t = 3; t >= 0; --t) {
     int bm, bn;
     blw_tile_dims(t, &bm, &bn);
     if (d.m % bm || d.n % bn) continue;
-    if ((d.m / bm) * (d.n / bn) * 4 >= 3 * (int64_t)g_num_cus) return t;
+    const int64_t tiles = (d.m / bm) * (d.n / bn);
+    if (tiles * 4 >= 3 * (int64_t)g_num_cus) {
+      if (legacy) return t;
+      gate = true;
+    }
+    const double cost = (double)((tiles + g_num_cus - 1) / g_num_cus) * (ca[t] + cb[t] * 16.0);
+    if (best < 0 || cost < best_t) best = t, best_t = cost;
   }
-  return -1;
+  return gate ? best : -1;
 }
 
 static const char *variant_name(int v) {
