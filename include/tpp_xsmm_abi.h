@@ -235,6 +235,25 @@ TPP_XSMM_EXPORT void xsmm_hip_synchronize(void);
 TPP_XSMM_EXPORT int xsmm_hip_host_resident(const void *ptr, int64_t bytes);
 TPP_XSMM_EXPORT int xsmm_hip_host_update(const void *ptr);
 TPP_XSMM_EXPORT int xsmm_hip_host_release(const void *ptr);
+/* Host cache (round 6; csrc/host_cache.h): the AUTOMATIC form of the host residents - for an unmodified harness that hands host
+ * pointers to every invoke (memref globals / malloc: lib/TPP/Runner/MLIRBench.cpp:207-246) and can be given environment variables only.
+ * enable = 1 (env TPP_HIP_HOST_CACHE=1): a host operand gets a device mirror that OUTLIVES the invoke; before a kernel uses mirror
+ * pages, the pages the host has written since the runtime last looked are uploaded again - and only those (the kernel's own write
+ * tracking says which: userfaultfd asynchronous write-protect + PAGEMAP_SCAN, Linux >= 6.7; no fault handler, no signal, no helper
+ * thread; system calls that write into tracked memory work as always). What kernels write goes back to exactly the host bytes they
+ * wrote: in synchronous mode before the invoke returns - the reference's contract (SURVEY.md 8b "Completion"), unchanged -, in
+ * asynchronous mode at the next synchronisation point (xsmm_hip_synchronize / perf_stop_timer / xsmm_hip_set_async(0) /
+ * xsmm_hip_set_stream). ASYNCHRONOUS MODE CONTRACT with host operands: the lifetime rule above, and between two synchronisation
+ * points the host neither reads outputs nor writes operands of the invokes in between (the runtime looks at an extent once per
+ * synchronisation epoch; the tile queue then sees device pointers, so TPP_HIP_ASYNC=1 TPP_HIP_TILE_QUEUE=1 TPP_HIP_HOST_CACHE=1 runs
+ * the compiler's tile invokes on host buffers as grouped launches). A range that was unmapped and mapped again, or cannot be tracked
+ * (file-backed / shared mappings), falls back to the plain per-invoke mirror. Returns the previous setting, or -1 if the kernel
+ * interface is missing (the cache stays off). Switching it off writes everything back and frees the mirrors.
+ * _stats: out[0] extents, [1] mirror bytes, [2] bytes uploaded, [3] page-table scans, [4] bytes written back, [5] pages NOT written back
+ * (their range changed hands or the host wrote them while a device write was pending), [6] extents created / grown / merged,
+ * [7] invokes translated on the lock-free path, [8] on the locked path, [9] extents given up. */
+TPP_XSMM_EXPORT int xsmm_hip_set_host_cache(int enable);
+TPP_XSMM_EXPORT void xsmm_hip_host_cache_stats(int64_t out[10]);
 /* Number of visible HIP devices (0 on a CPU-only host; never exits). */
 TPP_XSMM_EXPORT int xsmm_hip_device_count(void);
 /* Name of the HIP kernel variant a GEMM-like handle selected, for profiles. */

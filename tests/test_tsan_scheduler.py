@@ -24,7 +24,8 @@ def test_runtime_layer_is_race_free_under_tsan(tmp_path):
         pytest.skip("needs g++ and the HIP headers")
     exe = str(tmp_path / "tsan_driver")
     cmd = [gxx, "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-D__HIP_PLATFORM_AMD__", "-I" + HIP_INCLUDE,
-           os.path.join(ROOT, "tpp-mlir_amd", "csrc", "runtime.cpp"), os.path.join(ROOT, "tests", "tsan", "fake_hip.cpp"),
+           os.path.join(ROOT, "tpp-mlir_amd", "csrc", "runtime.cpp"), os.path.join(ROOT, "tpp-mlir_amd", "csrc", "host_cache.cpp"),
+           os.path.join(ROOT, "tests", "tsan", "fake_hip.cpp"),
            os.path.join(ROOT, "tests", "tsan", "driver.cpp"), "-o", exe, "-pthread", "-ldl"]
     b = subprocess.run(cmd, capture_output=True, text=True)
     if b.returncode != 0 and "tsan" in b.stderr.lower():
@@ -56,7 +57,8 @@ def test_runtime_layer_under_asan_and_ubsan(tmp_path):
     exe = str(tmp_path / "asan_driver")
     cmd = [gxx, "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
            "-D__HIP_PLATFORM_AMD__", "-I" + HIP_INCLUDE,
-           os.path.join(ROOT, "tpp-mlir_amd", "csrc", "runtime.cpp"), os.path.join(ROOT, "tests", "tsan", "fake_hip.cpp"),
+           os.path.join(ROOT, "tpp-mlir_amd", "csrc", "runtime.cpp"), os.path.join(ROOT, "tpp-mlir_amd", "csrc", "host_cache.cpp"),
+           os.path.join(ROOT, "tests", "tsan", "fake_hip.cpp"),
            os.path.join(ROOT, "tests", "tsan", "driver.cpp"), "-o", exe, "-pthread", "-ldl"]
     b = subprocess.run(cmd, capture_output=True, text=True)
     if b.returncode != 0 and ("asan" in b.stderr.lower() or "ubsan" in b.stderr.lower()):

@@ -17,6 +17,7 @@
 //                                     identity, ld 256 -> 32), 64 brgemm invokes (32^3, br 8), 64 un-pack invokes
 #include "../include/tpp_xsmm_abi.h"
 #include <hip/hip_runtime.h>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
@@ -69,7 +70,7 @@ static int run_case(int argc, char **argv) {
   bool kernel_args = false; // mlir-gen --kernel=args: the output is an argument, the matmul accumulates into it (no BETA_0)
   int vnni = 2, split = -1, variant = -1, repeats = 1;
   std::vector<int64_t> layers = {1024, 1024, 1024, 1024};
-  bool bias = false, relu = false, whole = false, chain = false, print = false, c1 = false, rnd = false, bf16 = false;
+  bool bias = false, relu = false, whole = false, chain = false, print = false, c1 = false, rnd = false, bf16 = false, host_buffers = false;
   int queue = 1, threads = 1;
   std::string script;
   int fold = 1;
@@ -100,10 +101,11 @@ static int run_case(int argc, char **argv) {
     else if (a == "--split") split = atoi(next());     // xsmm_hip_force_split for this case (-1: the runtime's model)
     else if (a == "--variant") variant = atoi(next()); // xsmm_hip_force_variant at dispatch (-1: the runtime's choice)
     else if (a == "--repeats") repeats = atoi(next()); // the timed loop R times (own timer each): min / median / max + the queue's abandon counter per case
+    else if (a == "--host-buffers") host_buffers = true; // what an UNMODIFIED tpp-run hands over: plain malloc'ed host memory, modes from the environment only
     else if (a == "--random") rnd = true; // uniform [-1, 1) * fill instead of constant fills (switching power)
     else { fprintf(stderr, "unknown flag %s\n", a.c_str()); return 2; }
   }
-  if (xsmm_hip_device_count() < 1) { fprintf(stderr, "tpp_replay: no HIP device (there is no CPU fallback)\n"); return 1; }
+  if (!host_buffers && xsmm_hip_device_count() < 1) { fprintf(stderr, "tpp_replay: no HIP device (there is no CPU fallback)\n"); return 1; }
   if (!script.empty()) return run_script(script, queue, n_iter, threads, fold);
   if (c1) {
     // A, W, C: 256x256 f32 filled 1.0; packed copies [8][8][32][32]; result 257 everywhere (C += A W)
@@ -166,9 +168,18 @@ static int run_case(int argc, char **argv) {
   auto to_bf16 = [](float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); };
   std::vector<void *> act(L + 1), W(L), B(L);
   auto dalloc = [&](size_t n, float v) {
-    void *d; CHECK(hipMalloc(&d, n * es));
     std::vector<float> h(n, v);
     if (rnd) for (auto &x : h) x = v * (float)(2.0 * rand() / (double)RAND_MAX - 1.0);
+    if (host_buffers) {
+      // --host-buffers: memref.alloc as the LLVM lowering emits it - malloc(bytes + alignment), the pointer rounded up to 64 bytes (and a
+      // memref.global sits 128-byte aligned in the JIT's data section: BuilderUtils.cpp:103) - never page aligned, never registered with HIP
+      char *raw = (char *)malloc(n * es + 64);
+      void *d = (void *)(((uintptr_t)raw + 63) & ~(uintptr_t)63);
+      if (bf16) for (size_t i = 0; i < n; ++i) ((uint16_t *)d)[i] = to_bf16(h[i]);
+      else memcpy(d, h.data(), n * 4);
+      return d;
+    }
+    void *d; CHECK(hipMalloc(&d, n * es));
     if (bf16) {
       std::vector<uint16_t> hb(n);
       for (size_t i = 0; i < n; ++i) hb[i] = to_bf16(h[i]);
@@ -182,11 +193,18 @@ static int run_case(int argc, char **argv) {
   for (int l = 0; l < L; ++l) { W[l] = dalloc((size_t)layers[l] * layers[l + 1], 1.0f / (float)layers[l]); B[l] = dalloc((size_t)layers[l + 1], 0.5f); }
 
   if (bf16) gflags |= XSMM_GEMM_WIRE_VNNI_B;
-  const int old_vf = xsmm_hip_set_vnni_factor(bf16 ? vnni : 2);
-  xsmm_hip_force_split(split);
-  xsmm_hip_force_variant(variant);
-  xsmm_hip_set_async(1);
-  xsmm_hip_set_tile_queue(queue);
+  // --host-buffers: NO xsmm_hip_* call before or inside the timed region - the program below is the reference's 13 + 2 symbols only,
+  // the runtime's modes come from the environment (TPP_HIP_ASYNC / TPP_HIP_TILE_QUEUE / TPP_HIP_HOST_CACHE), like under an unmodified tpp-run
+  const int old_vf = host_buffers ? 2 : xsmm_hip_set_vnni_factor(bf16 ? vnni : 2);
+  if (!host_buffers) {
+    xsmm_hip_force_split(split);
+    xsmm_hip_force_variant(variant);
+    xsmm_hip_set_async(1);
+    xsmm_hip_set_tile_queue(queue);
+  } else if ((bf16 && vnni != 2) || split != -1 || variant != -1 || chain) {
+    fprintf(stderr, "tpp_replay: --host-buffers takes its settings from the environment only (no --vnni 4 / --split / --variant / --chain)\n");
+    return 2;
+  }
   std::vector<int64_t> handle(L);
   const int64_t tn = tile_n ? tile_n : tile, tk = tile_k ? tile_k : tile; // blocks: A [MB][KB][tm][tk], W [NB][KB][tk][tn], C [MB][NB][tm][tn]
   for (int l = 0; l < L; ++l) {
@@ -196,7 +214,7 @@ static int run_case(int argc, char **argv) {
     else       // packed tiles: [MB][KB][t][t] x [NB][KB][t][t] -> [MB][NB][t][t]
       handle[l] = xsmm_fused_brgemm_dispatch(dt, tile, tn, tk, tk, tn, tn, tile * tk, tk * tn, gflags, 0, ukind, bflags, bkind);
   }
-  xsmm_hip_force_variant(-1);
+  if (!host_buffers) xsmm_hip_force_variant(-1);
   int chained = -1;
   std::vector<void *> pa(L), pb(L), pc(L), pd(L);
   std::vector<int64_t> z(L, 0), br(L);
@@ -236,7 +254,8 @@ static int run_case(int argc, char **argv) {
   };
   const int64_t warm = n_iter / 100 < 1 ? 1 : (n_iter / 100 > 50 ? 50 : n_iter / 100);
   for (int64_t i = 0; i < warm; ++i) kernel();
-  xsmm_hip_synchronize();
+  if (host_buffers) (void)perf_stop_timer(perf_start_timer()); // (the ABI's own synchronisation point)
+  else xsmm_hip_synchronize();
   const int64_t t0 = perf_start_timer();
   for (int64_t i = 0; i < n_iter; ++i) kernel();
   const double host_dt = (double)(perf_start_timer() - t0) * 1e-9; // all invokes returned (host side only)
@@ -272,6 +291,35 @@ static int run_case(int argc, char **argv) {
     xsmm_hip_tile_queue_stats(qs);
     fprintf(stderr, "tpp_replay: tile queue: %ld grouped launches, %ld invokes with full bookkeeping, %ld replayed, %ld groups ended by a known terminator, %ld replays abandoned\n",
             (long)qs[0], (long)qs[1], (long)qs[2], (long)qs[3], (long)qs[4]);
+  }
+  if (host_buffers) {
+    // the host reads its own output buffer, like tpp-run's print behind the timing loop (perf_stop_timer was the synchronisation
+    // point). Constant fills: every layer is K * 1 * (1/K) (+ 0.5) from an input of that value - closed form, checked here.
+    int64_t hs[10];
+    xsmm_hip_host_cache_stats(hs);
+    fprintf(stderr, "tpp_replay: host buffers (TPP_HIP_ASYNC=%s TPP_HIP_TILE_QUEUE=%s TPP_HIP_HOST_CACHE=%s): host cache %ld extents, %.1f MiB mirrored, %.1f MiB uploaded, "
+                    "%.1f MiB written back, %ld invokes translated lock-free / %ld locked\n", getenv("TPP_HIP_ASYNC") ? getenv("TPP_HIP_ASYNC") : "-",
+            getenv("TPP_HIP_TILE_QUEUE") ? getenv("TPP_HIP_TILE_QUEUE") : "-", getenv("TPP_HIP_HOST_CACHE") ? getenv("TPP_HIP_HOST_CACHE") : "-", (long)hs[0],
+            hs[1] / 1048576.0, hs[2] / 1048576.0, hs[4] / 1048576.0, (long)hs[7], (long)hs[8]);
+    if (!rnd && !kernel_args) {
+      double v = 1.0;
+      for (int l = 0; l < L; ++l) {
+        v = v * 1.0 + (bias ? 0.5 : 0.0); // sum_k a * (1/K) = a
+        if (relu && v < 0) v = 0;
+        if (bf16) { float f = (float)v; uint32_t u = (uint32_t)to_bf16(f) << 16; memcpy(&f, &u, 4); v = f; }
+      }
+      const size_t n_out = (size_t)batch * layers[L];
+      size_t bad = 0;
+      for (size_t i = 0; i < n_out; ++i) {
+        float got;
+        if (bf16) { uint32_t u = (uint32_t)((uint16_t *)act[L])[i] << 16; memcpy(&got, &u, 4); }
+        else got = ((float *)act[L])[i];
+        bad += !(fabs((double)got - v) <= 1e-5 * fabs(v) + (bf16 ? 0.01 * fabs(v) : 0.0));
+      }
+      if (bad) { fprintf(stderr, "tpp_replay --host-buffers: WRONG RESULT in the host's output buffer (%zu of %zu values, expected %g)\n", bad, n_out, v); return 1; }
+      fprintf(stderr, "tpp_replay: host output buffer checked (%zu values = %g)\n", n_out, v);
+    }
+    return 0; // (buffers live to the end of the process, like memref globals)
   }
   if (print) {
     std::vector<float> h(8);

@@ -14,8 +14,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO_NAME = "libtpp_xsmm_runner_utils.so"
 SO_PATH = os.path.join(HERE, SO_NAME)
-SOURCES = ["runtime.cpp", "brgemm_f32.hip", "brgemm_f32_lw.hip", "brgemm_f32_lw16.hip", "brgemm_bf16.hip", "brgemm_bf16_dma256.hip", "brgemm_bf16_small.hip", "brgemm_bf16_lw.hip", "eltwise.hip", "peer_gather.hip"]
-HEADERS = ["xsmm_desc.h", "gemm_common.h", "chain_args.h", "split_scratch.h", os.path.join("..", "..", "include", "tpp_xsmm_abi.h")]
+SOURCES = ["runtime.cpp", "host_cache.cpp", "brgemm_f32.hip", "brgemm_f32_lw.hip", "brgemm_f32_lw16.hip", "brgemm_bf16.hip", "brgemm_bf16_dma256.hip", "brgemm_bf16_small.hip", "brgemm_bf16_lw.hip", "eltwise.hip", "peer_gather.hip"]
+HEADERS = ["xsmm_desc.h", "host_cache.h", "gemm_common.h", "chain_args.h", "split_scratch.h", os.path.join("..", "..", "include", "tpp_xsmm_abi.h")]
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
@@ -62,7 +62,7 @@ def build(force=False, verbose=False):
     return SO_PATH
 
 
-ABLATION_SOURCES = ["runtime.cpp", "brgemm_f32.hip", "brgemm_bf16_lw.hip"]  # the translation units that look at TPP_HIP_ABLATION
+ABLATION_SOURCES = ["runtime.cpp", "host_cache.cpp", "brgemm_f32.hip", "brgemm_bf16_lw.hip"]  # the translation units that look at TPP_HIP_ABLATION
 
 
 def build_side(name, defs, sources=None, verbose=False):

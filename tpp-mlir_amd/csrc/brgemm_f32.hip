@@ -1126,7 +1126,9 @@ bool plan_gemm(GemmDesc &d, int forced_variant) {
     const int64_t t128 = (d.m / 128) * (d.n / 128);
     if (v == V_BF16_FAST || v == V_BF16_SMALL32 || (v == V_BF16_DMA128 && t128 * 4 < 3 * (int64_t)g_num_cus)) {
       const int lw = pick_bf16_lw_tile(d);
-      if (lw >= 0 && !(lw == 3 && v == V_BF16_DMA128)) v = V_BF16_LW_32x64 + lw;
+      // (round 6: the 128x128 loader-wave tile also where brgemm_bf16_dma128 used to stay - fewer than 3/4 of the CUs busy: 1024 x 2560 x
+      // 1024 = 160 tiles runs 10.2 us on it against 11.5 on dma128, profiles/r06_bf16_sweep_before.txt)
+      if (lw >= 0) v = V_BF16_LW_32x64 + lw;
     } else if (v == V_BF16_DMA128 && t128 <= (int64_t)g_num_cus && pick_bf16_lw_tile(d) == 3) {
       // ONE round of 128x128 tiles (the C4 layer 4096 x 1024, C5 2048 x 2048): since the end of round 3 the loader-wave tile is
       // at least as fast as brgemm_bf16_dma128 there (same box, profiles/r03_write_through_c_stores.txt: C5 18.2 against 18.7 us,

@@ -13,6 +13,7 @@
 #include "../../include/tpp_xsmm_abi.h"
 #include "xsmm_desc.h"
 #include "chain_args.h"
+#include "host_cache.h"
 
 #include <dlfcn.h>
 #include <linux/membarrier.h>
@@ -2234,6 +2235,49 @@ bool dt_defer(const UnaryDesc *d, void *pi, void *po, hipStream_t s) {
   return true;
 }
 
+// ---- host cache (round 6, host_cache.h): host operands translated to device mirrors that outlive the invoke ---------------------
+// One scope per ABI invoke: the constructor translates the host operands (their pointers are REPLACED by mirror addresses, so the
+// tile queue, the deferred transposes and the launch paths below see device memory), the destructor - behind the launch and, in
+// synchronous mode, behind finish()'s stream synchronisation - copies what was written back (synchronous mode) or remembers it for
+// the next synchronisation point (asynchronous mode) and ends the reader section.
+void hc_flush_hook() { flush_tile_queue(); }
+bool hc_is_device_hook(const void *p, int pos) {
+  DeviceRanges &dm = caller_state().devmem;
+  if (cfg().async.load(std::memory_order_relaxed)) dm.refresh();
+  else dm.known.clear(); // synchronous mode: every invoke is a point after which the caller may free buffers (see stage_in)
+  return dm.is_device(p, pos);
+}
+bool hc_setup() {
+  hc::set_hooks(hc::Hooks{&hc_flush_hook, &hc_is_device_hook});
+  if (const char *e = getenv("TPP_HIP_HOST_CACHE"))
+    if (atoi(e) != 0) (void)hc::set_enabled(1);
+  return true;
+}
+inline bool hc_on() {
+  static const bool once = hc_setup();
+  (void)once;
+  return hc::enabled();
+}
+struct HcScope {
+  hc::OpRef ops[4];
+  int n = 0, hits = 0;
+  bool async = false;
+  hipStream_t s = nullptr;
+  void add(void **pp, const Operand &o, bool read, bool written) {
+    ops[n++] = hc::OpRef{pp, o.bytes, o.rows, o.row_bytes, o.pitch, read, written, nullptr};
+  }
+  void go(hipStream_t stream) {
+    s = stream;
+    async = cfg().async.load(std::memory_order_relaxed) != 0;
+    hits = hc::translate(ops, n, async, g_devmem_epoch.load(std::memory_order_relaxed), s);
+  }
+  ~HcScope() {
+    if (!hits) return;
+    hc::complete(ops, n, async, s);
+    hc::leave();
+  }
+};
+
 void gemm_invoke_common(const char *who, bool want_fused, int64_t dtype, int64_t handle, void *a, int64_t off_a,
                         void *b, int64_t off_b, void *c, int64_t off_c, void *dptr, int64_t off_d, int64_t br) {
   const GemmDesc *d = as_desc<GemmDesc>(handle, KIND_GEMM, who);
@@ -2247,6 +2291,16 @@ void gemm_invoke_common(const char *who, bool want_fused, int64_t dtype, int64_t
   void *pd = dptr ? (char *)dptr + off_d * es : nullptr;
   if (d->bias && !dptr) die("%s: fused bias operand is null", who);
   hipStream_t s = cfg().stream.load(std::memory_order_relaxed);
+  HcScope hcs;
+  if (hc_on()) {
+    Operand A, B, C, D;
+    gemm_operands(d, pa, pb, pc, pd, br, A, B, C, D);
+    hcs.add(&pa, A, true, false);
+    hcs.add(&pb, B, true, false);
+    hcs.add(&pc, C, !d->beta0, true);
+    hcs.add(&pd, D, true, false);
+    hcs.go(s);
+  }
   if (g_dt_pending.load(std::memory_order_acquire)) { // a remembered transpose: this gemm reads its source instead, or it is launched now
     void *src = nullptr;
     if (const GemmDesc *sib = dt_gemm(d, pa, pb, pc, pd, br, s, &src)) {
@@ -2718,6 +2772,14 @@ static void unary_invoke_common(const char *who, int64_t dtype, int64_t handle, 
   if (use_scalar && (d->op == XSMM_UNARY_TRANSPOSE || d->op == XSMM_UNARY_VNNI2))
     die("%s: scalar input is meaningless for op %ld", who, (long)d->op);
   void *pi = use_scalar || d->op == XSMM_UNARY_ZERO ? nullptr : (char *)in + off_in * es, *po = (char *)out + off_out * es;
+  HcScope hcs;
+  if (hc_on()) {
+    Operand I, O;
+    unary_operands(d, pi, po, I, O);
+    hcs.add(&pi, I, true, false);
+    hcs.add(&po, O, false, true);
+    hcs.go(cfg().stream.load(std::memory_order_relaxed));
+  }
   unary_invoke_core(d, pi, scalar, use_scalar, po, true);
 }
 namespace {
@@ -2770,6 +2832,15 @@ extern "C" void xsmm_binary_invoke(int64_t dtype, int64_t handle, void *lhs, int
   const size_t es = esize(dtype);
   void *pl = (char *)lhs + off_lhs * es, *pr = (char *)rhs + off_rhs * es, *po = (char *)out + off_out * es;
   hipStream_t s = cfg().stream.load(std::memory_order_relaxed);
+  HcScope hcs;
+  if (hc_on()) {
+    Operand L, R, O;
+    binary_operands(d, pl, pr, po, L, R, O);
+    hcs.add(&pl, L, true, false);
+    hcs.add(&pr, R, true, false);
+    hcs.add(&po, O, false, true);
+    hcs.go(s);
+  }
   if (g_dt_pending.load(std::memory_order_acquire)) {
     Operand L, R, O;
     binary_operands(d, pl, pr, po, L, R, O);
@@ -2809,6 +2880,7 @@ extern "C" double perf_stop_timer(int64_t start) {
   if (cfg().async.load()) {
     HIP_OK(hipStreamSynchronize(cfg().stream.load())); // an asynchronous kernel fault must not read as a timing
     check_chain_errors();
+    hc::on_sync_point(cfg().stream.load()); // host cache: what the kernels of this region wrote goes back to the host now
   }
   const int64_t now = std::chrono::duration_cast<std::chrono::nanoseconds>(
                           std::chrono::high_resolution_clock::now().time_since_epoch())
@@ -2823,6 +2895,7 @@ extern "C" int xsmm_hip_set_async(int enable) {
   if (prev && !enable) { // leaving async mode restores "results visible on return" for everything already enqueued
     HIP_OK(hipStreamSynchronize(cfg().stream.load()));
     check_chain_errors();
+    hc::on_sync_point(cfg().stream.load());
     g_devmem_epoch.fetch_add(1, std::memory_order_relaxed);
   }
   return prev;
@@ -2835,6 +2908,7 @@ extern "C" void xsmm_hip_set_stream(void *s) {
   if (old != (hipStream_t)s && cfg().async.load(std::memory_order_relaxed)) {
     HIP_OK(hipStreamSynchronize(old));
     check_chain_errors();
+    hc::on_sync_point(old);
   }
 }
 extern "C" int xsmm_hip_set_tile_queue(int enable) {
@@ -2903,6 +2977,7 @@ extern "C" void xsmm_hip_synchronize(void) {
   g_devmem_epoch.fetch_add(1, std::memory_order_relaxed);
   HIP_OK(hipStreamSynchronize(cfg().stream.load()));
   check_chain_errors();
+  hc::on_sync_point(cfg().stream.load());
 }
 // ---- host residents (see the comment at Resident) ---------------------------------------------------------
 extern "C" int xsmm_hip_host_resident(const void *ptr, int64_t bytes) {
@@ -2944,6 +3019,19 @@ extern "C" int xsmm_hip_host_release(const void *ptr) {
     }
   return -1;
 }
+// ---- host cache (host_cache.h): host operands kept on the device between invokes, re-uploaded only where the host wrote -----
+extern "C" int xsmm_hip_set_host_cache(int enable) {
+  (void)hc_on(); // hooks + the environment switch first
+  if (!enable && hc::enabled()) { // off: launch what is queued, drain, write everything back, forget the mirrors
+    flush_tile_queue();
+    HIP_OK(hipStreamSynchronize(cfg().stream.load()));
+    check_chain_errors();
+    hc::on_sync_point(cfg().stream.load());
+    g_devmem_epoch.fetch_add(1, std::memory_order_relaxed);
+  }
+  return hc::set_enabled(enable != 0);
+}
+extern "C" void xsmm_hip_host_cache_stats(int64_t out[10]) { hc::stats(out); }
 extern "C" int xsmm_hip_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) {

@@ -96,6 +96,8 @@ _SIGNATURES = {
     "xsmm_hip_host_resident": (ctypes.c_int, [VP, I64]),
     "xsmm_hip_host_update": (ctypes.c_int, [VP]),
     "xsmm_hip_host_release": (ctypes.c_int, [VP]),
+    "xsmm_hip_set_host_cache": (ctypes.c_int, [ctypes.c_int]),
+    "xsmm_hip_host_cache_stats": (None, [ctypes.POINTER(ctypes.c_int64)]),
     "xsmm_hip_device_count": (ctypes.c_int, []),
     "xsmm_hip_kernel_name": (ctypes.c_char_p, [I64]),
     "xsmm_hip_last_grouped_kernel": (ctypes.c_char_p, []),
@@ -255,6 +257,19 @@ class XsmmRuntime:
 
     def host_release(self, buf):
         return self.lib.xsmm_hip_host_release(_addr(buf))
+
+    def set_host_cache(self, on):
+        """host operands keep a device mirror between invokes; only pages the host wrote are uploaded again (include/tpp_xsmm_abi.h).
+        Returns the previous setting, -1 if the kernel lacks userfaultfd WP_ASYNC / PAGEMAP_SCAN"""
+        return self.lib.xsmm_hip_set_host_cache(1 if on else 0)
+
+    def host_cache_stats(self):
+        """dict of the ten counters of xsmm_hip_host_cache_stats"""
+        out = (ctypes.c_int64 * 10)()
+        self.lib.xsmm_hip_host_cache_stats(out)
+        names = ("extents", "mirror_bytes", "uploaded_bytes", "scans", "written_back_bytes", "pages_not_written_back", "grows", "fast_invokes",
+                 "slow_invokes", "extents_dropped")
+        return dict(zip(names, out))
 
     def device_count(self):
         return self.lib.xsmm_hip_device_count()
