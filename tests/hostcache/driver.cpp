@@ -6,6 +6,9 @@
 // bit for bit; the counters say whether the cache did what it claims (no upload when nothing changed, one page when one page changed).
 // Exit code 0 + a last line "OK"; 77 = the kernel lacks the interface (the test skips).
 #include "../../include/tpp_xsmm_abi.h"
+#include <cstddef>
+extern "C" int hipMalloc(void **, size_t); // the fake device allocator of tests/tsan/fake_hip.cpp (hipError_t is an int-sized enum)
+extern "C" int hipFree(void *);
 #include <fcntl.h>
 #include <malloc.h>
 #include <sys/mman.h>
@@ -281,6 +284,44 @@ static void scenario_freed_before_sync() {
   munmap(C2, bytes);
 }
 
+// ---- scenario 5: a timing loop of ONE whole-matrix BRGEMM in asynchronous mode (BASELINE config 2 on host buffers), then the same
+// handle on device pointers with the cache still on, then everything switched off
+static void scenario_c2_async() {
+  xsmm_hip_set_host_cache(1);
+  xsmm_hip_set_async(1);
+  const int M = 256, N = 256, K = 64, BR = 4;
+  std::vector<void *> keep;
+  float *A = host_alloc((size_t)M * K * BR, keep), *B = host_alloc((size_t)K * BR * N, keep), *C = host_alloc((size_t)M * N, keep);
+  fill(A, (size_t)M * K * BR, 1);
+  fill(B, (size_t)K * BR * N, 2);
+  memset(C, 0, (size_t)M * N * 4);
+  const int64_t h = xsmm_brgemm_dispatch(XSMM_DTYPE_F32, M, N, K, K * BR, N, N, K, (int64_t)K * N, XSMM_GEMM_FLAG_BETA_0);
+  xsmm_brgemm_invoke(XSMM_DTYPE_F32, h, A, 0, B, 0, C, 0, BR);
+  xsmm_hip_synchronize();
+  const Stats s0;
+  const int64_t t0 = perf_start_timer();
+  for (int i = 0; i < 200; ++i) xsmm_brgemm_invoke(XSMM_DTYPE_F32, h, A, 0, B, 0, C, 0, BR);
+  (void)perf_stop_timer(t0);
+  const Stats s1;
+  EXPECT(s1.fast() - s0.fast() >= 199, "lock-free translations: %ld", (long)(s1.fast() - s0.fast()));
+  EXPECT(s1.uploaded() - s0.uploaded() <= 8 * 4096, "uploaded in the loop: %ld", (long)(s1.uploaded() - s0.uploaded()));
+  float *dA, *dB, *dC;
+  hipMalloc((void **)&dA, (size_t)M * K * BR * 4);
+  hipMalloc((void **)&dB, (size_t)K * BR * N * 4);
+  hipMalloc((void **)&dC, (size_t)M * N * 4);
+  memcpy(dA, A, (size_t)M * K * BR * 4);
+  memcpy(dB, B, (size_t)K * BR * N * 4);
+  xsmm_brgemm_invoke(XSMM_DTYPE_F32, h, dA, 0, dB, 0, dC, 0, BR);
+  xsmm_hip_synchronize();
+  EXPECT(!memcmp(C, dC, (size_t)M * N * 4), "host-buffer result != device-pointer result");
+  xsmm_hip_set_async(0);
+  xsmm_hip_set_host_cache(0);
+  hipFree(dA);
+  hipFree(dB);
+  hipFree(dC);
+  for (void *p : keep) free(p);
+}
+
 static bool same(const std::vector<float> &a, const std::vector<float> &b) { return a.size() == b.size() && !memcmp(a.data(), b.data(), a.size() * 4); }
 
 int main() {
@@ -324,6 +365,8 @@ int main() {
     EXPECT(same(off, on), "lifetime scenario: cache on != cache off");
     printf("lifetime: freed / re-mapped buffers never served from a stale mirror (%zu values identical)\n", on.size());
   }
+  scenario_c2_async();
+  printf("C2 loop, asynchronous: lock-free after the first invoke, nothing uploaded, equal to the device-pointer result\n");
   scenario_freed_before_sync();
   printf("freed before the synchronisation point: write-back skipped, no fault\n");
   if (g_fail) {

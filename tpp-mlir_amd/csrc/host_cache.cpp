@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cerrno>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -76,6 +77,8 @@ struct Extent {
   uintptr_t lo = 0, hi = 0, cap_lo = 0, cap_hi = 0;
   char *raw = nullptr, *mirror = nullptr; // mirror + (x - cap_lo) is the device address of host byte x
   std::vector<uint64_t> valid;
+  std::vector<uint64_t> armed; // (under g_mu) the page is write-protected as far as the runtime knows: a page the kernel reports written
+                               // although it is armed was written by the HOST; one that was never armed just reads as written
   std::atomic<uint64_t> polled_epoch{0};
   std::atomic<uint64_t> inval_gen{0}; // grows whenever a valid bit is cleared: what a thread's translation cache is checked against
   std::atomic<hipStream_t> stream{nullptr};
@@ -90,6 +93,17 @@ struct Extent {
     else {
       __atomic_fetch_and(&valid[i >> 6], ~(uint64_t(1) << (i & 63)), __ATOMIC_RELAXED);
       inval_gen.fetch_add(1, std::memory_order_release);
+    }
+  }
+  bool is_armed(uintptr_t page_addr) const {
+    const size_t i = (page_addr - cap_lo) / PG;
+    return (armed[i >> 6] >> (i & 63)) & 1;
+  }
+  void arm(uintptr_t a, uintptr_t b, bool v) { // pages of [a, b)
+    for (uintptr_t x = a; x < b; x += PG) {
+      const size_t i = (x - cap_lo) / PG;
+      if (v) armed[i >> 6] |= uint64_t(1) << (i & 63);
+      else armed[i >> 6] &= ~(uint64_t(1) << (i & 63));
     }
   }
   bool all_valid(uintptr_t a, uintptr_t b) const { // pages of [a, b), a and b page-aligned
@@ -129,6 +143,18 @@ struct Cached {
   uint64_t gen = 0, epoch = 0, inval = 0, pend_epoch = 0; // structure generation, synchronisation epoch, e->inval_gen; epoch in which the footprint was noted as written
   hipStream_t stream = nullptr;
 };
+struct Memo { // one whole invoke (asynchronous mode)
+  const void *desc = nullptr;
+  void *p[4] = {nullptr, nullptr, nullptr, nullptr};
+  int64_t br = 0;
+  char *dev[4] = {nullptr, nullptr, nullptr, nullptr};
+  Extent *e[4] = {nullptr, nullptr, nullptr, nullptr};
+  uint64_t inval[4] = {0, 0, 0, 0};
+  uint64_t gen = 0, epoch = 0, pend_epoch = 0;
+  hipStream_t stream = nullptr;
+  Pending wr{0, 0, 0, 0, 0}; // the written footprint (bytes == 0: none)
+  bool last = false; // of its set's two ways, the one stored last
+};
 struct alignas(64) ThreadState {
   std::atomic<int> active{0}; // inside a reader section: holds mirror addresses, extents must not move
   ThreadState *next = nullptr;
@@ -141,7 +167,13 @@ struct alignas(64) ThreadState {
   int depth = 0; // translate() .. leave() of this thread (an invoke issued from inside the flush hook - a remembered transpose - is not translated again)
   int64_t n_fast = 0, n_slow = 0; // (per thread: a shared counter would be the one line every caller writes)
   Cached cache[256];
-  Cached *slot(uintptr_t p) { return &cache[(p >> 6 ^ p >> 14) & 255]; }
+  Cached *slot(uintptr_t p) { return &cache[(p * 0x9E3779B97F4A7C15ull) >> 56]; } // (tile pointers are a power of two apart: multiplicative hash)
+  Memo memo[4096]; // 2048 sets of two ways (768 tile invokes per iteration of the reference's MLP: a direct-mapped table of this size
+                   // still has a third of them share a slot with another one and miss every time)
+  Memo *memo_set(const void *a, const void *c) { // (A, C) of a tile invoke: a layer's tiles differ in C, the layers in A
+    const uint64_t h = (uint64_t)(uintptr_t)c * 0x9E3779B97F4A7C15ull ^ (uint64_t)(uintptr_t)a * 0xC2B2AE3D27D4EB4Full;
+    return &memo[(h >> 53) * 2];
+  }
 };
 
 std::mutex g_mu;                    // every slow path (polls, uploads, write-backs, structure changes)
@@ -387,13 +419,16 @@ Extent *grow(uintptr_t lo, uintptr_t hi, hipStream_t s) {
   HC_HIP_OK(hipMalloc((void **)&n->raw, (n->cap_hi - n->cap_lo) + PG));
   n->mirror = (char *)pg_ceil((uintptr_t)n->raw);
   n->valid.assign(((n->cap_hi - n->cap_lo) / PG + 63) / 64, 0);
+  n->armed.assign(n->valid.size(), 0);
   n->stream.store(s, std::memory_order_relaxed);
   uint64_t ep = over.empty() ? 0 : ~uint64_t(0);
   for (Extent *e : over) {
     if (e->stream.load(std::memory_order_relaxed) != s) HC_HIP_OK(hipStreamSynchronize(e->stream.load(std::memory_order_relaxed)));
     HC_HIP_OK(hipMemcpyAsync(n->dev(e->lo), e->dev(e->lo), e->hi - e->lo, hipMemcpyDeviceToDevice, s));
-    for (uintptr_t x = e->lo; x < e->hi; x += PG)
+    for (uintptr_t x = e->lo; x < e->hi; x += PG) {
       if (e->get(x)) n->set(x, true);
+      if (e->is_armed(x)) n->arm(x, x + PG, true);
+    }
     ep = std::min(ep, e->polled_epoch.load(std::memory_order_relaxed));
   }
   if (!over.empty()) HC_HIP_OK(hipStreamSynchronize(s)); // the copies are done (and everything that used the old mirrors: the caller flushed the tile queue)
@@ -435,6 +470,7 @@ bool poll(Extent *e, uintptr_t lo, uintptr_t hi) {
     err = scan(lo, hi, true, PG_WRITTEN, 0, w);
   }
   if (err != 0) return false;
+  e->arm(lo, hi, true); // (written pages were protected again by the scan, the others were protected before or are now)
   for (const PmRegion &r : w) {
     HC_TRACE("poll [%#lx, %#lx): written [%#lx, %#lx)", (unsigned long)lo, (unsigned long)hi, (unsigned long)r.start, (unsigned long)r.end);
     for (uintptr_t x = std::max<uintptr_t>(r.start, lo); x < std::min<uintptr_t>(r.end, hi); x += PG) e->set(x, false);
@@ -469,6 +505,8 @@ struct Staging {
   }
 };
 Staging g_staging; // under g_mu
+char *g_scratch = nullptr; // scratch block of synchronous pure outputs (under g_sync_mu + g_mu)
+size_t g_scratch_cap = 0;
 
 void upload(Extent *e, uintptr_t lo, uintptr_t hi, hipStream_t s, bool &flushed) {
   if (e->stream.load(std::memory_order_relaxed) != s) { // the mirror's last user was another stream: order behind it
@@ -488,7 +526,7 @@ void upload(Extent *e, uintptr_t lo, uintptr_t hi, hipStream_t s, bool &flushed)
     // landed before it is in the bytes uploaded now.
     {
       std::vector<PmRegion> ign;
-      (void)scan(x, y, true, PG_WRITTEN, 0, ign);
+      if (scan(x, y, true, PG_WRITTEN, 0, ign) == 0) e->arm(x, y, true);
     }
     for (uintptr_t c = x; c < y;) {
       const size_t len = std::min<size_t>(y - c, Staging::SLOT);
@@ -534,8 +572,10 @@ void rearm(Extent *e, uintptr_t a, uintptr_t b, bool dense) {
   std::vector<PmRegion> w;
   if (scan(lo, hi, true, PG_WRITTEN, 0, w) != 0) { // lost its registration meanwhile: the next poll deals with it
     for (uintptr_t x = lo; x < hi; x += PG) e->set(x, false);
+    e->arm(lo, hi, false);
     return;
   }
+  e->arm(lo, hi, true);
   const uintptr_t full_lo = dense ? pg_ceil(a) : hi, full_hi = dense ? pg_floor(b) : hi; // pages entirely inside [a, b)
   HC_TRACE("written back [%#lx, %#lx)", (unsigned long)a, (unsigned long)b);
   for (const PmRegion &r : w)
@@ -549,7 +589,7 @@ void set_hooks(const Hooks &h) { g_hooks = h; }
 bool enabled() { return g_on.load(std::memory_order_relaxed) != 0; }
 
 int translate(OpRef *ops, int n, bool async, uint64_t epoch, hipStream_t s) {
-  for (int i = 0; i < n; ++i) ops[i].host = nullptr;
+  for (int i = 0; i < n; ++i) ops[i].host = nullptr, ops[i].kind = 0;
   if (!g_on.load(std::memory_order_relaxed)) return 0;
   ThreadState &t = tstate();
   if (t.depth) return 0; // issued from inside the flush hook: its operands are mirror addresses already
@@ -616,6 +656,7 @@ int translate(OpRef *ops, int n, bool async, uint64_t epoch, hipStream_t s) {
       if (dev[i]) {
         ops[i].host = *ops[i].ptr;
         *ops[i].ptr = dev[i];
+        ops[i].kind = 1;
       }
     ++t.n_fast;
     t.depth = 1;
@@ -627,10 +668,24 @@ int translate(OpRef *ops, int n, bool async, uint64_t epoch, hipStream_t s) {
   t.depth = 1; // (the flush hook may issue invokes of its own on this thread)
   std::unique_lock<std::mutex> lk(g_mu);
   Extent *ext[8];
+  bool scratch[8];
   bool need_writer = false;
+  // SYNCHRONOUS mode, a pure dense output whose inner pages no extent holds: nothing of it is worth keeping on the device - the host gets
+  // it at once anyway. It is computed into a scratch block and copied back by a DMA straight into the caller's pages, which is only
+  // fast while those pages are NOT registered with the userfaultfd (the driver pins registered pages one by one: 60 us a page
+  // measured); registering them for a mirror nobody will read would make every later copy-back crawl.
+  auto scratch_output = [&](int i) {
+    if (async || !pure_dense(ops[i])) return false;
+    const uintptr_t p = (uintptr_t)*ops[i].ptr, in_lo = pg_ceil(p), in_hi = pg_floor(p + ops[i].bytes);
+    if (in_lo >= in_hi) return false;
+    for (Extent *c : g_ext)
+      if (in_lo < c->hi && c->lo < in_hi) return false;
+    return true;
+  };
   for (int i = 0; i < n; ++i) {
     ext[i] = nullptr;
     dev[i] = nullptr;
+    scratch[i] = false;
     const uintptr_t p = (uintptr_t)*ops[i].ptr;
     if (!p || !ops[i].bytes) continue;
     const uintptr_t lo = pg_floor(p), hi = pg_ceil(p + ops[i].bytes);
@@ -640,6 +695,7 @@ int translate(OpRef *ops, int n, bool async, uint64_t epoch, hipStream_t s) {
     for (Extent *c : g_ext) overlaps = overlaps || (lo < c->hi && c->lo < hi);
     if (!overlaps && g_hooks.is_device && g_hooks.is_device((const void *)p, i)) continue;
     if (rejected(lo, hi)) continue;
+    if (scratch_output(i)) { scratch[i] = true; continue; }
     need_writer = true;
   }
   bool flushed = false;
@@ -661,12 +717,13 @@ int translate(OpRef *ops, int n, bool async, uint64_t epoch, hipStream_t s) {
       for (Extent *c : g_ext) overlaps = overlaps || (lo < c->hi && c->lo < hi);
       if (!overlaps && g_hooks.is_device && g_hooks.is_device((const void *)p, i)) continue;
       if (rejected(lo, hi)) continue;
+      if (scratch[i]) continue;
       ext[i] = grow(lo, hi, s);
     }
     // (a later operand's grow may have merged - deleted - the extent an earlier one was found in: look all of them up again)
     for (int i = 0; i < n; ++i) {
       const uintptr_t p = (uintptr_t)*ops[i].ptr;
-      ext[i] = (p && ops[i].bytes) ? find(pg_floor(p), pg_ceil(p + ops[i].bytes)) : nullptr;
+      ext[i] = (p && ops[i].bytes && !scratch[i]) ? find(pg_floor(p), pg_ceil(p + ops[i].bytes)) : nullptr;
     }
     readmit_readers();
   }
@@ -706,7 +763,22 @@ int translate(OpRef *ops, int n, bool async, uint64_t epoch, hipStream_t s) {
     if (ext[i]) {
       ops[i].host = *ops[i].ptr;
       *ops[i].ptr = ext[i]->dev((uintptr_t)ops[i].host);
+      ops[i].kind = 1;
       t.mru[i & 7] = ext[i];
+      ++hits;
+    } else if (scratch[i]) { // (one written operand per invoke, one synchronous host-cached invoke at a time: g_sync_mu)
+      const uintptr_t p = (uintptr_t)*ops[i].ptr;
+      if (g_scratch_cap < ops[i].bytes + 512) {
+        if (g_scratch) {
+          HC_HIP_OK(hipStreamSynchronize(s));
+          HC_HIP_OK(hipFree(g_scratch));
+        }
+        g_scratch_cap = std::max(ops[i].bytes + 512, 2 * g_scratch_cap);
+        HC_HIP_OK(hipMalloc((void **)&g_scratch, g_scratch_cap));
+      }
+      ops[i].host = (void *)p;
+      *ops[i].ptr = (char *)(((uintptr_t)g_scratch + 255) & ~(uintptr_t)255) + (p & 255); // (the caller's alignment class: kernel choices depend on it)
+      ops[i].kind = 2;
       ++hits;
     }
   t.mru_gen = g_struct_gen.load(std::memory_order_relaxed);
@@ -733,16 +805,54 @@ void leave() {
 }
 
 namespace {
-void copy_back(const Extent *e, uintptr_t host, size_t bytes, size_t rows, size_t row_bytes, size_t pitch, hipStream_t s) {
-  if (rows && row_bytes < pitch)
-    HC_HIP_OK(hipMemcpy2DAsync((void *)host, pitch, e->dev(host), pitch, row_bytes, rows, hipMemcpyDeviceToHost, s));
-  else
-    HC_HIP_OK(hipMemcpyAsync((void *)host, e->dev(host), bytes, hipMemcpyDeviceToHost, s));
-  st_wb_bytes.fetch_add((int64_t)(rows && row_bytes < pitch ? rows * row_bytes : bytes), std::memory_order_relaxed);
+// Write-backs go through the pinned staging buffer too, the host bytes are written by a CPU copy: a hipMemcpy INTO pageable memory of a
+// userfaultfd-registered mapping makes the driver pin those pages one by one through the slow get_user_pages path (measured: 60 ms for
+// 4 MiB, against 80 us into an unregistered buffer). The caller has unprotected the pages (no write-protect fault per page) and has
+// drained the stream behind the kernels; this function returns with the host bytes in place.
+void copy_back(Extent *e, uintptr_t host, size_t bytes, size_t rows, size_t row_bytes, size_t pitch, hipStream_t s) {
+  const bool strided = rows && row_bytes < pitch;
+  if (strided && row_bytes * 4 < pitch) { // narrow rows (a tile of a wide matrix): gather the rows on the device side of the copy
+    for (size_t r0 = 0; r0 < rows;) {
+      const size_t nr = std::min(rows - r0, Staging::SLOT / row_bytes);
+      int slot;
+      char *st = g_staging.acquire(&slot);
+      HC_HIP_OK(hipMemcpy2DAsync(st, row_bytes, e->dev(host + r0 * pitch), pitch, row_bytes, nr, hipMemcpyDeviceToHost, s));
+      HC_HIP_OK(hipStreamSynchronize(s));
+      for (size_t r = 0; r < nr; ++r) memcpy((void *)(host + (r0 + r) * pitch), st + r * row_bytes, row_bytes);
+      g_staging.release(slot, s);
+      r0 += nr;
+    }
+  } else { // dense, or rows that fill most of their pitch: whole spans through the staging buffer, only the written bytes to the host
+    for (size_t off = 0; off < bytes;) {
+      size_t len = std::min(bytes - off, Staging::SLOT);
+      if (strided && len < bytes - off) len = std::max<size_t>(len / pitch, 1) * pitch; // (whole rows per piece)
+      len = std::min(len, bytes - off);
+      int slot;
+      const auto t0 = std::chrono::steady_clock::now();
+      char *st = g_staging.acquire(&slot);
+      const auto t1 = std::chrono::steady_clock::now();
+      HC_HIP_OK(hipMemcpyAsync(st, e->dev(host + off), len, hipMemcpyDeviceToHost, s));
+      HC_HIP_OK(hipStreamSynchronize(s));
+      const auto t2 = std::chrono::steady_clock::now();
+      if (!strided) {
+        memcpy((void *)(host + off), st, len);
+      } else {
+        for (size_t r = 0; r * pitch < len; ++r) memcpy((void *)(host + off + r * pitch), st + r * pitch, std::min(row_bytes, len - r * pitch));
+      }
+      if (g_trace >= 2)
+        fprintf(stderr, "[tpp-xsmm-hip host cache] copy_back %zu B: staging slot %.0f us, D2H %.0f us, memcpy %.0f us\n", len,
+                std::chrono::duration<double, std::micro>(t1 - t0).count(), std::chrono::duration<double, std::micro>(t2 - t1).count(),
+                std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t2).count());
+      g_staging.release(slot, s);
+      off += len;
+    }
+  }
+  e->arm(pg_floor(host), pg_ceil(host + bytes), false);
+  st_wb_bytes.fetch_add((int64_t)(strided ? rows * row_bytes : bytes), std::memory_order_relaxed);
 }
 } // namespace
 
-void complete(OpRef *ops, int n, bool async, hipStream_t s) {
+void complete(OpRef *ops, int n, bool async, uint64_t epoch, hipStream_t s) {
   bool any = false;
   for (int i = 0; i < n; ++i) any = any || (ops[i].host && ops[i].written);
   if (!any) return;
@@ -752,8 +862,8 @@ void complete(OpRef *ops, int n, bool async, hipStream_t s) {
       if (!ops[i].host || !ops[i].written) continue;
       Cached *c = t.slot((uintptr_t)ops[i].host);
       if (c->host == (uintptr_t)ops[i].host && c->bytes == ops[i].bytes) {
-        if (c->pend_epoch == c->epoch && c->epoch != 0) continue; // this footprint is on the list of this epoch already
-        c->pend_epoch = c->epoch;
+        if (c->pend_epoch == epoch) continue; // this footprint is on the list of this epoch already
+        c->pend_epoch = epoch;
       }
       const uint64_t key = (uint64_t)(uintptr_t)ops[i].host * 0x9E3779B97F4A7C15ull ^ (uint64_t)ops[i].bytes * 0xC2B2AE3D27D4EB4Full ^ (uint64_t)ops[i].rows;
       std::lock_guard<SpinLock> lk(t.pmu);
@@ -769,6 +879,32 @@ void complete(OpRef *ops, int n, bool async, hipStream_t s) {
   for (int i = 0; i < n; ++i) {
     if (!ops[i].host || !ops[i].written) continue;
     const uintptr_t h = (uintptr_t)ops[i].host;
+    if (ops[i].kind == 2) {
+      // scratch output: the inner pages by DMA straight into the caller's (unregistered) pages; an edge page that some extent holds
+      // through the staging buffer + a CPU copy (the kernel's write tracking sees that write like any other host write)
+      const char *src = (const char *)*ops[i].ptr;
+      const uintptr_t end = h + ops[i].bytes, in_lo = pg_ceil(h), in_hi = pg_floor(end);
+      auto piece = [&](uintptr_t a, uintptr_t b) {
+        if (a >= b) return;
+        bool registered = false;
+        for (Extent *c : g_ext) registered = registered || (pg_floor(a) < c->hi && c->lo < pg_ceil(b));
+        if (!registered) {
+          HC_HIP_OK(hipMemcpyAsync((void *)a, src + (a - h), b - a, hipMemcpyDeviceToHost, s));
+        } else {
+          int slot;
+          char *st = g_staging.acquire(&slot);
+          HC_HIP_OK(hipMemcpyAsync(st, src + (a - h), b - a, hipMemcpyDeviceToHost, s));
+          HC_HIP_OK(hipStreamSynchronize(s));
+          memcpy((void *)a, st, b - a);
+          g_staging.release(slot, s);
+        }
+        st_wb_bytes.fetch_add((int64_t)(b - a), std::memory_order_relaxed);
+      };
+      piece(h, in_lo);
+      piece(in_lo, in_hi);
+      piece(in_hi, end);
+      continue;
+    }
     Extent *e = find(pg_floor(h), pg_ceil(h + ops[i].bytes));
     if (!e) continue; // (given up meanwhile: its range changed hands)
     uffd_unprotect(pg_floor(h), pg_ceil(h + ops[i].bytes)); // the copy below writes these pages: no write-protect fault per page
@@ -776,7 +912,7 @@ void complete(OpRef *ops, int n, bool async, hipStream_t s) {
   }
   HC_HIP_OK(hipStreamSynchronize(s));
   for (int i = 0; i < n; ++i) {
-    if (!ops[i].host || !ops[i].written) continue;
+    if (!ops[i].host || !ops[i].written || ops[i].kind == 2) continue;
     const uintptr_t h = (uintptr_t)ops[i].host;
     Extent *e = find(pg_floor(h), pg_ceil(h + ops[i].bytes));
     if (!e) continue;
@@ -788,6 +924,96 @@ void complete(OpRef *ops, int n, bool async, hipStream_t s) {
       rearm(e, h, h + ops[i].bytes, !(ops[i].rows && ops[i].row_bytes < ops[i].pitch));
     }
   }
+}
+
+void *memo_hit(const void *desc, void **p0, void **p1, void **p2, void **p3, int64_t br, uint64_t epoch, hipStream_t s) {
+  if (!g_on.load(std::memory_order_relaxed)) return nullptr;
+  ThreadState &t = tstate();
+  if (t.depth) return nullptr;
+  Memo *m = t.memo_set(*p0, *p2);
+  if (m->p[2] != *p2 || m->p[0] != *p0) ++m; // the other way of the set
+  if (g_trace >= 2) {
+    static std::atomic<long> why[9];
+    static const bool reg = (atexit([] { fprintf(stderr, "[memo] key-miss desc %ld p0 %ld p1 %ld p2 %ld p3 %ld br %ld epoch %ld stream %ld total %ld\n", why[0].load(), why[1].load(), why[2].load(), why[3].load(), why[4].load(), why[5].load(), why[6].load(), why[7].load(), why[8].load()); }), true);
+    (void)reg;
+    ++why[8];
+    if (m->desc != desc) ++why[0];
+    else if (m->p[0] != *p0) ++why[1];
+    else if (m->p[1] != *p1) ++why[2];
+    else if (m->p[2] != *p2) ++why[3];
+    else if (m->p[3] != *p3) ++why[4];
+    else if (m->br != br) ++why[5];
+    else if (m->epoch != epoch) ++why[6];
+    else if (m->stream != s) ++why[7];
+  }
+  if (m->desc != desc || m->p[0] != *p0 || m->p[1] != *p1 || m->p[2] != *p2 || m->p[3] != *p3 || m->br != br || m->epoch != epoch || m->stream != s) return nullptr;
+  announce(t);
+  bool good = m->gen == g_struct_gen.load(std::memory_order_acquire);
+  for (int i = 0; good && i < 4; ++i)
+    if (m->e[i]) good = m->inval[i] == m->e[i]->inval_gen.load(std::memory_order_acquire);
+  if (!good) {
+    t.active.store(0, std::memory_order_release);
+    return nullptr;
+  }
+  if (m->dev[0]) *p0 = m->dev[0];
+  if (m->dev[1]) *p1 = m->dev[1];
+  if (m->dev[2]) *p2 = m->dev[2];
+  if (m->dev[3]) *p3 = m->dev[3];
+  t.depth = 1;
+  ++t.n_fast;
+  return m;
+}
+
+void memo_done(void *token, uint64_t epoch) {
+  Memo *m = (Memo *)token;
+  ThreadState &t = tstate();
+  if (m->wr.bytes && m->pend_epoch != epoch) { // the written footprint goes on this epoch's list once
+    m->pend_epoch = epoch;
+    const uint64_t key = (uint64_t)m->wr.host * 0x9E3779B97F4A7C15ull ^ (uint64_t)m->wr.bytes * 0xC2B2AE3D27D4EB4Full ^ (uint64_t)m->wr.rows;
+    std::lock_guard<SpinLock> lk(t.pmu);
+    if (t.seen.insert(key).second) t.pending.push_back(m->wr);
+  }
+  t.active.store(0, std::memory_order_release);
+  t.depth = 0;
+}
+
+// after a translate() in asynchronous mode (inside its section: the extents cannot move)
+void memo_store(const void *desc, int64_t br, const OpRef *ops, int n, uint64_t epoch, hipStream_t s) {
+  if (n != 4) return;
+  ThreadState &t = tstate();
+  void *orig[4];
+  for (int i = 0; i < 4; ++i) orig[i] = ops[i].host ? ops[i].host : *ops[i].ptr;
+  Memo *m = t.memo_set(orig[0], orig[2]);
+  if (!(m->p[2] == orig[2] && m->p[0] == orig[0])) { // not in way 0: way 1 if it is there or free, else the way that was not stored last
+    Memo *w1 = m + 1;
+    if ((w1->p[2] == orig[2] && w1->p[0] == orig[0]) || !w1->desc) m = w1;
+    else if (m->desc && m->last) m = w1;
+  }
+  (m == t.memo_set(orig[0], orig[2]) ? m + 1 : m - 1)->last = false;
+  Memo fresh;
+  fresh.last = true;
+  fresh.desc = desc;
+  fresh.br = br;
+  fresh.gen = g_struct_gen.load(std::memory_order_acquire);
+  fresh.epoch = epoch;
+  fresh.stream = s;
+  for (int i = 0; i < 4; ++i) {
+    fresh.p[i] = orig[i];
+    if (!ops[i].host) continue; // device memory or null: stays as it is
+    if (ops[i].kind != 1) return; // (scratch outputs are a synchronous-mode thing)
+    const uintptr_t h = (uintptr_t)ops[i].host;
+    Extent *e = nullptr;
+    for (Extent *c : g_ext)
+      if (h >= c->lo && h + ops[i].bytes <= c->hi) { e = c; break; }
+    if (!e || e->polled_epoch.load(std::memory_order_relaxed) != epoch) return;
+    fresh.dev[i] = (char *)*ops[i].ptr;
+    fresh.e[i] = e;
+    fresh.inval[i] = e->inval_gen.load(std::memory_order_acquire);
+    if (!e->all_valid(pg_floor(h), pg_ceil(h + ops[i].bytes))) return; // (cannot happen right behind translate())
+    if (ops[i].written) fresh.wr = Pending{h, ops[i].bytes, ops[i].rows, ops[i].row_bytes, ops[i].pitch};
+  }
+  if (m->desc == desc && m->p[2] == orig[2] && m->wr.host == fresh.wr.host) fresh.pend_epoch = m->pend_epoch;
+  *m = fresh;
 }
 
 void on_sync_point(hipStream_t s) {
@@ -802,6 +1028,7 @@ void on_sync_point(hipStream_t s) {
     t->seen.clear();
   }
   if (all.empty()) return;
+  const auto t_begin = std::chrono::steady_clock::now();
   // the union of the written footprints as byte intervals (tiles of one buffer merge into a few long runs)
   std::vector<std::pair<uintptr_t, uintptr_t>> iv;
   for (const Pending &p : all) {
@@ -862,6 +1089,7 @@ void on_sync_point(hipStream_t s) {
       if (!(g.categories & PG_WRITTEN)) continue;
       for (uintptr_t x = std::max<uintptr_t>(g.start, lo); x < std::min<uintptr_t>(g.end, hi); x += PG) {
         if (x < full_lo || x >= full_hi) continue; // an edge page shared with other data: foreign writes there are legitimate
+        if (!e->is_armed(x)) continue; // never protected (a pure output's page: make_ready): it reads as written, nobody wrote it
         if (a < x) { copy_back(e, a, x - a, 0, 0, 0, s); done.push_back(Done{e, a, x}); }
         a = x + PG;
         st_wb_skipped.fetch_add(1, std::memory_order_relaxed);
@@ -871,7 +1099,11 @@ void on_sync_point(hipStream_t s) {
     if (a < r.second) { copy_back(e, a, r.second - a, 0, 0, 0, s); done.push_back(Done{e, a, r.second}); }
   }
   HC_HIP_OK(hipStreamSynchronize(s));
+  const auto t_copied = std::chrono::steady_clock::now();
   for (const Done &d : done) rearm(d.e, d.a, d.b, true);
+  HC_TRACE("synchronisation point: %zu footprints in %zu runs written back in %.0f us, protected again in %.0f us", all.size(), runs.size(),
+           std::chrono::duration<double, std::micro>(t_copied - t_begin).count(),
+           std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_copied).count());
 }
 
 int set_enabled(int on) {

@@ -36,6 +36,7 @@ struct OpRef {
   size_t rows, row_bytes, pitch; // 2-D footprint (rows == 0: one dense range)
   bool read, written;
   void *host;      // set by translate(): the original host pointer (nullptr: not translated)
+  int kind;        // set by translate(): 0 untouched, 1 mirror of an extent, 2 scratch (a pure output of a synchronous invoke)
 };
 
 struct Hooks {
@@ -52,8 +53,16 @@ int set_enabled(int on); // previous setting, or -1 if the kernel interface is m
 // leave() must still be called when it returned > 0 ... it is harmless otherwise).
 int translate(OpRef *ops, int n, bool async, uint64_t epoch, hipStream_t s);
 // synchronous mode: the kernel has completed - copy what it wrote back to the host now. asynchronous mode: remember the footprints.
-void complete(OpRef *ops, int n, bool async, hipStream_t s);
+void complete(OpRef *ops, int n, bool async, uint64_t epoch, hipStream_t s);
 void leave();
+// Asynchronous mode, whole-invoke memo: a timing loop issues the SAME invokes every iteration (descriptor, four pointers, batch count).
+// memo_hit() answers such an invoke from the calling thread's memo without looking at the operands at all - it replaces the pointers,
+// enters the reader section and returns a token for memo_done() (which notes the written footprint once per epoch and leaves the
+// section); nullptr: not in the memo (or no longer good: an extent moved, a page of one of its extents lost its valid bit, another
+// epoch / stream) - the caller takes translate() and offers the result to memo_store().
+void *memo_hit(const void *desc, void **p0, void **p1, void **p2, void **p3, int64_t br, uint64_t epoch, hipStream_t s);
+void memo_done(void *token, uint64_t epoch);
+void memo_store(const void *desc, int64_t br, const OpRef *ops, int n, uint64_t epoch, hipStream_t s);
 // the stream has been drained (synchronisation point): write back everything pending
 void on_sync_point(hipStream_t s);
 void stats(int64_t out[10]);

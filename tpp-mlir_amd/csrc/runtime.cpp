@@ -2263,17 +2263,24 @@ struct HcScope {
   int n = 0, hits = 0;
   bool async = false;
   hipStream_t s = nullptr;
+  void *memo = nullptr; // asynchronous mode: the invoke was answered from the thread's whole-invoke memo (hc::memo_hit)
   void add(void **pp, const Operand &o, bool read, bool written) {
-    ops[n++] = hc::OpRef{pp, o.bytes, o.rows, o.row_bytes, o.pitch, read, written, nullptr};
+    ops[n++] = hc::OpRef{pp, o.bytes, o.rows, o.row_bytes, o.pitch, read, written, nullptr, 0};
   }
+  uint64_t epoch = 0;
   void go(hipStream_t stream) {
     s = stream;
     async = cfg().async.load(std::memory_order_relaxed) != 0;
-    hits = hc::translate(ops, n, async, g_devmem_epoch.load(std::memory_order_relaxed), s);
+    epoch = g_devmem_epoch.load(std::memory_order_relaxed);
+    hits = hc::translate(ops, n, async, epoch, s);
   }
   ~HcScope() {
+    if (memo) {
+      hc::memo_done(memo, epoch);
+      return;
+    }
     if (!hits) return;
-    hc::complete(ops, n, async, s);
+    hc::complete(ops, n, async, epoch, s);
     hc::leave();
   }
 };
@@ -2293,13 +2300,19 @@ void gemm_invoke_common(const char *who, bool want_fused, int64_t dtype, int64_t
   hipStream_t s = cfg().stream.load(std::memory_order_relaxed);
   HcScope hcs;
   if (hc_on()) {
-    Operand A, B, C, D;
-    gemm_operands(d, pa, pb, pc, pd, br, A, B, C, D);
-    hcs.add(&pa, A, true, false);
-    hcs.add(&pb, B, true, false);
-    hcs.add(&pc, C, !d->beta0, true);
-    hcs.add(&pd, D, true, false);
-    hcs.go(s);
+    const bool async = cfg().async.load(std::memory_order_relaxed) != 0;
+    hcs.epoch = g_devmem_epoch.load(std::memory_order_relaxed);
+    if (async) hcs.memo = hc::memo_hit(d, &pa, &pb, &pc, &pd, br, hcs.epoch, s);
+    if (!hcs.memo) {
+      Operand A, B, C, D;
+      gemm_operands(d, pa, pb, pc, pd, br, A, B, C, D);
+      hcs.add(&pa, A, true, false);
+      hcs.add(&pb, B, true, false);
+      hcs.add(&pc, C, !d->beta0, true);
+      hcs.add(&pd, D, true, false);
+      hcs.go(s);
+      if (async && hcs.hits) hc::memo_store(d, br, hcs.ops, 4, hcs.epoch, s);
+    }
   }
   if (g_dt_pending.load(std::memory_order_acquire)) { // a remembered transpose: this gemm reads its source instead, or it is launched now
     void *src = nullptr;
