@@ -195,6 +195,12 @@ TPP_XSMM_EXPORT int xsmm_hip_fused_brgemm_chain_invoke(int64_t dtype, int64_t n,
                                                        const int64_t *off_a, void *const *b, const int64_t *off_b,
                                                        void *const *c, const int64_t *off_c, void *const *d,
                                                        const int64_t *off_d, const int64_t *num_batches);
+/* Sticky status of the chain launches: the number of journaled launches that were found starved at a synchronisation point and
+ * re-run call by call since process start (0: never). Round 6: every journaled launch has its own error word, so only the starved
+ * launch and the later ones of ITS stream are re-run (healthy earlier launches are left alone), the journal is kept per stream, and
+ * a launching thread that finds the pool of error words nearly used up synchronises and checks instead of dropping an entry.
+ * TPP_HIP_CHAIN_STRICT=1: a starved launch ends the process (stderr + exit(-1)) instead of being repaired. */
+TPP_XSMM_EXPORT int64_t xsmm_hip_chain_status(void);
 /* Peer-store all-gather (one process per GPU, no collective library call): every rank stores its row block straight into
  * every peer's output buffer through IPC-mapped pointers, completion by flags (csrc/peer_gather.hip; host-side protocol:
  * tpp-mlir_amd/peer.py). _peer_alloc returns a dedicated zeroed device allocation (IPC handles name whole allocations);

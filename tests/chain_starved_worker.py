@@ -84,6 +84,7 @@ else:
     free = [bool(rt.fused_brgemm_chain(BF16, calls(acts))) for _ in range(2)]
     rt.synchronize()
     out["free_one_launch"] = free
+    out["free_chain_status"] = rt.chain_status()
     out["free_identical"] = all(torch.equal(a.view(torch.int16), r.view(torch.int16)) for a, r in zip(acts, ref))
     for a in acts:
         a.fill_(float("nan"))
@@ -99,5 +100,6 @@ else:
     out["identical"] = all(torch.equal(a.view(torch.int16), r.view(torch.int16)) for a, r in zip(acts, ref))
     out["later_one_launch"] = bool(rt.fused_brgemm_chain(BF16, calls(acts)))
     rt.synchronize()
+out["chain_status"] = rt.chain_status()  # starved launches repaired since process start (the probation path of scenario A repairs none)
 out["hog_workgroups_started"] = int(started.cpu()[0])
 print(json.dumps(out), flush=True)

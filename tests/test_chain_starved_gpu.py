@@ -39,3 +39,6 @@ def test_chain_launches_starved_later_are_rerun_at_the_synchronisation_point():
     assert d["hogged_one_launch"] == [True, True, True], d  # launched asynchronously, found out at the synchronisation
     assert d["identical"] is True and d["later_one_launch"] is False, d
     assert "starved" in err and "re-run call by call" in err, err[-1500:]
+    # round 6: the sticky status counts the journaled launches that were repaired (the starved one and those behind it);
+    # the healthy launches before the hog were checked at their own synchronisation and left alone
+    assert d["free_chain_status"] == 0 and 1 <= d["chain_status"] <= 3, d

@@ -87,6 +87,11 @@ Config &cfg() {
   static Config c;
   return c;
 }
+// the stream an invoke of THIS thread launches on: the process-wide setting, unless the thread is re-running a journaled chain
+// launch on that launch's stream (check_chain_errors; ADVICE r5: the re-run must not change the setting other threads read)
+thread_local hipStream_t tl_stream_override = nullptr; 
+thread_local bool tl_has_stream_override = false;      
+inline hipStream_t invoke_stream() { return tl_has_stream_override ? tl_stream_override : cfg().stream.load(std::memory_order_relaxed); }
 
 // ---- tracing: with TPP_HIP_TRACE >= 1 every invoke runs inside a roctx range named after its
 // dispatch tuple and kernel, so `rocprofv3 --marker-trace --kernel-trace` timelines show which xsmm call a kernel
@@ -2297,7 +2302,7 @@ void gemm_invoke_common(const char *who, bool want_fused, int64_t dtype, int64_t
   void *pa = (char *)a + off_a * es, *pb = (char *)b + off_b * es, *pc = (char *)c + off_c * es;
   void *pd = dptr ? (char *)dptr + off_d * es : nullptr;
   if (d->bias && !dptr) die("%s: fused bias operand is null", who);
-  hipStream_t s = cfg().stream.load(std::memory_order_relaxed);
+  hipStream_t s = invoke_stream();
   HcScope hcs;
   if (hc_on()) {
     const bool async = cfg().async.load(std::memory_order_relaxed) != 0;
@@ -2359,6 +2364,12 @@ struct ChainBlock {
 //    in launch order before the synchronisation returns: what the caller then reads is what the calls compute from the operands as
 //    they are now. (Work that OTHERS enqueued between a starved launch and the synchronisation has read invalid outputs - the
 //    stderr line says so; the chain contract of include/tpp_xsmm_abi.h asks for the device to oneself for this reason.)
+// Round 6: every journaled launch has its OWN error word (a pool of pinned words), so the check knows WHICH launch
+// starved: only that launch and the later ones of the same stream are re-run (a healthy earlier launch whose inputs have since
+// been overwritten is left alone); the journal is looked at per stream - the one that has just been drained - and the entries of
+// other streams stay; when the pool runs dry the launching thread synchronises and checks instead of dropping entries; the re-run
+// goes to the launch's stream through a thread-local override (the process-wide stream setting is not touched);
+// xsmm_hip_chain_status() counts the repairs, TPP_HIP_CHAIN_STRICT=1 keeps fail-stop.
 struct ChainCall {
   int n;
   int64_t dtype;
@@ -2366,10 +2377,16 @@ struct ChainCall {
   void *a[CH_MAXL], *b[CH_MAXL], *c[CH_MAXL], *d[CH_MAXL];
   int64_t br[CH_MAXL];
   hipStream_t stream;
+  unsigned *err; // this launch's own error word (pinned host memory, from g_chain_err_free)
 };
-std::vector<ChainCall> g_chain_journal; // under g_chain_mu
+std::vector<ChainCall> g_chain_journal; // under g_chain_mu, in launch order
+std::vector<unsigned *> g_chain_err_free; // under g_chain_mu
+constexpr int CHAIN_ERR_POOL = 512;
+std::atomic<int> g_chain_journaled{0};  // entries in the journal (read without the lock: "is the pool about to run dry")
+std::atomic<int64_t> g_chain_repairs{0}; // starved launches found and re-run since process start (xsmm_hip_chain_status)
 std::atomic<bool> g_chain_shared{false}; // a chain launch was starved once: no more chain launches in this process
 std::mutex g_chain_mu;
+
 std::vector<ChainBlock> g_chain_blocks;
 std::atomic<int> g_chain_launched{0}; // chain launches since the last check of the err words
 
@@ -2385,36 +2402,51 @@ ChainBlock &chain_block(hipStream_t s, int tiles_m, int tiles_n, int nlayers) { 
   g_chain_blocks.push_back(b);
   return g_chain_blocks.back();
 }
-// after the stream has been drained: did a hand-off of any chain launch time out?
+// after stream `s` has been drained: did a hand-off of a chain launch on it time out?
 void dump_chain_stamps();
 void chain_rerun_call_by_call(const ChainCall &c);
-void check_chain_errors() {
-  if (!g_chain_launched.exchange(0, std::memory_order_acq_rel)) return;
+void check_chain_errors(hipStream_t s) {
+  if (!g_chain_launched.load(std::memory_order_acquire)) return;
   std::vector<ChainCall> redo;
   unsigned layer = 0;
   {
     std::lock_guard<std::mutex> lk(g_chain_mu);
     dump_chain_stamps();
-    for (ChainBlock &b : g_chain_blocks) {
-      const unsigned e = *(volatile unsigned *)b.err;
-      if (e) {
-        layer = e;
-        *(volatile unsigned *)b.err = 0;
+    std::vector<ChainCall> keep;
+    for (const ChainCall &c : g_chain_journal) {
+      if (c.stream != s) { // another stream's launch: not drained by this synchronisation, stays
+        keep.push_back(c);
+        continue;
       }
+      const unsigned e = *(volatile unsigned *)c.err;
+      if (e && !layer) layer = e;
+      if (layer) redo.push_back(c); // the first starved launch of this stream and every later one (they may have consumed its outputs)
+      *(volatile unsigned *)c.err = 0;
+      g_chain_err_free.push_back(c.err);
     }
-    if (layer) redo.swap(g_chain_journal);
-    g_chain_journal.clear();
+    g_chain_journal.swap(keep);
+    g_chain_journaled.store((int)g_chain_journal.size(), std::memory_order_relaxed);
+    if (g_chain_journal.empty()) g_chain_launched.store(0, std::memory_order_release);
   }
   if (!layer) return;
-  // starved: the device is shared. The journal's calls run again, call by call, in launch order; chains are off from now on.
+  static const bool strict = [] { const char *e = getenv("TPP_HIP_CHAIN_STRICT"); return e && atoi(e) != 0; }();
+  if (strict)
+    die("tpp-xsmm-hip: a fused-brgemm chain launch was starved (a hand-off for layer %u's input timed out: not every workgroup was resident - "
+        "the device is shared) and TPP_HIP_CHAIN_STRICT=1 asks for fail-stop", layer - 1);
+  // starved: the device is shared. The starved launch and the later ones of its stream run again, call by call, in launch order;
+  // chains are off from now on.
   g_chain_shared.store(true, std::memory_order_release);
+  g_chain_repairs.fetch_add((int64_t)redo.size(), std::memory_order_relaxed);
   fprintf(stderr, "[tpp-xsmm-hip] a fused-brgemm chain launch was starved (a hand-off for layer %u's input timed out: not every workgroup "
-                  "was resident - the device is shared); %zu chain call(s) since the last synchronisation are re-run call by call now, and "
-                  "chain invokes run call by call from here on. Work that others enqueued behind a starved launch has read invalid data.\n",
-          layer - 1, redo.size());
+                  "was resident - the device is shared); that launch and the %zu later one(s) of its stream are re-run call by call now "
+                  "(earlier launches completed and are left alone), and chain invokes run call by call from here on "
+                  "(xsmm_hip_chain_status() counts; TPP_HIP_CHAIN_STRICT=1 ends the process instead). Work that others enqueued behind a "
+                  "starved launch has read invalid data.\n",
+          layer - 1, redo.size() - 1);
   for (const ChainCall &c : redo) chain_rerun_call_by_call(c);
-  for (const ChainCall &c : redo) HIP_OK(hipStreamSynchronize(c.stream));
+  HIP_OK(hipStreamSynchronize(s));
 }
+void check_chain_errors() { check_chain_errors(cfg().stream.load()); }
 
 int chip_cus() { // compute units of the current device (0: unknown)
   int dev = 0, n = 0;
@@ -2606,10 +2638,38 @@ bool try_chain_launch(int n, const GemmDesc *const *d, void *const *pa, void *co
   for (int i = 0; i < n; ++i)
     c.L[i] = ChainLayer{pb[i], pd[i], pc[i], d[i]->ldb, d[i]->ldc, d[i]->stride_a, d[i]->stride_b, (int)d[i]->k, (int)br[i],
                         EP_BETA0 | (d[i]->bias ? EP_BIAS : 0) | (d[i]->relu ? EP_RELU : 0), 0};
+  // the pool of error words is about to run dry (hundreds of launches without a synchronisation): synchronise and check here
+  // instead of ever dropping a journal entry
+  if (g_chain_journaled.load(std::memory_order_relaxed) >= CHAIN_ERR_POOL - 8) {
+    std::vector<hipStream_t> streams;
+    {
+      std::lock_guard<std::mutex> lk0(g_chain_mu);
+      for (const ChainCall &j : g_chain_journal)
+        if (std::find(streams.begin(), streams.end(), j.stream) == streams.end()) streams.push_back(j.stream);
+    }
+    for (hipStream_t st : streams) {
+      HIP_OK(hipStreamSynchronize(st));
+      check_chain_errors(st);
+    }
+    if (g_chain_shared.load(std::memory_order_acquire)) return false; // (found a starved launch: call by call from here on)
+  }
   std::lock_guard<std::mutex> lk(g_chain_mu);
   ChainBlock &blk = chain_block(s, (int)(m / bm), (int)(nn / bn), n);
   c.cnt = blk.cnt;
-  c.err = blk.err;
+  c.err = blk.err; // probation launches: the block's word (checked right behind the launch)
+  if (blk.verified >= 1) {
+    if (g_chain_err_free.empty() && g_chain_journal.empty()) { // first use: the pool
+      unsigned *pool = nullptr;
+      HIP_OK(hipHostMalloc((void **)&pool, sizeof(unsigned) * CHAIN_ERR_POOL, hipHostMallocDefault));
+      for (int i = 0; i < CHAIN_ERR_POOL; ++i) {
+        pool[i] = 0;
+        g_chain_err_free.push_back(pool + i);
+      }
+    }
+    if (g_chain_err_free.empty()) return false; // (cannot happen: the check above keeps 8 words spare; call by call is always right)
+    c.err = g_chain_err_free.back();
+    g_chain_err_free.pop_back();
+  }
   c.target = ++blk.epoch * (unsigned)blk.tiles_n;
   c.stamps = chain_stamps((size_t)blk.tiles_m * (size_t)blk.tiles_n);
   if (f32) HIP_OK(launch_f32_chain(tile, c, s));
@@ -2629,40 +2689,35 @@ bool try_chain_launch(int n, const GemmDesc *const *d, void *const *pa, void *co
     ++blk.verified;
     return true;
   }
-  // journal: the calls of this launch, for a re-run should a later check find a starved launch (the last launch per output set)
+  // journal: the calls of this launch with its own error word, for a re-run should the check at the next synchronisation of this
+  // stream find it starved
   {
     ChainCall j;
     j.n = n;
     j.dtype = d[0]->dtype;
     j.stream = s;
+    j.err = c.err;
     for (int i = 0; i < n; ++i) {
       j.handle[i] = reinterpret_cast<int64_t>(d[i]);
       j.a[i] = pa[i]; j.b[i] = pb[i]; j.c[i] = pc[i]; j.d[i] = pd[i]; j.br[i] = br[i];
     }
-    bool replaced = false;
-    for (size_t q = 0; q < g_chain_journal.size() && !replaced; ++q) {
-      ChainCall &o = g_chain_journal[q];
-      bool same_out = o.n == n && o.stream == s;
-      for (int i = 0; i < n && same_out; ++i) same_out = o.c[i] == pc[i];
-      if (same_out) { // the same outputs again: only the later launch matters - it moves to the end (launch order)
-        g_chain_journal.erase(g_chain_journal.begin() + (long)q);
-        replaced = true;
-      }
-    }
     g_chain_journal.push_back(j);
+    g_chain_journaled.store((int)g_chain_journal.size(), std::memory_order_relaxed);
   }
   g_chain_launched.store(1, std::memory_order_release);
-  if (g_chain_journal.size() > 256) g_chain_journal.erase(g_chain_journal.begin()); // (bounded: hundreds of distinct chains between two synchronisations)
   return true;
 }
 
 // the calls of one journaled chain launch, one by one (operands are pointers with offsets applied: offsets 0)
 void chain_rerun_call_by_call(const ChainCall &c) {
-  const hipStream_t cur = cfg().stream.exchange(c.stream); // on the stream the launch went to
+  // on the stream the launch went to - through this thread's override: the process-wide setting is not touched (another thread may
+  // invoke, or call xsmm_hip_set_stream, meanwhile: ADVICE r5)
+  tl_stream_override = c.stream;
+  tl_has_stream_override = true;
   for (int i = 0; i < c.n; ++i)
     xsmm_fused_brgemm_invoke(c.dtype, c.handle[i], c.a[i], 0, c.b[i], 0, c.c[i], 0, c.d[i], 0, c.br[i]);
   flush_tile_queue();
-  cfg().stream.store(cur);
+  tl_has_stream_override = false;
 }
 
 } // namespace
@@ -2920,7 +2975,7 @@ extern "C" void xsmm_hip_set_stream(void *s) {
   // operands may be freed after they return: work enqueued on the stream being left must not outlive that promise
   if (old != (hipStream_t)s && cfg().async.load(std::memory_order_relaxed)) {
     HIP_OK(hipStreamSynchronize(old));
-    check_chain_errors();
+    check_chain_errors(old);
     hc::on_sync_point(old);
   }
 }
@@ -2977,6 +3032,7 @@ extern "C" int xsmm_hip_fused_brgemm_chain_invoke(int64_t dtype, int64_t n, cons
     xsmm_fused_brgemm_invoke(dtype, handles[i], a[i], off_a[i], b[i], off_b[i], c[i], off_c[i], d[i], off_d[i], num_batches[i]);
   return 0;
 }
+extern "C" int64_t xsmm_hip_chain_status(void) { return g_chain_repairs.load(std::memory_order_relaxed); }
 extern "C" void xsmm_hip_tile_queue_stats(int64_t out[5]) {
   out[0] = g_q_launches.load(std::memory_order_relaxed);
   out[1] = g_q_checked.load(std::memory_order_relaxed);

@@ -90,6 +90,7 @@ _SIGNATURES = {
     "xsmm_hip_peer_overlap": (ctypes.c_int, [ctypes.c_int]),
     "xsmm_hip_peer_wait_stream": (VP, []),
     "xsmm_hip_peer_drain": (None, []),
+    "xsmm_hip_chain_status": (ctypes.c_int64, []),
     "xsmm_hip_tile_queue_stats": (None, [ctypes.POINTER(ctypes.c_int64)]),
     "xsmm_hip_get_stream": (VP, []),
     "xsmm_hip_synchronize": (None, []),
@@ -244,6 +245,10 @@ class XsmmRuntime:
         out = (ctypes.c_int64 * 5)()
         self.lib.xsmm_hip_tile_queue_stats(out)
         return tuple(out)
+
+    def chain_status(self):
+        """starved chain launches found and re-run call by call since process start (0: never)"""
+        return int(self.lib.xsmm_hip_chain_status())
 
     def synchronize(self):
         self.lib.xsmm_hip_synchronize()
