@@ -195,6 +195,19 @@ TPP_XSMM_EXPORT int xsmm_hip_fused_brgemm_chain_invoke(int64_t dtype, int64_t n,
                                                        const int64_t *off_a, void *const *b, const int64_t *off_b,
                                                        void *const *c, const int64_t *off_c, void *const *d,
                                                        const int64_t *off_d, const int64_t *num_batches);
+/* STRICT mode (env TPP_HIP_STRICT=1): the kernel an invoke runs on - and with it the order of its floating-point additions - is a
+ * function of its descriptor, its batch count and the alignment of its OWN pointers only (libxsmm's JIT'd kernel is a function of
+ * the dispatch tuple: XsmmRunnerUtils.cpp:288-306). Off (default), the tile queue lets the GROUP choose: tile grids over flat operands
+ * are merged into one launch, transposes are folded into the gemm they feed, the kernel family and the split follow the size of the
+ * queued group - all within the 1e-5 bar, but the same invoke on the same data may return different last bits alone, in the first
+ * pass of a loop and in its replays. On: no grid merge, no folded transposes, every size-dependent choice is taken as for a group of
+ * one, a group holds invokes of one alignment class and one batch count only, single invokes of queue-sized tiles run on the kernel
+ * their group runs on, and a chain call runs as one launch only on the tile its layers were planned on. DETERMINISM: run to run
+ * always (no floating-point atomics anywhere); call to call - alone / first queued pass / replay - under strict mode
+ * (tests/test_strict_gpu.py). Choose the mode before the first queued invoke: returns the previous setting, -1 if the tile queue has
+ * already recorded groups under the other one. */
+TPP_XSMM_EXPORT int xsmm_hip_set_strict(int enable);
+TPP_XSMM_EXPORT int xsmm_hip_get_strict(void);
 /* Sticky status of the chain launches: the number of journaled launches that were found starved at a synchronisation point and
  * re-run call by call since process start (0: never). Round 6: every journaled launch has its own error word, so only the starved
  * launch and the later ones of ITS stream are re-run (healthy earlier launches are left alone), the journal is kept per stream, and

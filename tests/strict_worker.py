@@ -1,0 +1,80 @@
+"""Worker of tests/test_strict_gpu.py (its own process: strict mode is chosen before the first queued invoke). Three programs of the
+reference's benchmark set - the mha projection script (64 x 8 gemm tiles over flat operands: benchmarks/mlir/fp32-projection.mlir), one
+layer of --tiles=64,48,64 (benchmarks/config/matmul/128x768x2304.json) and one 32x32x32 MLP layer with bias + relu
+(benchmarks/config/base/base.json) - each run THREE ways on the same data: single invokes (tile queue off), the first pass of the tile
+queue (the group is collected and recorded), replayed passes. Prints one JSON line: per program, whether the three results are
+bit-identical, and the kernels they ran on."""
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("tpp-mlir_amd")
+rt = pkg.get_runtime()
+F32 = 1
+rng = np.random.default_rng(3)
+
+
+def dev(n):
+    return torch.from_numpy(rng.uniform(-1, 1, n).astype(np.float32)).cuda()
+
+
+def projection():
+    A, B = dev(2048 * 512), dev(512 * 512)
+    h = rt.gemm_dispatch(F32, 32, 64, 512, 512, 512, 512, 4)
+
+    def run(C):
+        for r in range(64):
+            for c in range(8):
+                rt.gemm(F32, h, A, r * 32 * 512, B, c * 64, C, r * 32 * 512 + c * 64)
+    return run, 2048 * 512
+
+
+def layer_64_48_64():
+    M, N, K, tm, tn, tk = 128, 768, 2304, 64, 48, 64
+    MB, NB, KB = M // tm, N // tn, K // tk
+    A, W = dev(M * K), dev(K * N)
+    h = rt.brgemm_dispatch(F32, tm, tn, tk, tk, tn, tn, tm * tk, tk * tn, 4)
+
+    def run(C):
+        for i in range(MB):
+            for j in range(NB):
+                rt.brgemm(F32, h, A, i * KB * tm * tk, W, j * KB * tk * tn, C, (i * NB + j) * tm * tn, KB)
+    return run, M * N
+
+
+def mlp_layer_32():
+    M, N, K, t = 256, 1024, 1024, 32
+    MB, NB, KB = M // t, N // t, K // t
+    A, W, bias = dev(M * K), dev(K * N), dev(N)
+    h = rt.fused_brgemm_dispatch(F32, t, t, t, t, t, t, t * t, t * t, 4, 0, 5, 4, 1)
+
+    def run(C):
+        for i in range(MB):
+            for j in range(NB):
+                rt.fused_brgemm(F32, h, A, i * KB * t * t, W, j * KB * t * t, C, (i * NB + j) * t * t, bias, j * t, KB)
+    return run, M * N
+
+
+out = {"strict": rt.get_strict()}
+rt.set_async(True)
+for name, make in (("projection", projection), ("layer_64_48_64", layer_64_48_64), ("mlp_layer_32", mlp_layer_32)):
+    run, n_out = make()
+    results, kernels = [], []
+    for way in ("single", "queued_first", "replay_1", "replay_2"):
+        rt.set_tile_queue(0 if way == "single" else 1)
+        C = torch.full((n_out,), float("nan"), device="cuda")
+        run(C)
+        rt.synchronize()
+        results.append(C.cpu().numpy().view(np.uint32).copy())
+        kernels.append(rt.last_grouped_kernel() if way != "single" else "single")
+    rt.set_tile_queue(0)
+    out[name] = {"identical": bool(all(np.array_equal(results[0], r) for r in results[1:])),
+                 "differing_elements": [int((results[0] != r).sum()) for r in results[1:]],
+                 "finite": bool(np.isfinite(results[0].view(np.float32)).all()), "kernels": kernels}
+print(json.dumps(out), flush=True)

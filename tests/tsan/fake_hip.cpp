@@ -132,6 +132,9 @@ void blw_tile_dims(int, int *bm, int *bn) { *bm = *bn = 128; }
 hipError_t launch_bf16_chain(int, int, const ChainArgs &, hipStream_t) { return hipErrorNotSupported; }
 int f32_chain_tile(const GemmDesc &) { return -1; }
 int force_gemm_split(int) { return -1; }
+static bool g_fake_strict = false;
+int set_strict_kernels(int on) { const int prev = g_fake_strict; g_fake_strict = on != 0; return prev; }
+bool strict_kernels() { return g_fake_strict; }
 bool f32_chain_tile_dims(int, int *bm, int *bn) { *bm = *bn = 64; return false; }
 hipError_t launch_f32_chain(int, const ChainArgs &, hipStream_t) { return hipErrorNotSupported; }
 const char *last_grouped_kernel() { return "fake_host_gemm"; }

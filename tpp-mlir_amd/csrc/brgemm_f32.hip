@@ -798,6 +798,9 @@ static std::atomic<int> g_forced_split{[] {
   return e ? atoi(e) : -1;
 }()};
 int force_gemm_split(int v) { return g_forced_split.exchange(v < -1 ? -1 : v); }
+static std::atomic<int> g_strict_kernels{0};
+int set_strict_kernels(int on) { return g_strict_kernels.exchange(on != 0); }
+bool strict_kernels() { return g_strict_kernels.load(std::memory_order_relaxed) != 0; }
 static int choose_f32_split(int tile, long long tiles, long long chunks) {
   const int forced = g_forced_split.load(std::memory_order_relaxed);
   if (tile < 1 || tile > 3 || tiles <= 0 || chunks < 2) return 1;
@@ -858,6 +861,9 @@ const char *last_refined_kernel() { return g_last_refined.load(std::memory_order
 hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_items, bool vec_ok, bool out_ok, bool pair_ok,
                                int64_t br_hint, hipStream_t stream) {
   if (d.m <= 0 || d.n <= 0 || n_items <= 0) return hipSuccess;
+  // n_dec: the number of items every size-dependent DECISION below is taken for. Normally the group's - the group is what fills the
+  // chip. In strict mode 1: a single invoke, the first pass of a queued group and its replays then all run on the same kernel.
+  const int64_t n_dec = strict_kernels() ? 1 : n_items;
   GemmArgs a;
   a.A = a.B = a.D = nullptr; a.C = nullptr;
   a.lda = d.lda; a.ldb = d.ldb; a.ldc = d.ldc; a.stride_a = d.stride_a; a.stride_b = d.stride_b;
@@ -888,7 +894,7 @@ hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_i
   // what tools/queue_fuzz.py checks bit for bit)
   {
     const int l16_tile = 0;
-    const int64_t t16 = (d.m % 32 == 0 && d.n % 16 == 0) ? (int64_t)n_items * (d.m / 32) * (d.n / 16) : 0;
+    const int64_t t16 = (d.m % 32 == 0 && d.n % 16 == 0) ? n_dec * (d.m / 32) * (d.n / 16) : 0;
     const bool k_ok = (d.k % BK == 0 && d.k > 0) || (k_pairs && d.n % 32 != 0);
     static const char *const l16_names[1][2] = {{"brgemm_f32_lw16<32x16,k4> grouped", "brgemm_f32_lw16<32x16,k4> grouped, 32-k pairs"}};
     if (vec && out_ok && lw16_on() && !d.generic_forced && t16 > 0 && t16 <= g_num_cus && k_ok && d.ldc % 4 == 0 && n_items <= 65535 && d.lda < (1 << 22) &&
@@ -900,8 +906,8 @@ hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_i
   const bool fam_ok = n_ragged ? (!d.generic_forced && d.n > 32 && (d.k % BK == 0 || k_pairs)) // (plan_gemm knows no tile for such an n: variant = generic)
                                : ((d.k % BK == 0 && d.variant != V_GENERIC) || (k_pairs && !d.generic_forced));
   if (vec && d.m % 32 == 0 && fam_ok && d.lda < (1 << 22) && d.ldb < (1 << 22) && d.ldc < (1 << 22)) {
-    const int64_t t64 = (d.m % 64 == 0 && d.n % 64 == 0) ? (int64_t)n_items * (d.m / 64) * (d.n / 64) : 0;
-    const int64_t t6432 = (d.m % 64 == 0) ? (int64_t)n_items * (d.m / 64) * ((d.n + 31) / 32) : 0;
+    const int64_t t64 = (d.m % 64 == 0 && d.n % 64 == 0) ? n_dec * (d.m / 64) * (d.n / 64) : 0;
+    const int64_t t6432 = (d.m % 64 == 0) ? n_dec * (d.m / 64) * ((d.n + 31) / 32) : 0;
     if (n_items <= 65535 * 2) { // grid.x carries the item index (x split)
       auto nm = [&](const char *plain, const char *pairs) { return d.k == 32 ? pairs : plain; };
       (void)nm;
@@ -912,7 +918,7 @@ hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_i
       return note_grouped("brgemm_f32_fast<32x32,k4> grouped", launch_fast_grouped_t<1, 1, 4, TPP_NACC, false>(a, items, n_items, stream));
 #else
       if (t64 >= g_num_cus) return note_grouped(t64 >= 2 * g_num_cus ? nm("brgemm_f32_lw<64x64> grouped", "brgemm_f32_lw<64x64> grouped, 32-k pairs") : nm("brgemm_f32_lw<64x64,k2> grouped", "brgemm_f32_lw<64x64,k2> grouped, 32-k pairs"), launch_f32_lw_grouped(t64 >= 2 * g_num_cus ? 0 : 1, a, items, n_items, 1, stream));
-      const int64_t t32 = (int64_t)n_items * (d.m / 32) * ((d.n + 31) / 32);
+      const int64_t t32 = n_dec * (d.m / 32) * ((d.n + 31) / 32);
       // (rounds of workgroups x per-chunk time, as pick_f32_variant: 1.5 rounds of 64x32 tiles lose to 3 half-rounds of 32x32 tiles)
       if (t6432 >= g_num_cus && !(0.23 * 1.05 * (double)((t32 + g_num_cus - 1) / g_num_cus) < 0.46 * (double)((t6432 + g_num_cus - 1) / g_num_cus)))
         return note_grouped(nm("brgemm_f32_lw<64x32,k4> grouped", "brgemm_f32_lw<64x32,k4> grouped, 32-k pairs"), launch_f32_lw_grouped(2, a, items, n_items, 1, stream));
@@ -937,12 +943,12 @@ hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_i
   // what fills the chip: round 5, the reference's fc / matmul shapes as 64,64,64 tile invokes: 1024 x 2560 x 1024 30.4 us on 32x32
   // tiles against 15 us whole-layer)
   if (vec16 && out_ok && d.variant >= V_BF16_FAST && (d.variant != V_BF16_SMALL32 || !d.variant_forced) && !d.generic_forced && bf16_fast_eligible(d) &&
-      (int64_t)n_items * (d.m / 64) * (d.n / 64) >= (3 * g_num_cus) / 4)
+      n_dec * (d.m / 64) * (d.n / 64) >= (3 * g_num_cus) / 4)
     return note_grouped("brgemm_bf16_fast<64x64> grouped", launch_bf16_grouped64(a, items, n_items, stream));
   // ... and the same family on a VNNI-4 B operand (--vnni=4 tile invokes: benchmarks/config/*/*_dp4_*; the generic kernel's MFMA path
   // took 30 us for 1024 x 2560 x 1024 against 19.5 on VNNI-2)
   if (vec16_4 && out_ok && !d.generic_forced && !d.vnni_c && d.k % BK == 0 && d.m % 64 == 0 && d.n % 64 == 0 && !((d.ldc | d.stride_b) & 7) && d.ldc < (1 << 22) &&
-      d.lda < (1 << 22) && d.ldb < (1 << 20) && (int64_t)n_items * (d.m / 64) * (d.n / 64) >= (3 * g_num_cus) / 4)
+      d.lda < (1 << 22) && d.ldb < (1 << 20) && n_dec * (d.m / 64) * (d.n / 64) >= (3 * g_num_cus) / 4)
     return note_grouped("brgemm_bf16_fast_vnni4<64x64> grouped", launch_bf16_grouped64(a, items, n_items, stream));
   // (VNNI-4 tile invokes - the compiler-native 32x32x32 tiles of a --vnni=4 pipeline, small groups of 64x64x64 tiles - on the same
   // kernel: its B fragment is then two 8-byte loads; a single invoke of such a handle stays on the generic kernel's MFMA path.
@@ -957,7 +963,7 @@ hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_i
     // a CU to itself - 128 x 1024 x 4096 as 64x64x64 tile invokes 12.0 -> 9.8 us at S = 2 (10.3 at 4, 13.1 at 8), 256 x 1024 x 4096
     // 12.3 -> 14.2 at S = 2. Hence the largest count with tiles x S <= CUs and at least 32 steps per workgroup, if it saves more
     // than the hand-off costs. xsmm_hip_force_split overrides.
-    const long long t32 = (long long)n_items * (d.m / 32) * ((d.n + 31) / 32), steps = (long long)br_hint * (d.k / 16);
+    const long long t32 = (long long)n_dec * (d.m / 32) * ((d.n + 31) / 32), steps = (long long)br_hint * (d.k / 16);
     int S = 1;
     const int forced = g_forced_split.load(std::memory_order_relaxed);
     if (forced >= 0) S = forced <= 1 ? 1 : (int)(forced < 16 ? forced : 16);

@@ -71,7 +71,17 @@ struct Config {
   std::atomic<int> vnni_factor{2}; // blocking factor of VNNI B operands dispatched from now on (xsmm_hip_set_vnni_factor / TPP_HIP_VNNI_FACTOR)
   int trace = 0; // TPP_HIP_TRACE: 1 = one stderr line per dispatch + a roctx range per invoke, 2 = also one stderr line per invoke
   std::atomic<int> fold_transpose{1}; // TPP_HIP_FOLD_TRANSPOSE / xsmm_hip_set_fold_transpose: transposes that feed a gemm's B operand are folded into it
+  // TPP_HIP_STRICT / xsmm_hip_set_strict (round 6): the kernel an invoke runs on is a function of its descriptor,
+  // batch count and own pointer alignment only - no grid merge, no folded transposes, no kernel family chosen by the size of the
+  // queued group, groups of one alignment class and one batch count only. The same invoke on the same data then returns the same
+  // bits whether it runs alone, in the first pass of a queued group or in a replay (libxsmm's JIT'd kernel is a function of the
+  // dispatch tuple: XsmmRunnerUtils.cpp:288-306).
+  std::atomic<int> strict{0};
   Config() {
+    if (const char *e = getenv("TPP_HIP_STRICT")) {
+      strict = atoi(e) != 0;
+      tpp::set_strict_kernels(strict.load());
+    }
     if (const char *e = getenv("TPP_HIP_FOLD_TRANSPOSE")) fold_transpose = atoi(e) != 0;
     if (const char *e = getenv("TPP_HIP_ASYNC")) async = atoi(e) != 0;
     if (const char *e = getenv("TPP_HIP_TRACE")) trace = atoi(e);
@@ -883,7 +893,7 @@ static bool grid_merge_on() {
     const char *e = getenv("TPP_HIP_GRID_MERGE");
     return !e || atoi(e) != 0;
   }();
-  return on;
+  return on && !cfg().strict.load(std::memory_order_relaxed); // (a merged grid sums in the merged problem's order: not in strict mode)
 }
 std::atomic<const char *> g_last_merged{nullptr}; // trace text of the merged descriptor if the most recent group launch was a merged one
 inline void detect_grid(Segment &S) {
@@ -1325,7 +1335,12 @@ __attribute__((always_inline)) inline void process_item(TileQueue &q, DeviceRang
   const Operand &out = o.op[o.out];
   const uintptr_t anchor_out = anchor(out);
   const int kind = *(const int *)desc;
-  if (conflicts_with_group(q, kind, desc, out, anchor_out, in, anchor_in, o.n_in, stream)) {
+  // strict mode: a group holds invokes of ONE alignment class and ONE batch count - the grouped launch takes its operand path from
+  // the AND of the members' alignment flags and its chunk count from the first member, so a mixed group would make a member's kernel
+  // depend on its neighbours
+  const bool strict_break = q.n > 0 && kind == KIND_GEMM && q.kind == KIND_GEMM && cfg().strict.load(std::memory_order_relaxed) &&
+                            (o.vec_ok != q.vec_ok || o.out_ok != q.out_ok || o.pair_ok != q.pair_ok || w.br != q.pinned[q.slot][0].br);
+  if (strict_break || conflicts_with_group(q, kind, desc, out, anchor_out, in, anchor_in, o.n_in, stream)) {
     const TraceItem term{desc, w, stream};
     q.flush(&term);
     if (try_start_replay(q, devmem, desc, w, stream)) return; // the group this invoke starts has been collected before
@@ -2194,7 +2209,7 @@ void dt_other(const void *const *reads, const size_t *read_bytes, int nr, const 
 }
 // a transpose invoke: true = remembered (nothing launched)
 bool dt_defer(const UnaryDesc *d, void *pi, void *po, hipStream_t s) {
-  if (d->dtype != DT_F32 || d->m > 64 || d->n > 64 || d->ldo != d->m || !cfg().fold_transpose.load(std::memory_order_relaxed) || !queue_active()) return false;
+  if (d->dtype != DT_F32 || d->m > 64 || d->n > 64 || d->ldo != d->m || !cfg().fold_transpose.load(std::memory_order_relaxed) || cfg().strict.load(std::memory_order_relaxed) || !queue_active()) return false;
   DeviceRanges &devmem = caller_state().devmem;
   if (devmem.refresh()) check_queue_device();
   if (!devmem.is_device(pi, 0) || !devmem.is_device(po, 1)) return false;
@@ -2239,6 +2254,28 @@ bool dt_defer(const UnaryDesc *d, void *pi, void *po, hipStream_t s) {
   mine->live.store(1, std::memory_order_release);
   return true;
 }
+
+// ---- strict mode: single invokes of queue-sized tiles run on the grouped launcher with a work list of ONE item. The kernels read
+// their item from device-visible memory: a per-thread ring of pinned (device-mapped) items, like the tile queue's lists; the stream
+// is drained once per lap of the ring, so a slot is never rewritten while a launch may still read it.
+struct StrictRing {
+  static constexpr int N = 1024;
+  WorkItem *items = nullptr;
+  int next = 0;
+  ~StrictRing() {
+    if (items) (void)hipHostFree(items);
+  }
+};
+WorkItem *strict_item_slot(hipStream_t s) {
+  thread_local StrictRing r;
+  if (!r.items) HIP_OK(hipHostMalloc((void **)&r.items, sizeof(WorkItem) * StrictRing::N, hipHostMallocDefault));
+  if (r.next == StrictRing::N) {
+    HIP_OK(hipStreamSynchronize(s));
+    r.next = 0;
+  }
+  return &r.items[r.next++];
+}
+void strict_item_done(hipStream_t) {}
 
 // ---- host cache (round 6, host_cache.h): host operands translated to device mirrors that outlive the invoke ---------------------
 // One scope per ABI invoke: the constructor translates the host operands (their pointers are REPLACED by mirror addresses, so the
@@ -2335,7 +2372,18 @@ void gemm_invoke_common(const char *who, bool want_fused, int64_t dtype, int64_t
   C.read = !d->beta0; // pure output under BETA_0: never uploaded
   std::vector<Operand *> ops = {&A, &B, &C, &D};
   stage_in(ops, s);
-  HIP_OK(launch_gemm(*d, A.dev, B.dev, C.dev, D.dev, br, s));
+  if (cfg().strict.load(std::memory_order_relaxed) && d->m <= 64 && d->n <= 64) {
+    // strict mode: a tile the queue would take runs on the kernel its group runs on - the grouped launcher with a work list of one
+    // (launch_gemm_grouped decides as if every list held one item: xsmm_desc.h strict_kernels)
+    const WorkItem one{A.dev, B.dev, C.dev, D.dev, br};
+    WorkItem *slot = strict_item_slot(s);
+    *slot = one;
+    HIP_OK(launch_gemm_grouped(*d, slot, 1, ((((uintptr_t)A.dev) | ((uintptr_t)B.dev)) & 15) == 0,
+                               (((uintptr_t)C.dev) & 15) == 0 && (((uintptr_t)D.dev) & 7) == 0, !(br & 1), br, s));
+    strict_item_done(s);
+  } else {
+    HIP_OK(launch_gemm(*d, A.dev, B.dev, C.dev, D.dev, br, s));
+  }
   finish(ops, s);
 }
 
@@ -2599,6 +2647,7 @@ bool try_chain_launch(int n, const GemmDesc *const *d, void *const *pa, void *co
   for (int i = 1; i < n && same; ++i) same = d[i]->variant == d[0]->variant;
   if (f32) tile = f32_tile;
   if (same && fits(planned)) tile = planned;
+  if (tile < 0 && cfg().strict.load(std::memory_order_relaxed)) NOCHAIN("strict mode: one launch only on the tile the layers were planned on");
   for (int t = 0; t < 4 && tile < 0; ++t)
     if (fits(t)) tile = t;
   if (tile < 0) NOCHAIN("more tiles than compute units");
@@ -3119,6 +3168,28 @@ extern "C" const char *xsmm_hip_last_grouped_kernel(void) {
 }
 extern "C" const char *xsmm_hip_last_refined_kernel(void) { return last_refined_kernel(); }
 extern "C" void xsmm_hip_force_variant(int v) { cfg().forced_variant.store(v); }
+// strict mode (see Config::strict). Meant to be chosen before the first invoke (TPP_HIP_STRICT=1): groups recorded by the tile queue's
+// trace cache under the other setting would replay on the kernel they were recorded for - a change after the queue has recorded
+// a group is refused (-1).
+extern "C" int xsmm_hip_set_strict(int enable) {
+  flush_tile_queue();
+  const int prev = cfg().strict.load();
+  if ((enable != 0) == (prev != 0)) return prev;
+  {
+    InlineQueue &iq = inl();
+    iq.dw.touch(thread_token());
+    std::lock_guard<SpinLock> lk(iq.mu);
+    if (!iq.q.segs.empty()) {
+      fprintf(stderr, "[tpp-xsmm-hip] xsmm_hip_set_strict(%d) refused: the tile queue has recorded groups under the other setting (choose the mode "
+                      "before the first queued invoke, or with TPP_HIP_STRICT)\n", enable);
+      return -1;
+    }
+    cfg().strict.store(enable != 0);
+    tpp::set_strict_kernels(enable != 0);
+  }
+  return prev;
+}
+extern "C" int xsmm_hip_get_strict(void) { return cfg().strict.load(); }
 extern "C" int xsmm_hip_set_fold_transpose(int enable) {
   flush_tile_queue(); // (launches a remembered transpose)
   return cfg().fold_transpose.exchange(enable != 0);

@@ -72,6 +72,11 @@ hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C,
 hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_items, bool vec_ok, bool out_ok, bool pair_ok,
                                int64_t br_hint, hipStream_t stream);
 int force_gemm_split(int workgroups_per_tile); // xsmm_hip_force_split (brgemm_f32.hip); returns the previous setting
+// STRICT mode (round 6; xsmm_hip_set_strict / TPP_HIP_STRICT=1): the kernel an invoke runs on - and with it the order of its additions -
+// is a function of its descriptor, its batch count and its own pointers' alignment only, never of the group it is queued with.
+// launch_gemm_grouped then takes every decision that depends on the size of the work list as if the list held ONE item.
+int set_strict_kernels(int on); // returns the previous setting
+bool strict_kernels();
 int f32_chain_tile(const GemmDesc &d); // 1 / 2 / 3 = the f32 chain tile the descriptor was planned on, -1 = none (brgemm_f32.hip)
 const char *last_grouped_kernel(); // kernel family of the most recent launch_gemm_grouped ("" before the first)
 const char *last_refined_kernel(); // most recent launch_gemm: the kernel an invoke-time refinement chose, "" = the descriptor's own

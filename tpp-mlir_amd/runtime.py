@@ -91,6 +91,8 @@ _SIGNATURES = {
     "xsmm_hip_peer_wait_stream": (VP, []),
     "xsmm_hip_peer_drain": (None, []),
     "xsmm_hip_chain_status": (ctypes.c_int64, []),
+    "xsmm_hip_set_strict": (ctypes.c_int, [ctypes.c_int]),
+    "xsmm_hip_get_strict": (ctypes.c_int, []),
     "xsmm_hip_tile_queue_stats": (None, [ctypes.POINTER(ctypes.c_int64)]),
     "xsmm_hip_get_stream": (VP, []),
     "xsmm_hip_synchronize": (None, []),
@@ -245,6 +247,13 @@ class XsmmRuntime:
         out = (ctypes.c_int64 * 5)()
         self.lib.xsmm_hip_tile_queue_stats(out)
         return tuple(out)
+
+    def set_strict(self, on):
+        """strict mode: kernel choice by descriptor + batch count only (include/tpp_xsmm_abi.h); -1 if refused"""
+        return self.lib.xsmm_hip_set_strict(1 if on else 0)
+
+    def get_strict(self):
+        return self.lib.xsmm_hip_get_strict()
 
     def chain_status(self):
         """starved chain launches found and re-run call by call since process start (0: never)"""
