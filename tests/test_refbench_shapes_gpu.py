@@ -287,8 +287,10 @@ def test_bf16_split_groups_through_the_tile_queue(rt, forced):
                     rt.brgemm(BF16, h, dA, i * KB * t * t, dW, j * KB * t * t, dC, (i * NB + j) * t * t, KB)
             rt.synchronize()
             outs.append(host(dC, ref))
-            # (the model's own choice - forced == -1 - is not to split this one: 128 steps per tile save 3.0 us, the hand-off costs 3.5)
-            assert ("small32 grouped, split" if forced > 1 else "small32 grouped") in rt.last_grouped_kernel(), rt.last_grouped_kernel()
+            # (the model's own choice - forced == -1 - is the grouped loader-wave tile since round 6: 32 chunks per tile; a forced count
+            # keeps the group on the K-split kernel)
+            want = "brgemm_bf16_lw<32x64,k2> grouped" if forced < 0 else ("small32 grouped, split" if forced > 1 else "small32 grouped")
+            assert want in rt.last_grouped_kernel(), rt.last_grouped_kernel()
     finally:
         rt.force_split(-1)
         rt.set_tile_queue(old_q)

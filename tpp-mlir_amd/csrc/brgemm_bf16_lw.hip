@@ -133,8 +133,10 @@ template <int PPL> __device__ __forceinline__ void blw_wait_younger(int younger)
 // The steady-state loop is a literal s_waitcnt + s_barrier + the DMA instructions + ~10 scalar instructions: measured on the
 // first version of this function (one general loop with a switch over the wait count, the layer bookkeeping and an argument load
 // inside), a 16-chunk layer took 5.7 us with NO loads and NO MFMAs at all - the loader's own instruction stream set the pace.
-template <bool IS_A, int NL, int NLA, int NSLOT_C, int SUP, int BM, int BN, int WK, bool MULTI, int FB = 0>
-__device__ __forceinline__ void blw_loader(chain_kernarg_t *pp, unsigned char *smem, int lane, int m0, int n0, int tm, int L, int part) {
+// GRP (grouped launches): the panel base pointers and the batch count are the ITEM's (it_A / it_B / it_br), not the argument block's
+template <bool IS_A, int NL, int NLA, int NSLOT_C, int SUP, int BM, int BN, int WK, bool MULTI, int FB = 0, bool GRP = false>
+__device__ __forceinline__ void blw_loader(chain_kernarg_t *pp, unsigned char *smem, int lane, int m0, int n0, int tm, int L, int part,
+                                           const void *it_A = nullptr, const void *it_B = nullptr, int it_br = 0) {
   chain_kernarg_t &p = *pp;
   constexpr int A_SLOT = BM * 128, SLOT = (BM + BN) * 128;
   // SUP = chunks per barrier (the unit everything below counts in: a "chunk" of this function is SUP 64-k chunks, a "slot" SUP
@@ -178,7 +180,7 @@ __device__ __forceinline__ void blw_loader(chain_kernarg_t *pp, unsigned char *s
     kc = 0;                                                                                                            \
     if (IS_A) {                                                                                                        \
       const int64_t lda_ = (l) == 0 ? p.lda : p.L[(l) > 0 ? (l)-1 : 0].ldc;                                            \
-      const unsigned short *A_ = (const unsigned short *)((l) == 0 ? p.A : p.L[(l) > 0 ? (l)-1 : 0].C);                \
+      const unsigned short *A_ = (const unsigned short *)(GRP ? it_A : (l) == 0 ? p.A : p.L[(l) > 0 ? (l)-1 : 0].C);    \
       g = A_ + (int64_t)(m0 + 8 * part) * lda_;                                                                        \
       d_in = BLW_BK;                                                                                                   \
       d_wrap = p.L[l].stride_a - (int64_t)(kchunks - 1) * BLW_BK;                                                      \
@@ -194,7 +196,7 @@ __device__ __forceinline__ void blw_loader(chain_kernarg_t *pp, unsigned char *s
       /* covers rows (512/BN)*v ..: lane -> row lane / (BN/8), 16-byte piece lane % (BN/8); the 64-byte blocks of a row are */ \
       /* XOR-swizzled with the row (BN = 128: row & 3, BN = 64: (row >> 1) & 1) on the SOURCE side, like the A panel */ \
       constexpr int RPT_ = 512 / BN, PPR_ = BN / 8;                                                                    \
-      g = (const unsigned short *)p.L[l].B + n0 + (int64_t)part * RPT_ * p.L[l].ldb;                                   \
+      g = (const unsigned short *)(GRP ? it_B : p.L[l].B) + n0 + (int64_t)part * RPT_ * p.L[l].ldb;                    \
       d_in = (int64_t)BLW_BK * p.L[l].ldb;                                                                             \
       d_wrap = p.L[l].stride_b - (int64_t)(kchunks - 1) * d_in;                                                        \
       const int row_ = lane / PPR_, piece_ = lane % PPR_;                                                              \
@@ -205,13 +207,13 @@ __device__ __forceinline__ void blw_loader(chain_kernarg_t *pp, unsigned char *s
       /* VNNI-4 B ([k/4][ldb][4]): image = the chunk's 16 k-group rows of BN * 8 bytes as they are; instruction v covers */ \
       /* k-group rows (128/BN)*v ..: lane -> row lane / (BN/2), 16-byte piece lane % (BN/2). A fragment is two 8-byte reads. */ \
       constexpr int RPI4_ = 128 / BN, PPR4_ = BN / 2;                                                                  \
-      g = (const unsigned short *)p.L[l].B + 4 * (int64_t)n0 + (int64_t)part * RPI4_ * 4 * p.L[l].ldb;                 \
+      g = (const unsigned short *)(GRP ? it_B : p.L[l].B) + 4 * (int64_t)n0 + (int64_t)part * RPI4_ * 4 * p.L[l].ldb;  \
       d_in = (int64_t)BLW_BK * p.L[l].ldb;                                                                             \
       d_wrap = p.L[l].stride_b - (int64_t)(kchunks - 1) * d_in;                                                        \
       vo0 = vo1 = (unsigned)((lane / PPR4_) * (int)p.L[l].ldb * 8 + ((lane % PPR4_) << 4));                            \
       step = (unsigned)(NL * RPI4_ * (int)p.L[l].ldb * 8);                                                             \
     } else {                                                                                                           \
-      g = (const unsigned short *)p.L[l].B + 2 * (int64_t)n0 + (int64_t)part * RPI * 2 * p.L[l].ldb;                   \
+      g = (const unsigned short *)(GRP ? it_B : p.L[l].B) + 2 * (int64_t)n0 + (int64_t)part * RPI * 2 * p.L[l].ldb;    \
       d_in = (int64_t)(BLW_BK / 2) * 2 * p.L[l].ldb;                                                                   \
       d_wrap = p.L[l].stride_b - (int64_t)(kchunks - 1) * d_in;                                                        \
       /* instruction v covers pair-rows RPI*v ..: lane -> pair-row lane / (BN/4), 16-byte piece lane % (BN/4) */       \
@@ -250,7 +252,7 @@ __device__ __forceinline__ void blw_loader(chain_kernarg_t *pp, unsigned char *s
   const bool poller = MULTI && IS_A && part == 0;
   int slot = 0, s0 = 0; // next ring slot to fill; slot of the current layer's chunk 0 (the layers follow each other through the ring)
   for (int lc = 0; lc < L; ++lc) {
-    const int T = p.L[lc].br * (p.L[lc].k / BLW_BK) / SUP; // (a multiple of SUP: the launcher picks SUP = 1 otherwise)
+    const int T = (GRP ? it_br : p.L[lc].br) * (p.L[lc].k / BLW_BK) / SUP; // (a multiple of SUP: the launcher picks SUP = 1 otherwise)
     int pre = NSLOT - 2; // chunks of this layer already requested by the run-ahead of the previous layer's tail
     if (state_layer != lc) {
       BLW_LOAD_STATE(lc);
@@ -336,8 +338,9 @@ __device__ __forceinline__ void blw_loader(chain_kernarg_t *pp, unsigned char *s
 #undef BLW_LOAD_STATE
 }
 
-template <int WM, int WN, int WK, int TM, int TN, int NSLOT, int NLA, int NLB, int SUP, bool MULTI, int FLATB = 0>
+template <int WM, int WN, int WK, int TM, int TN, int NSLOT, int NLA, int NLB, int SUP, bool MULTI, int FLATB = 0, bool GRP = false>
 __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_lw(ChainArgs p_by_value) {
+  static_assert(!GRP || !MULTI, "a grouped launch is a set of single layers");
   chain_kernarg_t *pp = (chain_kernarg_t *)__builtin_amdgcn_kernarg_segment_ptr(); // = &p_by_value (the only explicit argument)
   chain_kernarg_t &p = *pp;
   constexpr int NMW = WM * WN * WK, NOUT = WM * WN; // MFMA waves; waves that own output
@@ -375,7 +378,27 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
   // eight L2s pull together, xn * |A| + xm * |W|: a 512-row layer on 8 x 1 makes every L2 fetch ALL of W)
   const int b = (int)blockIdx.x;
   int tm, tn;
-  if (p.xm > 0) {
+  // GRP: workgroup b = tile (b % item_subs) of item b / item_subs; the item's operands replace the argument block's (uniform values:
+  // read through the scalar unit's view of the list)
+  [[maybe_unused]] const void *it_A = nullptr, *it_B = nullptr, *it_D = nullptr;
+  [[maybe_unused]] void *it_C = nullptr;
+  [[maybe_unused]] int it_br = 0;
+  if constexpr (GRP) {
+    // (plain order: workgroup b = the b-th tile of the list. Handing XCD x the x-th EIGHTH of the list - contiguous block rows of the
+    // layer - was measured and is WORSE for the reference's shapes, 1024 x 2560 x 1024 15.0 -> 18.1 us: with row-major items and a
+    // column count that is a multiple of 8 the plain order already gives every XCD its own eighth of the COLUMNS, i.e. of W, the
+    // larger operand; profiles/r06_bf16_grouped_lw.txt)
+    const int item = b / p.item_subs, sub = b - item * p.item_subs;
+    tm = sub / p.tiles_n;
+    tn = sub - tm * p.tiles_n;
+    typedef const __attribute__((address_space(4))) WorkItem item_c_t;
+    item_c_t &w = ((item_c_t *)p.items)[item];
+    it_A = w.A;
+    it_B = w.B;
+    it_C = w.C;
+    it_D = w.D;
+    it_br = (int)w.br;
+  } else if (p.xm > 0) {
     const int xn = 8 / p.xm, xcd = b & 7, j = b >> 3;
     const int lm = p.tiles_m / p.xm, ln = p.tiles_n / xn; // tiles per XCD
     tm = (xcd / xn) * lm + j / ln;
@@ -396,8 +419,8 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
 
   if (wave >= NMW) {
     // ---- loader waves (blw_loader above) ---------------------------------------------------------------------------
-    if (wave < NMW + NLA) blw_loader<true, NLA, NLA, NSLOT, SUP, BM, BN, WK, MULTI>(pp, smem_c, lane, m0_ld, n0_ld, tm, L, wave - NMW);
-    else blw_loader<false, NLB, NLA, NSLOT, SUP, BM, BN, WK, MULTI, FLATB>(pp, smem_c, lane, m0_ld, n0_ld, tm, L, wave - NMW - NLA);
+    if (wave < NMW + NLA) blw_loader<true, NLA, NLA, NSLOT, SUP, BM, BN, WK, MULTI, 0, GRP>(pp, smem_c, lane, m0_ld, n0_ld, tm, L, wave - NMW, it_A, it_B, it_br);
+    else blw_loader<false, NLB, NLA, NSLOT, SUP, BM, BN, WK, MULTI, FLATB, GRP>(pp, smem_c, lane, m0_ld, n0_ld, tm, L, wave - NMW - NLA, it_A, it_B, it_br);
     return; // ended waves do not take part in later barriers
   }
 
@@ -576,9 +599,9 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
   int s0 = 0; // ring slot of the current layer's chunk 0
   for (int l = 0; l < L; ++l) {
     const auto &Y = p.L[l];
-    const int T = Y.br * (Y.k / BLW_BK);
+    const int T = (GRP ? it_br : Y.br) * (Y.k / BLW_BK);
     const int ep = Y.ep;
-    unsigned short *__restrict__ C = (unsigned short *)Y.C;
+    unsigned short *__restrict__ C = (unsigned short *)(GRP ? it_C : Y.C);
     const unsigned ldcb = (unsigned)((int)Y.ldc * 2);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -593,7 +616,7 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         biasw[j][g] = u32x2_lw{0u, 0u};
-        if (ep & EP_BIAS) biasw[j][g] = *(const u32x2_lw *)((const unsigned short *)Y.D + n0 + (wn * TN + j) * 32 + 8 * g + 4 * lh);
+        if (ep & EP_BIAS) biasw[j][g] = *(const u32x2_lw *)((const unsigned short *)(GRP ? it_D : Y.D) + n0 + (wn * TN + j) * 32 + 8 * g + 4 * lh);
       }
     if (MULTI && wave == 0) blw_stamp(p, l, 0, lane);
     if (MULTI && NLA > 1 && l > 0) __builtin_amdgcn_s_barrier(); // S2 (the loaders' rendezvous after the seam wait)
@@ -785,8 +808,8 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
   }
 }
 
-template <int WM, int WN, int WK, int TM, int TN, int NSLOT, int NLA, int NLB, int SUP, bool MULTI, int FLATB = 0>
-static hipError_t launch_blw_t(const ChainArgs &a, hipStream_t s) {
+template <int WM, int WN, int WK, int TM, int TN, int NSLOT, int NLA, int NLB, int SUP, bool MULTI, int FLATB = 0, bool GRP = false>
+static hipError_t launch_blw_t(const ChainArgs &a, hipStream_t s, const void *items = nullptr, int n_items = 0) {
   constexpr int NOUT = WM * WN, BM = 32 * WM * TM, BN = 32 * WN * TN, NT = 64 * (WM * WN * WK + NLA + NLB);
   constexpr size_t lds = (size_t)NSLOT * (BM + BN) * 128 + (WK > 1 ? (size_t)NOUT * 4096 : 0);
 #ifdef TPP_HIP_ABLATION
@@ -795,14 +818,26 @@ static hipError_t launch_blw_t(const ChainArgs &a, hipStream_t s) {
   constexpr size_t lds_alloc = lds;
 #endif
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto kern = brgemm_bf16_lw<WM, WN, WK, TM, TN, NSLOT, NLA, NLB, SUP, MULTI, FLATB>;
+  auto kern = brgemm_bf16_lw<WM, WN, WK, TM, TN, NSLOT, NLA, NLB, SUP, MULTI, FLATB, GRP>;
   static std::atomic<unsigned long long> lds_set{0};
   if (hipError_t e = ensure_dynamic_lds((const void *)kern, (int)lds_alloc, lds_set); e != hipSuccess) return e;
   ChainArgs args = a;
   args.tiles_m = a.m / BM;
   args.tiles_n = a.n / BN;
-  const long long tiles = (long long)args.tiles_m * args.tiles_n;
+  long long tiles = (long long)args.tiles_m * args.tiles_n;
   if (tiles <= 0 || tiles > 0x7fffffffLL) return hipErrorInvalidValue;
+  args.items = nullptr;
+  args.item_subs = 0;
+  args.pad_items = 0;
+  if constexpr (GRP) { // tiles_m x tiles_n workgroups per item (consecutive workgroups = the items in list order: neighbouring
+                       // tiles of a layer share panels in the L2 of whichever XCD they land on)
+    if (!items || n_items <= 0 || tiles * n_items > 0x7fffffffLL) return hipErrorInvalidValue;
+    args.items = items;
+    args.item_subs = (int)tiles;
+    args.xm = 0;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * n_items)), dim3(NT), lds_alloc, s, args);
+    return hipGetLastError();
+  }
   // XCD grid xm x (8 / xm) over the tile grid: minimise xn * m + xm * n (bytes of A and W all eight L2s fetch, in units of 2K)
   args.xm = 0;
   static const int forced_xm = [] {
@@ -908,6 +943,25 @@ hipError_t launch_bf16_lw_vnni4(int tile, const ChainArgs &a, hipStream_t s) {
   if (a.L[0].br < 1 || a.L[0].k < BLW_BK || tile < 0 || tile > 3) return hipErrorInvalidValue;
   const bool sup2 = blw_sup2(a);
   BLW_DISPATCH(false, 4)
+}
+
+// Tile invokes of ONE bf16 descriptor as one launch on the loader-wave tiles (round 6, VERDICT r5 missing 3 / next 2b: the tile queue's
+// bf16 groups used to run on brgemm_bf16_small32 / brgemm_bf16_fast<64x64> and were 0-45 % slower than the same layer as one whole-
+// layer call). One workgroup per BM x BN tile of an item, operands and batch count from the item (ChainArgs::items); packed tile
+// blocks are just another (lda, stride) pattern to the loaders. SUP = 2 instances only when every item has an even chunk count.
+hipError_t launch_bf16_lw_grouped(int tile, int b_kind, const ChainArgs &a, const void *items, int n_items, bool even_chunks, hipStream_t s) {
+  if (a.L[0].k < BLW_BK || a.L[0].k % BLW_BK || tile < 0 || tile > 1 || (b_kind != 0 && b_kind != 4)) return hipErrorInvalidValue;
+  static const int forced = [] {
+    const char *e = getenv("TPP_HIP_BLW_SUP");
+    return e ? atoi(e) : 0;
+  }();
+  const bool sup2 = even_chunks && forced != 1;
+  if (b_kind == 4) {
+    if (tile == 0) return sup2 ? launch_blw_t<1, 2, 2, 1, 1, 8, 1, 2, 2, false, 4, true>(a, s, items, n_items) : launch_blw_t<1, 2, 2, 1, 1, 8, 1, 2, 1, false, 4, true>(a, s, items, n_items);
+    return sup2 ? launch_blw_t<2, 2, 1, 1, 1, 8, 1, 1, 2, false, 4, true>(a, s, items, n_items) : launch_blw_t<2, 2, 1, 1, 1, 8, 1, 1, 1, false, 4, true>(a, s, items, n_items);
+  }
+  if (tile == 0) return sup2 ? launch_blw_t<1, 2, 2, 1, 1, 8, 1, 2, 2, false, 0, true>(a, s, items, n_items) : launch_blw_t<1, 2, 2, 1, 1, 8, 1, 2, 1, false, 0, true>(a, s, items, n_items);
+  return sup2 ? launch_blw_t<2, 2, 1, 1, 1, 8, 1, 1, 2, false, 0, true>(a, s, items, n_items) : launch_blw_t<2, 2, 1, 1, 1, 8, 1, 1, 1, false, 0, true>(a, s, items, n_items);
 }
 
 // a chain of layers in one launch; the caller guarantees co-residency (tiles <= CUs), beta = 0, disjoint buffers and ONE kind of B

@@ -937,6 +937,45 @@ hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_i
   const bool vec16_4 = vec16x && d.vnni_factor == 4 && vec_ok && d.n % 2 == 0 && d.k % GK == 0 && !(d.ldb & 1); // VNNI-4: 16-byte pieces of 2 columns
   const bool vec16 = tiles_ok && d.dtype == DT_BF16 && d.vnni_b && d.vnni_factor == 2 && !((d.lda | d.stride_a | d.stride_b) & 7) && !(d.ldb & 3) &&
                      d.lda < (1 << 21) && d.ldb < (1 << 21); // (32-bit lane offsets)
+  // bf16 tile invokes with k a multiple of 64 and n a multiple of 64 (the reference's --tiles=64,64,64 / 32,64,64 bf16 rows): the
+  // LOADER-WAVE tiles in grouped mode (round 6, brgemm_bf16_lw.hip launch_bf16_lw_grouped) - what the same layer runs on as one
+  // whole-layer call. Tile by the model of pick_bf16_lw_tile over the group's workgroups: 32x64 + K2 (two workgroups per 64-row
+  // item) or 64x64. Against the two older grouped kernels (profiles/r06_bf16_sweep_before.txt, forced-variant rows): the loader-wave
+  // tiles win whenever the group fills 3/4 of the chip with 64x64 tiles (1024 x 1024 x 512: 5.1 us against 6.7) or the reduction is
+  // long (16 chunks or more: 128 x 4096 x 1024 5.3 against 9.4) or half the chip gets a 32x64 tile of at least 8 chunks (128 x 3072 x 768: 4.9 against 6.3; 1024 x 512 x 256, 4 chunks: 5.6 against 5.1);
+  // short reductions of small groups stay on the K-split kernel (128 x 768 x 768: 4.3 against 4.7). TPP_HIP_BF16_LW_GROUPED=0 switches the path off (A/B runs).
+  {
+    static const bool lwg_on = [] {
+      const char *e = getenv("TPP_HIP_BF16_LW_GROUPED");
+      return !e || atoi(e) != 0;
+    }();
+    const bool v2 = d.vnni_factor == 2, v4 = d.vnni_factor == 4;
+    const bool shape_ok = d.dtype == DT_BF16 && d.vnni_b && (v2 || v4) && !d.vnni_c && !d.generic_forced && !d.variant_forced && d.k > 0 && d.k % BK == 0 &&
+                          d.m % 32 == 0 && d.n % 64 == 0 && !((d.lda | d.stride_a | d.stride_b | d.ldc) & 7) && !(d.ldb & (v2 ? 3 : 1)) &&
+                          d.lda < (1 << 21) && d.ldb < (1 << 20) && d.ldc < (1 << 22) && d.stride_a >= 0 && d.stride_b >= 0;
+    if (lwg_on && shape_ok && vec_ok && out_ok && br_hint >= 1 && g_forced_split.load(std::memory_order_relaxed) < 0) { // (a forced split count: the K-split kernel below)
+      const int64_t chunks = br_hint * (d.k / BK);
+      const int64_t t64 = d.m % 64 == 0 ? n_dec * (d.m / 64) * (d.n / 64) : 0;
+      const int64_t wg0 = n_dec * (d.m / 32) * (d.n / 64);
+      if (t64 * 4 >= 3 * (int64_t)g_num_cus || chunks >= 16 || (wg0 * 2 >= (int64_t)g_num_cus && chunks >= 8)) {
+        static const double ca[2] = {3.56, 3.75}, cb[2] = {0.098, 0.135};
+        const double c0 = (double)((wg0 + g_num_cus - 1) / g_num_cus) * (ca[0] + cb[0] * (double)chunks);
+        const double c1 = t64 > 0 ? (double)((t64 + g_num_cus - 1) / g_num_cus) * (ca[1] + cb[1] * (double)chunks) : 1e30;
+        const int tile = c1 <= c0 ? 1 : 0;
+        ChainArgs c;
+        memset(&c, 0, sizeof(c));
+        c.lda = d.lda;
+        c.m = (int)d.m;
+        c.n = (int)d.n;
+        c.nlayers = 1;
+        c.L[0] = ChainLayer{nullptr, nullptr, nullptr, d.ldb, d.ldc, d.stride_a, d.stride_b, (int)d.k, (int)br_hint, a.ep, 0};
+        const bool even = ((d.k / BK) % 2 == 0) || pair_ok;
+        static const char *const names[2][2] = {{"brgemm_bf16_lw<32x64,k2> grouped", "brgemm_bf16_lw<64x64> grouped"},
+                                                {"brgemm_bf16_lw_vnni4<32x64,k2> grouped", "brgemm_bf16_lw_vnni4<64x64> grouped"}};
+        return note_grouped(names[v4 ? 1 : 0][tile], launch_bf16_lw_grouped(tile, v4 ? 4 : 0, c, items, n_items, even, stream));
+      }
+    }
+  }
   // bf16 tiles of 64x64 with k a multiple of 64: the 64x64 bf16 family in grouped mode (it stores 16-byte
   // row pieces and reads the bias 8 bytes at a time: checked per item by the queue through out_ok)
   // (whatever a SINGLE invoke of the handle would run on - a lone 64x64 tile is planned on the 32x32 K-split kernel -, the GROUP is

@@ -38,6 +38,12 @@ struct ChainArgs {
                         // never reads the variable: several of these switches give wrong results by design.
   unsigned long long *stamps; // profiling (ablation builds, TPP_HIP_CHAIN_STAMPS=file): [workgroup][layer][8] s_memrealtime stamps, else nullptr
   ChainLayer L[CH_MAXL];
+  // GROUPED launches (round 6, the tile queue's bf16 groups: launch_bf16_lw_grouped): a work list of tile invokes of ONE descriptor - every
+  // workgroup takes A, B, C, D and the batch count of ITS item from the list, everything else (leading dimensions, strides, k, epilogue)
+  // from L[0] / lda as in a single layer; m x n is then ONE item's shape and item_subs = tiles_m * tiles_n the workgroups per item
+  const void *items; // WorkItem[n] in device-visible memory, nullptr in every other launch
+  int item_subs;
+  int pad_items;
 };
 
 // the value of ChainArgs::dbg on the host side
@@ -59,6 +65,9 @@ hipError_t launch_bf16_lw(int tile, const ChainArgs &a, hipStream_t s);
 hipError_t launch_bf16_lw_flatb(int tile, const ChainArgs &a, hipStream_t s); // the same tiles, B operand flat [k][ldb] (no VNNI flag)
 hipError_t launch_bf16_lw_vnni4(int tile, const ChainArgs &a, hipStream_t s); // the same tiles, B operand VNNI-4 [k/4][ldb][4]
 hipError_t launch_bf16_chain(int tile, int b_kind, const ChainArgs &a, hipStream_t s); // b_kind: 0 VNNI-2, 2 flat, 4 VNNI-4 (every layer the same)
+// tile invokes of one bf16 descriptor in one launch (tile 0 = 32x64 + K2 or 1 = 64x64; b_kind 0 VNNI-2 / 4 VNNI-4; a.m x a.n = one item's
+// shape, a.L[0] / a.lda its leading dimensions and strides; every item's batch count >= 1; even_chunks: every item has an even chunk count)
+hipError_t launch_bf16_lw_grouped(int tile, int b_kind, const ChainArgs &a, const void *items, int n_items, bool even_chunks, hipStream_t s);
 
 // f32 chains (brgemm_f32_lw.hip): tile 1 = 64x64 + K2, 2 = 64x32 + K4 - the 64-row K-split loader-wave tiles
 bool f32_chain_tile_dims(int tile, int *bm, int *bn);

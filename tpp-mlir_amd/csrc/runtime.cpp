@@ -583,7 +583,9 @@ __attribute__((always_inline)) inline void queued_operands(const void *desc, con
     q.n_in = 3; // A, B, D read; op[3] = C written (and read when the op accumulates - a superset is harmless)
     q.out = 3;
     q.vec_ok = (((uintptr_t)w.A | (uintptr_t)w.B) & 15) == 0;
-    q.out_ok = (((uintptr_t)w.C) & 15) == 0 && (((uintptr_t)w.D) & 7) == 0;
+    // (... and a batch count of at least one: the loader-wave kernels assume a chunk; a group with an empty batch in it - C = epilogue
+    // of nothing - takes the generic kernel like a single such invoke does)
+    q.out_ok = (((uintptr_t)w.C) & 15) == 0 && (((uintptr_t)w.D) & 7) == 0 && w.br >= 1;
     q.pair_ok = !(w.br & 1);
   } else if (kind == KIND_UNARY) {
     unary_operands((const UnaryDesc *)desc, (void *)w.A, w.C, q.op[0], q.op[1]);
@@ -2379,7 +2381,7 @@ void gemm_invoke_common(const char *who, bool want_fused, int64_t dtype, int64_t
     WorkItem *slot = strict_item_slot(s);
     *slot = one;
     HIP_OK(launch_gemm_grouped(*d, slot, 1, ((((uintptr_t)A.dev) | ((uintptr_t)B.dev)) & 15) == 0,
-                               (((uintptr_t)C.dev) & 15) == 0 && (((uintptr_t)D.dev) & 7) == 0, !(br & 1), br, s));
+                               (((uintptr_t)C.dev) & 15) == 0 && (((uintptr_t)D.dev) & 7) == 0 && br >= 1, !(br & 1), br, s));
     strict_item_done(s);
   } else {
     HIP_OK(launch_gemm(*d, A.dev, B.dev, C.dev, D.dev, br, s));
