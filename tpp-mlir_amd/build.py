@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 SO_NAME = "libtpp_xsmm_runner_utils.so"
 SO_PATH = os.path.join(HERE, SO_NAME)
 SOURCES = ["runtime.cpp", "host_cache.cpp", "brgemm_f32.hip", "brgemm_f32_lw.hip", "brgemm_f32_lw16.hip", "brgemm_bf16.hip", "brgemm_bf16_dma256.hip", "brgemm_bf16_small.hip", "brgemm_bf16_lw.hip", "eltwise.hip", "peer_gather.hip"]
-HEADERS = ["xsmm_desc.h", "host_cache.h", "gemm_common.h", "chain_args.h", "split_scratch.h", os.path.join("..", "..", "include", "tpp_xsmm_abi.h")]
+HEADERS = ["xsmm_desc.h", "host_cache.h", "rt_core.h", "rt_mirror.h", "rt_registry.h", "rt_operands.h", "rt_tile_queue.h", "rt_scheduler.h", "rt_enqueue.h", "rt_rewrites.h", "rt_invoke.h", "rt_chain.h", "gemm_common.h", "chain_args.h", "split_scratch.h", os.path.join("..", "..", "include", "tpp_xsmm_abi.h")]
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

@@ -1,0 +1,105 @@
+// rt_core.h - error convention, configuration (environment switches), tracing
+// One of the subsystem units of runtime.cpp (round 6, VERDICT r5 next 7: the 3 000-line file split by subsystem, no behaviour
+// change). The units are INCLUDED into the one translation unit runtime.cpp, in dependence order, inside its anonymous namespace:
+// the per-invoke host path (14-18 ns: enqueue_item -> join_window -> Segment::mark) crosses four of them and is inlined across
+// their borders - as separate objects without LTO it would pay a call per border. Not a stand-alone header: include runtime.cpp's way only.
+
+
+[[noreturn]] void die(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vfprintf(stderr, fmt, ap);
+  va_end(ap);
+  fputc('\n', stderr);
+  fflush(stderr);
+  exit(-1); // XsmmRunnerUtils.cpp:132-137 convention
+}
+
+#define HIP_OK(expr)                                                                               \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess) die("tpp-xsmm-hip: %s failed: %s (no CPU fallback exists)", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+inline void cpu_relax() {
+#if defined(__x86_64__)
+  __builtin_ia32_pause();
+#else
+  asm volatile("" ::: "memory");
+#endif
+}
+
+struct Config {
+  std::atomic<int> async{0};
+  std::atomic<hipStream_t> stream{nullptr};
+  std::atomic<int> forced_variant{-1};
+  std::atomic<int> tile_queue{0};
+  std::atomic<int> vnni_factor{2}; // blocking factor of VNNI B operands dispatched from now on (xsmm_hip_set_vnni_factor / TPP_HIP_VNNI_FACTOR)
+  int trace = 0; // TPP_HIP_TRACE: 1 = one stderr line per dispatch + a roctx range per invoke, 2 = also one stderr line per invoke
+  std::atomic<int> fold_transpose{1}; // TPP_HIP_FOLD_TRANSPOSE / xsmm_hip_set_fold_transpose: transposes that feed a gemm's B operand are folded into it
+  // TPP_HIP_STRICT / xsmm_hip_set_strict (round 6): the kernel an invoke runs on is a function of its descriptor,
+  // batch count and own pointer alignment only - no grid merge, no folded transposes, no kernel family chosen by the size of the
+  // queued group, groups of one alignment class and one batch count only. The same invoke on the same data then returns the same
+  // bits whether it runs alone, in the first pass of a queued group or in a replay (libxsmm's JIT'd kernel is a function of the
+  // dispatch tuple: XsmmRunnerUtils.cpp:288-306).
+  std::atomic<int> strict{0};
+  Config() {
+    if (const char *e = getenv("TPP_HIP_STRICT")) {
+      strict = atoi(e) != 0;
+      tpp::set_strict_kernels(strict.load());
+    }
+    if (const char *e = getenv("TPP_HIP_FOLD_TRANSPOSE")) fold_transpose = atoi(e) != 0;
+    if (const char *e = getenv("TPP_HIP_ASYNC")) async = atoi(e) != 0;
+    if (const char *e = getenv("TPP_HIP_TRACE")) trace = atoi(e);
+    if (const char *e = getenv("TPP_HIP_VARIANT")) forced_variant = atoi(e);
+    if (const char *e = getenv("TPP_HIP_TILE_QUEUE")) tile_queue = atoi(e) < 0 ? 0 : atoi(e) > 2 ? 2 : atoi(e);
+    if (const char *e = getenv("TPP_HIP_VNNI_FACTOR")) {
+      if (atoi(e) == 2 || atoi(e) == 4) vnni_factor = atoi(e);
+      else fprintf(stderr, "[tpp-xsmm-hip] TPP_HIP_VNNI_FACTOR=%s ignored: the factor is 2 or 4\n", e);
+    }
+  }
+};
+Config &cfg() {
+  static Config c;
+  return c;
+}
+// the stream an invoke of THIS thread launches on: the process-wide setting, unless the thread is re-running a journaled chain
+// launch on that launch's stream (check_chain_errors; ADVICE r5: the re-run must not change the setting other threads read)
+thread_local hipStream_t tl_stream_override = nullptr; 
+thread_local bool tl_has_stream_override = false;      
+inline hipStream_t invoke_stream() { return tl_has_stream_override ? tl_stream_override : cfg().stream.load(std::memory_order_relaxed); }
+
+// ---- tracing: with TPP_HIP_TRACE >= 1 every invoke runs inside a roctx range named after its
+// dispatch tuple and kernel, so `rocprofv3 --marker-trace --kernel-trace` timelines show which xsmm call a kernel
+// belongs to. libroctx64 is looked up at run time (profiling tool, not a link dependency of the product).
+struct Roctx {
+  int (*push)(const char *) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    if (cfg().trace < 1) return;
+    // rocprofv3 (rocprofiler-sdk) traces the SDK's roctx library; the classic libroctx64 serves older tools
+    void *h = nullptr;
+    for (const char *name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "/opt/rocm/lib/librocprofiler-sdk-roctx.so",
+                             "libroctx64.so", "libroctx64.so.4", "/opt/rocm/lib/libroctx64.so"})
+      if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h) return;
+    push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
+    pop = (int (*)())dlsym(h, "roctxRangePop");
+    if (!push || !pop) push = nullptr, pop = nullptr;
+  }
+};
+Roctx &roctx() {
+  static Roctx r;
+  return r;
+}
+struct TraceRange {
+  bool on = false;
+  TraceRange(const char *who, const char *what) {
+    if (cfg().trace < 1) return;
+    if (cfg().trace >= 2) fprintf(stderr, "[tpp-xsmm-hip] %s %s\n", who, what);
+    if (roctx().push) on = roctx().push(what) >= 0;
+  }
+  ~TraceRange() {
+    if (on) roctx().pop();
+  }
+};

@@ -1,0 +1,303 @@
+// rt_rewrites.h - run-time rewrites of call sequences: GRID MERGE (a recorded tile grid over flat operands -> one launch) and DEFERRED TRANSPOSES (a transpose folded into the gemm it feeds)
+// One of the subsystem units of runtime.cpp (round 6, VERDICT r5 next 7: the 3 000-line file split by subsystem, no behaviour
+// change). The units are INCLUDED into the one translation unit runtime.cpp, in dependence order, inside its anonymous namespace:
+// the per-invoke host path (14-18 ns: enqueue_item -> join_window -> Segment::mark) crosses four of them and is inlined across
+// their borders - as separate objects without LTO it would pay a call per border. Not a stand-alone header: include runtime.cpp's way only.
+
+// GRID MERGE (round 5). The compiler tiles a contraction over FLAT operands into one gemm invoke per output tile (the mha projection,
+// benchmarks/mlir/fp32-projection.mlir: 64 x 8 invokes of [32,64,512,512,512,512] = one 2048 x 512 x 512 problem with lda = ldb = ldc =
+// 512). When a recorded group is exactly such a grid - every item the same f32 descriptor and batch count, A a function of the tile row
+// only (A0 + r m lda), B of the tile column only (B0 + c n, all columns inside one row of B: cols n <= ldb), C = C0 + r m ldc + c n, the
+// bias D0 + c n, every (r, c) once - a complete replay of it is launched as ONE invoke of the merged problem (rows m, cols n) on the
+// kernel plan_gemm picks for THAT shape (64x64 tiles instead of 1024 workgroups of 32x32 with 8 chunks each: 13.0 -> ~10.5 us). Same
+// reads, same writes, the same sums per element in a different (fixed) order: like every kernel choice that depends on the group.
+// Packed block layouts (mlir-gen's tiles) are never grids: their B tiles are not columns of one row. TPP_HIP_GRID_MERGE=0: off.
+static bool grid_merge_on() {
+  static const bool on = [] {
+    const char *e = getenv("TPP_HIP_GRID_MERGE");
+    return !e || atoi(e) != 0;
+  }();
+  return on && !cfg().strict.load(std::memory_order_relaxed); // (a merged grid sums in the merged problem's order: not in strict mode)
+}
+std::atomic<const char *> g_last_merged{nullptr}; // trace text of the merged descriptor if the most recent group launch was a merged one
+inline void detect_grid(Segment &S) {
+  S.grid_state = -1;
+  const size_t n = S.items.size();
+  if (!grid_merge_on() || n < 4) return;
+  const void *desc = S.items[0].desc;
+  if (*(const int *)desc != KIND_GEMM) return;
+  const GemmDesc *d = (const GemmDesc *)desc;
+  if (d->dtype != DT_F32 || d->vnni_b || d->vnni_c || d->b_trans || d->generic_forced || d->variant_forced || d->m <= 0 || d->n <= 0 || d->k <= 0) return;
+  const int64_t br = S.items[0].w.br;
+  std::vector<uintptr_t> ua, ub;
+  ua.reserve(n);
+  ub.reserve(n);
+  for (const TraceItem &t : S.items) {
+    if (t.desc != desc || t.w.br != br || t.stream != S.items[0].stream) return;
+    ua.push_back((uintptr_t)t.w.A);
+    ub.push_back((uintptr_t)t.w.B);
+  }
+  std::sort(ua.begin(), ua.end());
+  ua.erase(std::unique(ua.begin(), ua.end()), ua.end());
+  std::sort(ub.begin(), ub.end());
+  ub.erase(std::unique(ub.begin(), ub.end()), ub.end());
+  const size_t R = ua.size(), Cn = ub.size();
+  if (R * Cn != n || br < 1) return;
+  const uintptr_t sa = (uintptr_t)d->m * (uintptr_t)d->lda * 4, sb = (uintptr_t)d->n * 4;
+  for (size_t r = 0; r < R; ++r)
+    if (ua[r] != ua[0] + r * sa) return;
+  for (size_t c = 0; c < Cn; ++c)
+    if (ub[c] != ub[0] + c * sb) return;
+  if ((int64_t)Cn * d->n > d->ldb || (int64_t)Cn * d->n > d->ldc) return;
+  uintptr_t c0 = 0, d0 = 0;
+  for (const TraceItem &t : S.items)
+    if ((uintptr_t)t.w.A == ua[0] && (uintptr_t)t.w.B == ub[0]) c0 = (uintptr_t)t.w.C, d0 = (uintptr_t)t.w.D;
+  if (!c0) return;
+  std::vector<char> seen(n, 0);
+  for (const TraceItem &t : S.items) {
+    const size_t r = ((uintptr_t)t.w.A - ua[0]) / sa, c = ((uintptr_t)t.w.B - ub[0]) / sb;
+    if ((uintptr_t)t.w.C != c0 + ((uintptr_t)r * d->m * d->ldc + (uintptr_t)c * d->n) * 4) return;
+    if (d->bias && (uintptr_t)t.w.D != d0 + (uintptr_t)c * d->n * 4) return;
+    if (seen[r * Cn + c]++) return;
+  }
+  const int64_t M = (int64_t)R * d->m, N = (int64_t)Cn * d->n;
+  std::vector<int64_t> key = {KIND_GEMM, -31, (int64_t)(uintptr_t)d, M, N};
+  bool ok = true;
+  const GemmDesc *e = (const GemmDesc *)intern(key, [&]() {
+    GemmDesc *g = new GemmDesc(*d);
+    g->m = M;
+    g->n = N;
+    ok = plan_gemm(*g, -1);
+    snprintf(g->trace, sizeof(g->trace), "tile grid %zu x %zu of gemm[%ld,%ld,%ld] merged -> [%ld,%ld,%ld,%ld,%ld,%ld] %s", R, Cn, (long)d->m, (long)d->n,
+             (long)d->k, (long)M, (long)N, (long)d->k, (long)d->lda, (long)d->ldb, (long)d->ldc, g->name);
+    return (void *)g;
+  });
+  if (!ok || e->variant == GEMM_VARIANT_GENERIC) return; // (no fast tile for the merged shape: the grouped launch stays)
+  S.grid_desc = e;
+  S.grid_w = WorkItem{(const void *)ua[0], (const void *)ub[0], (void *)c0, d->bias ? (const void *)d0 : nullptr, br};
+  S.grid_state = 1;
+}
+
+
+// ---- deferred transposes (round 5) ------------------------------------------------------------------------------------
+// A contraction whose B operand is transposed in memory reaches the runtime as TWO invokes per tile: xsmm.unary transpose into a
+// small temporary, then xsmm.gemm reading it (ConvertLinalgToXsmm; test/Conversion/LinalgToXsmm/linalg-to-gemm.mlir:46-62 has the
+// query-times-key benchmark lowered exactly so: transpose [32,64,512,32] + gemm [32,32,64,512,32,32] per (batch, head), ONE
+// temporary for every tile of a caller). Through the tile queue that is a chain of true and anti dependences on the temporary:
+// every invoke its own launch (1024 launches for benchmarks/mlir/fp32-query-times-key.mlir, 3.6 ms; the queue cannot help).
+// So a transpose of a small tile into a DENSE destination (ldo = m) is not launched when it is invoked but REMEMBERED - one record
+// per calling thread (the reference's OpenMP callers own a temporary each) - and
+//   * a gemm of the same thread whose B operand is exactly that destination (k = the transpose's n, n = its m, ldb = ldo, one batch
+//     element, f32, no operand of it overlapping the destination, C not overlapping the transpose's source) runs on a SIBLING
+//     descriptor that reads B transposed straight from the transpose's source (GemmDesc::b_trans - the generic kernel). All such
+//     gemms of a loop, of every thread, share that sibling: the queue groups them into one launch;
+//   * a second transpose of the same thread, the same descriptor and the same destination REPLACES the record: the remembered one is
+//     dead - fully overwritten, and its only readers were served from its source;
+//   * any other invoke of the owning thread launches the remembered transpose first, the ordinary way (dt_launch); an invoke of
+//     ANOTHER thread does so if one of its operands overlaps the record's destination, or if it writes into the record's source (a
+//     race-free program orders such an invoke behind the transpose's invoke: it then sees the record); a flush and every
+//     synchronisation point launch every record - the destination holds what the program wrote whenever anything can look at it.
+// Between a transpose's invoke and its launch only folded gemms of its own thread and invokes that touch neither its destination
+// nor (writing) its source run: the deferred launch reads what the immediate one would have read.
+// Summation order of a folded gemm = the generic kernel's (what a single invoke of the same gemm on the generic kernel adds).
+struct DeferredTranspose {
+  const UnaryDesc *d = nullptr;
+  void *src = nullptr, *dst = nullptr;
+  hipStream_t stream = nullptr;
+  const GemmDesc *sib_of = nullptr, *sib = nullptr; // the last gemm descriptor folded and its sibling
+};
+struct alignas(64) DtSlot {
+  // line 0 - what EVERY thread reads per invoke while records exist; written when a record appears or goes, not per tile:
+  std::atomic<uintptr_t> owner{0};   // thread_token() of the thread that owns the slot (0: free)
+  std::atomic<int> live{0};          // a record is remembered
+  // the record's destination, and the hull of the sources it has had (the source changes with every tile of a loop - the next
+  // transpose replaces the record -, the hull stops growing after one pass: eight callers that each rewrote a line the seven others
+  // read per invoke took 2.5 us per tile). For the other threads' overlap test: written under mu before live = 1 (release), read after live
+  // (acquire). A reader that races with a replacement may see either record's source range - both belong to invokes it is not ordered with.
+  std::atomic<uintptr_t> d_lo{0}, d_hi{0}, s_lo{0}, s_hi{0};
+  // line 1 - the owner's (and, rarely, of a thread that launches the record):
+  alignas(64) SpinLock mu;           // the record and its hand-over
+  DeferredTranspose r;               // under mu
+  std::atomic<int64_t> folded{0}, dropped{0}; // statistics (the owner's relaxed adds)
+};
+constexpr int DT_SLOTS = 64;
+DtSlot g_dt_slots[DT_SLOTS];
+std::atomic<int> g_dt_top{0}; // slots [0, top) have been claimed at some time
+std::atomic<int64_t> g_dt_launched{0}; // statistics (xsmm_hip_fold_transpose_stats; folded / dropped: per slot)
+static __thread bool tl_dt_busy = false; // this thread is inside dt_launch's hand-over (its own flush_tile_queue calls must not re-enter)
+void unary_invoke_core(const UnaryDesc *d, void *pi, float scalar, bool use_scalar, void *po, bool may_defer);
+// Launches the slot's remembered transpose, if there is one (any thread). The record stays live until the transpose HAS BEEN handed to
+// the queue / launched, and the lock is held across that: a thread that then sees live = 0 (and goes on to queue an invoke that reads
+// the destination) is ordered behind the transpose.
+void dt_launch(DtSlot &sl) {
+  if (tl_dt_busy) return;
+  std::lock_guard<SpinLock> lk(sl.mu);
+  if (!sl.live.load(std::memory_order_relaxed)) return;
+  const DeferredTranspose r = sl.r;
+  g_dt_launched.fetch_add(1, std::memory_order_relaxed);
+  if (cfg().stream.load(std::memory_order_relaxed) != r.stream) die("tpp-xsmm-hip: a deferred transpose outlived its stream"); // (xsmm_hip_set_stream flushes first)
+  tl_dt_busy = true;
+  unary_invoke_core(r.d, r.src, 0.0f, false, r.dst, false);
+  tl_dt_busy = false;
+  sl.live.store(0, std::memory_order_release);
+  g_dt_pending.fetch_sub(1, std::memory_order_release);
+}
+void dt_materialize() { // every record (flush, synchronisation points)
+  if (tl_dt_busy) return;
+  const int top = g_dt_top.load(std::memory_order_acquire);
+  for (int i = 0; i < top; ++i)
+    if (g_dt_slots[i].live.load(std::memory_order_acquire)) dt_launch(g_dt_slots[i]);
+}
+struct DtRange {
+  uintptr_t lo, hi;
+};
+inline DtRange dt_range(const void *p, size_t bytes) { return DtRange{(uintptr_t)p, p ? (uintptr_t)p + bytes : 0}; }
+inline bool dt_overlap(const void *a, size_t na, const void *b, size_t nb) {
+  return a && b && na && nb && (uintptr_t)a < (uintptr_t)b + nb && (uintptr_t)b < (uintptr_t)a + na;
+}
+// the records of OTHER threads that this invoke (reads rd[0..nr), writes wr[0..nw)) must see launched
+void dt_scan_foreign(const DtSlot *mine, const DtRange *rd, int nr, const DtRange *wr, int nw) {
+  const int top = g_dt_top.load(std::memory_order_acquire);
+  for (int i = 0; i < top; ++i) {
+    DtSlot &sl = g_dt_slots[i];
+    if (&sl == mine || !sl.live.load(std::memory_order_acquire)) continue;
+    const uintptr_t dl = sl.d_lo.load(std::memory_order_relaxed), dh = sl.d_hi.load(std::memory_order_relaxed);
+    const uintptr_t slo = sl.s_lo.load(std::memory_order_relaxed), shi = sl.s_hi.load(std::memory_order_relaxed);
+    bool hit = false;
+    for (int k = 0; k < nr && !hit; ++k) hit = rd[k].lo < dh && dl < rd[k].hi;
+    for (int k = 0; k < nw && !hit; ++k) hit = (wr[k].lo < dh && dl < wr[k].hi) || (wr[k].lo < shi && slo < wr[k].hi);
+    if (hit) dt_launch(sl);
+  }
+}
+// the owning thread ends: the slot is free for another thread once its record (if any) has been launched by a flush
+void dt_release_slot(int slot) { g_dt_slots[slot].owner.store(0, std::memory_order_release); }
+DtSlot *dt_my_slot(bool claim) {
+  CallerState &tl = caller_state();
+  if (tl.dt_slot >= 0) return &g_dt_slots[tl.dt_slot];
+  if (!claim) return nullptr;
+  const uintptr_t me = thread_token();
+  for (int i = 0; i < DT_SLOTS; ++i) {
+    DtSlot &sl = g_dt_slots[i];
+    uintptr_t none = 0;
+    if (sl.owner.load(std::memory_order_relaxed) == 0 && !sl.live.load(std::memory_order_acquire) && sl.owner.compare_exchange_strong(none, me)) {
+      int top = g_dt_top.load(std::memory_order_relaxed);
+      while (top < i + 1 && !g_dt_top.compare_exchange_weak(top, i + 1, std::memory_order_release)) {
+      }
+      tl.dt_slot = i;
+      return &sl;
+    }
+  }
+  return nullptr; // more transposing threads than slots: this one's transposes are launched as they come
+}
+const GemmDesc *dt_sibling(const GemmDesc *d, int64_t ld_src) {
+  std::vector<int64_t> key = {KIND_GEMM, -29, (int64_t)(uintptr_t)d, ld_src};
+  return (const GemmDesc *)intern(key, [&]() {
+    GemmDesc *e = new GemmDesc(*d);
+    e->b_trans = 1;
+    e->ldb = ld_src;
+    e->variant = GEMM_VARIANT_GENERIC;
+    e->generic_forced = 1;
+    snprintf(e->name, sizeof(e->name), "brgemm_grouped(generic), B read transposed");
+    snprintf(e->trace, sizeof(e->trace), "gemm[%ld,%ld,%ld,%ld,(%ld)^T,%ld] dt%ld flags%ld %s (transpose folded)", (long)d->m, (long)d->n, (long)d->k,
+             (long)d->lda, (long)ld_src, (long)d->ldc, (long)d->dtype, (long)d->wire_flags, e->name);
+    return (void *)e;
+  });
+}
+// a gemm invoke while transposes are remembered: the sibling descriptor + the transpose's source if it folds into this thread's record
+// (which stays), else nullptr - this thread's record, and every other thread's record the gemm's operands touch, launched first
+const GemmDesc *dt_gemm(const GemmDesc *d, void *pa, void *pb, void *pc, void *pd, int64_t br, hipStream_t s, void **src) {
+  const size_t es = esize(d->dtype);
+  DtSlot *mine = dt_my_slot(false);
+  const GemmDesc *sib = nullptr;
+  if (mine && mine->live.load(std::memory_order_acquire)) {
+    {
+      std::lock_guard<SpinLock> lk(mine->mu);
+      if (mine->live.load(std::memory_order_relaxed)) {
+        DeferredTranspose &r = mine->r;
+        const UnaryDesc *t = r.d;
+        const size_t dst_bytes = (size_t)t->n * t->m * 4, src_bytes = span(t->m, t->ldi, t->n) * 4;
+        if (pb == r.dst && br == 1 && d->dtype == DT_F32 && !d->vnni_b && !d->vnni_c && !d->b_trans && d->k == t->n && d->n == t->m && d->ldb == t->ldo &&
+            s == r.stream && d->m <= 64 && d->n <= 64 && queue_active() && !dt_overlap(pa, span(d->m, d->lda, d->k) * 4, r.dst, dst_bytes) &&
+            !dt_overlap(pc, span(d->m, d->ldc, d->n) * 4, r.dst, dst_bytes) && !dt_overlap(pd, d->bias ? (size_t)d->n * 4 : 0, r.dst, dst_bytes) &&
+            !dt_overlap(pc, span(d->m, d->ldc, d->n) * 4, r.src, src_bytes)) {
+          if (r.sib_of != d) {
+            r.sib = dt_sibling(d, t->ldi);
+            r.sib_of = d;
+          }
+          *src = r.src;
+          sib = r.sib;
+          mine->folded.store(mine->folded.load(std::memory_order_relaxed) + 1, std::memory_order_relaxed);
+        }
+      }
+    }
+    if (!sib) dt_launch(*mine);
+  }
+  if (g_dt_pending.load(std::memory_order_relaxed) > (sib ? 1 : 0)) { // other threads' records
+    const GemmDesc *e = sib ? sib : d;
+    const void *b = sib ? *src : pb;
+    const int64_t vf = e->vnni_factor ? e->vnni_factor : 2;
+    const size_t bspan = e->vnni_b ? span((e->k + vf - 1) / vf, vf * e->ldb, vf * e->n) : e->b_trans ? span(e->n, e->ldb, e->k) : span(e->k, e->ldb, e->n);
+    const size_t nb = br > 0 ? (size_t)(br - 1) : 0;
+    const DtRange rd[4] = {dt_range(pa, (nb * e->stride_a + span(e->m, e->lda, e->k)) * es), dt_range(b, (nb * e->stride_b + bspan) * es),
+                           dt_range(pd, e->bias ? (size_t)e->n * es : 0), dt_range(pc, span(e->m, e->ldc, e->n) * es * (e->vnni_c ? 2 : 1))};
+    dt_scan_foreign(mine, rd, 4, rd + 3, 1);
+  }
+  return sib;
+}
+// any other invoke while transposes are remembered: this thread's record first, then the other threads' records it touches
+void dt_other(const void *const *reads, const size_t *read_bytes, int nr, const void *out, size_t out_bytes) {
+  if (DtSlot *mine = dt_my_slot(false)) {
+    if (mine->live.load(std::memory_order_acquire)) dt_launch(*mine);
+  }
+  if (g_dt_pending.load(std::memory_order_relaxed) == 0) return;
+  DtRange rd[3], wr[1] = {dt_range(out, out_bytes)};
+  for (int i = 0; i < nr && i < 3; ++i) rd[i] = dt_range(reads[i], read_bytes[i]);
+  dt_scan_foreign(nullptr, rd, nr < 3 ? nr : 3, wr, 1);
+}
+// a transpose invoke: true = remembered (nothing launched)
+bool dt_defer(const UnaryDesc *d, void *pi, void *po, hipStream_t s) {
+  if (d->dtype != DT_F32 || d->m > 64 || d->n > 64 || d->ldo != d->m || !cfg().fold_transpose.load(std::memory_order_relaxed) || cfg().strict.load(std::memory_order_relaxed) || !queue_active()) return false;
+  DeviceRanges &devmem = caller_state().devmem;
+  if (devmem.refresh()) check_queue_device();
+  if (!devmem.is_device(pi, 0) || !devmem.is_device(po, 1)) return false;
+  const size_t dst_bytes = (size_t)d->n * d->m * 4, src_bytes = span(d->m, d->ldi, d->n) * 4;
+  if (dt_overlap(pi, src_bytes, po, dst_bytes)) return false;
+  DtSlot *mine = dt_my_slot(true);
+  if (!mine) return false;
+  const uintptr_t s_lo = (uintptr_t)pi, s_hi = (uintptr_t)pi + src_bytes;
+  bool replaced = false, launch_old = false;
+  if (mine->live.load(std::memory_order_acquire)) {
+    std::lock_guard<SpinLock> lk(mine->mu);
+    if (mine->live.load(std::memory_order_relaxed)) {
+      DeferredTranspose &r = mine->r;
+      if (r.d == d && r.dst == po && r.stream == s) {
+        r.src = pi; // the remembered transpose is dead: fully overwritten, its readers were served from its source
+        // (the published source range only GROWS while the record lives: the hull of the sources of the loop's transposes - after one
+        // pass over the source tensor the line the other threads read is not written any more)
+        if (s_lo < mine->s_lo.load(std::memory_order_relaxed)) mine->s_lo.store(s_lo, std::memory_order_relaxed);
+        if (s_hi > mine->s_hi.load(std::memory_order_relaxed)) mine->s_hi.store(s_hi, std::memory_order_relaxed);
+        mine->dropped.store(mine->dropped.load(std::memory_order_relaxed) + 1, std::memory_order_relaxed);
+        replaced = true;
+      } else {
+        launch_old = true;
+      }
+    }
+  }
+  if (launch_old) dt_launch(*mine);
+  // the other threads' records this transpose touches (it will read its source and write its destination when it is launched)
+  if (g_dt_pending.load(std::memory_order_relaxed) > (replaced ? 1 : 0)) {
+    const DtRange rd[1] = {dt_range(pi, src_bytes)}, wr[1] = {dt_range(po, dst_bytes)};
+    dt_scan_foreign(mine, rd, 1, wr, 1);
+  }
+  if (replaced) return true;
+  std::lock_guard<SpinLock> lk(mine->mu);
+  if (mine->live.load(std::memory_order_relaxed)) return false; // (cannot happen: only the owner makes a record live)
+  mine->r = DeferredTranspose{d, pi, po, s, nullptr, nullptr};
+  mine->d_lo.store((uintptr_t)po, std::memory_order_relaxed);
+  mine->d_hi.store((uintptr_t)po + dst_bytes, std::memory_order_relaxed);
+  mine->s_lo.store(s_lo, std::memory_order_relaxed);
+  mine->s_hi.store(s_hi, std::memory_order_relaxed);
+  g_dt_pending.fetch_add(1, std::memory_order_relaxed);
+  mine->live.store(1, std::memory_order_release);
+  return true;
+}
