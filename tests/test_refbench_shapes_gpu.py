@@ -289,7 +289,7 @@ def test_bf16_split_groups_through_the_tile_queue(rt, forced):
             outs.append(host(dC, ref))
             # (the model's own choice - forced == -1 - is the grouped loader-wave tile since round 6: 32 chunks per tile; a forced count
             # keeps the group on the K-split kernel)
-            want = "brgemm_bf16_lw<32x64,k2> grouped" if forced < 0 else ("small32 grouped, split" if forced > 1 else "small32 grouped")
+            want = "brgemm_bf16_lw<32x32,k2> grouped" if forced < 0 else ("small32 grouped, split" if forced > 1 else "small32 grouped")
             assert want in rt.last_grouped_kernel(), rt.last_grouped_kernel()
     finally:
         rt.force_split(-1)

@@ -388,7 +388,17 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
     // layer - was measured and is WORSE for the reference's shapes, 1024 x 2560 x 1024 15.0 -> 18.1 us: with row-major items and a
     // column count that is a multiple of 8 the plain order already gives every XCD its own eighth of the COLUMNS, i.e. of W, the
     // larger operand; profiles/r06_bf16_grouped_lw.txt)
-    const int item = b / p.item_subs, sub = b - item * p.item_subs;
+    // ... but the tiles of ONE item (2 or 4 workgroups that share the item's A rows / B columns) go to ONE XCD: workgroup b runs on XCD
+    // b % 8 (observed, used for speed only), so within every run of 8 * subs workgroups XCD x takes the subs tiles of the x-th item
+    int u = b;
+    {
+      const int subs = p.item_subs, total = (int)gridDim.x;
+      if (subs > 1 && total % (8 * subs) == 0) {
+        const int xcd = b & 7, j = b >> 3;
+        u = (j / subs) * (8 * subs) + xcd * subs + (j % subs);
+      }
+    }
+    const int item = u / p.item_subs, sub = u - item * p.item_subs;
     tm = sub / p.tiles_n;
     tn = sub - tm * p.tiles_n;
     typedef const __attribute__((address_space(4))) WorkItem item_c_t;
@@ -950,7 +960,16 @@ hipError_t launch_bf16_lw_vnni4(int tile, const ChainArgs &a, hipStream_t s) {
 // layer call). One workgroup per BM x BN tile of an item, operands and batch count from the item (ChainArgs::items); packed tile
 // blocks are just another (lda, stride) pattern to the loaders. SUP = 2 instances only when every item has an even chunk count.
 hipError_t launch_bf16_lw_grouped(int tile, int b_kind, const ChainArgs &a, const void *items, int n_items, bool even_chunks, hipStream_t s) {
-  if (a.L[0].k < BLW_BK || a.L[0].k % BLW_BK || tile < 0 || tile > 1 || (b_kind != 0 && b_kind != 4)) return hipErrorInvalidValue;
+  if (a.L[0].k < BLW_BK || a.L[0].k % BLW_BK || tile < 0 || (tile > 1 && tile != 4) || (b_kind != 0 && b_kind != 4)) return hipErrorInvalidValue;
+  if (tile == 4) { // 32x32 + K2 (launch_bf16_lw's tile 4, VNNI-2 only): four workgroups per 64x64 item - skinny groups with a long reduction
+    if (b_kind != 0) return hipErrorInvalidValue;
+    static const int forced4 = [] {
+      const char *e = getenv("TPP_HIP_BLW_SUP");
+      return e ? atoi(e) : 0;
+    }();
+    return even_chunks && forced4 != 1 ? launch_blw_t<1, 1, 2, 1, 1, 8, 1, 1, 2, false, 0, true>(a, s, items, n_items)
+                                       : launch_blw_t<1, 1, 2, 1, 1, 8, 1, 1, 1, false, 0, true>(a, s, items, n_items);
+  }
   static const int forced = [] {
     const char *e = getenv("TPP_HIP_BLW_SUP");
     return e ? atoi(e) : 0;

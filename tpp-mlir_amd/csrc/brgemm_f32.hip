@@ -961,7 +961,12 @@ hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_i
         static const double ca[2] = {3.56, 3.75}, cb[2] = {0.098, 0.135};
         const double c0 = (double)((wg0 + g_num_cus - 1) / g_num_cus) * (ca[0] + cb[0] * (double)chunks);
         const double c1 = t64 > 0 ? (double)((t64 + g_num_cus - 1) / g_num_cus) * (ca[1] + cb[1] * (double)chunks) : 1e30;
-        const int tile = c1 <= c0 ? 1 : 0;
+        int tile = c1 <= c0 ? 1 : 0;
+        // 32x32 + K2 (VNNI-2): twice the workgroups of the 32x64 tile pulling panels - for skinny groups with a long reduction, as
+        // launch_gemm does for the whole-layer call (one round of workgroups at most, 16 chunks or more; (a, b) = (3.52, 0.072) from
+        // 128 x 1024 x 1024 / x 4096 on that tile)
+        const int64_t wg4 = n_dec * (d.m / 32) * (d.n / 32);
+        if (v2 && wg4 <= (int64_t)g_num_cus && chunks >= 16 && 3.52 + 0.072 * (double)chunks < (c1 < c0 ? c1 : c0)) tile = 4;
         ChainArgs c;
         memset(&c, 0, sizeof(c));
         c.lda = d.lda;
@@ -972,7 +977,8 @@ hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_i
         const bool even = ((d.k / BK) % 2 == 0) || pair_ok;
         static const char *const names[2][2] = {{"brgemm_bf16_lw<32x64,k2> grouped", "brgemm_bf16_lw<64x64> grouped"},
                                                 {"brgemm_bf16_lw_vnni4<32x64,k2> grouped", "brgemm_bf16_lw_vnni4<64x64> grouped"}};
-        return note_grouped(names[v4 ? 1 : 0][tile], launch_bf16_lw_grouped(tile, v4 ? 4 : 0, c, items, n_items, even, stream));
+        return note_grouped(tile == 4 ? "brgemm_bf16_lw<32x32,k2> grouped" : names[v4 ? 1 : 0][tile],
+                            launch_bf16_lw_grouped(tile, v4 ? 4 : 0, c, items, n_items, even, stream));
       }
     }
   }

@@ -65,7 +65,7 @@ hipError_t launch_bf16_lw(int tile, const ChainArgs &a, hipStream_t s);
 hipError_t launch_bf16_lw_flatb(int tile, const ChainArgs &a, hipStream_t s); // the same tiles, B operand flat [k][ldb] (no VNNI flag)
 hipError_t launch_bf16_lw_vnni4(int tile, const ChainArgs &a, hipStream_t s); // the same tiles, B operand VNNI-4 [k/4][ldb][4]
 hipError_t launch_bf16_chain(int tile, int b_kind, const ChainArgs &a, hipStream_t s); // b_kind: 0 VNNI-2, 2 flat, 4 VNNI-4 (every layer the same)
-// tile invokes of one bf16 descriptor in one launch (tile 0 = 32x64 + K2 or 1 = 64x64; b_kind 0 VNNI-2 / 4 VNNI-4; a.m x a.n = one item's
+// tile invokes of one bf16 descriptor in one launch (tile 0 = 32x64 + K2, 1 = 64x64, 4 = 32x32 + K2 (VNNI-2 only); b_kind 0 VNNI-2 / 4 VNNI-4; a.m x a.n = one item's
 // shape, a.L[0] / a.lda its leading dimensions and strides; every item's batch count >= 1; even_chunks: every item has an even chunk count)
 hipError_t launch_bf16_lw_grouped(int tile, int b_kind, const ChainArgs &a, const void *items, int n_items, bool even_chunks, hipStream_t s);
 
