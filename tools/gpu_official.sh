@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round deliverable session (round 5 adds: refbench table, split sweep, the N = 2 rig bench, PMC of the skinny-shape kernels): full parity suite, smoke, the driver's bench command, rocprofv3 kernel stats of the SAME bench
+# Round deliverable session (round 6 adds: the host-buffer rows (host cache), the bf16 tile-family sweep, the probes behind the round's decisions; round 5 added: refbench table, split sweep, the N = 2 rig bench, PMC of the skinny-shape kernels): full parity suite, smoke, the driver's bench command, rocprofv3 kernel stats of the SAME bench
 # command, default bench, MFMA-busy PMC passes, the per-rank MLP step probe + in-kernel stamps, shape sweeps, tile-queue replays,
 # eltwise bandwidth. Results in gpurun_out/<tag>/.   usage: gpurun --timeout 2400 -- 'bash tools/gpu_official.sh r03_official1'
 TAG=${1:-official}; OUT=gpurun_out/$TAG; mkdir -p $OUT
@@ -59,6 +59,14 @@ tools/ubench/fillmix.out > $OUT/fill_paths.txt 2>&1
 tools/ubench/tr16_probe.out > $OUT/tr16_probe.txt 2>&1
 timeout 200 python tools/queue_fuzz.py 45 5 2>&1 | tail -1 > $OUT/queue_fuzz.txt
 bash tools/gpu_replay.sh $TAG > /dev/null 2>&1
+# round 6: host buffers (the unmodified harness: plain malloc'ed operands, modes from the environment), bf16 sweep, probes
+timeout 600 python tools/bf16_sweep.py -n 300 > $OUT/bf16_sweep.txt 2> $OUT/bf16_sweep.err
+bash tools/gpu_host_buffers.sh > $OUT/host_buffers.txt 2>&1
+timeout 120 tools/ubench/pageable_probe.out > $OUT/pageable_probe.txt 2>&1
+g++ -O2 -std=c++17 tools/ubench/wp_async_probe.cpp -o /tmp/wp_async_probe -include malloc.h && /tmp/wp_async_probe > $OUT/wp_async_probe.txt 2>&1
+timeout 200 tools/ubench/split_handoff.out > $OUT/split_handoff.txt 2>&1
+echo "# matmul_128x768x768 as tile invokes (32,64,64), 50 timed loops of 200 calls each (VERDICT r5 weak 9: the 51 us row)" > $OUT/outlier.txt
+timeout 300 tools/tpp_replay --batch 128 --layers 768,768 --kernel args --tiles 32,64,64 --queue 1 -n 200 --repeats 50 2>&1 | grep -v "^[0-9.e-]*$" >> $OUT/outlier.txt
 python tools/eltwise_bw.py > $OUT/eltwise_bw.txt 2>/dev/null
 python tools/vendor_compare.py > $OUT/vendor_compare.txt 2>/dev/null
 tail -n 1 $OUT/bench_steps20.json | head -c 900; echo; head -8 $OUT/rocprof_kernel_stats.csv | cut -c1-160; cat $OUT/mlp_probe.txt | cut -c1-14,50-200 | tail -4
