@@ -312,7 +312,9 @@ TPP_XSMM_EXPORT int xsmm_hip_force_split(int workgroups_per_tile);
  * the program wrote. Results of a folded gemm are those of the generic kernel on the same values. One remembered transpose per
  * calling thread (the reference's OpenMP callers own a temporary each); an invoke of another thread launches it first only if it
  * touches the destination or writes the source. 0 turns it off (also TPP_HIP_FOLD_TRANSPOSE=0); returns the previous setting.
- * stats: [0] gemm invokes served from a transpose's source, [1] remembered transposes dropped as dead, [2] launched after all. */
+ * stats: [0] gemm invokes served from a transpose's source, [1] remembered transposes dropped as dead, [2] launched after all.
+ *  Between a transpose invoke and the gemm invoke that consumes its temporary, no OTHER thread may write the transpose's
+ * source: the folded gemm reads the source when it is enqueued, not when the transpose was invoked. */
 TPP_XSMM_EXPORT int xsmm_hip_set_fold_transpose(int enable);
 TPP_XSMM_EXPORT void xsmm_hip_fold_transpose_stats(int64_t out[3]);
 /* The VNNI blocking factor v of bf16 B operands ([k/v][ldb][v]) of gemm / brgemm / fused_brgemm handles dispatched FROM NOW ON with
