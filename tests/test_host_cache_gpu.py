@@ -39,11 +39,20 @@ def test_golden_fixture_through_host_pointers_with_the_cache(rt_cache, path):
     fr.run_fixture(path, AbiBackend("host"))
 
 
+_keep = []
+
+
 def unaligned(n, dtype, off=192):
-    """memref.alloc-style: 64-byte aligned inside a larger allocation, never page aligned"""
-    raw = np.empty(n * np.dtype(dtype).itemsize + 4096 + off, np.uint8)
-    start = (-raw.ctypes.data) % 64 + off
-    return raw[start:start + n * np.dtype(dtype).itemsize].view(dtype)
+    """memref.alloc-style: 64-byte aligned, never page aligned - in a FRESH anonymous mapping: pages the ROCm runtime has never been handed.
+    (A buffer that was once the source / destination of a plain hipMemcpy stays in the runtime's pin cache, and the driver write-faults its
+    pages again after every later piece of driver activity: the kernel's write tracking then reports the whole buffer written - the host
+    cache uploads it again, correct but no faster than the plain path. tools/ubench/wp_vs_hipmemcpy.cpp, profiles/r06_wp_vs_hipmemcpy.txt.
+    numpy's allocator re-uses the heap addresses of earlier tests' arrays, which went through exactly such copies.)"""
+    import mmap
+    nbytes = n * np.dtype(dtype).itemsize
+    m = mmap.mmap(-1, nbytes + 8192)
+    _keep.append(m)
+    return np.frombuffer(m, dtype=np.uint8, count=nbytes, offset=off + 64)[:nbytes].view(dtype)
 
 
 def test_c2_sync_loop_with_host_edits(rt_cache):
@@ -84,13 +93,9 @@ def test_c2_sync_loop_with_host_edits(rt_cache):
     for g, w in zip(got, want):
         assert np.array_equal(g.view(np.uint32), w.view(np.uint32))
     # 12 MiB of operands, four invokes: the plain path uploads 8-12 MiB per invoke (44 MiB); the cache uploads everything once, the pages
-    # edited, and C a second time (the BETA_0 invoke leaves its pure output untracked: the accumulating invoke behind it reads it again):
-    # 16-17 MiB when this test runs in a fresh process (tools/sessions of round 6). Inside the whole suite - a process that has been
-    # running for a minute - the kernel reports whole arrays written again that nobody wrote (profiles/README.md, round 6: suspected NUMA
-    # balancing's hinting faults dropping the write-protect bit; not reproducible in a short-lived process, with or without huge pages):
-    # the cache then uploads them again - never less than it must, which is what this test can assert everywhere.
+    # edited, and C a second time (the BETA_0 invoke leaves its pure output untracked: the accumulating invoke behind it reads it again)
     up = s1["uploaded_bytes"] - s0["uploaded_bytes"]
-    assert 12 * 2 ** 20 <= up <= 44 * 2 ** 20 + 64 * 4096, up
+    assert 12 * 2 ** 20 <= up <= 16 * 2 ** 20 + 64 * 4096, up
 
 
 def test_c2_async_loop_runs_at_device_speed_and_writes_back_at_the_sync_point(rt_cache):
@@ -115,9 +120,8 @@ def test_c2_async_loop_runs_at_device_speed_and_writes_back_at_the_sync_point(rt
         rt.brgemm(F32, h, A, 0, B, 0, C, 0, br)
     dt = rt.perf_stop_timer(t0)
     s1 = rt.host_cache_stats()
-    # (the edge pages of the run written back at the sync point, and pages of numpy's huge-page-advised arrays the kernel reports
-    # written after the first scan split their mapping: a few dozen of 3072)
-    assert s1["uploaded_bytes"] - s0["uploaded_bytes"] <= 64 * 4096, s1
+    # (the edge pages of the run written back at the sync point)
+    assert s1["uploaded_bytes"] - s0["uploaded_bytes"] <= 16 * 4096, s1
     assert s1["fast_invokes"] - s0["fast_invokes"] >= 199
     dA, dB = torch.from_numpy(A.copy()).cuda(), torch.from_numpy(B.copy()).cuda()
     dC = torch.zeros(m * n, device="cuda")

@@ -1082,20 +1082,14 @@ void on_sync_point(hipStream_t s) {
       ours = ours && (g.categories & PG_WPALLOWED);
     }
     if (!ours || covered != hi - lo) { st_wb_skipped.fetch_add((int64_t)((hi - lo) / PG), std::memory_order_relaxed); continue; }
-    const uintptr_t full_lo = pg_ceil(r.first), full_hi = pg_floor(r.second);
+    // (Round 6, first version: a page inside the run that read as written although it was armed was taken for a host write - a
+    // contract violation, or free()'s list pointers in a chunk freed too early - and left alone. WRONG: pages of a buffer that was
+    // ever the source / destination of a plain hipMemcpy are write-faulted again by the driver behind everybody's back (the ROCm
+    // runtime's pin cache: profiles/r06_wp_vs_hipmemcpy.txt) and read as written, and a skipped write-back is a stale output on the host -
+    // tests/test_host_cache_gpu.py caught it inside the whole suite. The device's bytes always go back to pages that are still
+    // mapped and still ours; what protects a range that changed hands is the check above, nothing finer.)
     uintptr_t a = r.first;
     uffd_unprotect(lo, hi); // the copies below write these pages: no write-protect fault per page (rearm protects them again)
-    for (const PmRegion &g : reg) {
-      if (!(g.categories & PG_WRITTEN)) continue;
-      for (uintptr_t x = std::max<uintptr_t>(g.start, lo); x < std::min<uintptr_t>(g.end, hi); x += PG) {
-        if (x < full_lo || x >= full_hi) continue; // an edge page shared with other data: foreign writes there are legitimate
-        if (!e->is_armed(x)) continue; // never protected (a pure output's page: make_ready): it reads as written, nobody wrote it
-        if (a < x) { copy_back(e, a, x - a, 0, 0, 0, s); done.push_back(Done{e, a, x}); }
-        a = x + PG;
-        st_wb_skipped.fetch_add(1, std::memory_order_relaxed);
-        e->set(x, false);
-      }
-    }
     if (a < r.second) { copy_back(e, a, r.second - a, 0, 0, 0, s); done.push_back(Done{e, a, r.second}); }
   }
   HC_HIP_OK(hipStreamSynchronize(s));

@@ -21,6 +21,11 @@
 //     the extent is dropped; a freed-and-reused heap chunk reads as "written". Nothing is ever trusted that the kernel does not vouch for.
 //   * no fault handler, no signal, no thread: system calls that write into tracked memory just work (tools/ubench/wp_async_probe.cpp).
 //
+//   * one thing defeats the tracking without breaking it: a buffer that was ever the source / destination of a plain hipMemcpy stays in
+//     the ROCm runtime's pin cache, and the driver validates its pages again WITH WRITE ACCESS after every later piece of driver activity -
+//     they then read as written (tools/ubench/wp_vs_hipmemcpy.cpp). The cache uploads such a buffer again and again: correct, as slow as
+//     the plain path. The cache itself never hands caller pages to a driver copy (its own pinned staging buffer + CPU copies).
+//
 // OFF by default (TPP_HIP_HOST_CACHE=1 / xsmm_hip_set_host_cache(1)); needs Linux >= 6.7 with userfaultfd(UFFD_USER_MODE_ONLY).
 #pragma once
 #include <hip/hip_runtime.h>
