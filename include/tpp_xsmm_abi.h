@@ -208,6 +208,15 @@ TPP_XSMM_EXPORT int xsmm_hip_fused_brgemm_chain_invoke(int64_t dtype, int64_t n,
  * already recorded groups under the other one. */
 TPP_XSMM_EXPORT int xsmm_hip_set_strict(int enable);
 TPP_XSMM_EXPORT int xsmm_hip_get_strict(void);
+/* The launch thread (round 6; TPP_HIP_LAUNCH_THREAD=0|1, default 1; tile queue + asynchronous mode only). A recorded group that is
+ * replayed completely is launched by a helper thread of the runtime instead of the calling thread: the caller goes on queueing the
+ * next group while hipLaunchKernel (2.3-2.6 us of host time) runs beside it. Stream order is unchanged - the hand-overs leave in
+ * order, and everything else that launches / copies / synchronises first waits until they have left. The thread spins while
+ * launches keep coming, sleeps after ~1 ms without one and ends after ~2 s. Kernel choice and results do not depend on the setting.
+ * xsmm_hip_set_launch_thread returns the previous setting; stats: out[0] = launches handed over since process start, out[1] = 1 if
+ * the thread exists right now. */
+TPP_XSMM_EXPORT int xsmm_hip_set_launch_thread(int enable);
+TPP_XSMM_EXPORT void xsmm_hip_launch_thread_stats(int64_t out[2]);
 /* Sticky status of the chain launches: the number of journaled launches that were found starved at a synchronisation point and
  * re-run call by call since process start (0: never). Round 6: every journaled launch has its own error word, so only the starved
  * launch and the later ones of ITS stream are re-run (healthy earlier launches are left alone), the journal is kept per stream, and

@@ -19,13 +19,19 @@ extern "C" int hipFree(void *);
 
 static const int NT = 8, M = 128, N = 128, K = 128, TS = 32, KB = 32, LAYERS = 3;
 
-static int thread_count() {
+static int launch_thread_exists() { // the runtime's launch thread (rt_launcher.h): exists while complete replays keep coming (+ ~2 s)
+  int64_t st[2] = {0, 0};
+  xsmm_hip_launch_thread_stats(st);
+  return (int)st[1];
+}
+static int thread_count() { // threads of the process, the launch thread not counted
+  const int lt = launch_thread_exists();
   int n = 0;
   if (DIR *d = opendir("/proc/self/task")) {
     while (dirent *e = readdir(d)) n += e->d_name[0] != '.';
     closedir(d);
   }
-  return n;
+  return n - lt;
 }
 
 static float *dev_alloc(size_t n) {
@@ -371,6 +377,32 @@ int main(int argc, char **argv) {
   }
   bad += run_mlp(true, 2, "tile queue, zero/brgemm/relu tiles, 8 callers");
   bad += run_transposes(8, "tile queue, transposes folded into gemms");
+  // 3a'. the launch thread (rt_launcher.h): complete replays leave through it, everything else waits for it; off = the closing
+  //      thread launches; it leaves after ~2 s without a hand-over and the next one starts a successor
+  {
+    int64_t lt0[2], lt1[2], lt2[2], lt3[2];
+    xsmm_hip_launch_thread_stats(lt0);
+    bad += run_fused(8, "launch thread on, fused tiles, 8 callers");
+    xsmm_hip_launch_thread_stats(lt1);
+    const int prev = xsmm_hip_set_launch_thread(0);
+    bad += run_fused(8, "launch thread off, fused tiles, 8 callers");
+    xsmm_hip_launch_thread_stats(lt2);
+    xsmm_hip_set_launch_thread(1);
+    int waited_lt = 0;
+    while (launch_thread_exists() && waited_lt < 100) {
+      usleep(100000);
+      ++waited_lt;
+    }
+    const int gone = !launch_thread_exists();
+    bad += run_solo_handover(12, "tile queue after the launch thread left");
+    xsmm_hip_launch_thread_stats(lt3);
+    printf("launch thread: %ld + %ld launches handed over, %ld while off, gone after %.1f s idle: %d, back: %d\n", (long)(lt1[0] - lt0[0]),
+           (long)(lt3[0] - lt2[0]), (long)(lt2[0] - lt1[0]), waited_lt * 0.1, gone, (int)lt3[1]);
+    if (prev != 1 || lt1[0] - lt0[0] < 1 || lt2[0] != lt1[0] || !gone || lt3[0] - lt2[0] < 1) {
+      printf("launch thread: UNEXPECTED\n");
+      ++bad;
+    }
+  }
   // 3b. mode 2: several callers hand their invokes to the ring + scheduler thread
   xsmm_hip_set_tile_queue(2);
   bad += run_mlp(true, 6, "tile queue, device operands, 8 callers");

@@ -148,8 +148,8 @@ def main():
     for l in r.stderr.splitlines():
         if "GFLOP/s (BENCH_TOTAL_FLOPS" in l:
             got.append(pat.search(l))
-        elif rpat.search(l) and got:
-            reps[len(got) - 1] = rpat.search(l)
+        elif rpat.search(l):
+            reps[len(got)] = rpat.search(l)  # (tpp_replay prints a case's repeats line BEFORE its result line)
     if len(got) != len(cs):
         sys.stderr.write(r.stderr[-4000:])
         raise SystemExit("refbench: %d cases, %d result lines (rc %d)" % (len(cs), len(got), r.returncode))

@@ -447,7 +447,8 @@ static int run_script(const std::string &name, int queue, int64_t n_iter, int th
   xsmm_hip_synchronize();
   std::vector<float> res(out_n);
   CHECK(hipMemcpy(res.data(), out, out_n * 4, hipMemcpyDeviceToHost));
-  if (!check(res)) { fprintf(stderr, "tpp_replay --script %s: WRONG RESULT\n", name.c_str()); return 1; }
+  const bool no_check = getenv("TPP_REPLAY_NO_CHECK") != nullptr; // the host-path rig (tools/host_path_rig.sh: this file against tests/tsan/fake_hip.cpp with FAKE_HIP_NO_COMPUTE=1)
+  if (!no_check && !check(res)) { fprintf(stderr, "tpp_replay --script %s: WRONG RESULT\n", name.c_str()); return 1; }
   const int64_t warm = n_iter / 100 < 1 ? 1 : (n_iter / 100 > 50 ? 50 : n_iter / 100);
   for (int64_t i = 0; i < warm; ++i) kernel();
   xsmm_hip_synchronize();
@@ -469,7 +470,7 @@ static int run_script(const std::string &name, int queue, int64_t n_iter, int th
   kernel();
   xsmm_hip_synchronize();
   CHECK(hipMemcpy(res.data(), out, out_n * 4, hipMemcpyDeviceToHost));
-  if (!check(res)) { fprintf(stderr, "tpp_replay --script %s: WRONG RESULT after the timed calls\n", name.c_str()); return 1; }
+  if (!no_check && !check(res)) { fprintf(stderr, "tpp_replay --script %s: WRONG RESULT after the timed calls\n", name.c_str()); return 1; }
   if (name == "mha_qk") {
     int64_t f[3];
     xsmm_hip_fold_transpose_stats(f);

@@ -37,7 +37,10 @@ std::atomic<int> g_dt_pending{0}; // number of remembered transposes (see "defer
 void dt_materialize();
 void flush_tile_queue() {
   if (g_dt_pending.load(std::memory_order_acquire)) dt_materialize();
-  if (!cfg().tile_queue.load(std::memory_order_relaxed)) return;
+  if (!cfg().tile_queue.load(std::memory_order_relaxed)) {
+    launcher_drain(); // (the queue was switched off behind a flush: nothing queued, but a handed-over launch may not have left yet)
+    return;
+  }
   InlineQueue &iq = inl();
   if (!iq.scheduled.load(std::memory_order_acquire)) {
     iq.dw.touch(thread_token());
@@ -45,9 +48,11 @@ void flush_tile_queue() {
     if (!iq.scheduled.load(std::memory_order_relaxed)) {
       iq.q.flush();
       iq.foreign = 0;
+      launcher_drain(); // whatever the caller does next on the stream (launch, copy, synchronise) is behind every queued launch
       return;
     }
   }
+  launcher_drain();
   if (Scheduler *p = g_sched.load(std::memory_order_acquire)) p->drain();
 }
 

@@ -179,7 +179,10 @@ struct Segment {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cs) != hipSuccess) (void)hipGetLastError();
     else if (cs != hipStreamCaptureStatusNone) return false;
-    if (list_used) HIP_OK(hipStreamSynchronize(list_stream)); // the buffers carried another recording's items: its last launch must be done
+    if (list_used) { // the buffers carried another recording's items: its last launch must be done (and, first, issued)
+      launcher_drain();
+      HIP_OK(hipStreamSynchronize(list_stream));
+    }
     list_used = false;
     if (list_cap < items.size()) {
       if (list) HIP_OK(hipHostFree(list));
@@ -471,17 +474,29 @@ struct TileQueue {
     pending.armed = false;
     Segment &S = segs[pending.seg];
     if (pending.kind == KIND_GEMM && S.grid_state == 0) detect_grid(S);
+    LaunchReq r;
+    r.stream = pending.stream;
     if (pending.kind == KIND_GEMM && S.grid_state == 1) {
-      HIP_OK(launch_gemm(*S.grid_desc, S.grid_w.A, S.grid_w.B, S.grid_w.C, S.grid_w.D, S.grid_w.br, pending.stream));
+      r.kind = -1;
+      r.desc = S.grid_desc;
+      r.w = S.grid_w;
       g_last_merged.store(S.grid_desc->trace, std::memory_order_relaxed);
-      return;
+    } else {
+      g_last_merged.store(nullptr, std::memory_order_relaxed);
+      r.kind = pending.kind;
+      r.desc = pending.desc;
+      r.list = S.list_dev;
+      r.n = pending.n;
+      r.vec_ok = pending.vec_ok, r.out_ok = pending.out_ok, r.pair_ok = pending.pair_ok;
+      r.br = S.items[0].w.br;
+      S.list_used = true; // (from the hand-over on: whoever rebuilds the list drains the launch thread, then the stream)
+      S.list_stream = pending.stream;
     }
-    g_last_merged.store(nullptr, std::memory_order_relaxed);
-    if (pending.kind == KIND_GEMM) HIP_OK(launch_gemm_grouped(*(const GemmDesc *)pending.desc, S.list_dev, pending.n, pending.vec_ok, pending.out_ok, pending.pair_ok, S.items[0].w.br, pending.stream));
-    else if (pending.kind == KIND_UNARY) HIP_OK(launch_unary_grouped(*(const UnaryDesc *)pending.desc, S.list_dev, pending.n, pending.stream));
-    else HIP_OK(launch_binary_grouped(*(const BinaryDesc *)pending.desc, S.list_dev, pending.n, pending.stream));
-    S.list_used = true;
-    S.list_stream = pending.stream;
+    // the inline queue's complete replays leave through the launch thread (rt_launcher.h): by value - the segment may be re-recorded
+    // before the launch is issued, its list is not rewritten before ensure_list has drained both
+    if (dw && launcher().push(r)) return;
+    launcher_drain(); // (switched off a moment ago, or the scheduler thread's queue: behind whatever was handed over before)
+    issue_launch(r);
   }
 
   void ensure_slot() {
@@ -562,6 +577,7 @@ struct TileQueue {
       pending = Pending{true, kind, desc, rp, n, vec_ok, out_ok, pair_ok, stream};
       if (!defer) issue_pending();
     } else {
+      launcher_drain(); // (launches handed to the launch thread come first on the stream)
       if (kind == KIND_GEMM) g_last_merged.store(nullptr, std::memory_order_relaxed);
       if (kind == KIND_GEMM) HIP_OK(launch_gemm_grouped(*(const GemmDesc *)desc, pinned[slot], n, vec_ok, out_ok, pair_ok, pinned[slot][0].br, stream));
       else if (kind == KIND_UNARY) HIP_OK(launch_unary_grouped(*(const UnaryDesc *)desc, pinned[slot], n, stream));

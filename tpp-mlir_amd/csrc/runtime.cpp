@@ -16,6 +16,7 @@
 #include "host_cache.h"
 
 #include <dlfcn.h>
+#include <linux/futex.h>
 #include <linux/membarrier.h>
 #include <sched.h>
 #include <sys/syscall.h>
@@ -43,6 +44,7 @@ namespace {
 #include "rt_mirror.h"    // device-pointer classification, per-invoke host mirror, host residents   (before the registry: Operand)
 #include "rt_registry.h"  // descriptors: hash-consing, dispatch-time validation
 #include "rt_operands.h"  // operands / footprints of one invoke
+#include "rt_launcher.h"  // the launch thread: complete replayed groups are launched off the calling thread
 #include "rt_tile_queue.h" // tile queue state: footprints, trace cache (segments), direct window, group bookkeeping
 #include "rt_scheduler.h"  // per-caller rings merged by ONE scheduler thread
 #include "rt_enqueue.h"    // the ways into the queue, caller state, enqueue_item (the per-invoke host path)
@@ -471,6 +473,16 @@ extern "C" int xsmm_hip_set_strict(int enable) {
   return prev;
 }
 extern "C" int xsmm_hip_get_strict(void) { return cfg().strict.load(); }
+// the launch thread (rt_launcher.h): returns the previous setting; out[0] = launches handed over since process start, out[1] = the
+// thread exists right now
+extern "C" int xsmm_hip_set_launch_thread(int enable) {
+  flush_tile_queue(); // (drains it)
+  return launcher().on.exchange(enable != 0);
+}
+extern "C" void xsmm_hip_launch_thread_stats(int64_t out[2]) {
+  out[0] = launcher().handed.load(std::memory_order_relaxed);
+  out[1] = launcher().running.load(std::memory_order_relaxed) ? 1 : 0;
+}
 extern "C" int xsmm_hip_set_fold_transpose(int enable) {
   flush_tile_queue(); // (launches a remembered transpose)
   return cfg().fold_transpose.exchange(enable != 0);

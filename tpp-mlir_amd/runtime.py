@@ -93,6 +93,8 @@ _SIGNATURES = {
     "xsmm_hip_chain_status": (ctypes.c_int64, []),
     "xsmm_hip_set_strict": (ctypes.c_int, [ctypes.c_int]),
     "xsmm_hip_get_strict": (ctypes.c_int, []),
+    "xsmm_hip_set_launch_thread": (ctypes.c_int, [ctypes.c_int]),
+    "xsmm_hip_launch_thread_stats": (None, [ctypes.POINTER(ctypes.c_int64)]),
     "xsmm_hip_tile_queue_stats": (None, [ctypes.POINTER(ctypes.c_int64)]),
     "xsmm_hip_get_stream": (VP, []),
     "xsmm_hip_synchronize": (None, []),
@@ -254,6 +256,16 @@ class XsmmRuntime:
 
     def get_strict(self):
         return self.lib.xsmm_hip_get_strict()
+
+    def set_launch_thread(self, on):
+        """complete replayed groups launched by the runtime's launch thread (default) or by the caller; previous setting"""
+        return self.lib.xsmm_hip_set_launch_thread(1 if on else 0)
+
+    def launch_thread_stats(self):
+        """(launches handed to the launch thread since process start, 1 if the thread exists right now)"""
+        out = (ctypes.c_int64 * 2)()
+        self.lib.xsmm_hip_launch_thread_stats(out)
+        return tuple(out)
 
     def chain_status(self):
         """starved chain launches found and re-run call by call since process start (0: never)"""
