@@ -663,3 +663,62 @@ def test_single_layer_timing_loop_replays_without_abandoning(rtq):
     mag = (np.abs(Af) @ np.abs(Wf)).reshape(MB, tm, NB, tn).transpose(0, 2, 1, 3).reshape(-1)
     bar = 1e-5 * np.abs(ref) + iters * (K + 2) * 2.0 ** -24 * (mag + np.abs(ref))
     assert (np.abs(got - ref) <= bar).all(), float((np.abs(got - ref) / bar).max())
+
+
+def test_launch_thread_on_off_same_bits_same_order():
+    """The launch thread (include/tpp_xsmm_abi.h xsmm_hip_set_launch_thread; csrc/rt_launcher.h): complete replayed groups are
+    launched by a helper thread, everything else - the first (recorded) pass, partial groups, invokes outside the queue, copies,
+    synchronisation points - waits for the hand-overs to have left. A chain of three DEPENDENT packed layers repeated 12 times
+    (replays from the second pass on), with an unqueued whole-layer invoke and an in-place unary between the passes (both read
+    what the last group wrote and are read by the next one): the bits with the thread on equal the bits with it off, the thread
+    took hand-overs while on and none while off."""
+    rt = pkg.get_runtime()
+    prev_async, prev_q = rt.set_async(True), rt.set_tile_queue(1)
+    try:
+        MB, NB, KB = 4, 8, 8
+        rng = np.random.default_rng(606)
+        X = rng.uniform(-1, 1, MB * KB * 1024).astype(np.float32)
+        Ws = [rng.uniform(-0.3, 0.3, NB * KB * 1024).astype(np.float32) for _ in range(3)]
+        bs = [rng.uniform(-0.3, 0.3, NB * 32).astype(np.float32) for _ in range(3)]
+        disp = (F32, 32, 32, 32, 32, 32, 32, 1024, 1024, 4, 0, 5, 4, 1)
+        h = rt.fused_brgemm_dispatch(*disp)
+        # the unqueued invoke: one big plain gemm over the flat view of the last activations (128 x 256 = [128][256] floats) into a side buffer
+        hb = rt.gemm_dispatch(F32, 128, 128, 256, 256, 128, 128, 4)
+        hr = rt.unary_dispatch(5, F32, 128, 256, 256, 256, 0)  # relu in place, a whole-buffer invoke (not queue-sized)
+        Wside = rng.uniform(-0.1, 0.1, 256 * 128).astype(np.float32)
+
+        def run(on):
+            prev = rt.set_launch_thread(on)
+            assert prev in (0, 1)
+            dX, dW, db = dev(X), [dev(w) for w in Ws], [dev(b) for b in bs]
+            dA = [dev(np.zeros(MB * NB * 1024, dtype=np.float32)) for _ in range(3)]
+            dS, dWs = dev(np.zeros(128 * 128, dtype=np.float32)), dev(Wside)
+            s0 = rt.launch_thread_stats()
+            sides = []
+            for it in range(12):
+                cur = dX
+                for l in range(3):
+                    for i in range(MB):
+                        for j in range(NB):
+                            rt.fused_brgemm(F32, h, cur, i * KB * 1024, dW[l], j * KB * 1024, dA[l], (i * NB + j) * 1024, db[l], j * 32, KB)
+                    cur = dA[l]
+                rt.gemm(F32, hb, dA[2], 0, dWs, 0, dS, 0)  # outside the queue: behind the last group's launch
+                rt.unary(F32, hr, dA[2], 0, dA[2], 0)
+                if it in (0, 5, 11):
+                    rt.synchronize()
+                    sides.append(host(dS, X).copy())
+            rt.synchronize()
+            s1 = rt.launch_thread_stats()
+            return [host(a, X).copy() for a in dA] + sides, s1[0] - s0[0]
+
+        on, handed_on = run(True)
+        off, handed_off = run(False)
+        rt.set_launch_thread(True)
+        assert handed_on >= 3 * 8 and handed_off == 0, (handed_on, handed_off)
+        for a, b in zip(on, off):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        assert np.abs(on[2]).max() > 0
+    finally:
+        rt.synchronize()
+        rt.set_tile_queue(prev_q)
+        rt.set_async(prev_async)

@@ -31,6 +31,7 @@
 
 namespace tpp {
 namespace hc {
+std::atomic<int> g_on{0}; // (external linkage: host_cache.h enabled() reads it inline - once per invoke of every entry point)
 namespace {
 
 struct PmRegion {
@@ -184,7 +185,6 @@ std::mutex g_mu;                    // every slow path (polls, uploads, write-ba
 // points.) Synchronous invokes serialise on the stream and its drain anyway.
 std::mutex g_sync_mu;
 std::atomic<int> g_writer{0};       // a structure change is waiting for / excluding the readers (set and cleared under g_mu)
-std::atomic<int> g_on{0};
 std::atomic<ThreadState *> g_threads{nullptr};
 std::vector<Extent *> g_ext;        // sorted by lo, disjoint; changed only with every other reader outside its section
 std::atomic<uint64_t> g_struct_gen{1};
@@ -586,7 +586,6 @@ void rearm(Extent *e, uintptr_t a, uintptr_t b, bool dense) {
 } // namespace
 
 void set_hooks(const Hooks &h) { g_hooks = h; }
-bool enabled() { return g_on.load(std::memory_order_relaxed) != 0; }
 
 int translate(OpRef *ops, int n, bool async, uint64_t epoch, hipStream_t s) {
   for (int i = 0; i < n; ++i) ops[i].host = nullptr, ops[i].kind = 0;

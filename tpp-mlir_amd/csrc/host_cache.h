@@ -29,6 +29,7 @@
 // OFF by default (TPP_HIP_HOST_CACHE=1 / xsmm_hip_set_host_cache(1)); needs Linux >= 6.7 with userfaultfd(UFFD_USER_MODE_ONLY).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstddef>
 #include <cstdint>
 
@@ -50,7 +51,8 @@ struct Hooks {
 };
 void set_hooks(const Hooks &h);
 
-bool enabled();
+extern std::atomic<int> g_on;
+inline bool enabled() { return g_on.load(std::memory_order_relaxed) != 0; }
 int set_enabled(int on); // previous setting, or -1 if the kernel interface is missing (the cache stays off)
 
 // One invoke. translate() maps every host operand to its mirror (creating / growing extents, polling, uploading); the calling thread is

@@ -378,10 +378,10 @@ bool try_chain_launch(int n, const GemmDesc *const *d, void *const *pa, void *co
 void chain_rerun_call_by_call(const ChainCall &c) {
   // on the stream the launch went to - through this thread's override: the process-wide setting is not touched (another thread may
   // invoke, or call xsmm_hip_set_stream, meanwhile: ADVICE r5)
-  tl_stream_override = c.stream;
-  tl_has_stream_override = true;
+  tl_hot.stream_override = c.stream;
+  tl_hot.has_stream_override = true;
   for (int i = 0; i < c.n; ++i)
     xsmm_fused_brgemm_invoke(c.dtype, c.handle[i], c.a[i], 0, c.b[i], 0, c.c[i], 0, c.d[i], 0, c.br[i]);
   flush_tile_queue();
-  tl_has_stream_override = false;
+  tl_hot.has_stream_override = false;
 }

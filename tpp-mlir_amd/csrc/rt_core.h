@@ -65,9 +65,24 @@ Config &cfg() {
 }
 // the stream an invoke of THIS thread launches on: the process-wide setting, unless the thread is re-running a journaled chain
 // launch on that launch's stream (check_chain_errors; ADVICE r5: the re-run must not change the setting other threads read)
-thread_local hipStream_t tl_stream_override = nullptr; 
-thread_local bool tl_has_stream_override = false;      
-inline hipStream_t invoke_stream() { return tl_has_stream_override ? tl_stream_override : cfg().stream.load(std::memory_order_relaxed); }
+// (in the static TLS block - initial-exec: a %fs-relative load; the general-dynamic model of a shared library calls __tls_get_addr per
+// access, twice per gemm invoke here. 16 bytes of the loader's static-TLS reserve; -DTPP_TLS_DEFAULT_MODEL: see rt_enqueue.h tl_fast)
+struct TlHot {
+  hipStream_t stream_override;
+  bool has_stream_override;
+};
+#ifdef TPP_TLS_DEFAULT_MODEL
+static __thread TlHot tl_hot = {nullptr, false};
+#else
+static __thread TlHot tl_hot __attribute__((tls_model("initial-exec"))) = {nullptr, false};
+#endif
+inline hipStream_t invoke_stream() { return tl_hot.has_stream_override ? tl_hot.stream_override : cfg().stream.load(std::memory_order_relaxed); }
+// membarrier(PRIVATE_EXPEDITED) is registered and usable (the asymmetric fences of the direct window, the scheduler's parking and the
+// deferred transposes' owner sections); TPP_HIP_NO_MEMBARRIER: never (the two-sided protocols everywhere)
+inline bool membarrier_ok() {
+  static const bool ok = !getenv("TPP_HIP_NO_MEMBARRIER") && syscall(__NR_membarrier, MEMBARRIER_CMD_REGISTER_PRIVATE_EXPEDITED, 0) == 0;
+  return ok;
+}
 
 // ---- tracing: with TPP_HIP_TRACE >= 1 every invoke runs inside a roctx range named after its
 // dispatch tuple and kernel, so `rocprofv3 --marker-trace --kernel-trace` timelines show which xsmm call a kernel
@@ -94,8 +109,11 @@ Roctx &roctx() {
 }
 struct TraceRange {
   bool on = false;
-  TraceRange(const char *who, const char *what) {
-    if (cfg().trace < 1) return;
+  __attribute__((always_inline)) TraceRange(const char *who, const char *what) {
+    if (__builtin_expect(cfg().trace < 1, 1)) return; // (inline: one load per invoke when tracing is off)
+    begin(who, what);
+  }
+  __attribute__((noinline)) void begin(const char *who, const char *what) {
     if (cfg().trace >= 2) fprintf(stderr, "[tpp-xsmm-hip] %s %s\n", who, what);
     if (roctx().push) on = roctx().push(what) >= 0;
   }

@@ -105,6 +105,7 @@ struct DeferredTranspose {
   void *src = nullptr, *dst = nullptr;
   hipStream_t stream = nullptr;
   const GemmDesc *sib_of = nullptr, *sib = nullptr; // the last gemm descriptor folded and its sibling
+  size_t a_bytes = 0, c_bytes = 0, d_bytes = 0;     // ... and the footprints of that descriptor's A / C / bias operands (sib_of != nullptr)
 };
 struct alignas(64) DtSlot {
   // line 0 - what EVERY thread reads per invoke while records exist; written when a record appears or goes, not per tile:
@@ -116,9 +117,59 @@ struct alignas(64) DtSlot {
   // (acquire). A reader that races with a replacement may see either record's source range - both belong to invokes it is not ordered with.
   std::atomic<uintptr_t> d_lo{0}, d_hi{0}, s_lo{0}, s_hi{0};
   // line 1 - the owner's (and, rarely, of a thread that launches the record):
-  alignas(64) SpinLock mu;           // the record and its hand-over
-  DeferredTranspose r;               // under mu
+  alignas(64) SpinLock mu;           // the record and its hand-over: every thread but the owner, and the owner when `contended`
+  DeferredTranspose r;               // under mu / inside an owner section
   std::atomic<int64_t> folded{0}, dropped{0}; // statistics (the owner's relaxed adds)
+  // OWNER SECTIONS (round 6): the owner touches its record twice per tile (the transpose replaces it, the gemm folds into it) and an
+  // uncontended spin lock was two locked exchanges of the ~35 ns that pair costs. The owner now brackets its section with oseq (odd
+  // inside; plain stores) and looks at `contended`; any OTHER thread that wants the record takes mu, sets contended, issues
+  // membarrier(PRIVATE_EXPEDITED) - a full barrier at a precise point of the owner's instruction stream - and waits for an even oseq:
+  // either the owner's oseq store had retired when the barrier landed (the other thread waits for the section to end) or the owner's
+  // load of `contended` had not retired either and sees 1 (the owner takes mu like everybody else). The same pair as the direct
+  // window's SOLO sections (rt_tile_queue.h), per slot and reversible. Other threads want a record at flush points and on a real
+  // overlap only. No membarrier: the owner locks as before.
+  std::atomic<uint64_t> oseq{0};
+  std::atomic<int> contended{0};
+};
+struct DtOwnerSection { // the calling thread OWNS the slot
+  DtSlot &sl;
+  bool locked = true;
+  __attribute__((always_inline)) explicit DtOwnerSection(DtSlot &s) : sl(s) {
+    if (membarrier_ok()) {
+      const uint64_t q = sl.oseq.load(std::memory_order_relaxed);
+      sl.oseq.store(q + 1, std::memory_order_relaxed);
+      std::atomic_signal_fence(std::memory_order_seq_cst); // (the compiler keeps the order; the other side's membarrier makes it hold)
+      if (!sl.contended.load(std::memory_order_acquire)) {
+        locked = false;
+        return;
+      }
+      sl.oseq.store(q + 2, std::memory_order_release);
+    }
+    sl.mu.lock();
+  }
+  __attribute__((always_inline)) ~DtOwnerSection() {
+    if (locked) {
+      sl.mu.unlock();
+      return;
+    }
+    std::atomic_signal_fence(std::memory_order_seq_cst);
+    sl.oseq.store(sl.oseq.load(std::memory_order_relaxed) + 1, std::memory_order_release);
+  }
+};
+struct DtForeignSection { // any other thread (or nobody's slot)
+  DtSlot &sl;
+  explicit DtForeignSection(DtSlot &s) : sl(s) {
+    sl.mu.lock();
+    if (membarrier_ok()) {
+      sl.contended.store(1, std::memory_order_seq_cst);
+      if (syscall(__NR_membarrier, MEMBARRIER_CMD_PRIVATE_EXPEDITED, 0) != 0) die("tpp-xsmm-hip: membarrier failed");
+      while (sl.oseq.load(std::memory_order_acquire) & 1) cpu_relax();
+    }
+  }
+  ~DtForeignSection() {
+    sl.contended.store(0, std::memory_order_release);
+    sl.mu.unlock();
+  }
 };
 constexpr int DT_SLOTS = 64;
 DtSlot g_dt_slots[DT_SLOTS];
@@ -129,9 +180,7 @@ void unary_invoke_core(const UnaryDesc *d, void *pi, float scalar, bool use_scal
 // Launches the slot's remembered transpose, if there is one (any thread). The record stays live until the transpose HAS BEEN handed to
 // the queue / launched, and the lock is held across that: a thread that then sees live = 0 (and goes on to queue an invoke that reads
 // the destination) is ordered behind the transpose.
-void dt_launch(DtSlot &sl) {
-  if (tl_dt_busy) return;
-  std::lock_guard<SpinLock> lk(sl.mu);
+void dt_launch_locked(DtSlot &sl) { // inside a section of the slot
   if (!sl.live.load(std::memory_order_relaxed)) return;
   const DeferredTranspose r = sl.r;
   g_dt_launched.fetch_add(1, std::memory_order_relaxed);
@@ -141,6 +190,16 @@ void dt_launch(DtSlot &sl) {
   tl_dt_busy = false;
   sl.live.store(0, std::memory_order_release);
   g_dt_pending.fetch_sub(1, std::memory_order_release);
+}
+void dt_launch(DtSlot &sl) {
+  if (tl_dt_busy) return;
+  if (sl.owner.load(std::memory_order_relaxed) == thread_token()) {
+    DtOwnerSection sec(sl);
+    dt_launch_locked(sl);
+  } else {
+    DtForeignSection sec(sl);
+    dt_launch_locked(sl);
+  }
 }
 void dt_materialize() { // every record (flush, synchronisation points)
   if (tl_dt_busy) return;
@@ -211,22 +270,29 @@ const GemmDesc *dt_gemm(const GemmDesc *d, void *pa, void *pb, void *pc, void *p
   const GemmDesc *sib = nullptr;
   if (mine && mine->live.load(std::memory_order_acquire)) {
     {
-      std::lock_guard<SpinLock> lk(mine->mu);
+      DtOwnerSection sec(*mine);
       if (mine->live.load(std::memory_order_relaxed)) {
         DeferredTranspose &r = mine->r;
         const UnaryDesc *t = r.d;
         const size_t dst_bytes = (size_t)t->n * t->m * 4, src_bytes = span(t->m, t->ldi, t->n) * 4;
-        if (pb == r.dst && br == 1 && d->dtype == DT_F32 && !d->vnni_b && !d->vnni_c && !d->b_trans && d->k == t->n && d->n == t->m && d->ldb == t->ldo &&
-            s == r.stream && d->m <= 64 && d->n <= 64 && queue_active() && !dt_overlap(pa, span(d->m, d->lda, d->k) * 4, r.dst, dst_bytes) &&
-            !dt_overlap(pc, span(d->m, d->ldc, d->n) * 4, r.dst, dst_bytes) && !dt_overlap(pd, d->bias ? (size_t)d->n * 4 : 0, r.dst, dst_bytes) &&
-            !dt_overlap(pc, span(d->m, d->ldc, d->n) * 4, r.src, src_bytes)) {
-          if (r.sib_of != d) {
-            r.sib = dt_sibling(d, t->ldi);
-            r.sib_of = d;
+        // (the descriptor-level conditions and footprints were established when this descriptor was folded into this record last: the
+        // record keeps its transpose descriptor for as long as it lives)
+        const bool known = r.sib_of == d;
+        if (pb == r.dst && br == 1 && s == r.stream && queue_active() &&
+            (known || (d->dtype == DT_F32 && !d->vnni_b && !d->vnni_c && !d->b_trans && d->k == t->n && d->n == t->m && d->ldb == t->ldo && d->m <= 64 && d->n <= 64))) {
+          const size_t a_bytes = known ? r.a_bytes : span(d->m, d->lda, d->k) * 4, c_bytes = known ? r.c_bytes : span(d->m, d->ldc, d->n) * 4,
+                       d_bytes = known ? r.d_bytes : (d->bias ? (size_t)d->n * 4 : 0);
+          if (!dt_overlap(pa, a_bytes, r.dst, dst_bytes) && !dt_overlap(pc, c_bytes, r.dst, dst_bytes) && !dt_overlap(pd, d_bytes, r.dst, dst_bytes) &&
+              !dt_overlap(pc, c_bytes, r.src, src_bytes)) {
+            if (!known) {
+              r.sib = dt_sibling(d, t->ldi);
+              r.sib_of = d;
+              r.a_bytes = a_bytes, r.c_bytes = c_bytes, r.d_bytes = d_bytes;
+            }
+            *src = r.src;
+            sib = r.sib;
+            mine->folded.store(mine->folded.load(std::memory_order_relaxed) + 1, std::memory_order_relaxed);
           }
-          *src = r.src;
-          sib = r.sib;
-          mine->folded.store(mine->folded.load(std::memory_order_relaxed) + 1, std::memory_order_relaxed);
         }
       }
     }
@@ -267,7 +333,7 @@ bool dt_defer(const UnaryDesc *d, void *pi, void *po, hipStream_t s) {
   const uintptr_t s_lo = (uintptr_t)pi, s_hi = (uintptr_t)pi + src_bytes;
   bool replaced = false, launch_old = false;
   if (mine->live.load(std::memory_order_acquire)) {
-    std::lock_guard<SpinLock> lk(mine->mu);
+    DtOwnerSection sec(*mine);
     if (mine->live.load(std::memory_order_relaxed)) {
       DeferredTranspose &r = mine->r;
       if (r.d == d && r.dst == po && r.stream == s) {
@@ -290,9 +356,9 @@ bool dt_defer(const UnaryDesc *d, void *pi, void *po, hipStream_t s) {
     dt_scan_foreign(mine, rd, 1, wr, 1);
   }
   if (replaced) return true;
-  std::lock_guard<SpinLock> lk(mine->mu);
+  DtOwnerSection sec(*mine);
   if (mine->live.load(std::memory_order_relaxed)) return false; // (cannot happen: only the owner makes a record live)
-  mine->r = DeferredTranspose{d, pi, po, s, nullptr, nullptr};
+  mine->r = DeferredTranspose{d, pi, po, s, nullptr, nullptr, 0, 0, 0};
   mine->d_lo.store((uintptr_t)po, std::memory_order_relaxed);
   mine->d_hi.store((uintptr_t)po + dst_bytes, std::memory_order_relaxed);
   mine->s_lo.store(s_lo, std::memory_order_relaxed);
