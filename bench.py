@@ -532,6 +532,12 @@ def compact_line(line, detail_path=None):
     o_ = first("mlir-gen mlp 3x1024 bs=256 bias+relu (fp32 unless noted), tile queue, tiles 32,32,32 (")
     if o_:
         configs["ref_mlp_bs256_tile_invokes_us"] = o_.get("us_per_step")
+    o_ = first("mlir-gen mlp 3x1024 bs=256 bias+relu (fp32 unless noted), tile queue, tiles 32,32,32, bf16 + VNNI-2 W (")
+    if o_:
+        configs["ref_mlp_bs256_tile_invokes_bf16_us"] = o_.get("us_per_step")
+    o_ = first("mlir-gen mlp 3x1024 bs=256 bias+relu (fp32 unless noted), tile queue, tiles 32,32,32, bf16 + VNNI-2 W, launch thread off")
+    if o_:
+        configs["ref_mlp_bs256_tile_invokes_bf16_launch_thread_off_us"] = o_.get("us_per_step")
     o_ = first("the reference's benchmark shape set, f32")
     if o_ and "rows" in o_:
         configs["refbench_f32"] = {"at_bar": o_.get("rows_at_0.45_of_peak_or_within_2x_the_launch_floor"), "of": o_.get("rows"),
@@ -1145,9 +1151,11 @@ def main():
                                  ("tile queue, tiles 64,64,64", ["--tiles", "64", "--queue", "1", "-n", "200"]),
                                  ("tile queue, tiles 32,32,32, bf16 + VNNI-2 W", ["--tiles", "32", "--queue", "1", "-n", "200", "--bf16"]),
                                  ("tile queue, tiles 64,64,64, bf16 + VNNI-2 W", ["--tiles", "64", "--queue", "1", "-n", "200", "--bf16"]),
+                                 ("tile queue, tiles 32,32,32, bf16 + VNNI-2 W, launch thread off (TPP_HIP_LAUNCH_THREAD=0)", ["--tiles", "32", "--queue", "1", "-n", "200", "--bf16"]),
                                  ("whole-layer dispatch", ["--whole-layer", "-n", "1000"])):
+                env_ = dict(os.environ, TPP_HIP_LAUNCH_THREAD="0") if "launch thread off" in label else None
                 r = subprocess.run([replay, "--batch", "256", "--layers", "1024,1024,1024,1024", "--bias", "--relu"] + extra,
-                                   capture_output=True, text=True, timeout=300)
+                                   capture_output=True, text=True, timeout=300, env=env_)
                 mm = re.search(r"mean ([0-9.]+) us[^,]*, ([0-9.]+) GFLOP/s", r.stderr)
                 if mm:
                     others.append({"workload": "mlir-gen mlp 3x1024 bs=256 bias+relu (fp32 unless noted), " + label + " (tools/tpp_replay)",

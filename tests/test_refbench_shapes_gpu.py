@@ -337,3 +337,67 @@ def test_f32_32k_pair_tiles_with_a_long_batch_split_in_the_group(rt):
         b2 = np.abs(B[(it % 3) * br * t * t:][:br * t * t]).reshape(br, t, t).astype(np.float64)
         mag[it * t * t:(it + 1) * t * t] += (np.einsum("bik,bkj->ij", a2, b2) + np.abs(bias[(it % 3) * t:(it % 3 + 1) * t])[None, :]).reshape(-1)
     check_close(outs[0], ref, F32, "32-k pairs + split", mag=mag, K=br * t)
+
+
+@pytest.mark.parametrize("fc", [False, True], ids=["matmul_beta1", "fc_beta0_bias_relu"])
+@pytest.mark.parametrize("vn", [2, 4], ids=["vnni2", "vnni4"])
+@pytest.mark.parametrize("M,N,K", [(1024, 1280, 256), (512, 2560, 128), (1024, 2560, 1024)], ids=lambda v: str(v))
+def test_bf16_64_tile_invokes_replayed_as_quads_on_the_128_tile(rt, M, N, K, vn, fc):
+    """QUADS (csrc/rt_rewrites.h detect_quads, brgemm_bf16_lw GRP = 2): a recorded group of 64x64x64 bf16 tile invokes over packed
+    blocks (benchmarks/config/fc/1024x2560x1024.json:40-64 as mlir-gen emits it: 16 x 40 invokes, br = 16) that forms a grid of
+    item rows and item columns is REPLAYED as 2 x 2 blocks on the 128x128 loader-wave tile when the tile model prefers it. Three
+    passes of the same layer: recorded (items on the grouped 64x64 tile), replayed twice (quads). Against the oracle after every
+    pass (the matmul flavour accumulates: C += X W, rounded to bf16 each pass - the oracle's pass starts from the device's previous
+    result), and the BETA_0 flavour bit-identical between the item pass and the quad passes (same k order per element)."""
+    tm = tn = tk = 64
+    old_v = rt.set_vnni_factor(vn)
+    old_o = orc.set_vnni_factor(vn)
+    old_async, old_q = rt.set_async(True), rt.set_tile_queue(1)
+    try:
+        rng = np.random.default_rng(M + N + K + vn)
+        X = rng.uniform(-1, 1, (M, K)).astype(np.float32)
+        W = (rng.uniform(-1, 1, (K, N)) / np.sqrt(K)).astype(np.float32)
+        C0 = rng.uniform(-1, 1, (M, N)).astype(np.float32)
+        bias = rng.uniform(-1, 1, N).astype(np.float32)
+        X, W, C0, bias = (orc.bf16_to_f32(orc.f32_to_bf16(v.reshape(-1))).reshape(v.shape) for v in (X, W, C0, bias))
+        conv = orc.f32_to_bf16
+        flags = VB | (4 if fc else 0)
+        Wv = np.ascontiguousarray(W.reshape(K // vn, vn, N).transpose(0, 2, 1)).reshape(-1)  # flat VNNI-vn [K/vn][N][vn] for the oracle
+        a_o, w_o, b_o = conv(X.reshape(-1)), conv(Wv), conv(bias)
+        dA, dW, dB = dev(conv(pack_a(X, M, K, tm, tk))), dev(conv(pack_w(W, K, N, tk, tn, vn))), dev(conv(bias))
+        dC = dev(conv(pack_c(C0, M, N, tm, tn)))
+        disp = (BF16, tm, tn, tk, tk, tn, tn, tm * tk, tk * tn, flags)
+        h = rt.fused_brgemm_dispatch(*disp, 0, 5, 4, 1) if fc else rt.brgemm_dispatch(*disp)
+        MB, NB, KB = M // tm, N // tn, K // tk
+        kernels, outs = [], []
+        for p in range(3):
+            # (the accumulating flavour: the oracle's pass starts from what the device holds - a rounding flip of an earlier pass, allowed
+            # by the bar, must not be counted again in the next one)
+            start = host(dC, conv(C0.reshape(-1)))
+            ref = orc.f32_to_bf16(unpack_c(orc.bf16_to_f32(start), M, N, tm, tn).reshape(-1))
+            for i in range(MB):
+                for j in range(NB):
+                    if fc:
+                        rt.fused_brgemm(BF16, h, dA, i * KB * tm * tk, dW, j * KB * tk * tn, dC, (i * NB + j) * tm * tn, dB, j * tn, KB)
+                    else:
+                        rt.brgemm(BF16, h, dA, i * KB * tm * tk, dW, j * KB * tk * tn, dC, (i * NB + j) * tm * tn, KB)
+            rt.synchronize()
+            kernels.append(rt.last_grouped_kernel())
+            got = host(dC, ref)
+            outs.append(got.copy())
+            if fc:
+                orc.fused_brgemm(BF16, M, N, K, K, N, N, 0, 0, flags, 0, 5, 4, 1, a_o, 0, w_o, 0, ref, 0, b_o, 0, 1)
+            else:
+                orc.brgemm(BF16, M, N, K, K, N, N, 0, 0, flags, a_o, 0, w_o, 0, ref, 0, 1)
+            flat = unpack_c(orc.bf16_to_f32(got), M, N, tm, tn).reshape(-1)
+            check_close(orc.f32_to_bf16(flat), ref, BF16, "pass %d %s vnni%d [%s]" % (p, (M, N, K), vn, kernels[-1]), K=K)
+        assert "quads" not in kernels[0] and "quads" in kernels[1] and "quads" in kernels[2], kernels
+        assert ("vnni4" in kernels[1]) == (vn == 4), kernels
+        if fc:
+            assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[1], outs[2]), "items pass and quad passes differ in bits"
+    finally:
+        rt.synchronize()
+        rt.set_tile_queue(old_q)
+        rt.set_async(old_async)
+        rt.set_vnni_factor(old_v)
+        orc.set_vnni_factor(old_o)

@@ -143,6 +143,8 @@ hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *it, int n, boo
   for (int i = 0; i < n; ++i) (void)launch_gemm(d, it[i].A, it[i].B, it[i].C, it[i].D, it[i].br, s);
   return hipSuccess;
 }
+bool gemm_quads_pay(const GemmDesc &, int, int64_t) { return false; } // (plan_gemm above refuses bf16: no quads on the host stand-in)
+hipError_t launch_gemm_quads(const GemmDesc &, const QuadItem *, int, int64_t, hipStream_t) { return hipErrorNotSupported; }
 hipError_t launch_unary(const UnaryDesc &d, const void *in_, float scalar, bool use_scalar, void *out_, hipStream_t) {
   const float *in = (const float *)in_;
   float *out = (float *)out_;

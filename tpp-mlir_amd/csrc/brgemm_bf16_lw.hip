@@ -134,9 +134,14 @@ template <int PPL> __device__ __forceinline__ void blw_wait_younger(int younger)
 // first version of this function (one general loop with a switch over the wait count, the layer bookkeeping and an argument load
 // inside), a 16-chunk layer took 5.7 us with NO loads and NO MFMAs at all - the loader's own instruction stream set the pace.
 // GRP (grouped launches): the panel base pointers and the batch count are the ITEM's (it_A / it_B / it_br), not the argument block's
-template <bool IS_A, int NL, int NLA, int NSLOT_C, int SUP, int BM, int BN, int WK, bool MULTI, int FB = 0, bool GRP = false>
+// GRP = 2 (QUADS, round 6): the 128x128 tile over a 2 x 2 block of 64x64 ITEMS (QuadItem, chain_args.h): rows 64 .. 127 of the A panel
+// come from the lower item row's block (q_delta = its distance from the upper one, minus the 64 rows the instruction offsets already
+// cover), columns 64 .. 127 of the B panel from the right item column's block (q_delta = its distance from the left one): the LDS
+// image is the flat 128-wide tile's, only the source addresses of the DMA instructions differ.
+template <bool IS_A, int NL, int NLA, int NSLOT_C, int SUP, int BM, int BN, int WK, bool MULTI, int FB = 0, int GRP = 0>
 __device__ __forceinline__ void blw_loader(chain_kernarg_t *pp, unsigned char *smem, int lane, int m0, int n0, int tm, int L, int part,
-                                           const void *it_A = nullptr, const void *it_B = nullptr, int it_br = 0) {
+                                           const void *it_A = nullptr, const void *it_B = nullptr, int it_br = 0, unsigned q_delta = 0) {
+  static_assert(GRP != 2 || (BM == 128 && BN == 128 && NL == 1 && (FB == 0 || FB == 4)), "quads: the 128x128 tile, one loader wave per panel, VNNI-2 / VNNI-4 B");
   chain_kernarg_t &p = *pp;
   constexpr int A_SLOT = BM * 128, SLOT = (BM + BN) * 128;
   // SUP = chunks per barrier (the unit everything below counts in: a "chunk" of this function is SUP 64-k chunks, a "slot" SUP
@@ -211,6 +216,7 @@ __device__ __forceinline__ void blw_loader(chain_kernarg_t *pp, unsigned char *s
       d_in = (int64_t)BLW_BK * p.L[l].ldb;                                                                             \
       d_wrap = p.L[l].stride_b - (int64_t)(kchunks - 1) * d_in;                                                        \
       vo0 = vo1 = (unsigned)((lane / PPR4_) * (int)p.L[l].ldb * 8 + ((lane % PPR4_) << 4));                            \
+      if (GRP == 2) vo0 = vo1 = (unsigned)(((lane & 31) << 4)) + ((lane & 32) ? q_delta : 0u); /* 64 pieces = one k-group row: 32 per item */ \
       step = (unsigned)(NL * RPI4_ * (int)p.L[l].ldb * 8);                                                             \
     } else {                                                                                                           \
       g = (const unsigned short *)(GRP ? it_B : p.L[l].B) + 2 * (int64_t)n0 + (int64_t)part * RPI * 2 * p.L[l].ldb;    \
@@ -218,6 +224,7 @@ __device__ __forceinline__ void blw_loader(chain_kernarg_t *pp, unsigned char *s
       d_wrap = p.L[l].stride_b - (int64_t)(kchunks - 1) * d_in;                                                        \
       /* instruction v covers pair-rows RPI*v ..: lane -> pair-row lane / (BN/4), 16-byte piece lane % (BN/4) */       \
       vo0 = vo1 = (unsigned)((lane / (BN / 4)) * (int)p.L[l].ldb * 4 + ((lane % (BN / 4)) << 4));                      \
+      if (GRP == 2) vo0 = vo1 = (unsigned)((lane >> 5) * (int)p.L[l].ldb * 4 + ((lane & 15) << 4)) + ((lane & 16) ? q_delta : 0u); /* 32 pieces = one pair-row: 16 per item */ \
       step = (unsigned)(NL * RPI * (int)p.L[l].ldb * 4);                                                               \
     }                                                                                                                  \
     flat = d_wrap == d_in;                                                                                             \
@@ -235,7 +242,8 @@ __device__ __forceinline__ void blw_loader(chain_kernarg_t *pp, unsigned char *s
             __builtin_amdgcn_raw_ptr_buffer_load_lds(r_, (lds_void_b *)(base_ + v * NL * 1024), 16, (v & 1) ? vo1 : vo0, v * step, 0, 16); \
       } else {                                                                                                         \
         _Pragma("unroll") for (int v = 0; v < PPC; ++v)                                                                \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_, (lds_void_b *)(base_ + v * NL * 1024), 16, (v & 1) ? vo1 : vo0, v * step, 0, 0); \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_, (lds_void_b *)(base_ + v * NL * 1024), 16, (v & 1) ? vo1 : vo0,   \
+                                                     v * step + ((GRP == 2 && IS_A && v >= 8) ? q_delta : 0u), 0, 0);      \
       }                                                                                                                \
       BLW_DBG_EXEC_ON();                                                                                               \
       if (flat) { /* the batch elements continue each other (whole-layer dispatches): one 64-bit add */               \
@@ -338,9 +346,10 @@ __device__ __forceinline__ void blw_loader(chain_kernarg_t *pp, unsigned char *s
 #undef BLW_LOAD_STATE
 }
 
-template <int WM, int WN, int WK, int TM, int TN, int NSLOT, int NLA, int NLB, int SUP, bool MULTI, int FLATB = 0, bool GRP = false>
+template <int WM, int WN, int WK, int TM, int TN, int NSLOT, int NLA, int NLB, int SUP, bool MULTI, int FLATB = 0, int GRP = 0>
 __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_lw(ChainArgs p_by_value) {
   static_assert(!GRP || !MULTI, "a grouped launch is a set of single layers");
+  static_assert(GRP != 2 || (WM == 2 && WN == 2 && WK == 1 && TM == 2 && TN == 2), "quads: every MFMA wave owns one item's 64x64 output");
   chain_kernarg_t *pp = (chain_kernarg_t *)__builtin_amdgcn_kernarg_segment_ptr(); // = &p_by_value (the only explicit argument)
   chain_kernarg_t &p = *pp;
   constexpr int NMW = WM * WN * WK, NOUT = WM * WN; // MFMA waves; waves that own output
@@ -383,7 +392,22 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
   [[maybe_unused]] const void *it_A = nullptr, *it_B = nullptr, *it_D = nullptr;
   [[maybe_unused]] void *it_C = nullptr;
   [[maybe_unused]] int it_br = 0;
-  if constexpr (GRP) {
+  [[maybe_unused]] unsigned q_da = 0, q_db = 0;
+  if constexpr (GRP == 2) {
+    // QUADS: workgroup b = the b-th 2 x 2 block of items. Panels: the upper-left item's A rows / B columns + the two distances; output
+    // and bias: MFMA wave (wm, wn) owns item (wm, wn)'s 64x64 block outright (its own base pointer, the items' ldc)
+    typedef const __attribute__((address_space(4))) QuadItem quad_c_t;
+    quad_c_t &w = ((quad_c_t *)p.items)[b];
+    const int qi = wave < WM * WN * WK ? wave : 0; // (= wm * 2 + wn; the loader waves do not store)
+    it_A = w.A;
+    it_B = w.B;
+    it_C = w.C[qi];
+    it_D = w.D[qi & 1];
+    it_br = (int)w.br;
+    q_da = w.da;
+    q_db = w.db;
+    tm = tn = 0;
+  } else if constexpr (GRP) {
     // (plain order: workgroup b = the b-th tile of the list. Handing XCD x the x-th EIGHTH of the list - contiguous block rows of the
     // layer - was measured and is WORSE for the reference's shapes, 1024 x 2560 x 1024 15.0 -> 18.1 us: with row-major items and a
     // column count that is a multiple of 8 the plain order already gives every XCD its own eighth of the COLUMNS, i.e. of W, the
@@ -433,8 +457,8 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
 
   if (wave >= NMW) {
     // ---- loader waves (blw_loader above) ---------------------------------------------------------------------------
-    if (wave < NMW + NLA) blw_loader<true, NLA, NLA, NSLOT, SUP, BM, BN, WK, MULTI, 0, GRP>(pp, smem_c, lane, m0_ld, n0_ld, tm, L, wave - NMW, it_A, it_B, it_br);
-    else blw_loader<false, NLB, NLA, NSLOT, SUP, BM, BN, WK, MULTI, FLATB, GRP>(pp, smem_c, lane, m0_ld, n0_ld, tm, L, wave - NMW - NLA, it_A, it_B, it_br);
+    if (wave < NMW + NLA) blw_loader<true, NLA, NLA, NSLOT, SUP, BM, BN, WK, MULTI, 0, GRP>(pp, smem_c, lane, m0_ld, n0_ld, tm, L, wave - NMW, it_A, it_B, it_br, q_da);
+    else blw_loader<false, NLB, NLA, NSLOT, SUP, BM, BN, WK, MULTI, FLATB, GRP>(pp, smem_c, lane, m0_ld, n0_ld, tm, L, wave - NMW - NLA, it_A, it_B, it_br, q_db);
     return; // ended waves do not take part in later barriers
   }
 
@@ -630,7 +654,7 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         biasw[j][g] = u32x2_lw{0u, 0u};
-        if (ep & EP_BIAS) biasw[j][g] = *(const u32x2_lw *)((const unsigned short *)(GRP ? it_D : Y.D) + n0 + (wn * TN + j) * 32 + 8 * g + 4 * lh);
+        if (ep & EP_BIAS) biasw[j][g] = *(const u32x2_lw *)((const unsigned short *)(GRP ? it_D : Y.D) + n0 + ((GRP == 2 ? 0 : wn * TN) + j) * 32 + 8 * g + 4 * lh);
       }
     if (MULTI && wave == 0) blw_stamp(p, l, 0, lane);
     if (MULTI && NLA > 1 && l > 0) __builtin_amdgcn_s_barrier(); // S2 (the loaders' rendezvous after the seam wait)
@@ -738,7 +762,7 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
       // lane (li, lh) owns row 32*i + li of the wave's row block i and, in registers 4g..4g+3 of tile (i, j),
       // columns 32*j + 8*g + 4*lh + (0..3)
       const __amdgpu_buffer_rsrc_t rsrcC = __builtin_amdgcn_make_buffer_rsrc(
-          (void *)(C + (int64_t)(m0 + wm * 32 * TM) * Y.ldc + n0 + wn * 32 * TN), 0, 0x7fffffff, 0x00020000);
+          (void *)(GRP == 2 ? C : C + (int64_t)(m0 + wm * 32 * TM) * Y.ldc + n0 + wn * 32 * TN), 0, 0x7fffffff, 0x00020000);
       if constexpr (!MULTI) {
         if (!(ep & EP_BETA0)) { // beta = 1: add C before the single rounding (8-byte loads, rare path)
 #pragma unroll
@@ -822,7 +846,7 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
   }
 }
 
-template <int WM, int WN, int WK, int TM, int TN, int NSLOT, int NLA, int NLB, int SUP, bool MULTI, int FLATB = 0, bool GRP = false>
+template <int WM, int WN, int WK, int TM, int TN, int NSLOT, int NLA, int NLB, int SUP, bool MULTI, int FLATB = 0, int GRP = 0>
 static hipError_t launch_blw_t(const ChainArgs &a, hipStream_t s, const void *items = nullptr, int n_items = 0) {
   constexpr int NOUT = WM * WN, BM = 32 * WM * TM, BN = 32 * WN * TN, NT = 64 * (WM * WN * WK + NLA + NLB);
   constexpr size_t lds = (size_t)NSLOT * (BM + BN) * 128 + (WK > 1 ? (size_t)NOUT * 4096 : 0);
@@ -985,6 +1009,16 @@ hipError_t launch_bf16_lw_grouped(int tile, int b_kind, const ChainArgs &a, cons
   }
   if (tile == 0) return sup2 ? launch_blw_t<1, 2, 2, 1, 1, 8, 1, 2, 2, false, 0, true>(a, s, items, n_items) : launch_blw_t<1, 2, 2, 1, 1, 8, 1, 2, 1, false, 0, true>(a, s, items, n_items);
   return sup2 ? launch_blw_t<2, 2, 1, 1, 1, 8, 1, 1, 2, false, 0, true>(a, s, items, n_items) : launch_blw_t<2, 2, 1, 1, 1, 8, 1, 1, 1, false, 0, true>(a, s, items, n_items);
+}
+
+// QUADS (round 6): a group of 64x64 items that forms an R x C grid of item rows (A blocks) and item columns (B blocks), R and C even,
+// as 2 x 2 blocks on the 128x128 tile - what the same layer runs on as one whole-layer call when it is large (1024 x 2560 x 1024:
+// 640 items on 64x64 tiles 15.3 us, 160 workgroups of 128x128 10.2). a.m = a.n = 128 (one tile per quad), lda / ldb / ldc / strides /
+// k the items'; quads = QuadItem[n_quads] in device-visible memory.
+hipError_t launch_bf16_lw_quads(int b_kind, const ChainArgs &a, const void *quads, int n_quads, hipStream_t s) {
+  if (a.L[0].k < BLW_BK || a.L[0].k % BLW_BK || a.m != 128 || a.n != 128 || (b_kind != 0 && b_kind != 4)) return hipErrorInvalidValue;
+  if (b_kind == 4) return launch_blw_t<2, 2, 1, 2, 2, 4, 1, 1, 1, false, 4, 2>(a, s, quads, n_quads);
+  return launch_blw_t<2, 2, 1, 2, 2, 4, 1, 1, 1, false, 0, 2>(a, s, quads, n_quads);
 }
 
 // a chain of layers in one launch; the caller guarantees co-residency (tiles <= CUs), beta = 0, disjoint buffers and ONE kind of B

@@ -1030,6 +1030,43 @@ hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_i
   return note_grouped("brgemm_grouped<bf16,flat>", launch_grouped_t<unsigned short, false, false>(a, items, n_items, stream));
 }
 
+// QUADS (round 6; xsmm_desc.h QuadItem, brgemm_bf16_lw.hip GRP = 2): a group of 64x64 bf16 tile invokes that forms a grid of item rows and
+// item columns runs as 2 x 2 blocks on the 128x128 loader-wave tile when the tile model says so - the kernel the same layer gets as
+// ONE whole-layer call once it is large enough (pick_bf16_lw_tile). 1024 x 2560 x 1024 as 640 invokes: 3 rounds of 64x64 tiles
+// (15.3 us) against 160 workgroups of 128x128 (whole-layer call 10.2 us). TPP_HIP_BF16_QUADS=0: off (A/B runs).
+static bool quads_shape_ok(const GemmDesc &d) {
+  const bool v2 = d.vnni_factor == 2 || d.vnni_factor == 0, v4 = d.vnni_factor == 4;
+  return d.dtype == DT_BF16 && d.vnni_b && (v2 || v4) && !d.vnni_c && !d.b_trans && !d.generic_forced && !d.variant_forced && d.m == 64 && d.n == 64 && d.k > 0 &&
+         d.k % BK == 0 && !((d.lda | d.stride_a | d.stride_b | d.ldc) & 7) && !(d.ldb & (v4 ? 1 : 3)) && d.lda < (1 << 21) && d.ldb < (1 << 20) &&
+         d.ldc < (1 << 22) && d.stride_a >= 0 && d.stride_b >= 0;
+}
+bool gemm_quads_pay(const GemmDesc &d, int n_items, int64_t br) {
+  static const bool on = [] {
+    const char *e = getenv("TPP_HIP_BF16_QUADS");
+    return !e || atoi(e) != 0;
+  }();
+  if (!on || strict_kernels() || !quads_shape_ok(d) || br < 1 || n_items < 4 || (n_items & 3) || g_forced_split.load(std::memory_order_relaxed) >= 0) return false;
+  const double chunks = (double)(br * (d.k / BK));
+  const int64_t cus = g_num_cus;
+  // (a, b) of the tile model: 64x64 (3.75, 0.135), 32x64 + K2 (3.56, 0.098) - what the grouped path would pick from - and 128x128 (6.06, 0.236)
+  const double c64 = (double)((n_items + cus - 1) / cus) * (3.75 + 0.135 * chunks), c32 = (double)((2 * (int64_t)n_items + cus - 1) / cus) * (3.56 + 0.098 * chunks);
+  const double cq = (double)((n_items / 4 + cus - 1) / cus) * (6.06 + 0.236 * chunks);
+  return cq * 1.05 < (c64 < c32 ? c64 : c32);
+}
+hipError_t launch_gemm_quads(const GemmDesc &d, const QuadItem *quads, int n_quads, int64_t br, hipStream_t stream) {
+  if (!quads_shape_ok(d) || br < 1 || n_quads <= 0) return hipErrorInvalidValue;
+  ChainArgs c;
+  memset(&c, 0, sizeof(c));
+  c.lda = d.lda;
+  c.m = 128;
+  c.n = 128;
+  c.nlayers = 1;
+  const int ep = (d.beta0 ? EP_BETA0 : 0) | (d.bias ? EP_BIAS : 0) | (d.relu ? EP_RELU : 0);
+  c.L[0] = ChainLayer{nullptr, nullptr, nullptr, d.ldb, d.ldc, d.stride_a, d.stride_b, (int)d.k, (int)br, ep, 0};
+  const bool v4 = d.vnni_factor == 4;
+  return note_grouped(v4 ? "brgemm_bf16_lw_vnni4<128x128> quads" : "brgemm_bf16_lw<128x128> quads", launch_bf16_lw_quads(v4 ? 4 : 0, c, quads, n_quads, stream));
+}
+
 
 static int pick_f32_variant(const GemmDesc &d) {
   if (d.k <= 0 || d.k % BK) return V_GENERIC;

@@ -68,6 +68,8 @@ hipError_t launch_bf16_chain(int tile, int b_kind, const ChainArgs &a, hipStream
 // tile invokes of one bf16 descriptor in one launch (tile 0 = 32x64 + K2, 1 = 64x64, 4 = 32x32 + K2 (VNNI-2 only); b_kind 0 VNNI-2 / 4 VNNI-4; a.m x a.n = one item's
 // shape, a.L[0] / a.lda its leading dimensions and strides; every item's batch count >= 1; even_chunks: every item has an even chunk count)
 hipError_t launch_bf16_lw_grouped(int tile, int b_kind, const ChainArgs &a, const void *items, int n_items, bool even_chunks, hipStream_t s);
+// 2 x 2 blocks of 64x64 items on the 128x128 tile (quads: QuadItem[n_quads], xsmm_desc.h; a.m = a.n = 128, leading dimensions / strides / k the items')
+hipError_t launch_bf16_lw_quads(int b_kind, const ChainArgs &a, const void *quads, int n_quads, hipStream_t s);
 
 // f32 chains (brgemm_f32_lw.hip): tile 1 = 64x64 + K2, 2 = 64x32 + K4 - the 64-row K-split loader-wave tiles
 bool f32_chain_tile_dims(int tile, int *bm, int *bn);

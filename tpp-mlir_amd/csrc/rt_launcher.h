@@ -19,7 +19,7 @@
 // ends the process like on any caller (die). TPP_HIP_LAUNCH_THREAD=0 / xsmm_hip_set_launch_thread(0): launches stay on the thread
 // that closes the group (round 5's behaviour). Kernel choice, work lists and results are the same either way.
 struct LaunchReq {
-  int kind = 0;               // KIND_GEMM / KIND_UNARY / KIND_BINARY; -1: a merged tile grid (launch_gemm of `desc` on `w`)
+  int kind = 0;               // KIND_GEMM / KIND_UNARY / KIND_BINARY; -1: a merged tile grid (launch_gemm of `desc` on `w`); -2: 2 x 2 blocks of items (list = QuadItem[n])
   const void *desc = nullptr;
   const WorkItem *list = nullptr;
   int n = 0;
@@ -30,6 +30,7 @@ struct LaunchReq {
 };
 inline void issue_launch(const LaunchReq &r) {
   if (r.kind == -1) HIP_OK(launch_gemm(*(const GemmDesc *)r.desc, r.w.A, r.w.B, r.w.C, r.w.D, r.w.br, r.stream));
+  else if (r.kind == -2) HIP_OK(launch_gemm_quads(*(const GemmDesc *)r.desc, (const QuadItem *)r.list, r.n, r.br, r.stream));
   else if (r.kind == KIND_GEMM) HIP_OK(launch_gemm_grouped(*(const GemmDesc *)r.desc, r.list, r.n, r.vec_ok, r.out_ok, r.pair_ok, r.br, r.stream));
   else if (r.kind == KIND_UNARY) HIP_OK(launch_unary_grouped(*(const UnaryDesc *)r.desc, r.list, r.n, r.stream));
   else HIP_OK(launch_binary_grouped(*(const BinaryDesc *)r.desc, r.list, r.n, r.stream));

@@ -78,6 +78,98 @@ inline void detect_grid(Segment &S) {
   S.grid_state = 1;
 }
 
+// QUADS (round 6). mlir-gen tiles a bf16 layer into 64x64x64 invokes over PACKED blocks (A [MB][KB][64][64], B VNNI [NB][KB][..]): never
+// a tile grid over flat operands (no grid merge), and as items the group runs on 64x64 tiles - three rounds of workgroups for
+// benchmarks/config/fc/1024x2560x1024.json (15.3 us) where the same layer as one call runs on 128x128 tiles in one round (10.2 us).
+// When a recorded group is such a grid - one bf16 descriptor and batch count, every item = (item row r, item column c) with A a
+// function of r only, B and the bias of c only, every (r, c) once, R and C even - and the tile model prefers it (gemm_quads_pay), a
+// complete replay is launched as R C / 4 blocks of 2 x 2 items on the 128x128 loader-wave tile: rows 64 .. 127 of a block's A panel
+// come from the lower item row's block, columns 64 .. 127 of its B panel from the right item column's block (two byte distances per
+// block: same allocation, ascending, below 2 GiB), each of its four 64x64 outputs goes to its own item's C. Same reads, same
+// writes, the same k order per element. Not in strict mode (the kernel would depend on the group), not while the stream is captured.
+inline void detect_quads(Segment &S, hipStream_t stream) {
+  S.quad_state = -1;
+  const size_t n = S.items.size();
+  if (n < 4 || (n & 3) || cfg().strict.load(std::memory_order_relaxed)) return;
+  const void *desc = S.items[0].desc;
+  if (*(const int *)desc != KIND_GEMM) return;
+  const GemmDesc *d = (const GemmDesc *)desc;
+  const int64_t br = S.items[0].w.br;
+  if (!S.vec_ok || !S.out_ok || !gemm_quads_pay(*d, (int)n, br)) return;
+  std::vector<uintptr_t> ua, ub;
+  ua.reserve(n);
+  ub.reserve(n);
+  for (const TraceItem &t : S.items) {
+    if (t.desc != desc || t.w.br != br || t.stream != S.items[0].stream) return;
+    if ((((uintptr_t)t.w.A | (uintptr_t)t.w.B | (uintptr_t)t.w.C) & 15) || ((uintptr_t)t.w.D & 7)) return;
+    ua.push_back((uintptr_t)t.w.A);
+    ub.push_back((uintptr_t)t.w.B);
+  }
+  std::sort(ua.begin(), ua.end());
+  ua.erase(std::unique(ua.begin(), ua.end()), ua.end());
+  std::sort(ub.begin(), ub.end());
+  ub.erase(std::unique(ub.begin(), ub.end()), ub.end());
+  const size_t R = ua.size(), Cn = ub.size();
+  if (R * Cn != n || (R & 1) || (Cn & 1)) return;
+  // (r, c) -> item; the bias is the column's
+  std::vector<int> at(n, -1);
+  std::vector<uintptr_t> dcol(Cn, 0);
+  for (size_t i = 0; i < n; ++i) {
+    const TraceItem &t = S.items[i];
+    const size_t r = (size_t)(std::lower_bound(ua.begin(), ua.end(), (uintptr_t)t.w.A) - ua.begin());
+    const size_t c = (size_t)(std::lower_bound(ub.begin(), ub.end(), (uintptr_t)t.w.B) - ub.begin());
+    if (at[r * Cn + c] >= 0) return;
+    at[r * Cn + c] = (int)i;
+    if (r == 0) dcol[c] = (uintptr_t)t.w.D;
+  }
+  for (size_t r = 0; r < R; ++r)
+    for (size_t c = 0; c < Cn; ++c)
+      if (d->bias && (uintptr_t)S.items[at[r * Cn + c]].w.D != dcol[c]) return;
+  const uint64_t a_rows = (uint64_t)64 * (uint64_t)d->lda * 2; // bytes the instruction offsets of rows 64 .. 127 already cover
+  const uint64_t lim = (uint64_t)1 << 30;                      // (buffer offsets are 32 bits against a 2 GiB range: distance + panel below that)
+  for (size_t r = 0; r < R; r += 2)
+    if (ua[r + 1] - ua[r] < a_rows || ua[r + 1] - ua[r] >= lim) return;
+  for (size_t c = 0; c < Cn; c += 2)
+    if (ub[c + 1] - ub[c] >= lim) return;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cs) != hipSuccess) (void)hipGetLastError();
+  else if (cs != hipStreamCaptureStatusNone) {
+    S.quad_state = 0; // (not now: look again at the next complete replay)
+    return;
+  }
+  const size_t nq = n / 4;
+  if (S.quad_used) { // the buffers carried another recording's blocks: its last launch must be done (and, first, issued)
+    launcher_drain();
+    HIP_OK(hipStreamSynchronize(S.quad_stream));
+    S.quad_used = false;
+  }
+  if (S.quad_cap < nq) {
+    if (S.quad_host) HIP_OK(hipHostFree(S.quad_host));
+    if (S.quad_dev) HIP_OK(hipFree(S.quad_dev));
+    S.quad_cap = nq < 256 ? 256 : nq;
+    HIP_OK(hipHostMalloc((void **)&S.quad_host, sizeof(QuadItem) * S.quad_cap, hipHostMallocDefault));
+    HIP_OK(hipMalloc((void **)&S.quad_dev, sizeof(QuadItem) * S.quad_cap));
+  }
+  size_t k = 0;
+  for (size_t r = 0; r < R; r += 2)
+    for (size_t c = 0; c < Cn; c += 2) {
+      QuadItem &q = S.quad_host[k++];
+      const WorkItem &w00 = S.items[at[r * Cn + c]].w, &w01 = S.items[at[r * Cn + c + 1]].w, &w10 = S.items[at[(r + 1) * Cn + c]].w,
+                     &w11 = S.items[at[(r + 1) * Cn + c + 1]].w;
+      q.A = w00.A;
+      q.B = w00.B;
+      q.C[0] = w00.C, q.C[1] = w01.C, q.C[2] = w10.C, q.C[3] = w11.C;
+      q.D[0] = w00.D, q.D[1] = w01.D;
+      q.br = br;
+      q.da = (uint32_t)(ua[r + 1] - ua[r] - a_rows);
+      q.db = (uint32_t)(ub[c + 1] - ub[c]);
+    }
+  HIP_OK(hipMemcpyAsync(S.quad_dev, S.quad_host, sizeof(QuadItem) * nq, hipMemcpyHostToDevice, stream));
+  S.quad_used = true; // (the copy reads quad_host)
+  S.quad_stream = stream;
+  S.n_quads = (int)nq;
+  S.quad_state = 1;
+}
 
 // ---- deferred transposes (round 5) ------------------------------------------------------------------------------------
 // A contraction whose B operand is transposed in memory reaches the runtime as TWO invokes per tile: xsmm.unary transpose into a

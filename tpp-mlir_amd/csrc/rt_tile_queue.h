@@ -168,6 +168,14 @@ struct Segment {
   int grid_state = 0;
   const GemmDesc *grid_desc = nullptr;
   WorkItem grid_w{};
+  // QUADS (round 6, detect_quads in rt_rewrites.h): the group's 64x64 bf16 invokes form an R x C grid of item rows and item columns
+  // (R, C even) and the tile model prefers the 128x128 tile: a complete replay is ONE launch of R C / 4 2 x 2 blocks. 0: not looked
+  // at yet, 1: quad_dev holds the blocks, -1: no. The buffers travel with the segment like the work list and follow its rules.
+  int quad_state = 0, n_quads = 0;
+  QuadItem *quad_host = nullptr, *quad_dev = nullptr;
+  size_t quad_cap = 0;
+  bool quad_used = false;
+  hipStream_t quad_stream = nullptr;
   // Called with the inline queue's lock held, once per RECORDING (a steady-state replay never comes here). The buffers are sized
   // for the largest group (TileQueue::CAP) the first time a segment needs them and then travel with it (store_recording swaps
   // segments, so at most NSEG + 1 sets exist per queue: allocation is a start-up cost, not a per-recording one); they live as long
@@ -274,6 +282,7 @@ struct Segment {
     n_alloc = -1;
     dev_epoch = 0;
     grid_state = 0;
+    quad_state = 0;
   }
   int index_of(const void *d, const WorkItem &w, hipStream_t st) const {
     if (table.empty()) return -1;
@@ -290,6 +299,7 @@ struct Segment {
 };
 
 inline void detect_grid(Segment &S); // rt_rewrites.h (GRID MERGE)
+inline void detect_quads(Segment &S, hipStream_t stream); // rt_rewrites.h (QUADS)
 static bool grid_merge_on();
 extern std::atomic<const char *> g_last_merged;
 
@@ -476,11 +486,21 @@ struct TileQueue {
     if (pending.kind == KIND_GEMM && S.grid_state == 0) detect_grid(S);
     LaunchReq r;
     r.stream = pending.stream;
+    if (pending.kind == KIND_GEMM && S.grid_state != 1 && S.quad_state == 0) detect_quads(S, pending.stream);
     if (pending.kind == KIND_GEMM && S.grid_state == 1) {
       r.kind = -1;
       r.desc = S.grid_desc;
       r.w = S.grid_w;
       g_last_merged.store(S.grid_desc->trace, std::memory_order_relaxed);
+    } else if (pending.kind == KIND_GEMM && S.quad_state == 1) {
+      g_last_merged.store(nullptr, std::memory_order_relaxed);
+      r.kind = -2;
+      r.desc = pending.desc;
+      r.list = (const WorkItem *)S.quad_dev;
+      r.n = S.n_quads;
+      r.br = S.items[0].w.br;
+      S.quad_used = true;
+      S.quad_stream = pending.stream;
     } else {
       g_last_merged.store(nullptr, std::memory_order_relaxed);
       r.kind = pending.kind;

@@ -60,6 +60,18 @@ struct WorkItem {
   int64_t br;
 };
 
+// A 2 x 2 block of queued 64x64 bf16 invokes (tile queue, rt_rewrites.h detect_quads): item rows r0 < r1 (A blocks), item columns
+// c0 < c1 (B blocks). A / B: the (r0, c0) item's; da = (byte distance of r1's A block from r0's) - 64 rows of lda, db = byte distance
+// of c1's B block from c0's; C[2 r + c], D[c]: the four outputs and the two bias pieces. brgemm_bf16_lw's 128x128 tile (GRP = 2).
+struct QuadItem {
+  const void *A;
+  const void *B;
+  void *C[4];
+  const void *D[2];
+  int64_t br;
+  uint32_t da, db;
+};
+
 // ---- kernel launchers (all enqueue on `stream`, never synchronise) --------------
 // pointers are device pointers with element offsets already applied.
 hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C, const void *D,
@@ -75,6 +87,11 @@ int force_gemm_split(int workgroups_per_tile); // xsmm_hip_force_split (brgemm_f
 // STRICT mode (round 6; xsmm_hip_set_strict / TPP_HIP_STRICT=1): the kernel an invoke runs on - and with it the order of its additions -
 // is a function of its descriptor, its batch count and its own pointers' alignment only, never of the group it is queued with.
 // launch_gemm_grouped then takes every decision that depends on the size of the work list as if the list held ONE item.
+// QUADS: would a group of n_items invokes of `d` (batch count br each, all operands 16-byte aligned) run faster as n_items / 4
+// 2 x 2 blocks on the 128x128 loader-wave tile than as items on the grouped 64x64 / 32x64 tiles? (the tile model of pick_bf16_lw_tile;
+// bf16 VNNI-2 / VNNI-4, m = n = 64, k a multiple of 64; never in strict mode)
+bool gemm_quads_pay(const GemmDesc &d, int n_items, int64_t br);
+hipError_t launch_gemm_quads(const GemmDesc &d, const QuadItem *quads, int n_quads, int64_t br, hipStream_t stream);
 int set_strict_kernels(int on); // returns the previous setting
 bool strict_kernels();
 int f32_chain_tile(const GemmDesc &d); // 1 / 2 / 3 = the f32 chain tile the descriptor was planned on, -1 = none (brgemm_f32.hip)
