@@ -61,20 +61,39 @@ def mlp_layer_32():
     return run, M * N
 
 
+def bf16_layer_64_quad_grid():
+    """320 invokes of 64x64x64 bf16 + VNNI-2 tiles over packed blocks (16 item rows x 20 item columns, br = 2): without the switch the
+    replays run as 2 x 2 blocks on the 128x128 tile (quads); under the switch they must not - the kernel would depend on the group"""
+    M, N, K, t = 1024, 1280, 128, 64
+    MB, NB, KB = M // t, N // t, K // t
+    bf = lambda n: torch.from_numpy(rng.uniform(-1, 1, n).astype(np.float32)).cuda().to(torch.bfloat16)
+    A, W, bias = bf(M * K), bf(K * N), bf(N)
+    h = rt.fused_brgemm_dispatch(2, t, t, t, t, t, t, t * t, t * t, 4 | 2048, 0, 5, 4, 1)
+
+    def run(C):
+        for i in range(MB):
+            for j in range(NB):
+                rt.fused_brgemm(2, h, A, i * KB * t * t, W, j * KB * t * t, C, (i * NB + j) * t * t, bias, j * t, KB)
+    return run, -(M * N)  # (negative: a bf16 output)
+
+
 out = {"strict": rt.get_strict()}
 rt.set_async(True)
-for name, make in (("projection", projection), ("layer_64_48_64", layer_64_48_64), ("mlp_layer_32", mlp_layer_32)):
+for name, make in (("projection", projection), ("layer_64_48_64", layer_64_48_64), ("mlp_layer_32", mlp_layer_32), ("bf16_layer_64_quad_grid", bf16_layer_64_quad_grid)):
     run, n_out = make()
+    is_bf16 = n_out < 0
+    n_out = abs(n_out)
     results, kernels = [], []
     for way in ("single", "queued_first", "replay_1", "replay_2"):
         rt.set_tile_queue(0 if way == "single" else 1)
-        C = torch.full((n_out,), float("nan"), device="cuda")
+        C = torch.full((n_out,), float("nan"), device="cuda", dtype=torch.bfloat16 if is_bf16 else torch.float32)
         run(C)
         rt.synchronize()
-        results.append(C.cpu().numpy().view(np.uint32).copy())
+        results.append(C.cpu().view(torch.int16).numpy().view(np.uint16).copy() if is_bf16 else C.cpu().numpy().view(np.uint32).copy())
         kernels.append(rt.last_grouped_kernel() if way != "single" else "single")
     rt.set_tile_queue(0)
     out[name] = {"identical": bool(all(np.array_equal(results[0], r) for r in results[1:])),
                  "differing_elements": [int((results[0] != r).sum()) for r in results[1:]],
-                 "finite": bool(np.isfinite(results[0].view(np.float32)).all()), "kernels": kernels}
+                 "finite": bool(np.isfinite((results[0].astype(np.uint32) << 16).view(np.float32) if is_bf16 else results[0].view(np.float32)).all()),
+                 "kernels": kernels}
 print(json.dumps(out), flush=True)

@@ -401,3 +401,48 @@ def test_bf16_64_tile_invokes_replayed_as_quads_on_the_128_tile(rt, M, N, K, vn,
         rt.set_async(old_async)
         rt.set_vnni_factor(old_v)
         orc.set_vnni_factor(old_o)
+
+
+@pytest.mark.parametrize("case", ["odd_rows", "bias_not_by_column", "partial_replay"])
+def test_groups_that_are_not_item_grids_stay_items(rt, case):
+    """detect_quads refuses what is not a complete even grid of item rows x item columns: an odd number of item rows; a bias pointer
+    that does not follow the item column; and a replay in which not every member arrives is launched from the gathered list as before
+    (strict mode: tests/test_strict_gpu.py, its own process). Every pass against the oracle, no pass on the quad kernel."""
+    tm = tn = tk = 64
+    M, N, K = (960 if case == "odd_rows" else 1024), 1280, 128
+    old_async, old_q = rt.set_async(True), rt.set_tile_queue(1)
+    try:
+        rng = np.random.default_rng(len(case))
+        X = rng.uniform(-1, 1, (M, K)).astype(np.float32)
+        W = (rng.uniform(-1, 1, (K, N)) / np.sqrt(K)).astype(np.float32)
+        bias = rng.uniform(-1, 1, N).astype(np.float32)
+        X, W, bias = (orc.bf16_to_f32(orc.f32_to_bf16(v.reshape(-1))).reshape(v.shape) for v in (X, W, bias))
+        conv = orc.f32_to_bf16
+        flags = VB | 4
+        Wv = np.ascontiguousarray(W.reshape(K // 2, 2, N).transpose(0, 2, 1)).reshape(-1)
+        a_o, w_o, b_o = conv(X.reshape(-1)), conv(Wv), conv(bias)
+        ref = conv(np.zeros(M * N, np.float32))
+        orc.fused_brgemm(BF16, M, N, K, K, N, N, 0, 0, flags, 0, 5, 4, 1, a_o, 0, w_o, 0, ref, 0, b_o, 0, 1)
+        MB, NB, KB = M // tm, N // tn, K // tk
+        # bias_not_by_column: the item of (row 3, column 5) reads a COPY of its bias piece at another address (same values)
+        bias_dev = np.concatenate([bias, bias[5 * tn:6 * tn]])
+        dA, dW, dB = dev(conv(pack_a(X, M, K, tm, tk))), dev(conv(pack_w(W, K, N, tk, tn, 2))), dev(conv(bias_dev))
+        dC = dev(conv(np.zeros(M * N, np.float32)))
+        h = rt.fused_brgemm_dispatch(BF16, tm, tn, tk, tk, tn, tn, tm * tk, tk * tn, flags, 0, 5, 4, 1)
+        kernels = []
+        for p in range(3):
+            for i in range(MB):
+                for j in range(NB):
+                    if case == "partial_replay" and p >= 1 and i == MB - 1 and j >= NB - 4:
+                        continue  # the last four tiles are not invoked in the replays: their outputs keep pass 0's (equal) values
+                    off_d = N if (case == "bias_not_by_column" and i == 3 and j == 5) else j * tn
+                    rt.fused_brgemm(BF16, h, dA, i * KB * tm * tk, dW, j * KB * tk * tn, dC, (i * NB + j) * tm * tn, dB, off_d, KB)
+            rt.synchronize()
+            kernels.append(rt.last_grouped_kernel())
+            flat = unpack_c(orc.bf16_to_f32(host(dC, ref)), M, N, tm, tn).reshape(-1)
+            check_close(orc.f32_to_bf16(flat), ref, BF16, "%s pass %d [%s]" % (case, p, kernels[-1]), K=K)
+        assert not any("quads" in k for k in kernels), kernels
+    finally:
+        rt.synchronize()
+        rt.set_tile_queue(old_q)
+        rt.set_async(old_async)

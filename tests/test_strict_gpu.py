@@ -25,8 +25,9 @@ def worker(strict):
 def test_strict_mode_gives_call_to_call_identical_bits():
     d = worker(True)
     assert d["strict"] == 1
-    for prog in ("projection", "layer_64_48_64", "mlp_layer_32"):
+    for prog in ("projection", "layer_64_48_64", "mlp_layer_32", "bf16_layer_64_quad_grid"):
         assert d[prog]["finite"] and d[prog]["identical"], (prog, d[prog])
+    assert not any("quads" in k for k in d["bf16_layer_64_quad_grid"]["kernels"]), d["bf16_layer_64_quad_grid"]["kernels"]
 
 
 def test_default_mode_stays_within_its_documented_behaviour():
@@ -34,6 +35,7 @@ def test_default_mode_stays_within_its_documented_behaviour():
     against the oracle); here only: the run completes, results are finite, and WHICH programs differ call to call is printed"""
     d = worker(False)
     assert d["strict"] == 0
-    for prog in ("projection", "layer_64_48_64", "mlp_layer_32"):
+    for prog in ("projection", "layer_64_48_64", "mlp_layer_32", "bf16_layer_64_quad_grid"):
         assert d[prog]["finite"], (prog, d[prog])
+    assert "quads" in d["bf16_layer_64_quad_grid"]["kernels"][-1], d["bf16_layer_64_quad_grid"]["kernels"]  # (the replays of the 16 x 20 item grid)
     print({p: (d[p]["identical"], d[p]["differing_elements"], d[p]["kernels"]) for p in ("projection", "layer_64_48_64", "mlp_layer_32")})
