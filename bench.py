@@ -1162,9 +1162,9 @@ def main():
                                    "value": float(mm.group(2)), "unit": "GFLOP/s", "us_per_step": float(mm.group(1))})
             # the same MLP as emitted, on plain HOST buffers (malloc, 64-byte aligned: what an unmodified tpp-run hands over), the program
             # issues the reference's symbols only, the runtime's modes come from the environment (tools/tpp_replay --host-buffers)
-            for label, extra, env_ in (("host buffers, TPP_HIP_ASYNC=1 TPP_HIP_TILE_QUEUE=1 TPP_HIP_HOST_CACHE=1", ["--tiles", "32", "-n", "200", "--repeats", "5"],
+            for label, extra, env_ in (("host buffers, TPP_HIP_ASYNC=1 TPP_HIP_TILE_QUEUE=1 TPP_HIP_HOST_CACHE=1", ["--tiles", "32", "-n", "200", "--repeats", "9"],
                                         {"TPP_HIP_ASYNC": "1", "TPP_HIP_TILE_QUEUE": "1", "TPP_HIP_HOST_CACHE": "1"}),
-                                       ("host buffers, the same, 8 OpenMP callers", ["--tiles", "32", "-n", "200", "--repeats", "5", "--threads", "8"],
+                                       ("host buffers, the same, 8 OpenMP callers", ["--tiles", "32", "-n", "200", "--repeats", "9", "--threads", "8"],
                                         {"TPP_HIP_ASYNC": "1", "TPP_HIP_TILE_QUEUE": "1", "TPP_HIP_HOST_CACHE": "1"}),
                                        ("host buffers, no environment (768 synchronous mirrored invokes per iteration)", ["--tiles", "32", "-n", "3"], {})):
                 r = subprocess.run([replay, "--host-buffers", "--batch", "256", "--layers", "1024,1024,1024,1024", "--bias", "--relu"] + extra,
@@ -1175,8 +1175,9 @@ def main():
                     row = {"workload": "mlir-gen mlp 3x1024 bs=256 bias+relu fp32 as tile invokes 32,32,32, " + label + " (tools/tpp_replay --host-buffers; the "
                                        "host's output buffer checked behind the loop)", "value": float(mm.group(2)), "unit": "GFLOP/s",
                            "us_per_step": float(mm.group(1))}
-                    if md:
-                        row["us_median_of_5_loops"] = float(md.group(2))
+                    if md:  # (the first loop of a process carries a one-off 7-10 ms stall of the runtime's first device-to-host copy: profiles/r06_host_cache_first_writeback.txt)
+                        row["us_median_of_5_loops"] = float(md.group(2))  # (key kept; nine loops since the second half of round 6)
+                        row["us_min_max_of_9_loops"] = [float(md.group(1)), float(md.group(3))]
                     others.append(row)
             # the plain gemm row of the reference's headline config (base.json:34 gemm_fp32_mlir: no bias, no relu) - the shape the CPU
             # row's `headline_shape` quotes - as the compiler emits it

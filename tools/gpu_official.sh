@@ -67,6 +67,19 @@ g++ -O2 -std=c++17 tools/ubench/wp_async_probe.cpp -o /tmp/wp_async_probe -inclu
 timeout 200 tools/ubench/split_handoff.out > $OUT/split_handoff.txt 2>&1
 echo "# matmul_128x768x768 as tile invokes (32,64,64), 50 timed loops of 200 calls each (VERDICT r5 weak 9: the 51 us row)" > $OUT/outlier.txt
 timeout 300 tools/tpp_replay --batch 128 --layers 768,768 --kernel args --tiles 32,64,64 --queue 1 -n 200 --repeats 50 2>&1 | grep -v "^[0-9.e-]*$" >> $OUT/outlier.txt
+# round 6, second half: the launch thread and the quads, on / off on this box (short forms of profiles/r06_launch_thread_ab.txt, r06_bf16_quads_ab.txt)
+{
+R=tools/tpp_replay; M="--batch 256 --layers 1024,1024,1024,1024 --tiles 32 --bias --relu"
+for lt in 0 1 0 1; do echo "### TPP_HIP_LAUNCH_THREAD=$lt"; export TPP_HIP_LAUNCH_THREAD=$lt
+  $R $M --queue 1 -n 300 --repeats 5 2>&1 | grep "repeats" | sed 's/^/MLP tiles f32:  /'
+  $R $M --bf16 --queue 1 -n 300 --repeats 5 2>&1 | grep "repeats" | sed 's/^/MLP tiles bf16: /'
+  for s in mha_qk mha_sv pack_a unpack_c; do $R --script $s --queue 1 -n 1000 2>&1 | grep "mean" | cut -c1-130; done
+done; unset TPP_HIP_LAUNCH_THREAD
+for q in 0 1 0 1; do echo "### TPP_HIP_BF16_QUADS=$q"
+  for v in 2 4; do TPP_HIP_BF16_QUADS=$q $R --batch 1024 --layers 1024,2560 --tiles 64,64,64 --bf16 --vnni $v --queue 1 -n 300 --repeats 3 2>&1 | grep "repeats\|mean" | cut -c1-230; done
+done
+$R --batch 1024 --layers 1024,2560 --whole-layer --bf16 -n 300 --repeats 3 2>&1 | grep "repeats\|mean" | cut -c1-230
+} > $OUT/launch_thread_and_quads.txt 2>&1
 python tools/eltwise_bw.py > $OUT/eltwise_bw.txt 2>/dev/null
 python tools/vendor_compare.py > $OUT/vendor_compare.txt 2>/dev/null
 tail -n 1 $OUT/bench_steps20.json | head -c 900; echo; head -8 $OUT/rocprof_kernel_stats.csv | cut -c1-160; cat $OUT/mlp_probe.txt | cut -c1-14,50-200 | tail -4
