@@ -101,8 +101,10 @@ struct CallerState {
   }
 };
 
+InlineQueue *g_iq_fast = nullptr; // = &inl(), set before any thread's tl_fast (enqueue_item's fast path reads it without the static's guard)
 static __attribute__((noinline)) CallerState &caller_state_slow() {
   thread_local CallerState tl;
+  if (!__atomic_load_n(&g_iq_fast, __ATOMIC_ACQUIRE)) __atomic_store_n(&g_iq_fast, &inl(), __ATOMIC_RELEASE);
   tl_fast = &tl;
   return tl;
 }
@@ -111,7 +113,54 @@ static inline CallerState &caller_state() {
   return p ? *p : caller_state_slow();
 }
 
-bool enqueue_item(const void *desc, const WorkItem &item, const void *const *ptrs, int n_ptrs, hipStream_t s) {
+bool enqueue_item_slow(const void *desc, const WorkItem &item, const void *const *ptrs, int n_ptrs, hipStream_t s);
+// THE per-invoke path of compiled code that repeats itself from one thread (round 6): a SOLO caller whose invoke is the member the
+// recorded group expects next, in a group whose pointers are proven for this epoch. Inlined into the entry points - no call, no
+// callee-saved registers to spill, no hash: bracket (seq), window check, seven compares against items[hint], mark, count. Anything else
+// - several callers, no window, another member, an unproven group, the first invoke of a thread - is enqueue_item_slow (the
+// complete protocol, which starts with the same attempt; a failed attempt here leaves nothing behind but a tag / count reset that the
+// slow path would have done too).
+__attribute__((always_inline)) inline bool enqueue_item(const void *desc, const WorkItem &item, const void *const *ptrs, int n_ptrs, hipStream_t s) {
+  CallerState *tl = tl_fast;
+  if (__builtin_expect(tl != nullptr, 1)) {
+    InlineQueue &iq = *g_iq_fast;
+    DirectWindow::Caller *me = tl->me;
+    const uint64_t c = iq.dw.cur.load(std::memory_order_acquire);
+    const uint64_t epoch = g_devmem_epoch.load(std::memory_order_relaxed);
+    if (c && me && tl->devmem.epoch == epoch) {
+      const uint64_t seq0 = me->seq.load(std::memory_order_relaxed);
+      me->seq.store(seq0 + 1, std::memory_order_relaxed); // BRACKET FIRST, then `multi`: see enqueue_item_slow
+      std::atomic_signal_fence(std::memory_order_seq_cst);
+      bool joined = false;
+      if (!iq.dw.multi.load(std::memory_order_relaxed)) {
+        me->busy.store(c, std::memory_order_relaxed);
+        std::atomic_signal_fence(std::memory_order_seq_cst);
+        if (iq.dw.cur.load(std::memory_order_relaxed) == c) {
+          Segment &S = iq.q.segs[(c & 127) - 1];
+          if (S.dev_epoch == epoch) {
+            if (me->tag != c) {
+              me->tag = c;
+              me->count = 0;
+            }
+            const uint32_t hint = me->hint;
+            const TraceItem *it = S.items.data() + hint;
+            if (it < S.items.data() + S.items.size() && it->same(desc, item, s) && S.mark_solo((int)hint)) {
+              ++me->count;
+              me->hint = hint + 1;
+              joined = true;
+            }
+          }
+        }
+        me->busy.store(0, std::memory_order_release);
+        std::atomic_signal_fence(std::memory_order_seq_cst);
+      }
+      me->seq.store(seq0 + 2, std::memory_order_release);
+      if (joined) return true;
+    }
+  }
+  return enqueue_item_slow(desc, item, ptrs, n_ptrs, s);
+}
+__attribute__((noinline)) bool enqueue_item_slow(const void *desc, const WorkItem &item, const void *const *ptrs, int n_ptrs, hipStream_t s) {
   CallerState &tl = caller_state();
   DeviceRanges &devmem = tl.devmem;
   static InlineQueue &iq = inl();

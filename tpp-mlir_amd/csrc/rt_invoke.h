@@ -76,7 +76,29 @@ struct HcScope {
   }
 };
 
-void gemm_invoke_common(const char *who, bool want_fused, int64_t dtype, int64_t handle, void *a, int64_t off_a,
+// the invoke outside the tile queue (host operands, big descriptors, synchronous mode, strict-mode single items): out of line - the
+// entry points inline gemm_invoke_common's front (checks, host-cache memo, folded transposes, the queue's fast path) and call this
+__attribute__((noinline)) void gemm_invoke_unqueued(const GemmDesc *d, void *pa, void *pb, void *pc, void *pd, int64_t br, hipStream_t s) {
+  Operand A, B, C, D;
+  gemm_operands(d, pa, pb, pc, pd, br, A, B, C, D);
+  C.read = !d->beta0; // pure output under BETA_0: never uploaded
+  std::vector<Operand *> ops = {&A, &B, &C, &D};
+  stage_in(ops, s);
+  if (cfg().strict.load(std::memory_order_relaxed) && d->m <= 64 && d->n <= 64) {
+    // strict mode: a tile the queue would take runs on the kernel its group runs on - the grouped launcher with a work list of one
+    // (launch_gemm_grouped decides as if every list held one item: xsmm_desc.h strict_kernels)
+    const WorkItem one{A.dev, B.dev, C.dev, D.dev, br};
+    WorkItem *slot = strict_item_slot(s);
+    *slot = one;
+    HIP_OK(launch_gemm_grouped(*d, slot, 1, ((((uintptr_t)A.dev) | ((uintptr_t)B.dev)) & 15) == 0,
+                               (((uintptr_t)C.dev) & 15) == 0 && (((uintptr_t)D.dev) & 7) == 0 && br >= 1, !(br & 1), br, s));
+    strict_item_done(s);
+  } else {
+    HIP_OK(launch_gemm(*d, A.dev, B.dev, C.dev, D.dev, br, s));
+  }
+  finish(ops, s);
+}
+__attribute__((always_inline)) inline void gemm_invoke_common(const char *who, bool want_fused, int64_t dtype, int64_t handle, void *a, int64_t off_a,
                         void *b, int64_t off_b, void *c, int64_t off_c, void *dptr, int64_t off_d, int64_t br) {
   const GemmDesc *d = as_desc<GemmDesc>(handle, KIND_GEMM, who);
   if (d->dtype != dtype) die("%s: invoke dtype %ld != dispatch dtype %ld", who, (long)dtype, (long)d->dtype);
@@ -107,7 +129,9 @@ void gemm_invoke_common(const char *who, bool want_fused, int64_t dtype, int64_t
   }
   if (g_dt_pending.load(std::memory_order_acquire)) { // a remembered transpose: this gemm reads its source instead, or it is launched now
     void *src = nullptr;
-    if (const GemmDesc *sib = dt_gemm(d, pa, pb, pc, pd, br, s, &src)) {
+    const GemmDesc *sib = dt_gemm_fast(d, pa, pb, pc, pd, br, s, &src);
+    if (!sib) sib = dt_gemm(d, pa, pb, pc, pd, br, s, &src);
+    if (sib) {
       d = sib;
       pb = src;
     }
@@ -116,22 +140,5 @@ void gemm_invoke_common(const char *who, bool want_fused, int64_t dtype, int64_t
     if (cfg().async.load(std::memory_order_relaxed) && try_enqueue(d, pa, pb, pc, pd, br, s)) return;
     flush_tile_queue();
   }
-  Operand A, B, C, D;
-  gemm_operands(d, pa, pb, pc, pd, br, A, B, C, D);
-  C.read = !d->beta0; // pure output under BETA_0: never uploaded
-  std::vector<Operand *> ops = {&A, &B, &C, &D};
-  stage_in(ops, s);
-  if (cfg().strict.load(std::memory_order_relaxed) && d->m <= 64 && d->n <= 64) {
-    // strict mode: a tile the queue would take runs on the kernel its group runs on - the grouped launcher with a work list of one
-    // (launch_gemm_grouped decides as if every list held one item: xsmm_desc.h strict_kernels)
-    const WorkItem one{A.dev, B.dev, C.dev, D.dev, br};
-    WorkItem *slot = strict_item_slot(s);
-    *slot = one;
-    HIP_OK(launch_gemm_grouped(*d, slot, 1, ((((uintptr_t)A.dev) | ((uintptr_t)B.dev)) & 15) == 0,
-                               (((uintptr_t)C.dev) & 15) == 0 && (((uintptr_t)D.dev) & 7) == 0 && br >= 1, !(br & 1), br, s));
-    strict_item_done(s);
-  } else {
-    HIP_OK(launch_gemm(*d, A.dev, B.dev, C.dev, D.dev, br, s));
-  }
-  finish(ops, s);
+  gemm_invoke_unqueued(d, pa, pb, pc, pd, br, s);
 }

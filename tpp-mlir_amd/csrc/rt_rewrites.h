@@ -198,6 +198,10 @@ struct DeferredTranspose {
   hipStream_t stream = nullptr;
   const GemmDesc *sib_of = nullptr, *sib = nullptr; // the last gemm descriptor folded and its sibling
   size_t a_bytes = 0, c_bytes = 0, d_bytes = 0;     // ... and the footprints of that descriptor's A / C / bias operands (sib_of != nullptr)
+  // the owner's fast path (dt_defer_fast): the device allocation the record's sources have been seen in, validated in this
+  // synchronisation epoch by the full path (0: not); a source inside it needs no further look at the allocation table
+  uintptr_t src_alloc_b = 0, src_alloc_e = 0;
+  uint64_t valid_epoch = 0;
 };
 struct alignas(64) DtSlot {
   // line 0 - what EVERY thread reads per invoke while records exist; written when a record appears or goes, not per tile:
@@ -412,6 +416,64 @@ void dt_other(const void *const *reads, const size_t *read_bytes, int nr, const 
   for (int i = 0; i < nr && i < 3; ++i) rd[i] = dt_range(reads[i], read_bytes[i]);
   dt_scan_foreign(nullptr, rd, nr < 3 ? nr : 3, wr, 1);
 }
+// The steady state of the query-times-key loop, inlined into xsmm_unary_invoke (round 6): this thread's live record is this very
+// transpose (descriptor, destination, stream), nobody else holds the slot, no other record exists, and the new source lies inside the
+// device allocation the full path validated in this epoch and inside the hull already published to the other threads: the record's
+// source is replaced - the remembered transpose is dead - and nothing else happens. Everything else: dt_defer.
+__attribute__((always_inline)) inline bool dt_defer_fast(const UnaryDesc *d, void *pi, void *po, hipStream_t s) {
+  CallerState *tl = tl_fast;
+  if (!tl || tl->dt_slot < 0 || !membarrier_ok()) return false;
+  DtSlot &sl = g_dt_slots[tl->dt_slot];
+  if (!sl.live.load(std::memory_order_acquire) || g_dt_pending.load(std::memory_order_relaxed) != 1) return false;
+  bool done = false;
+  const uint64_t q = sl.oseq.load(std::memory_order_relaxed);
+  sl.oseq.store(q + 1, std::memory_order_relaxed); // an owner section (DtOwnerSection), lock-free or not at all
+  std::atomic_signal_fence(std::memory_order_seq_cst);
+  if (!sl.contended.load(std::memory_order_acquire) && sl.live.load(std::memory_order_relaxed)) {
+    DeferredTranspose &r = sl.r;
+    const uintptr_t a = (uintptr_t)pi;
+    if (r.d == d && r.dst == po && r.stream == s && r.valid_epoch == g_devmem_epoch.load(std::memory_order_relaxed) && a >= r.src_alloc_b) {
+      const size_t src_bytes = span(d->m, d->ldi, d->n) * 4, dst_bytes = (size_t)d->n * d->m * 4;
+      if (a + src_bytes <= r.src_alloc_e && a >= sl.s_lo.load(std::memory_order_relaxed) && a + src_bytes <= sl.s_hi.load(std::memory_order_relaxed) &&
+          !dt_overlap(pi, src_bytes, po, dst_bytes) && cfg().fold_transpose.load(std::memory_order_relaxed) && queue_active()) {
+        r.src = pi;
+        sl.dropped.store(sl.dropped.load(std::memory_order_relaxed) + 1, std::memory_order_relaxed);
+        done = true;
+      }
+    }
+  }
+  std::atomic_signal_fence(std::memory_order_seq_cst);
+  sl.oseq.store(q + 2, std::memory_order_release);
+  return done;
+}
+// ... and of the gemm that follows it, inlined into the gemm entry points: the descriptor this record folded last, B = the record's
+// destination, one batch element, the record's stream, no operand on the destination, C off the source - the sibling and the source.
+__attribute__((always_inline)) inline const GemmDesc *dt_gemm_fast(const GemmDesc *d, void *pa, void *pb, void *pc, void *pd, int64_t br, hipStream_t s, void **src) {
+  CallerState *tl = tl_fast;
+  if (!tl || tl->dt_slot < 0 || !membarrier_ok()) return nullptr;
+  DtSlot &sl = g_dt_slots[tl->dt_slot];
+  if (!sl.live.load(std::memory_order_acquire) || g_dt_pending.load(std::memory_order_relaxed) != 1) return nullptr;
+  const GemmDesc *sib = nullptr;
+  const uint64_t q = sl.oseq.load(std::memory_order_relaxed);
+  sl.oseq.store(q + 1, std::memory_order_relaxed);
+  std::atomic_signal_fence(std::memory_order_seq_cst);
+  if (!sl.contended.load(std::memory_order_acquire) && sl.live.load(std::memory_order_relaxed)) {
+    DeferredTranspose &r = sl.r;
+    if (r.sib_of == d && pb == r.dst && br == 1 && s == r.stream && queue_active()) {
+      const UnaryDesc *t = r.d;
+      const size_t dst_bytes = (size_t)t->n * t->m * 4, src_bytes = span(t->m, t->ldi, t->n) * 4;
+      if (!dt_overlap(pa, r.a_bytes, r.dst, dst_bytes) && !dt_overlap(pc, r.c_bytes, r.dst, dst_bytes) && !dt_overlap(pd, r.d_bytes, r.dst, dst_bytes) &&
+          !dt_overlap(pc, r.c_bytes, r.src, src_bytes)) {
+        *src = r.src;
+        sib = r.sib;
+        sl.folded.store(sl.folded.load(std::memory_order_relaxed) + 1, std::memory_order_relaxed);
+      }
+    }
+  }
+  std::atomic_signal_fence(std::memory_order_seq_cst);
+  sl.oseq.store(q + 2, std::memory_order_release);
+  return sib;
+}
 // a transpose invoke: true = remembered (nothing launched)
 bool dt_defer(const UnaryDesc *d, void *pi, void *po, hipStream_t s) {
   if (d->dtype != DT_F32 || d->m > 64 || d->n > 64 || d->ldo != d->m || !cfg().fold_transpose.load(std::memory_order_relaxed) || cfg().strict.load(std::memory_order_relaxed) || !queue_active()) return false;
@@ -430,6 +492,11 @@ bool dt_defer(const UnaryDesc *d, void *pi, void *po, hipStream_t s) {
       DeferredTranspose &r = mine->r;
       if (r.d == d && r.dst == po && r.stream == s) {
         r.src = pi; // the remembered transpose is dead: fully overwritten, its readers were served from its source
+        {           // (for dt_defer_fast: pi and po were just seen to be device memory in devmem's epoch)
+          const Range al = devmem.range_of(pi);
+          r.src_alloc_b = al.b, r.src_alloc_e = al.e;
+          r.valid_epoch = al.e ? devmem.epoch : 0;
+        }
         // (the published source range only GROWS while the record lives: the hull of the sources of the loop's transposes - after one
         // pass over the source tensor the line the other threads read is not written any more)
         if (s_lo < mine->s_lo.load(std::memory_order_relaxed)) mine->s_lo.store(s_lo, std::memory_order_relaxed);
@@ -450,7 +517,12 @@ bool dt_defer(const UnaryDesc *d, void *pi, void *po, hipStream_t s) {
   if (replaced) return true;
   DtOwnerSection sec(*mine);
   if (mine->live.load(std::memory_order_relaxed)) return false; // (cannot happen: only the owner makes a record live)
-  mine->r = DeferredTranspose{d, pi, po, s, nullptr, nullptr, 0, 0, 0};
+  mine->r = DeferredTranspose{d, pi, po, s, nullptr, nullptr, 0, 0, 0, 0, 0, 0};
+  {
+    const Range al = devmem.range_of(pi);
+    mine->r.src_alloc_b = al.b, mine->r.src_alloc_e = al.e;
+    mine->r.valid_epoch = al.e ? devmem.epoch : 0;
+  }
   mine->d_lo.store((uintptr_t)po, std::memory_order_relaxed);
   mine->d_hi.store((uintptr_t)po + dst_bytes, std::memory_order_relaxed);
   mine->s_lo.store(s_lo, std::memory_order_relaxed);

@@ -162,7 +162,7 @@ extern "C" void xsmm_fused_brgemm_invoke(int64_t dtype, int64_t handle, void *a,
                      num_batches);
 }
 
-static void unary_invoke_common(const char *who, int64_t dtype, int64_t handle, void *in, int64_t off_in,
+__attribute__((always_inline)) static inline void unary_invoke_common(const char *who, int64_t dtype, int64_t handle, void *in, int64_t off_in,
                                 float scalar, bool use_scalar, void *out, int64_t off_out) {
   const UnaryDesc *d = as_desc<UnaryDesc>(handle, KIND_UNARY, who);
   if (d->dtype != dtype) die("%s: invoke dtype %ld != dispatch dtype %ld", who, (long)dtype, (long)d->dtype);
@@ -180,6 +180,8 @@ static void unary_invoke_common(const char *who, int64_t dtype, int64_t handle, 
     hcs.add(&po, O, false, true);
     hcs.go(cfg().stream.load(std::memory_order_relaxed));
   }
+  // (the steady state of a transpose-then-gemm loop: the record's source is replaced, nothing else - rt_rewrites.h)
+  if (d->op == XSMM_UNARY_TRANSPOSE && pi && !hcs.hits && dt_defer_fast(d, pi, po, cfg().stream.load(std::memory_order_relaxed))) return;
   unary_invoke_core(d, pi, scalar, use_scalar, po, true);
 }
 namespace {
