@@ -212,7 +212,7 @@ TPP_XSMM_EXPORT int xsmm_hip_get_strict(void);
  * replayed completely is launched by a helper thread of the runtime instead of the calling thread: the caller goes on queueing the
  * next group while hipLaunchKernel (2.3-2.6 us of host time) runs beside it. Stream order is unchanged - the hand-overs leave in
  * order, and everything else that launches / copies / synchronises first waits until they have left. The thread spins while
- * launches keep coming, sleeps after ~1 ms without one and ends after ~2 s. Kernel choice and results do not depend on the setting.
+ * launches keep coming, sleeps after ~0.2 ms without one and ends after ~2 s. Kernel choice and results do not depend on the setting.
  * xsmm_hip_set_launch_thread returns the previous setting; stats: out[0] = launches handed over since process start, out[1] = 1 if
  * the thread exists right now. */
 TPP_XSMM_EXPORT int xsmm_hip_set_launch_thread(int enable);

@@ -14,7 +14,7 @@
 //     Segment::ensure_list, flush_tile_queue(): every such path already started with one of the three);
 //   * producers are serialised by what serialises the queue state (the inline queue's lock); the scheduler thread's own queue
 //     (tile-queue mode 2) launches directly - it is off the callers' path already.
-// The thread spins while launches keep coming (a hand-over is picked up in ~0.2 us), parks on a futex after ~1 ms without one and
+// The thread spins while launches keep coming (a hand-over is picked up in ~0.2 us), parks on a futex after ~0.1-0.2 ms without one and
 // leaves after ~2 s (a library used once does not keep a thread); the next hand-over wakes / restarts it. A fatal HIP error on it
 // ends the process like on any caller (die). TPP_HIP_LAUNCH_THREAD=0 / xsmm_hip_set_launch_thread(0): launches stay on the thread
 // that closes the group (round 5's behaviour). Kernel choice, work lists and results are the same either way.
@@ -136,7 +136,7 @@ struct Launcher {
         continue;
       }
       if (stop.load(std::memory_order_relaxed)) break;
-      if (++idle < (1u << 15)) {
+      if (++idle < (1u << 12)) { // ~0.1-0.2 ms of polling behind the last launch (a timing loop hands over every 4-8 us), then the futex
         cpu_relax();
         continue;
       }
