@@ -545,6 +545,9 @@ def compact_line(line, detail_path=None):
         for k_ in ("benchmarks_at_bar", "benchmarks"):
             if k_ in o_:
                 configs["refbench_f32"][k_] = o_[k_]
+    o_ = first("benchmarks/mlir/*.mlir as xsmm call scripts")
+    if o_ and isinstance(o_.get("rows"), list):  # the hand-written benchmark files as call scripts: us per call, one caller
+        configs["mlir_scripts_us"] = {os.path.basename(str(r_.get("file", "?")).split(":")[0]).replace("fp32-", "").replace(".mlir", ""): r_.get("us") for r_ in o_["rows"]}
     if configs:
         roof["configs"] = configs
     out["roofline"] = roof
