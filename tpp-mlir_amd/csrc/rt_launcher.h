@@ -123,6 +123,9 @@ struct Launcher {
     }
   }
   void run() {
+    // (like the scheduler thread: the mask the PROCESS had at load time, not the one CPU of a pinned OpenMP caller that happened to
+    // start this thread - rt_operands.h g_process_mask)
+    if (g_have_process_mask) (void)sched_setaffinity(0, sizeof(g_process_mask), &g_process_mask);
     (void)hipSetDevice(device);
     uint64_t h = head.load(std::memory_order_relaxed);
     unsigned idle = 0, naps = 0;
