@@ -69,6 +69,7 @@ static int run_case(int argc, char **argv) {
   int64_t batch = 256, tile = 32, tile_n = 0, tile_k = 0, n_iter = 100;
   bool kernel_args = false; // mlir-gen --kernel=args: the output is an argument, the matmul accumulates into it (no BETA_0)
   int vnni = 2, split = -1, variant = -1, repeats = 1;
+  int64_t block_pad = 0; // --block-pad P (experiments): P elements between consecutive packed blocks of A and of W (the block strides stop being powers of two)
   std::vector<int64_t> layers = {1024, 1024, 1024, 1024};
   bool bias = false, relu = false, whole = false, chain = false, print = false, c1 = false, rnd = false, bf16 = false, host_buffers = false;
   int queue = 1, threads = 1;
@@ -100,6 +101,7 @@ static int run_case(int argc, char **argv) {
     else if (a == "--kernel") kernel_args = std::string(next()) == "args"; // const (default): zero fill folded into BETA_0; args: C += ...
     else if (a == "--split") split = atoi(next());     // xsmm_hip_force_split for this case (-1: the runtime's model)
     else if (a == "--variant") variant = atoi(next()); // xsmm_hip_force_variant at dispatch (-1: the runtime's choice)
+    else if (a == "--block-pad") block_pad = atoll(next());
     else if (a == "--repeats") repeats = atoi(next()); // the timed loop R times (own timer each): min / median / max + the queue's abandon counter per case
     else if (a == "--host-buffers") host_buffers = true; // what an UNMODIFIED tpp-run hands over: plain malloc'ed host memory, modes from the environment only
     else if (a == "--random") rnd = true; // uniform [-1, 1) * fill instead of constant fills (switching power)
@@ -189,8 +191,9 @@ static int run_case(int argc, char **argv) {
     }
     return d;
   };
-  for (int l = 0; l <= L; ++l) act[l] = dalloc((size_t)batch * layers[l], 1.0f);
-  for (int l = 0; l < L; ++l) { W[l] = dalloc((size_t)layers[l] * layers[l + 1], 1.0f / (float)layers[l]); B[l] = dalloc((size_t)layers[l + 1], 0.5f); }
+  const size_t padx = block_pad > 0 ? 2 : 1; // (padded blocks: room for the gaps - constant fills, so the gaps hold the same value)
+  for (int l = 0; l <= L; ++l) act[l] = dalloc(padx * (size_t)batch * layers[l], 1.0f);
+  for (int l = 0; l < L; ++l) { W[l] = dalloc(padx * (size_t)layers[l] * layers[l + 1], 1.0f / (float)layers[l]); B[l] = dalloc((size_t)layers[l + 1], 0.5f); }
 
   if (bf16) gflags |= XSMM_GEMM_WIRE_VNNI_B;
   // --host-buffers: NO xsmm_hip_* call before or inside the timed region - the program below is the reference's 13 + 2 symbols only,
@@ -212,7 +215,7 @@ static int run_case(int argc, char **argv) {
     if (whole) // one dispatch per layer on the flat row-major tensors
       handle[l] = xsmm_fused_brgemm_dispatch(dt, batch, N, 64, K, N, N, 64, 64 * N, gflags, 0, ukind, bflags, bkind);
     else       // packed tiles: [MB][KB][t][t] x [NB][KB][t][t] -> [MB][NB][t][t]
-      handle[l] = xsmm_fused_brgemm_dispatch(dt, tile, tn, tk, tk, tn, tn, tile * tk, tk * tn, gflags, 0, ukind, bflags, bkind);
+      handle[l] = xsmm_fused_brgemm_dispatch(dt, tile, tn, tk, tk, tn, tn, tile * tk + block_pad, tk * tn + block_pad, gflags, 0, ukind, bflags, bkind);
   }
   if (!host_buffers) xsmm_hip_force_variant(-1);
   int chained = -1;
@@ -234,14 +237,14 @@ static int run_case(int argc, char **argv) {
         auto run = [&](int64_t t0, int64_t t1) { // tiles [t0, t1) of the MB x NB grid, row-major (static schedule)
           for (int64_t t = t0; t < t1; ++t) {
             const int64_t i = t / NB, j = t % NB;
-            xsmm_fused_brgemm_invoke(dt, handle[l], act[l], i * KB * tile * tk, W[l], j * KB * tk * tn, act[l + 1],
+            xsmm_fused_brgemm_invoke(dt, handle[l], act[l], i * KB * (tile * tk + block_pad), W[l], j * KB * (tk * tn + block_pad), act[l + 1],
                                      (i * NB + j) * tile * tn, B[l], j * tn, KB);
           }
         };
         if (threads <= 1) { // the lowered scf.forall: two nested loops (no index arithmetic per tile)
           for (int64_t i = 0; i < MB; ++i)
             for (int64_t j = 0; j < NB; ++j)
-              xsmm_fused_brgemm_invoke(dt, handle[l], act[l], i * KB * tile * tk, W[l], j * KB * tk * tn, act[l + 1],
+              xsmm_fused_brgemm_invoke(dt, handle[l], act[l], i * KB * (tile * tk + block_pad), W[l], j * KB * (tk * tn + block_pad), act[l + 1],
                                        (i * NB + j) * tile * tn, B[l], j * tn, KB);
         }
         else { // the reference's scf.parallel -> OpenMP parallel-for over the tile grid (static schedule, barrier at the end)

@@ -227,6 +227,10 @@ __device__ __forceinline__ void blw_loader(chain_kernarg_t *pp, unsigned char *s
       if (GRP == 2) vo0 = vo1 = (unsigned)((lane >> 5) * (int)p.L[l].ldb * 4 + ((lane & 15) << 4)) + ((lane & 16) ? q_delta : 0u); /* 32 pieces = one pair-row: 16 per item */ \
       step = (unsigned)(NL * RPI * (int)p.L[l].ldb * 4);                                                               \
     }                                                                                                                  \
+    /* one chunk per batch element (the compiler's 64-k tile invokes over packed blocks): EVERY advance is the wrap - the same   */ \
+    /* single add as the flat case, instead of a count-and-branch per chunk in the loader's instruction stream, which sets the */ \
+    /* pace of the small tiles (32x32 + K2 grouped at K = 4096: 8.97 -> see profiles/r06_bf16_loader_advance_ab.txt)            */ \
+    if (kchunks == 1) d_in = d_wrap;                                                                                   \
     flat = d_wrap == d_in;                                                                                             \
   } while (0)
   // request the next SUP 64-k chunks of the issue state into ring slot `slot` (SUP consecutive 64-k slots), advance state and slot
