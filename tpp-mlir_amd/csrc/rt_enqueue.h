@@ -143,8 +143,7 @@ __attribute__((always_inline)) inline bool enqueue_item(const void *desc, const 
               me->count = 0;
             }
             const uint32_t hint = me->hint;
-            const TraceItem *it = S.items.data() + hint;
-            if (it < S.items.data() + S.items.size() && it->same(desc, item, s) && S.mark_solo((int)hint)) {
+            if (hint < S.n_items && S.items[hint].same(desc, item, s) && S.mark_solo((int)hint)) {
               ++me->count;
               me->hint = hint + 1;
               joined = true;

@@ -155,6 +155,7 @@ struct Segment {
                               // exchanges: callers mark their own arrivals while a direct window is open (DirectWindow)
   std::vector<int32_t> table; // open addressing over items, -1 = empty
   uint32_t round = 0;
+  uint32_t n_items = 0; // = items.size() of a stored segment (build()): the per-invoke fast path compares an index, no division by sizeof(TraceItem)
   bool vec_ok = true, out_ok = true, pair_ok = true;
   uint64_t last_use = 0;
   // The group's work list as the grouped kernels read it: items[i].w in recorded order, in pinned host memory, written once when
@@ -277,6 +278,7 @@ struct Segment {
       table[at] = (int32_t)i;
     }
     seen.assign(items.size(), 0);
+    n_items = (uint32_t)items.size();
     round = 0;
     list_valid = false;
     n_alloc = -1;
