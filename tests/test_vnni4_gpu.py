@@ -305,3 +305,67 @@ def test_vnni4_groups_of_64x64_tiles_run_on_the_64x64_family(rt):
             check_close(got[sel], ref[sel], BF16, "64x64 tiles vnni %d flags %d" % (v, flags))
             outs[(flags, v)] = got
         assert np.array_equal(outs[(flags, 2)], outs[(flags, 4)]), "VNNI-4 and VNNI-2 images of one matrix must give the same bits"
+
+
+@pytest.mark.parametrize("fc", [False, True], ids=["matmul_beta1", "fc_beta0_bias_relu"])
+@pytest.mark.parametrize("M,N,K", [(128, 1024, 2048), (256, 768, 1024)], ids=lambda v: str(v))
+def test_vnni4_skinny_long_reduction_groups_on_the_32x32_k2_tile(rt, vnni4, M, N, K, fc):
+    """Round 6: tile invokes of a VNNI-4 layer with a skinny output and a long reduction (benchmarks/config/*: the dp4 rows of
+    128x1024x4096, 256x768x3072 ...) run on the 32x32 + K2 instance of the grouped loader-wave kernel like their VNNI-2 twins (four
+    workgroups per 64x64 item; the VNNI-4 image of a 32-column tile = 256-byte k-group rows, four per DMA instruction). Recorded pass
+    and two replays against the oracle (factor 4); the kernel says so."""
+    from test_refbench_shapes_gpu import pack_a, pack_c, pack_w, unpack_c
+    tm = tn = tk = 64
+    old_async, old_q = rt.set_async(True), rt.set_tile_queue(1)
+    try:
+        rng = np.random.default_rng(M + N + K)
+        X = rng.uniform(-1, 1, (M, K)).astype(np.float32)
+        W = (rng.uniform(-1, 1, (K, N)) / np.sqrt(K)).astype(np.float32)
+        C0 = rng.uniform(-1, 1, (M, N)).astype(np.float32)
+        bias = rng.uniform(-1, 1, N).astype(np.float32)
+        X, W, C0, bias = (orc.bf16_to_f32(orc.f32_to_bf16(v.reshape(-1))).reshape(v.shape) for v in (X, W, C0, bias))
+        conv = orc.f32_to_bf16
+        flags = VB | (4 if fc else 0)
+        Wv = np.ascontiguousarray(W.reshape(K // 4, 4, N).transpose(0, 2, 1)).reshape(-1)
+        a_o, w_o, b_o = conv(X.reshape(-1)), conv(Wv), conv(bias)
+        dA, dW, dB = dev(conv(pack_a(X, M, K, tm, tk))), dev(conv(pack_w(W, K, N, tk, tn, 4))), dev(conv(bias))
+        dC = dev(conv(pack_c(C0, M, N, tm, tn)))
+        disp = (BF16, tm, tn, tk, tk, tn, tn, tm * tk, tk * tn, flags)
+        h = rt.fused_brgemm_dispatch(*disp, 0, 5, 4, 1) if fc else rt.brgemm_dispatch(*disp)
+        MB, NB, KB = M // tm, N // tn, K // tk
+        for p in range(3):
+            start = host(dC, conv(C0.reshape(-1)))
+            ref = orc.f32_to_bf16(unpack_c(orc.bf16_to_f32(start), M, N, tm, tn).reshape(-1))
+            for i in range(MB):
+                for j in range(NB):
+                    if fc:
+                        rt.fused_brgemm(BF16, h, dA, i * KB * tm * tk, dW, j * KB * tk * tn, dC, (i * NB + j) * tm * tn, dB, j * tn, KB)
+                    else:
+                        rt.brgemm(BF16, h, dA, i * KB * tm * tk, dW, j * KB * tk * tn, dC, (i * NB + j) * tm * tn, KB)
+            rt.synchronize()
+            kernel = rt.last_grouped_kernel()
+            if fc:
+                orc.fused_brgemm(BF16, M, N, K, K, N, N, 0, 0, flags, 0, 5, 4, 1, a_o, 0, w_o, 0, ref, 0, b_o, 0, 1)
+            else:
+                orc.brgemm(BF16, M, N, K, K, N, N, 0, 0, flags, a_o, 0, w_o, 0, ref, 0, 1)
+            flat = unpack_c(orc.bf16_to_f32(host(dC, ref)), M, N, tm, tn).reshape(-1)
+            check_close(orc.f32_to_bf16(flat), ref, BF16, "pass %d %s vnni4 [%s]" % (p, (M, N, K), kernel), K=K)
+            assert "vnni4<32x32,k2> grouped" in kernel, kernel
+    finally:
+        rt.synchronize()
+        rt.set_tile_queue(old_q)
+        rt.set_async(old_async)
+
+
+@pytest.mark.parametrize("m,n,k,br", [(128, 1024, 64, 64), (256, 768, 64, 16), (128, 1024, 64, 15), (256, 768, 128, 8)])
+def test_vnni4_whole_layer_skinny_long_reduction_on_the_32x32_k2_tile(rt, vnni4, m, n, k, br):
+    """Round 6: a whole-layer VNNI-4 call with at most one 32x32 tile per CU and K = k br >= 1024 is refined at invoke time from the
+    32x64 + K2 tile to the 32x32 + K2 instance (as VNNI-2 operands are): against the oracle (packed and flat operand), both
+    accumulator starts, an odd chunk count; K < 1024 stays on the planned tile."""
+    for (beta0, bias, relu) in ((True, True, True), (False, False, False)):
+        run_case(rt, m, n, k, br, bias=bias, relu=relu, beta0=beta0, seed=m + n + k + br, expect="vnni4")
+        refined = rt.last_refined_kernel()
+        if k * br >= 1024:
+            assert "vnni4<32x32,k2> (long reduction)" in refined, refined
+        else:
+            assert "32x32,k2" not in refined, refined

@@ -376,7 +376,7 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
                 "several chunks per barrier: the tiles that read a whole chunk of fragments ahead");
   constexpr int NLW = NLA + NLB; // loader waves
   static_assert(FLATB == 0 || FLATB == 2 || FLATB == 4, "0: VNNI-2 B image, 2: flat B image + transpose reads, 4: VNNI-4 B image + 8-byte reads");
-  static_assert(FLATB != 4 || BN >= 64, "VNNI-4 image: whole k-group rows per DMA instruction");
+  static_assert(FLATB != 4 || BN >= 32, "VNNI-4 image: whole k-group rows per DMA instruction (BN = 32: four rows of 256 bytes)");
   static_assert(FLATB != 2 || BN >= 64, "transpose-read image: 64-byte blocks swizzled inside rows of >= 128 bytes");
   static_assert(BN == 32 || BN == 64 || BN == 128, "B pair-rows per DMA instruction");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_c[];
@@ -982,8 +982,9 @@ hipError_t launch_bf16_lw_flatb(int tile, const ChainArgs &a, hipStream_t s) {
 // configurations with the B image and the fragment reads of FLATB = 4 - the chunk's 16 k-group rows go into the LDS as they are and a
 // fragment is two 8-byte reads (256 B/clk against the 128 B/clk of the VNNI-2 image's 4-byte reads).
 hipError_t launch_bf16_lw_vnni4(int tile, const ChainArgs &a, hipStream_t s) {
-  if (a.L[0].br < 1 || a.L[0].k < BLW_BK || tile < 0 || tile > 3) return hipErrorInvalidValue;
+  if (a.L[0].br < 1 || a.L[0].k < BLW_BK || tile < 0 || tile > 4) return hipErrorInvalidValue;
   const bool sup2 = blw_sup2(a);
+  if (tile == 4) return sup2 ? launch_blw_t<1, 1, 2, 1, 1, 8, 1, 1, 2, false, 4>(a, s) : launch_blw_t<1, 1, 2, 1, 1, 8, 1, 1, 1, false, 4>(a, s); // 32x32 + K2 (round 6)
   BLW_DISPATCH(false, 4)
 }
 
@@ -993,12 +994,14 @@ hipError_t launch_bf16_lw_vnni4(int tile, const ChainArgs &a, hipStream_t s) {
 // blocks are just another (lda, stride) pattern to the loaders. SUP = 2 instances only when every item has an even chunk count.
 hipError_t launch_bf16_lw_grouped(int tile, int b_kind, const ChainArgs &a, const void *items, int n_items, bool even_chunks, hipStream_t s) {
   if (a.L[0].k < BLW_BK || a.L[0].k % BLW_BK || tile < 0 || (tile > 1 && tile != 4) || (b_kind != 0 && b_kind != 4)) return hipErrorInvalidValue;
-  if (tile == 4) { // 32x32 + K2 (launch_bf16_lw's tile 4, VNNI-2 only): four workgroups per 64x64 item - skinny groups with a long reduction
-    if (b_kind != 0) return hipErrorInvalidValue;
+  if (tile == 4) { // 32x32 + K2 (launch_bf16_lw's tile 4): four workgroups per 64x64 item - skinny groups with a long reduction
     static const int forced4 = [] {
       const char *e = getenv("TPP_HIP_BLW_SUP");
       return e ? atoi(e) : 0;
     }();
+    if (b_kind == 4) // (VNNI-4 operands: grouped form only - the image rows of a 32-column tile are 256 bytes, four per DMA instruction)
+      return even_chunks && forced4 != 1 ? launch_blw_t<1, 1, 2, 1, 1, 8, 1, 1, 2, false, 4, true>(a, s, items, n_items)
+                                         : launch_blw_t<1, 1, 2, 1, 1, 8, 1, 1, 1, false, 4, true>(a, s, items, n_items);
     return even_chunks && forced4 != 1 ? launch_blw_t<1, 1, 2, 1, 1, 8, 1, 1, 2, false, 0, true>(a, s, items, n_items)
                                        : launch_blw_t<1, 1, 2, 1, 1, 8, 1, 1, 1, false, 0, true>(a, s, items, n_items);
   }

@@ -966,7 +966,11 @@ hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_i
         // launch_gemm does for the whole-layer call (one round of workgroups at most, 16 chunks or more; (a, b) = (3.52, 0.072) from
         // 128 x 1024 x 1024 / x 4096 on that tile)
         const int64_t wg4 = n_dec * (d.m / 32) * (d.n / 32);
-        if (v2 && wg4 <= (int64_t)g_num_cus && chunks >= 16 && 3.52 + 0.072 * (double)chunks < (c1 < c0 ? c1 : c0)) tile = 4;
+        static const bool t4_v4 = [] { // (A/B runs: TPP_HIP_BF16_LW_T4_VNNI4=0 keeps VNNI-4 groups on the 32x64 / 64x64 tiles)
+          const char *e = getenv("TPP_HIP_BF16_LW_T4_VNNI4");
+          return !e || atoi(e) != 0;
+        }();
+        if ((v2 || (v4 && t4_v4)) && wg4 <= (int64_t)g_num_cus && chunks >= 16 && 3.52 + 0.072 * (double)chunks < (c1 < c0 ? c1 : c0)) tile = 4;
         ChainArgs c;
         memset(&c, 0, sizeof(c));
         c.lda = d.lda;
@@ -977,7 +981,7 @@ hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_i
         const bool even = ((d.k / BK) % 2 == 0) || pair_ok;
         static const char *const names[2][2] = {{"brgemm_bf16_lw<32x64,k2> grouped", "brgemm_bf16_lw<64x64> grouped"},
                                                 {"brgemm_bf16_lw_vnni4<32x64,k2> grouped", "brgemm_bf16_lw_vnni4<64x64> grouped"}};
-        return note_grouped(tile == 4 ? "brgemm_bf16_lw<32x32,k2> grouped" : names[v4 ? 1 : 0][tile],
+        return note_grouped(tile == 4 ? (v4 ? "brgemm_bf16_lw_vnni4<32x32,k2> grouped" : "brgemm_bf16_lw<32x32,k2> grouped") : names[v4 ? 1 : 0][tile],
                             launch_bf16_lw_grouped(tile, v4 ? 4 : 0, c, items, n_items, even, stream));
       }
     }
@@ -1391,6 +1395,13 @@ hipError_t launch_gemm(const GemmDesc &d, const void *A, const void *B, void *C,
     c.m = a.m; c.n = a.n; c.nlayers = 1; c.tiles_m = c.tiles_n = 0; c.xm = 0; c.stamps = nullptr;
     c.dbg = chain_ablation_bits();
     c.L[0] = ChainLayer{a.B, a.D, a.C, a.ldb, a.ldc, a.stride_a, a.stride_b, a.k, a.br, a.ep, 0};
+    // (round 6) skinny outputs with a long reduction: the 32x32 + K2 instance, as for VNNI-2 operands above - at most one 32x32 tile
+    // per CU and K >= 1024: twice the workgroups of the 32x64 tile pulling panels (128 x 1024 x 4096: 9.3 -> 7.6 us)
+    if (v == V_BF16_LW4_32x64 && !d.variant_forced && !d.generic_forced && bf16_lw32_on() && d.m % 32 == 0 && d.n % 32 == 0 &&
+        (d.m / 32) * (d.n / 32) <= (int64_t)g_num_cus && (int64_t)a.br * d.k >= 1024) {
+      g_last_refined.store("brgemm_bf16_lw_vnni4<32x32,k2> (long reduction)", std::memory_order_relaxed);
+      return launch_bf16_lw_vnni4(4, c, stream);
+    }
     return launch_bf16_lw_vnni4(v - V_BF16_LW4_32x64, c, stream);
   }
   case V_BF16_LWF_32x64:
