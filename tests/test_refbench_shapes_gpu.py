@@ -457,3 +457,64 @@ def test_groups_that_are_not_item_grids_stay_items(rt, case):
         rt.synchronize()
         rt.set_tile_queue(old_q)
         rt.set_async(old_async)
+
+
+@pytest.mark.parametrize("fc", [False, True], ids=["matmul_beta1", "fc_beta0_bias_relu"])
+@pytest.mark.parametrize("vn", [2, 4], ids=["vnni2", "vnni4"])
+@pytest.mark.parametrize("M,N,K,tiles", [(128, 768, 2304, (64, 48, 64)), (64, 480, 1024, (32, 48, 64)), (256, 336, 1152, (64, 48, 64))],
+                         ids=lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else str(v))
+def test_bf16_ragged_n_items_on_the_32x32_k2_tile(rt, M, N, K, tiles, vn, fc):
+    """RAGGED n (csrc/brgemm_bf16_lw.hip skip_cols; brgemm_f32.hip "ragged n"): bf16 tile invokes whose n is 16 more than a multiple of
+    32 - benchmarks/config/fc/128x768x2304.json:40-64 and matmul/128x768x2304.json: --tiles=64,48,64 - with a long reduction run on the
+    32x32 + K2 loader-wave instance: ceil(n / 32) column tiles per item, the last one moved left to end at column n; it recomputes the
+    16 columns it shares with its neighbour and stores only its own. Three passes (beta = 1 accumulates: a column stored twice would
+    show), VNNI-2 and VNNI-4, 64x48 and 32x48 items (the tile queue takes items of at most 64 x 64), against the oracle; the kernel says so."""
+    tm, tn, tk = tiles
+    old_v = rt.set_vnni_factor(vn)
+    old_o = orc.set_vnni_factor(vn)
+    old_async, old_q = rt.set_async(True), rt.set_tile_queue(1)
+    try:
+        rng = np.random.default_rng(M + N + K + vn + 7)
+        X = rng.uniform(-1, 1, (M, K)).astype(np.float32)
+        W = (rng.uniform(-1, 1, (K, N)) / np.sqrt(K)).astype(np.float32)
+        C0 = rng.uniform(-1, 1, (M, N)).astype(np.float32)
+        bias = rng.uniform(-1, 1, N).astype(np.float32)
+        X, W, C0, bias = (orc.bf16_to_f32(orc.f32_to_bf16(v.reshape(-1))).reshape(v.shape) for v in (X, W, C0, bias))
+        conv = orc.f32_to_bf16
+        flags = VB | (4 if fc else 0)
+        Wv = np.ascontiguousarray(W.reshape(K // vn, vn, N).transpose(0, 2, 1)).reshape(-1)
+        a_o, w_o, b_o = conv(X.reshape(-1)), conv(Wv), conv(bias)
+        dA, dW, dB = dev(conv(pack_a(X, M, K, tm, tk))), dev(conv(pack_w(W, K, N, tk, tn, vn))), dev(conv(bias))
+        dC = dev(conv(pack_c(C0, M, N, tm, tn)))
+        disp = (BF16, tm, tn, tk, tk, tn, tn, tm * tk, tk * tn, flags)
+        h = rt.fused_brgemm_dispatch(*disp, 0, 5, 4, 1) if fc else rt.brgemm_dispatch(*disp)
+        MB, NB, KB = M // tm, N // tn, K // tk
+        outs = []
+        for p in range(3):
+            start = host(dC, conv(C0.reshape(-1)))
+            ref = orc.f32_to_bf16(unpack_c(orc.bf16_to_f32(start), M, N, tm, tn).reshape(-1))
+            for i in range(MB):
+                for j in range(NB):
+                    if fc:
+                        rt.fused_brgemm(BF16, h, dA, i * KB * tm * tk, dW, j * KB * tk * tn, dC, (i * NB + j) * tm * tn, dB, j * tn, KB)
+                    else:
+                        rt.brgemm(BF16, h, dA, i * KB * tm * tk, dW, j * KB * tk * tn, dC, (i * NB + j) * tm * tn, KB)
+            rt.synchronize()
+            kernel = rt.last_grouped_kernel()
+            got = host(dC, ref)
+            outs.append(got.copy())
+            if fc:
+                orc.fused_brgemm(BF16, M, N, K, K, N, N, 0, 0, flags, 0, 5, 4, 1, a_o, 0, w_o, 0, ref, 0, b_o, 0, 1)
+            else:
+                orc.brgemm(BF16, M, N, K, K, N, N, 0, 0, flags, a_o, 0, w_o, 0, ref, 0, 1)
+            flat = unpack_c(orc.bf16_to_f32(got), M, N, tm, tn).reshape(-1)
+            check_close(orc.f32_to_bf16(flat), ref, BF16, "pass %d %s tiles %s vnni%d [%s]" % (p, (M, N, K), tiles, vn, kernel), K=K)
+            assert "ragged n" in kernel and ("vnni4" in kernel) == (vn == 4), kernel
+        if fc:
+            assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[1], outs[2])
+    finally:
+        rt.synchronize()
+        rt.set_tile_queue(old_q)
+        rt.set_async(old_async)
+        rt.set_vnni_factor(old_v)
+        orc.set_vnni_factor(old_o)

@@ -454,8 +454,16 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
   // traffic - and stores its own tile: what the K loop costs when no byte comes from beyond the L2
   const bool alias_ = (p.dbg & 512) != 0;
   const int m0 = tm * BM, n0 = tn * BN, m0_ld = alias_ ? 0 : m0, n0_ld = alias_ ? 0 : n0;
+  [[maybe_unused]] constexpr int skip_cols = 0; // (timing builds: no ragged items)
 #else
-  const int m0 = tm * BM, n0 = tn * BN, m0_ld = m0, n0_ld = n0;
+  // RAGGED n of grouped items (round 6: the reference's --tiles=64,48,64 rows): an item whose n is not a multiple of the tile's width
+  // gets ceil(n / BN) column tiles, the LAST one moved left to end at column n - it recomputes the columns it shares with its
+  // neighbour (panels in bounds, no masking of loads) and stores only its own (skip_cols: the first columns of its tile are the
+  // neighbour's). Everything else: skip_cols = 0.
+  const int m0 = tm * BM;
+  const int n0 = (GRP == 1 && (tn + 1) * BN > p.n) ? p.n - BN : tn * BN;
+  [[maybe_unused]] const int skip_cols = tn * BN - n0;
+  const int m0_ld = m0, n0_ld = n0;
 #endif
   const int L = MULTI ? p.nlayers : 1;
 
@@ -831,6 +839,7 @@ __global__ __launch_bounds__(64 * (WM * WN * WK + NLA + NLB)) void brgemm_bf16_l
           const int row = it * RPP + lane / LPR, ch = lane % LPR;
           const u32x4 v = *(const u32x4 *)(ot + row * ES + ch * 16);
           const unsigned voff = (unsigned)(32 * i + row) * ldcb + (unsigned)(ch * 16);
+          if (GRP == 1 && ch * 8 < skip_cols) continue; // (a ragged item's last column tile: these columns are the neighbour tile's)
           if (MULTI && l + 1 < L && !(dbg & 4)) __builtin_amdgcn_raw_buffer_store_b128(v, rsrcC, voff, 0, 16); // sc1: write-through (hand-off)
           else __builtin_amdgcn_raw_buffer_store_b128(v, rsrcC, voff, 0, C_STORE_AUX); // (last layer / single layer: gemm_common.h)
         }
@@ -865,7 +874,7 @@ static hipError_t launch_blw_t(const ChainArgs &a, hipStream_t s, const void *it
   if (hipError_t e = ensure_dynamic_lds((const void *)kern, (int)lds_alloc, lds_set); e != hipSuccess) return e;
   ChainArgs args = a;
   args.tiles_m = a.m / BM;
-  args.tiles_n = a.n / BN;
+  args.tiles_n = GRP == 1 ? (a.n + BN - 1) / BN : a.n / BN; // (grouped items: a ragged last column tile, see the kernel)
   long long tiles = (long long)args.tiles_m * args.tiles_n;
   if (tiles <= 0 || tiles > 0x7fffffffLL) return hipErrorInvalidValue;
   args.items = nullptr;

@@ -953,6 +953,35 @@ hipError_t launch_gemm_grouped(const GemmDesc &d, const WorkItem *items, int n_i
     const bool shape_ok = d.dtype == DT_BF16 && d.vnni_b && (v2 || v4) && !d.vnni_c && !d.generic_forced && !d.variant_forced && d.k > 0 && d.k % BK == 0 &&
                           d.m % 32 == 0 && d.n % 64 == 0 && !((d.lda | d.stride_a | d.stride_b | d.ldc) & 7) && !(d.ldb & (v2 ? 3 : 1)) &&
                           d.lda < (1 << 21) && d.ldb < (1 << 20) && d.ldc < (1 << 22) && d.stride_a >= 0 && d.stride_b >= 0;
+    // RAGGED n (round 6): items whose n is 16 more than a multiple of 32 - the reference's --tiles=64,48,64 rows (fc / matmul 128x768x2304)
+    // - on the 32x32 + K2 instance: ceil(n / 32) column tiles per item, the last moved left to end at column n (it recomputes the 16
+    // columns it shares with its neighbour and stores its own 16: brgemm_bf16_lw.hip skip_cols). Skinny groups with a long reduction
+    // only, like the instance's other uses; everything else with such an n stays on the K-split kernel below.
+    {
+      static const bool ragged_on = [] {
+        const char *e = getenv("TPP_HIP_BF16_LW_RAGGED");
+        return !e || atoi(e) != 0;
+      }();
+      const bool ragged_ok = ragged_on && d.dtype == DT_BF16 && d.vnni_b && (v2 || v4) && !d.vnni_c && !d.generic_forced && !d.variant_forced && d.k > 0 && d.k % BK == 0 &&
+                             d.m % 32 == 0 && d.n % 32 == 16 && d.n >= 48 && !((d.lda | d.stride_a | d.stride_b | d.ldc) & 7) && !(d.ldb & (v2 ? 3 : 1)) &&
+                             d.lda < (1 << 21) && d.ldb < (1 << 20) && d.ldc < (1 << 22) && d.stride_a >= 0 && d.stride_b >= 0;
+      if (lwg_on && ragged_ok && vec_ok && out_ok && br_hint >= 1 && g_forced_split.load(std::memory_order_relaxed) < 0) {
+        const int64_t chunks = br_hint * (d.k / BK);
+        const int64_t wg4 = n_dec * (d.m / 32) * ((d.n + 31) / 32);
+        if (wg4 <= (int64_t)g_num_cus && chunks >= 16) {
+          ChainArgs c;
+          memset(&c, 0, sizeof(c));
+          c.lda = d.lda;
+          c.m = (int)d.m;
+          c.n = (int)d.n;
+          c.nlayers = 1;
+          c.L[0] = ChainLayer{nullptr, nullptr, nullptr, d.ldb, d.ldc, d.stride_a, d.stride_b, (int)d.k, (int)br_hint, a.ep, 0};
+          const bool even = ((d.k / BK) % 2 == 0) || pair_ok;
+          return note_grouped(v4 ? "brgemm_bf16_lw_vnni4<32x32,k2> grouped, ragged n" : "brgemm_bf16_lw<32x32,k2> grouped, ragged n",
+                              launch_bf16_lw_grouped(4, v4 ? 4 : 0, c, items, n_items, even, stream));
+        }
+      }
+    }
     if (lwg_on && shape_ok && vec_ok && out_ok && br_hint >= 1 && g_forced_split.load(std::memory_order_relaxed) < 0) { // (a forced split count: the K-split kernel below)
       const int64_t chunks = br_hint * (d.k / BK);
       const int64_t t64 = d.m % 64 == 0 ? n_dec * (d.m / 64) * (d.n / 64) : 0;
